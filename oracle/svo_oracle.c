@@ -1,0 +1,1497 @@
+/* svo_oracle.c -- CPU restatement of the stereo-VO hot path.  TEST INFRASTRUCTURE (see svo_oracle.h).
+ *
+ * Citations: H  = libstereo-odometry/include/libstereo-odometry.h
+ *            P  = libstereo-odometry/src/process_new_image_pair.cpp
+ *            S2 = .../stage2_detect.cpp   S3 = .../stage3_match_left_right.cpp
+ *            S4 = .../stage4_match_consecutive.cpp   S5 = .../stage5_optimization.cpp
+ *            C  = .../common.cpp          SAD = .../compute_SAD8.cpp
+ * all under /root/reference.  Where the reference calls OpenCV / MRPT / Eigen (absent: SURVEY.md 8c) the
+ * published algorithm is restated and FROZEN here; those places are marked [frozen].
+ *
+ * Compile with -ffp-contract=off: the float formulas below are written so that the HIP kernels can match
+ * them bit for bit (one IEEE operation per written operator, no fused multiply-add).
+ */
+#include "svo_oracle.h"
+#include "../include/svo_orb_tables.h"
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define EDGE_THRESHOLD 31          /* S2:486 */
+#define HARRIS_BLOCK 7
+#define RANSAC_MAX_HYP 256         /* [frozen] */
+#define RANSAC_SEED 0x5EEDF00DCAFE1234ULL
+#define MAXOCT SVO_MAX_OCTAVES
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small helpers                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: OOM\n"); abort(); } return p; }
+static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s ? s : 1); if (!p) { fprintf(stderr, "oracle: OOM\n"); abort(); } return p; }
+
+/* total order on floats via their bit pattern (no NaNs on this path) */
+static uint32_t ord32(float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+static int cmp_u64_desc(const void* a, const void* b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? 1 : (x > y ? -1 : 0); }
+static int cmp_u64_asc(const void* a, const void* b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : (x > y ? 1 : 0); }
+static int cmp_u32_desc(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? 1 : (x > y ? -1 : 0); }
+
+void svo_oracle_params_defaults(svo_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->nOctaves = 3;                         /* S1:27-30 (forced to 1 for dmORB, S1:80) */
+    p->detect_method = SVO_DM_ORB;           /* north-star selector (reference default dmFASTER, S2:45) */
+    p->non_maximal_suppression = 1;          /* S2:49 */
+    p->nmsMethod = SVO_NMS_STANDARD;         /* S2:50 */
+    p->min_distance = 3;                     /* S2:51 */
+    p->orb_nfeats = 500;                     /* S2:52 */
+    p->orb_nlevels = 8;                      /* S2:53 */
+    p->minimum_ORB_response = 0.0;           /* S2:54 */
+    p->fast_min_th = 5; p->fast_max_th = 30; /* S2:55 */
+    p->initial_FAST_threshold = 20;          /* S2:56 */
+    p->match_method = SVO_SM_DESC_BF;        /* north-star selector (reference default smSAD, S3:47) */
+    p->orb_max_distance = 40;                /* S3:50 */
+    p->orb_min_th = 30; p->orb_max_th = 100; /* S3:51 */
+    p->enable_robust_1to1_match = 0;         /* S3:52 */
+    p->max_y_diff = 0;                       /* S3:54 */
+    p->ifm_method = SVO_IFM_DESC_BF;         /* H:610 */
+    p->ifm_win_w = 16; p->ifm_win_h = 16;    /* no reference default (C:84); SURVEY appendix A #13 */
+    p->filter_fund_matrix = 0;
+    p->use_robust_kernel = 1;                /* C:70 */
+    p->kernel_param = 3.0;                   /* C:71 */
+    p->max_iters = 100;                      /* C:72 */
+    p->initial_max_iters = 10;               /* C:73 */
+    p->min_mod_out_vector = 1e-3;            /* C:74 */
+    p->max_incr_cost = 3;                    /* C:76 */
+    p->residual_threshold = 10.0;            /* C:77 */
+    p->bad_tracking_th = 5;                  /* C:78 */
+    p->use_previous_pose_as_initial = 1;     /* C:79 */
+    p->use_custom_initial_pose = 0;          /* C:80 */
+    p->vo_use_matches_ids = 0;               /* P:35 */
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* compute_SAD8_default  (SAD:71-98) -- known-answer only                                           */
+/* ------------------------------------------------------------------------------------------------ */
+uint32_t svo_oracle_sad8(const uint8_t* l, const uint8_t* r, size_t stride, int lx, int ly, int rx, int ry)
+{
+    const uint8_t* pl = l + stride * (size_t)(ly - 3) + (lx - 3);   /* window [x-3,x+4] x [y-3,y+4] */
+    const uint8_t* pr = r + stride * (size_t)(ry - 3) + (rx - 3);
+    uint32_t sum = 0;
+    for (int y = 0; y < 8; y++) {
+        for (int x = 0; x < 8; x++) { int d = (int)pl[x] - (int)pr[x]; sum += (uint32_t)(d > 0 ? d : -d); }
+        pl += stride; pr += stride;
+    }
+    return sum;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* pyramids                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+/* [frozen] ORB level geometry: scale_l = (float)1.2^l, size = round(W/scale) (S2:484-485 -> cv::ORB). */
+int svo_oracle_pyramid_sizes(int w, int h, int nlevels, int* lw, int* lh, float* scale)
+{
+    for (int l = 0; l < nlevels; l++) {
+        float sf = (float)pow(1.2, (double)l);
+        scale[l] = sf;
+        lw[l] = (int)lrintf((float)w / sf);
+        lh[l] = (int)lrintf((float)h / sf);
+    }
+    return nlevels;
+}
+
+/* [frozen] integer bilinear sampling table: source coordinate (d+0.5)*src/dst-0.5 in exact rational
+ * arithmetic, fraction quantised to 11 bits (the 2048 scale of 8-bit bilinear resizers). */
+static void resize_table(int src, int dst, int* idx, int* frac)
+{
+    for (int d = 0; d < dst; d++) {
+        int64_t num = (int64_t)(2 * d + 1) * src - dst;
+        int64_t den = 2 * (int64_t)dst;
+        int64_t q = num >= 0 ? num / den : -((-num + den - 1) / den);
+        int64_t r = num - q * den;
+        int f = (int)((r * 2048 + den / 2) / den);
+        if (q < 0) { q = 0; f = 0; }
+        if (q >= src - 1) { q = src - 1; f = 0; }
+        idx[d] = (int)q; frac[d] = f;
+    }
+}
+
+void svo_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh)
+{
+    int* xi = (int*)xmalloc(sizeof(int) * (size_t)dw), *xf = (int*)xmalloc(sizeof(int) * (size_t)dw);
+    int* yi = (int*)xmalloc(sizeof(int) * (size_t)dh), *yf = (int*)xmalloc(sizeof(int) * (size_t)dh);
+    resize_table(sw, dw, xi, xf);
+    resize_table(sh, dh, yi, yf);
+    for (int y = 0; y < dh; y++) {
+        int y0 = yi[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1, ay = yf[y];
+        const uint8_t* r0 = src + (size_t)y0 * sstride, *r1 = src + (size_t)y1 * sstride;
+        for (int x = 0; x < dw; x++) {
+            int x0 = xi[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, ax = xf[x];
+            int v = r0[x0] * (2048 - ax) * (2048 - ay) + r0[x1] * ax * (2048 - ay)
+                  + r1[x0] * (2048 - ax) * ay + r1[x1] * ax * ay;
+            dst[(size_t)y * dw + x] = (uint8_t)((v + (1 << 21)) >> 22);
+        }
+    }
+    free(xi); free(xf); free(yi); free(yf);
+}
+
+/* [frozen] mrpt CImagePyramid::buildPyramidFast smooth halving (S1:82-83): 2x2 box average, round half up */
+void svo_oracle_half_smooth(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst)
+{
+    int dw = sw / 2, dh = sh / 2;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const uint8_t* p = src + (size_t)(2 * y) * sstride + 2 * x;
+            dst[(size_t)y * dw + x] = (uint8_t)((p[0] + p[1] + p[sstride] + p[sstride + 1] + 2) >> 2);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* FAST-9/16 [frozen]  (Rosten & Drummond; stands in for the FAST inside cv::ORB, S2:482-493, and     */
+/* cv::FastFeatureDetector, S2:510-511)                                                              */
+/* ------------------------------------------------------------------------------------------------ */
+static const int fast_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+static const int fast_dy[16] = { -3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3 };
+
+/* score = largest t for which the pixel is still a FAST-9 corner at threshold t
+ *       = max over the 16 arcs of 9 contiguous circle pixels of min one-sided difference, minus 1.
+ * returns 0 when score < th (not a corner at the requested threshold) */
+static int fast_score_px(const uint8_t* p, int stride, int th)
+{
+    int c = p[0], d[16];
+    unsigned bright = 0, dark = 0;
+    for (int i = 0; i < 16; i++) {
+        d[i] = (int)p[fast_dy[i] * stride + fast_dx[i]] - c;
+        if (d[i] > th) bright |= 1u << i;
+        if (-d[i] > th) dark |= 1u << i;
+    }
+    /* 9 contiguous set bits in a 16-bit ring */
+    unsigned hit = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        unsigned m = pass ? dark : bright, r = m | (m << 16);
+        unsigned x = r & (r >> 1); x &= x >> 2; x &= x >> 4; x &= r >> 8;
+        if (x & 0xFFFFu) hit = 1;
+    }
+    if (!hit) return 0;
+    int best = 0;
+    for (int s = 0; s < 16; s++) {
+        int mb = 255, md = 255;
+        for (int k = 0; k < 9; k++) { int v = d[(s + k) & 15]; if (v < mb) mb = v; if (-v < md) md = -v; }
+        if (mb > best) best = mb;
+        if (md > best) best = md;
+    }
+    return best - 1;
+}
+
+static void fast_score_region(const uint8_t* img, int w, int h, int stride, int th, int x0, int y0, int x1, int y1, uint8_t* score /* w*h, zeroed */)
+{
+    if (x0 < 3) x0 = 3; if (y0 < 3) y0 = 3; if (x1 > w - 3) x1 = w - 3; if (y1 > h - 3) y1 = h - 3;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++)
+            score[(size_t)y * w + x] = (uint8_t)fast_score_px(img + (size_t)y * stride + x, stride, th);
+}
+
+void svo_oracle_fast_score_map(const uint8_t* img, int w, int h, int stride, int th, uint8_t* score)
+{
+    memset(score, 0, (size_t)w * h);
+    fast_score_region(img, w, h, stride, th, 3, 3, w - 3, h - 3, score);
+}
+
+/* 3x3 non-max suppression (strictly greater than all 8 neighbours), then border filter
+ * x,y in [EDGE, dim-EDGE). Appends key32 = score<<24 | (0xFFFFFF - pos), pos = y*w+x, row-major. */
+static int fast_nms_candidates(const uint8_t* score, int w, int h, uint32_t* keys, int cap)
+{
+    int n = 0;
+    for (int y = EDGE_THRESHOLD; y < h - EDGE_THRESHOLD; y++)
+        for (int x = EDGE_THRESHOLD; x < w - EDGE_THRESHOLD; x++) {
+            const uint8_t* s = score + (size_t)y * w + x;
+            int v = s[0];
+            if (!v) continue;
+            if (v > s[-1] && v > s[1] && v > s[-w - 1] && v > s[-w] && v > s[-w + 1] && v > s[w - 1] && v > s[w] && v > s[w + 1]) {
+                if (n < cap) keys[n] = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * w + x));
+                n++;
+            }
+        }
+    return n < cap ? n : cap;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Harris, orientation, steered BRIEF  [frozen]  (Rublee et al. 2011; cv::ORB stand-in)             */
+/* ------------------------------------------------------------------------------------------------ */
+static float harris_response(const uint8_t* img, int stride, int x, int y)
+{
+    int a = 0, b = 0, c = 0;
+    const int r = HARRIS_BLOCK / 2;
+    for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) {
+            const uint8_t* p = img + (size_t)(y + dy) * stride + (x + dx);
+            int Ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-stride + 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[stride - 1]);
+            int Iy = ((int)p[stride] - (int)p[-stride]) * 2 + ((int)p[stride - 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[-stride + 1]);
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+    const float s = 1.0f / (4.0f * 7.0f * 255.0f);
+    const float s2 = s * s;
+    const float s4 = s2 * s2;
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    const float det = fa * fb - fc * fc;
+    const float tr = fa + fb;
+    const float k = 0.04f * (tr * tr);
+    return (det - k) * s4;
+}
+
+/* polynomial atan2 in degrees, 0..360 (the classic 7th-order minimax fit used by fast image-processing
+ * libraries; ~0.3 deg max error).  One IEEE float operation per operator. */
+static float atan2_deg(float y, float x)
+{
+    const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + 2.220446e-16f);
+        c2 = c * c;
+        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
+static void orb_angle_desc(const uint8_t* img, int stride, int x, int y, float* angle_out, uint8_t* desc)
+{
+    const uint8_t* c = img + (size_t)y * stride + x;
+    /* intensity centroid over the radius-15 disc */
+    int m10 = 0, m01 = 0;
+    for (int v = -SVO_HALF_PATCH; v <= SVO_HALF_PATCH; v++) {
+        int um = svo_umax[v < 0 ? -v : v];
+        for (int u = -um; u <= um; u++) { int I = c[v * stride + u]; m10 += u * I; m01 += v * I; }
+    }
+    float angle = atan2_deg((float)m01, (float)m10);
+    *angle_out = angle;
+    int bin = (int)(angle * (1.0f / 12.0f) + 0.5f);
+    if (bin >= SVO_BRIEF_NBINS) bin -= SVO_BRIEF_NBINS;
+    /* 7x7 sigma=2 integer Gaussian of the 31x31 patch (separable, exact integer sums, one rounding) */
+    int tmp[37][31];
+    uint8_t bl[31][31];
+    for (int r = 0; r < 37; r++)
+        for (int q = 0; q < 31; q++) {
+            const uint8_t* p = c + (r - 18) * stride + (q - 15);
+            int s = 0;
+            for (int k = 0; k < 7; k++) s += svo_gauss7[k] * p[k - 3];
+            tmp[r][q] = s;
+        }
+    for (int r = 0; r < 31; r++)
+        for (int q = 0; q < 31; q++) {
+            int s = 0;
+            for (int k = 0; k < 7; k++) s += svo_gauss7[k] * tmp[r + k][q];
+            bl[r][q] = (uint8_t)((s + 32768) >> 16);
+        }
+    memset(desc, 0, SVO_DESC_BYTES);
+    for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) {
+        const int8_t* pr = svo_brief_rot[bin][i];
+        int a = bl[pr[1] + 15][pr[0] + 15], b = bl[pr[3] + 15][pr[2] + 15];
+        if (a < b) desc[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* cv::ORB::detectAndCompute stand-in  [frozen]   (call site S2:482-493)                            */
+/* ------------------------------------------------------------------------------------------------ */
+static void orb_level_quota(int nfeatures, int nlevels, int* q)
+{
+    float factor = (float)(1.0 / 1.2);
+    float nd = (float)nfeatures * (1.0f - factor) / (1.0f - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { q[l] = (int)lrintf(nd); sum += q[l]; nd *= factor; }
+    q[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+}
+
+int svo_oracle_orb_detect(const uint8_t* img, int w, int h, int stride, int nfeatures, int nlevels,
+                          int fast_th, svo_keypoint* kps, uint8_t* desc, int cap)
+{
+    if (nlevels < 1) nlevels = 1; if (nlevels > 16) nlevels = 16;
+    int lw[16], lh[16], quota[16]; float sc[16];
+    svo_oracle_pyramid_sizes(w, h, nlevels, lw, lh, sc);
+    orb_level_quota(nfeatures, nlevels, quota);
+    uint8_t* bufs[16]; const uint8_t* lv[16]; int ls[16];
+    lv[0] = img; ls[0] = stride; bufs[0] = NULL;
+    for (int l = 1; l < nlevels; l++) {
+        bufs[l] = (uint8_t*)xmalloc((size_t)lw[l] * lh[l]);
+        svo_oracle_resize(lv[l - 1], lw[l - 1], lh[l - 1], ls[l - 1], bufs[l], lw[l], lh[l]);
+        lv[l] = bufs[l]; ls[l] = lw[l];
+    }
+    int n = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const int W = lw[l], H = lh[l];
+        if (W <= 2 * EDGE_THRESHOLD || H <= 2 * EDGE_THRESHOLD || quota[l] <= 0) continue;
+        uint8_t* score = (uint8_t*)xcalloc((size_t)W * H, 1);
+        fast_score_region(lv[l], W, H, ls[l], fast_th, EDGE_THRESHOLD - 1, EDGE_THRESHOLD - 1, W - EDGE_THRESHOLD + 1, H - EDGE_THRESHOLD + 1, score);
+        int ccap = (W - 2 * EDGE_THRESHOLD) * (H - 2 * EDGE_THRESHOLD);
+        uint32_t* keys = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)ccap);
+        int nc = fast_nms_candidates(score, W, H, keys, ccap);
+        free(score);
+        /* keep the best 2*quota by (FAST score desc, position asc) */
+        qsort(keys, (size_t)nc, sizeof(uint32_t), cmp_u32_desc);
+        if (nc > 2 * quota[l]) nc = 2 * quota[l];
+        /* Harris response, keep the best quota by (response desc, position asc) */
+        uint64_t* hk = (uint64_t*)xmalloc(sizeof(uint64_t) * (size_t)(nc ? nc : 1));
+        for (int i = 0; i < nc; i++) {
+            uint32_t pos = 0xFFFFFFu - (keys[i] & 0xFFFFFFu);
+            int x = (int)(pos % (uint32_t)W), y = (int)(pos / (uint32_t)W);
+            float r = harris_response(lv[l], ls[l], x, y);
+            hk[i] = ((uint64_t)ord32(r) << 32) | (uint64_t)(0xFFFFFFFFu - pos);
+        }
+        qsort(hk, (size_t)nc, sizeof(uint64_t), cmp_u64_desc);
+        if (nc > quota[l]) nc = quota[l];
+        for (int i = 0; i < nc && n < cap; i++) {
+            uint32_t pos = 0xFFFFFFFFu - (uint32_t)(hk[i] & 0xFFFFFFFFu);
+            int x = (int)(pos % (uint32_t)W), y = (int)(pos / (uint32_t)W);
+            svo_keypoint* k = &kps[n];
+            float ang;
+            orb_angle_desc(lv[l], ls[l], x, y, &ang, desc + (size_t)n * SVO_DESC_BYTES);
+            k->x = (float)x * sc[l]; k->y = (float)y * sc[l];
+            k->size = 31.0f * sc[l];
+            k->angle = ang;
+            k->response = harris_response(lv[l], ls[l], x, y);
+            k->octave = l; k->class_id = -1;
+            n++;
+        }
+        free(hk); free(keys);
+    }
+    for (int l = 1; l < nlevels; l++) free(bufs[l]);
+    return n;
+}
+
+/* cv::FastFeatureDetector::detect (threshold, NMS on, TYPE_9_16) + cv::ORB::create()->compute  [frozen]
+ * (call site S2:510-512): keypoints in row-major order, size 7, response = FAST score; compute() drops
+ * those closer than 31 px to the border and adds orientation + descriptor at level 0. */
+int svo_oracle_fast_orb_detect(const uint8_t* img, int w, int h, int stride, int fast_th,
+                               svo_keypoint* kps, uint8_t* desc, int cap)
+{
+    if (w <= 2 * EDGE_THRESHOLD || h <= 2 * EDGE_THRESHOLD) return 0;
+    uint8_t* score = (uint8_t*)xcalloc((size_t)w * h, 1);
+    fast_score_region(img, w, h, stride, fast_th, EDGE_THRESHOLD - 1, EDGE_THRESHOLD - 1, w - EDGE_THRESHOLD + 1, h - EDGE_THRESHOLD + 1, score);
+    int n = 0;
+    for (int y = EDGE_THRESHOLD; y < h - EDGE_THRESHOLD; y++)
+        for (int x = EDGE_THRESHOLD; x < w - EDGE_THRESHOLD; x++) {
+            const uint8_t* s = score + (size_t)y * w + x;
+            int v = s[0];
+            if (!v) continue;
+            if (!(v > s[-1] && v > s[1] && v > s[-w - 1] && v > s[-w] && v > s[-w + 1] && v > s[w - 1] && v > s[w] && v > s[w + 1])) continue;
+            if (n >= cap) continue;
+            svo_keypoint* k = &kps[n];
+            float ang;
+            orb_angle_desc(img, stride, x, y, &ang, desc + (size_t)n * SVO_DESC_BYTES);
+            k->x = (float)x; k->y = (float)y; k->size = 7.0f; k->angle = ang; k->response = (float)v;
+            k->octave = 0; k->class_id = -1;
+            n++;
+        }
+    free(score);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* m_non_max_sup  (S2:225-283 mask overload, S2:296-370 copying overload)                            */
+/* ------------------------------------------------------------------------------------------------ */
+/* DEVIATION: the reference's unstable std::sort on response (S2:242, 324) is replaced
+ * by the total order (response desc, input index asc). */
+static int nms_walk(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h, int num_out_points,
+                    int32_t* out_order, uint8_t* survivors)
+{
+    if (n <= 0) return 0;
+    uint64_t* keys = (uint64_t*)xmalloc(sizeof(uint64_t) * (size_t)n);
+    for (int i = 0; i < n; i++) keys[i] = ((uint64_t)ord32(kps[i].response) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+    qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64_desc);                       /* S2:322-324 */
+    const unsigned cell = (unsigned)((double)min_distance / 2.0);                   /* S2:331 */
+    const float inv = 1.0f / (float)cell;                                           /* S2:332 */
+    const unsigned glx = (unsigned)(1 + (float)(size_t)img_w * inv);                /* S2:334 */
+    const unsigned gly = (unsigned)(1 + (float)(size_t)img_h * inv);                /* S2:335 */
+    uint8_t* occ = (uint8_t*)xcalloc((size_t)glx * gly, 1);                         /* S2:337-338 */
+    int k = 0, c = 0;
+    while (c < num_out_points && k < n) {                                           /* S2:342 */
+        int idx = (int)(0xFFFFFFFFu - (uint32_t)(keys[k++] & 0xFFFFFFFFu));
+        const svo_keypoint* kp = &kps[idx];
+        size_t sx = (size_t)(kp->x * inv), sy = (size_t)(kp->y * inv);              /* S2:348-349 */
+        if (sx >= glx || sy >= gly) continue;   /* out of the grid: undefined in the reference; skipped */
+        if (occ[sx * gly + sy]) continue;                                           /* S2:351 */
+        occ[sx * gly + sy] = 1;                                                     /* S2:355-359 */
+        if (sx > 0) occ[(sx - 1) * gly + sy] = 1;
+        if (sy > 0) occ[sx * gly + sy - 1] = 1;
+        if (sx < glx - 1) occ[(sx + 1) * gly + sy] = 1;
+        if (sy < gly - 1) occ[sx * gly + sy + 1] = 1;
+        if (out_order) out_order[c] = idx;                                          /* S2:362-363 */
+        if (survivors) survivors[idx] = 1;                                          /* S2:279 */
+        ++c;
+    }
+    free(occ); free(keys);
+    return c;
+}
+
+int svo_oracle_nms_copy(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h, int num_out_points, int32_t* out_order)
+{
+    return nms_walk(kps, n, min_distance, img_w, img_h, num_out_points, out_order, NULL);
+}
+
+void svo_oracle_nms_mask(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h, int num_out_points, uint8_t* survivors)
+{
+    memset(survivors, 0, (size_t)(n > 0 ? n : 0));                                  /* S2:238 */
+    nms_walk(kps, n, min_distance, img_w, img_h, num_out_points, NULL, survivors);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* m_update_indexes(order=true)  (S2:65-130)                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+/* DEVIATION (appendix A #7): unstable sort on pt.y (S2:89) -> total order (pt.y asc, input index asc). */
+void svo_oracle_row_sort_index(const svo_keypoint* kps, int n, int img_h, int32_t* order, int64_t* idx)
+{
+    uint64_t* keys = (uint64_t*)xmalloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) keys[i] = ((uint64_t)ord32(kps[i].y) << 32) | (uint32_t)i;
+    qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64_asc);
+    for (int i = 0; i < n; i++) order[i] = (int32_t)(keys[i] & 0xFFFFFFFFu);
+    free(keys);
+    for (int r = 0; r < img_h; r++) idx[r] = 0;                                     /* S2:74 fresh vector */
+    int64_t from = 0; size_t feats_till_now = 0, current_row = 0;
+    for (int i = 0; i < n; i++) {                                                   /* S2:107-129 */
+        const svo_keypoint* f = &kps[order[i]];
+        if (i == 0) { current_row = (size_t)f->y; from = (int64_t)current_row; continue; }   /* S2:110-117 (zeros already there) */
+        if (f->y == (float)(int)current_row) { ++feats_till_now; continue; }         /* S2:119-123 */
+        current_row = (size_t)f->y;                                                 /* S2:124 */
+        int64_t to = (int64_t)current_row;
+        ++feats_till_now;
+        for (int64_t r = from; r < to && r < img_h; r++) idx[r] = (int64_t)feats_till_now;   /* S2:126-127 */
+        from = to;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Hamming brute force  [frozen]  (cv::BFMatcher(NORM_HAMMING,false).match; S3:88-94, S4:141-142)    */
+/* ------------------------------------------------------------------------------------------------ */
+static int hamming256(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int k = 0; k < 4; k++) { uint64_t x, y; memcpy(&x, a + 8 * k, 8); memcpy(&y, b + 8 * k, 8); d += __builtin_popcountll(x ^ y); }
+    return d;
+}
+
+/* one best train index per query row, FIRST minimum on ties; idx = -1 when there is no train row */
+void svo_oracle_hamming_bf(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist)
+{
+    for (int i = 0; i < nq; i++) {
+        int best = 0x7FFFFFFF, bj = -1;
+        for (int j = 0; j < nt; j++) {
+            int d = hamming256(q + (size_t)i * SVO_DESC_BYTES, t + (size_t)j * SVO_DESC_BYTES);
+            if (d < best) { best = d; bj = j; }
+        }
+        idx[i] = bj; dist[i] = bj < 0 ? 0 : best;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* stage 3: left-right matching  (S3:62-484)                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+#define INVALID_IDX (-1)
+
+static int match_lr_bf(const svo_params* p, int orb_th, const svo_keypoint* kl, const uint8_t* dl, int nl,
+                       const svo_keypoint* kr, const uint8_t* dr, int nr, int img_w, svo_dmatch* out, int cap)
+{
+    if (nl <= 0 || nr <= 0) return 0;
+    int32_t* bi = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)nl), *bd = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)nl);
+    svo_oracle_hamming_bf(dl, nl, dr, nr, bi, bd);                                  /* S3:91-94 */
+    uint8_t* keep = (uint8_t*)xmalloc((size_t)nl);
+    memset(keep, 1, (size_t)nl);
+    if (p->enable_robust_1to1_match) {                                              /* S3:124-148 */
+        double* cd = (double*)xmalloc(sizeof(double) * (size_t)nr);
+        int32_t* cq = (int32_t*)xcalloc((size_t)nr, sizeof(int32_t));
+        for (int j = 0; j < nr; j++) cd[j] = -1.0;
+        for (int k = 0; k < nl; k++) {
+            int idR = bi[k];
+            if (cd[idR] < 0 || cd[idR] > (double)(float)bd[k]) { cd[idR] = (double)(float)bd[k]; cq[idR] = k; }
+        }
+        for (int k = 0; k < nl; k++) if (k != cq[bi[k]]) keep[k] = 0;
+        free(cd); free(cq);
+    }
+    const double min_disp = 1, max_disp = (double)img_w;                            /* S3:155-156 */
+    int m = 0;
+    for (int k = 0; k < nl; k++) {                                                  /* S3:159-175 */
+        if (!keep[k]) continue;
+        const int diff = (int)(kl[k].y - kr[bi[k]].y);                              /* S3:162 float diff -> int */
+        const int disp = (int)(kl[k].x - kr[bi[k]].x);                              /* S3:163 */
+        const float distance = (float)bd[k];
+        if ((double)abs(diff) > p->max_y_diff || distance > (float)orb_th || (double)disp < min_disp || (double)disp > max_disp) continue;
+        if (m < cap) { out[m].queryIdx = k; out[m].trainIdx = bi[k]; out[m].imgIdx = 0; out[m].distance = distance; }
+        m++;
+    }
+    free(bi); free(bd); free(keep);
+    return m < cap ? m : cap;
+}
+
+/* smDescRbR (S3:185-419) with its quirks kept */
+static int match_lr_rbr(const svo_params* p, const svo_keypoint* kl, const uint8_t* dl, int nl, const int64_t* idxL,
+                        const svo_keypoint* kr, const uint8_t* dr, int nr, const int64_t* idxR,
+                        int img_w, int img_h, int detect_method, svo_dmatch* out, int cap)
+{
+    double minimum_response = 0;                                                    /* S3:189-193 */
+    if (detect_method == SVO_DM_ORB) minimum_response = p->minimum_ORB_response;
+    const size_t max_distance = (size_t)p->orb_max_distance;                        /* S3:205 */
+    const double max_ratio = 1;                                                     /* S3:196 */
+    int* left_matches = (int*)xmalloc(sizeof(int) * (size_t)(nl > 0 ? nl : 1));
+    int* ra_first = (int*)xmalloc(sizeof(int) * (size_t)(nr > 0 ? nr : 1));
+    uint32_t* ra_second = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)(nr > 0 ? nr : 1));
+    for (int i = 0; i < nl; i++) left_matches[i] = INVALID_IDX;                     /* S3:228 */
+    for (int j = 0; j < nr; j++) { ra_first[j] = INVALID_IDX; ra_second[j] = 0xFFFFFFFFu; }   /* S3:229 */
+    const int max_disparity = (int)((double)img_w * 0.7);                           /* S3:247 */
+    const int d_round = (int)round(p->max_y_diff);
+    for (size_t y = 0; y + 1 < (size_t)img_h; y++) {                                /* S3:250 */
+        const size_t L0 = (size_t)idxL[y], L1 = (size_t)idxL[y + 1];                /* S3:253 */
+        const int mrr = (int)y - d_round;
+        const size_t min_row_right = (size_t)(mrr > 0 ? mrr : 0);                   /* S3:254 */
+        size_t max_row_right = y + (size_t)d_round;                                 /* S3:255 */
+        if (max_row_right > (size_t)(img_h - 1)) max_row_right = (size_t)(img_h - 1);
+        const size_t R0 = (size_t)idxR[min_row_right], R1 = (size_t)idxR[max_row_right];   /* S3:256 */
+        const size_t nFL = L1 - L0, nFR = R1 - R0;                                  /* S3:259-260 (unsigned wrap kept) */
+        if (nFL == 0 || nFR == 0) continue;                                         /* S3:262 */
+        if (L1 < L0 || R1 < R0) continue;   /* wrapped ranges: the reference's for-loops simply do not execute */
+        for (size_t iL = L0; iL < L1; iL++) {                                       /* S3:265 */
+            const svo_keypoint* fL = &kl[iL];
+            uint32_t min_1 = 0xFFFFFFFFu, min_2 = 0xFFFFFFFFu; int min_idx = INVALID_IDX;   /* S3:270-272 */
+            for (size_t iR = R0; iR < R1; iR++) {                                   /* S3:274 */
+                const svo_keypoint* fR = &kr[iR];
+                if ((double)fL->response < minimum_response || (double)fR->response < minimum_response) continue;   /* S3:279 */
+                const int disparity = (int)(fL->x - fR->x);                         /* S3:283 */
+                if (disparity < 1 || disparity > max_disparity) continue;           /* S3:284 */
+                uint8_t d = 0;                                                      /* S3:321-329: uint8_t accumulator wraps */
+                for (int k = 0; k < SVO_DESC_BYTES; k++) {
+                    uint8_t x_or = dl[iL * SVO_DESC_BYTES + k] ^ dr[iR * SVO_DESC_BYTES + k];
+                    uint8_t count; for (count = 0; x_or; count++) x_or &= (uint8_t)(x_or - 1);
+                    d = (uint8_t)(d + count);
+                }
+                const size_t dist = (size_t)d;                                      /* S3:331 */
+                if (dist > max_distance) continue;                                  /* S3:334 */
+                if (dist < min_1) { min_2 = min_1; min_1 = (uint32_t)dist; min_idx = (int)iR; }   /* S3:338-343 */
+                else if (dist < min_2) min_2 = (uint32_t)dist;
+                (void)max_ratio;                                                    /* S3:347-349: no effect */
+            }
+            if (min_idx != INVALID_IDX) {                                           /* S3:357 */
+                if (p->enable_robust_1to1_match) {                                  /* S3:359-377 */
+                    if (ra_first[min_idx] == INVALID_IDX) { left_matches[iL] = min_idx; ra_first[min_idx] = (int)iL; ra_second[min_idx] = min_1; }
+                    else if (min_1 < ra_second[min_idx]) { left_matches[ra_first[min_idx]] = INVALID_IDX; left_matches[iL] = min_idx; ra_first[min_idx] = (int)iL; ra_second[min_idx] = min_1; }
+                } else if (ra_first[min_idx] == INVALID_IDX) {                      /* S3:381-386 */
+                    left_matches[iL] = min_idx; ra_first[min_idx] = (int)iL; ra_second[min_idx] = min_1;
+                }
+            }
+        }
+    }
+    int m = 0;
+    for (int i = 0; i < nl; i++)                                                    /* S3:398-409 */
+        if (left_matches[i] != INVALID_IDX) {
+            int fr = left_matches[i];
+            /* DMatch(i,fr,d): three-argument constructor = (queryIdx, trainIdx, distance); imgIdx = -1 */
+            if (m < cap) { out[m].queryIdx = i; out[m].trainIdx = fr; out[m].imgIdx = -1; out[m].distance = (float)ra_second[fr]; }
+            m++;
+        }
+    free(left_matches); free(ra_first); free(ra_second);
+    return m < cap ? m : cap;
+}
+
+/* matches_lr_row_index (S3:425-445).  DEVIATION (appendix A #11): entry [imgH] = number of pairings,
+ * not number of left keypoints (the reference value makes S4:530,557-561 read out of bounds). */
+static void matches_row_index(const svo_dmatch* m, int nm, const svo_keypoint* kl, int img_h, int64_t* ri)
+{
+    int idx = 0;
+    for (int y = 0; y < img_h; y++) {
+        ri[y] = idx;
+        while (idx < nm && kl[m[idx].queryIdx].y <= (float)y) idx++;                /* S3:441 */
+    }
+    ri[img_h] = nm;
+}
+
+int svo_oracle_match_lr(const svo_params* p, int orb_th, const svo_keypoint* kl, const uint8_t* dl, int nl,
+                        const int64_t* idxl, const svo_keypoint* kr, const uint8_t* dr, int nr,
+                        const int64_t* idxr, int img_w, int img_h, svo_dmatch* out, int cap, int64_t* row_index)
+{
+    int m;
+    if (p->match_method == SVO_SM_DESC_BF) m = match_lr_bf(p, orb_th, kl, dl, nl, kr, dr, nr, img_w, out, cap);
+    else if (p->match_method == SVO_SM_DESC_RBR) m = match_lr_rbr(p, kl, dl, nl, idxl, kr, dr, nr, idxr, img_w, img_h, p->detect_method, out, cap);
+    else return -2;
+    if (row_index) matches_row_index(out, m, kl, img_h, row_index);
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* fundamental-matrix RANSAC  [frozen]  (cv::findFundamentalMat(FM_RANSAC,1.0,0.99); S4:202,237,684,696) */
+/* ------------------------------------------------------------------------------------------------ */
+static uint64_t splitmix64(uint64_t x) { x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31); }
+static uint64_t xs64star(uint64_t* s) { uint64_t x = *s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *s = x; return x * 0x2545F4914F6CDD1DULL; }
+
+static void ransac_sample(int h, int n, int* idx)
+{
+    uint64_t s = splitmix64(RANSAC_SEED + (uint64_t)h);
+    if (!s) s = 1;
+    for (int j = 0; j < 8; j++) {
+        int v, dup;
+        do { v = (int)((uint32_t)(xs64star(&s) >> 32) % (uint32_t)n); dup = 0; for (int k = 0; k < j; k++) if (idx[k] == v) dup = 1; } while (dup);
+        idx[j] = v;
+    }
+}
+
+/* normalised linear 8-point solution (Hartley) through the null vector of the 8x9 system, found by
+ * Gauss-Jordan elimination with full pivoting.  No rank-2 enforcement (hypothesis scoring only). */
+static void eight_point(const float* p1, const float* p2, const int* s, double* F)
+{
+    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+    for (int i = 0; i < 8; i++) { c1x += (double)p1[2 * s[i]]; c1y += (double)p1[2 * s[i] + 1]; c2x += (double)p2[2 * s[i]]; c2y += (double)p2[2 * s[i] + 1]; }
+    c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
+    double d1 = 0, d2 = 0;
+    for (int i = 0; i < 8; i++) {
+        double ax = (double)p1[2 * s[i]] - c1x, ay = (double)p1[2 * s[i] + 1] - c1y;
+        double bx = (double)p2[2 * s[i]] - c2x, by = (double)p2[2 * s[i] + 1] - c2y;
+        d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
+    }
+    const double s1 = 11.313708498984761 / d1;    /* sqrt(2) / (d1/8) */
+    const double s2 = 11.313708498984761 / d2;
+    double A[8][9];
+    for (int i = 0; i < 8; i++) {
+        double x1 = ((double)p1[2 * s[i]] - c1x) * s1, y1 = ((double)p1[2 * s[i] + 1] - c1y) * s1;
+        double x2 = ((double)p2[2 * s[i]] - c2x) * s2, y2 = ((double)p2[2 * s[i] + 1] - c2y) * s2;
+        A[i][0] = x2 * x1; A[i][1] = x2 * y1; A[i][2] = x2; A[i][3] = y2 * x1; A[i][4] = y2 * y1; A[i][5] = y2; A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
+    }
+    int perm[9]; for (int j = 0; j < 9; j++) perm[j] = j;
+    for (int k = 0; k < 8; k++) {
+        double best = -1.0; int pi = k, pj = k;
+        for (int i = k; i < 8; i++) for (int j = k; j < 9; j++) { double v = fabs(A[i][j]); if (v > best) { best = v; pi = i; pj = j; } }
+        if (pi != k) for (int j = 0; j < 9; j++) { double t = A[k][j]; A[k][j] = A[pi][j]; A[pi][j] = t; }
+        if (pj != k) { for (int i = 0; i < 8; i++) { double t = A[i][k]; A[i][k] = A[i][pj]; A[i][pj] = t; } int t = perm[k]; perm[k] = perm[pj]; perm[pj] = t; }
+        const double piv = A[k][k];
+        for (int j = k; j < 9; j++) A[k][j] = A[k][j] / piv;
+        for (int i = 0; i < 8; i++) { if (i == k) continue; const double f = A[i][k]; for (int j = k; j < 9; j++) A[i][j] = A[i][j] - f * A[k][j]; }
+    }
+    double f[9];
+    f[perm[8]] = 1.0;
+    for (int i = 0; i < 8; i++) f[perm[i]] = -A[i][8];
+    /* F = T2^T * F0 * T1 */
+    const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
+    double M[3][3];
+    for (int r = 0; r < 3; r++) {
+        M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
+        M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
+    }
+    for (int c = 0; c < 3; c++) {
+        F[c] = s2 * M[0][c]; F[3 + c] = s2 * M[1][c];
+        F[6 + c] = (t2x * M[0][c] + t2y * M[1][c]) + M[2][c];
+    }
+}
+
+/* symmetric point-to-epipolar-line error, max of the two squared distances */
+static int fm_inlier(const double* F, float fx1, float fy1, float fx2, float fy2)
+{
+    const double x1 = (double)fx1, y1 = (double)fy1, x2 = (double)fx2, y2 = (double)fy2;
+    double a = (F[0] * x1 + F[1] * y1) + F[2], b = (F[3] * x1 + F[4] * y1) + F[5], c = (F[6] * x1 + F[7] * y1) + F[8];
+    const double sB = 1.0 / (a * a + b * b), dB = (x2 * a + y2 * b) + c;
+    a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; c = (F[2] * x2 + F[5] * y2) + F[8];
+    const double sA = 1.0 / (a * a + b * b), dA = (x1 * a + y1 * b) + c;
+    const double eA = (dA * dA) * sA, eB = (dB * dB) * sB;
+    const double e = eA > eB ? eA : eB;
+    return e <= 1.0;   /* threshold 1.0 px, squared */
+}
+
+int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9, int* best_hyp, int* n_hyp_used)
+{
+    for (int i = 0; i < n; i++) mask[i] = 0;
+    if (best_hyp) *best_hyp = -1;
+    if (n_hyp_used) *n_hyp_used = 0;
+    if (n < 8) return 0;
+    int niters = RANSAC_MAX_HYP, best_cnt = 0, best_k = -1;
+    double Fbest[9] = { 0 };
+    int k;
+    for (k = 0; k < niters; k++) {
+        int s[8]; double F[9];
+        ransac_sample(k, n, s);
+        eight_point(p1, p2, s, F);
+        int cnt = 0;
+        for (int i = 0; i < n; i++) cnt += fm_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+        if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
+            best_cnt = cnt; best_k = k; memcpy(Fbest, F, sizeof(F));
+            /* confidence 0.99: smallest K with (1 - w^8)^K <= 0.01, by repeated multiplication (no log) */
+            const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
+            double acc = 1.0; int K = 0;
+            while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
+            niters = K;
+        }
+    }
+    if (n_hyp_used) *n_hyp_used = k;
+    if (best_k < 0) return 0;
+    int cnt = 0;
+    for (int i = 0; i < n; i++) { mask[i] = (uint8_t)fm_inlier(Fbest, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]); cnt += mask[i]; }
+    if (F9) memcpy(F9, Fbest, sizeof(Fbest));
+    if (best_hyp) *best_hyp = best_k;
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* stage 4: inter-frame tracking  (S4:71-801)                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+static int track_bf(int orb_th,
+                    const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr, const svo_dmatch* pm, int npm,
+                    const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr, const svo_dmatch* cm, int ncm,
+                    svo_index_pair* out, int cap)
+{
+    if (npm <= 0 || ncm <= 0) return 0;
+    /* S4:105-131 gather the descriptors of the matched features */
+    uint8_t* preL = (uint8_t*)xmalloc((size_t)npm * 32), *preR = (uint8_t*)xmalloc((size_t)npm * 32);
+    uint8_t* curL = (uint8_t*)xmalloc((size_t)ncm * 32), *curR = (uint8_t*)xmalloc((size_t)ncm * 32);
+    for (int k = 0; k < npm; k++) { memcpy(preL + (size_t)k * 32, pdl + (size_t)pm[k].queryIdx * 32, 32); memcpy(preR + (size_t)k * 32, pdr + (size_t)pm[k].trainIdx * 32, 32); }
+    for (int k = 0; k < ncm; k++) { memcpy(curL + (size_t)k * 32, cdl + (size_t)cm[k].queryIdx * 32, 32); memcpy(curR + (size_t)k * 32, cdr + (size_t)cm[k].trainIdx * 32, 32); }
+    int32_t* tL = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)npm), *dL = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)npm);
+    int32_t* tR = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)npm), *dR = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)npm);
+    svo_oracle_hamming_bf(preL, npm, curL, ncm, tL, dL);                            /* S4:141 */
+    svo_oracle_hamming_bf(preR, npm, curR, ncm, tR, dR);                            /* S4:142 */
+    /* S4:145-160 joint sequential distance + collision filter (only KEPT entries mark) */
+    uint8_t* ltm = (uint8_t*)xcalloc((size_t)ncm, 1), *rtm = (uint8_t*)xcalloc((size_t)ncm, 1);
+    int* kq = (int*)xmalloc(sizeof(int) * (size_t)npm);
+    int nk = 0;
+    for (int k = 0; k < npm; k++) {
+        if ((float)dL[k] > (float)orb_th || (float)dR[k] > (float)orb_th || ltm[tL[k]] || rtm[tR[k]]) continue;
+        ltm[tL[k]] = rtm[tR[k]] = 1;
+        kq[nk++] = k;
+    }
+    /* S4:171-241 fundamental matrix on left-left, then right-right pixel pairs */
+    float* p1 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(nk ? nk : 1)), *p2 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(nk ? nk : 1));
+    uint8_t* inL = (uint8_t*)xmalloc((size_t)(nk ? nk : 1)), *inR = (uint8_t*)xmalloc((size_t)(nk ? nk : 1));
+    for (int i = 0; i < nk; i++) {
+        int k = kq[i];
+        const svo_keypoint* a = &pkl[pm[k].queryIdx], *b = &ckl[cm[tL[k]].queryIdx];   /* S4:183-189 */
+        p1[2 * i] = a->x; p1[2 * i + 1] = a->y; p2[2 * i] = b->x; p2[2 * i + 1] = b->y;
+    }
+    const int numInL = svo_oracle_ransac_fundamental(p1, p2, nk, inL, NULL, NULL, NULL);   /* S4:202-205 */
+    for (int i = 0; i < nk; i++) {
+        int k = kq[i];
+        const svo_keypoint* a = &pkr[pm[k].trainIdx], *b = &ckr[cm[tR[k]].trainIdx];   /* S4:218-224 */
+        p1[2 * i] = a->x; p1[2 * i + 1] = a->y; p2[2 * i] = b->x; p2[2 * i + 1] = b->y;
+    }
+    const int numInR = svo_oracle_ransac_fundamental(p1, p2, nk, inR, NULL, NULL, NULL);   /* S4:237-240 */
+    const int goodFL = numInL >= 8, goodFR = numInR >= 8;
+    int t = 0;
+    for (int i = 0; i < nk; i++) {
+        int k = kq[i];
+        if (goodFL && goodFR && (inL[i] == 0 || inR[i] == 0)) continue;             /* S4:243-255 */
+        if (tL[k] != tR[k]) continue;                                               /* S4:282 consistency */
+        if (t < cap) { out[t].first = k; out[t].second = tL[k]; }                   /* S4:285 */
+        t++;
+    }
+    free(preL); free(preR); free(curL); free(curR); free(tL); free(dL); free(tR); free(dR);
+    free(ltm); free(rtm); free(kq); free(p1); free(p2); free(inL); free(inR);
+    return t < cap ? t : cap;
+}
+
+/* ifmDescWin (S4:435-738) with its quirks kept */
+static int track_win(const svo_params* p,
+                     const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const svo_dmatch* pm, int npm, const int64_t* pri,
+                     const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const svo_dmatch* cm, int ncm, const int64_t* cri,
+                     int img_w, int img_h, svo_index_pair* out, int cap)
+{
+    const int WIN_W = p->ifm_win_w, WIN_H = p->ifm_win_h;                           /* S4:442-443 */
+    const int awx = img_w - 1, awy = img_h - 1;                                     /* S4:489-490 */
+    int* cmf = (int*)xmalloc(sizeof(int) * (size_t)(ncm > 0 ? ncm : 1));
+    uint32_t* cms = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)(ncm > 0 ? ncm : 1));
+    for (int i = 0; i < ncm; i++) { cmf[i] = INVALID_IDX; cms[i] = 0xFFFFFFFFu; }   /* S4:509 */
+    for (int y = 0; y < img_h - 1; y++) {                                           /* S4:514 */
+        const int64_t p0 = pri[y], p1 = pri[y + 1];                                 /* S4:517-518 */
+        if (p1 - p0 <= 0) continue;
+        const int wy_min = (y - WIN_W) > 0 ? (y - WIN_W) : 0;                       /* S4:525 */
+        const int wy_max = awy < (y + WIN_W) ? awy : (y + WIN_W);                   /* S4:526 */
+        const int64_t c0 = cri[wy_min], c1 = cri[wy_max + 1];                       /* S4:529-530 */
+        if (c1 - c0 <= 0) continue;
+        for (int64_t pi = p0; pi < p1; pi++) {
+            const svo_keypoint* pl = &pkl[pm[pi].queryIdx], *pr = &pkr[pm[pi].trainIdx];
+            int64_t best_c = -1; uint8_t best_orb = 255;                            /* S4:543-545 */
+            const int a = (int)(pl->x - (float)WIN_H), b = (int)(pl->x + (float)WIN_H);
+            const int c = (int)(pr->x - (float)WIN_H), d = (int)(pr->x + (float)WIN_H);
+            const int wxl0 = a > 0 ? a : 0, wxl1 = awx < b ? awx : b;               /* S4:552-553 */
+            const int wxr0 = c > 0 ? c : 0, wxr1 = awx < d ? awx : d;               /* S4:554-555 */
+            for (int64_t ci = c0; ci < c1; ci++) {                                  /* S4:557 */
+                const svo_keypoint* fl = &ckl[cm[ci].queryIdx], *fr = &ckr[cm[ci].trainIdx];
+                if (fl->x < (float)wxl0 || fl->x > (float)wxl1 || fr->x < (float)wxr0 || fr->x > (float)wxr1) continue;   /* S4:567 */
+                uint8_t orb_l = 0;                                                  /* S4:596-609: left only, uint8_t wrap */
+                for (int k = 0; k < SVO_DESC_BYTES; k++) {
+                    uint8_t x_or = pdl[(size_t)pm[pi].queryIdx * 32 + k] ^ cdl[(size_t)cm[ci].queryIdx * 32 + k];
+                    uint8_t count; for (count = 0; x_or; count++) x_or &= (uint8_t)(x_or - 1);
+                    orb_l = (uint8_t)(orb_l + count);
+                }
+                if ((uint32_t)orb_l < (uint32_t)best_orb) { best_orb = orb_l; best_c = ci; }   /* S4:614-618 */
+            }
+            if (best_c >= 0) {                                                      /* S4:622-636 */
+                const uint32_t bp = (uint32_t)best_orb;
+                if (cmf[best_c] == INVALID_IDX) { cmf[best_c] = (int)pi; cms[best_c] = bp; }
+                if (cmf[best_c] != INVALID_IDX && bp < cms[best_c]) { cmf[best_c] = (int)pi; cms[best_c] = bp; }
+            }
+        }
+    }
+    /* S4:640-679 survivors in ascending current index */
+    int np = 0;
+    for (int i = 0; i < ncm; i++) if (cmf[i] != INVALID_IDX) np++;
+    float* l1 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(np ? np : 1)), *l2 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(np ? np : 1));
+    float* r1 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(np ? np : 1)), *r2 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(np ? np : 1));
+    svo_index_pair* pot = (svo_index_pair*)xmalloc(sizeof(svo_index_pair) * (size_t)(np ? np : 1));
+    int j = 0;
+    for (int i = 0; i < ncm; i++) if (cmf[i] != INVALID_IDX) {
+        int pi = cmf[i];
+        l1[2 * j] = pkl[pm[pi].queryIdx].x; l1[2 * j + 1] = pkl[pm[pi].queryIdx].y;
+        r1[2 * j] = pkr[pm[pi].trainIdx].x; r1[2 * j + 1] = pkr[pm[pi].trainIdx].y;
+        l2[2 * j] = ckl[cm[i].queryIdx].x; l2[2 * j + 1] = ckl[cm[i].queryIdx].y;
+        r2[2 * j] = ckr[cm[i].trainIdx].x; r2[2 * j + 1] = ckr[cm[i].trainIdx].y;
+        pot[j].first = pi; pot[j].second = i; j++;
+    }
+    uint8_t* inL = (uint8_t*)xmalloc((size_t)(np ? np : 1)), *inR = (uint8_t*)xmalloc((size_t)(np ? np : 1));
+    int use_f = svo_oracle_ransac_fundamental(l1, l2, np, inL, NULL, NULL, NULL) >= 8;   /* S4:684-687 */
+    if (use_f) use_f = svo_oracle_ransac_fundamental(r1, r2, np, inR, NULL, NULL, NULL) >= 8;   /* S4:696-699 */
+    int t = 0;
+    for (int i = 0; i < np; i++) {                                                  /* S4:708-714 */
+        if (use_f && (!inL[i] || !inR[i])) continue;
+        if (t < cap) out[t] = pot[i];
+        t++;
+    }
+    free(cmf); free(cms); free(l1); free(l2); free(r1); free(r2); free(pot); free(inL); free(inR);
+    return t < cap ? t : cap;
+}
+
+int svo_oracle_track(const svo_params* p, int orb_th,
+                     const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr,
+                     const svo_dmatch* pm, int npm, const int64_t* pri,
+                     const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr,
+                     const svo_dmatch* cm, int ncm, const int64_t* cri,
+                     int img_w, int img_h, svo_index_pair* out, int cap)
+{
+    if (p->ifm_method == SVO_IFM_DESC_BF) return track_bf(orb_th, pkl, pdl, pkr, pdr, pm, npm, ckl, cdl, ckr, cdr, cm, ncm, out, cap);
+    if (p->ifm_method == SVO_IFM_DESC_WIN) return track_win(p, pkl, pdl, pkr, pm, npm, pri, ckl, cdl, ckr, cm, ncm, cri, img_w, img_h, out, cap);
+    return -2;   /* S4:740 THROW_EXCEPTION("Undefined inter-frame matching method") */
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* stage 5: projection + Jacobian  (S5:35-257)                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct { double r[9]; double dr[3][9]; int small; } rot_t;
+
+static void rodrigues_with_derivs(const double* dp, rot_t* R)
+{
+    const double w1 = dp[0], w2 = dp[1], w3 = dp[2];
+    const double w12 = w1 * w1, w22 = w2 * w2, w32 = w3 * w3;
+    const double tt = sqrt(w1 * w1 + w2 * w2 + w3 * w3);                            /* S5:55 */
+    const double tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt;
+    const double sin_tt = sin(tt), cos_tt = cos(tt);
+    double* r = R->r; double (*d)[9] = R->dr;
+    memset(R, 0, sizeof(*R));
+    if (tt < 1e-5) {                                                                /* S5:65-97 */
+        R->small = 1;
+        r[0] = 1; r[1] = -w3; r[2] = w2; r[3] = w3; r[4] = 1; r[5] = -w1; r[6] = -w2; r[7] = w1; r[8] = 1;
+        d[2][1] = -1; d[1][2] = 1; d[2][3] = 1; d[0][5] = -1; d[1][6] = -1; d[0][7] = 1;
+        return;
+    }
+    const double u = (cos_tt - 1) / tt2;                                            /* S5:102-110 */
+    const double dudw1 = ((-sin_tt * w1 / tt) * tt2 - (cos_tt - 1) * 2 * w1) / tt4;
+    const double dudw2 = ((-sin_tt * w2 / tt) * tt2 - (cos_tt - 1) * 2 * w2) / tt4;
+    const double dudw3 = ((-sin_tt * w3 / tt) * tt2 - (cos_tt - 1) * 2 * w3) / tt4;
+    const double v = sin_tt / tt;
+    const double dvdw1 = w1 * (tt * cos_tt - sin_tt) / tt3;
+    const double dvdw2 = w2 * (tt * cos_tt - sin_tt) / tt3;
+    const double dvdw3 = w3 * (tt * cos_tt - sin_tt) / tt3;
+    r[0] = (w22 + w32) * u + 1; r[1] = -w3 * v - w1 * w2 * u; r[2] = w2 * v - w1 * w3 * u;      /* S5:113-123 */
+    r[3] = w3 * v - w1 * w2 * u; r[4] = (w12 + w32) * u + 1; r[5] = -w1 * v - w2 * w3 * u;
+    r[6] = -w2 * v - w1 * w3 * u; r[7] = w1 * v - w2 * w3 * u; r[8] = (w12 + w22) * u + 1;
+    /* first row S5:126-136 */
+    d[0][0] = (w22 + w32) * dudw1; d[1][0] = 2 * w2 * u + (w22 + w32) * dudw2; d[2][0] = 2 * w3 * u + (w22 + w32) * dudw3;
+    d[0][1] = -w3 * dvdw1 - (w2 * u + w1 * w2 * dudw1); d[1][1] = -w3 * dvdw2 - (w1 * u + w1 * w2 * dudw2); d[2][1] = -(v + w3 * dvdw3) - w1 * w2 * dudw3;
+    d[0][2] = w2 * dvdw1 - (w3 * u + w1 * w3 * dudw1); d[1][2] = (v + w2 * dvdw2) - w1 * w3 * dudw2; d[2][2] = w2 * dvdw3 - (w1 * u + w1 * w3 * dudw3);
+    /* second row S5:139-149 */
+    d[0][3] = w3 * dvdw1 - (w2 * u + w1 * w2 * dudw1); d[1][3] = w3 * dvdw2 - (w1 * u + w1 * w2 * dudw2); d[2][3] = (v + w3 * dvdw3) - w1 * w2 * dudw3;
+    d[0][4] = 2 * w1 * u + (w12 + w32) * dudw1; d[1][4] = (w12 + w32) * dudw2; d[2][4] = 2 * w3 * u + (w12 + w32) * dudw3;
+    d[0][5] = -(v + w1 * dvdw1) - w2 * w3 * dudw1; d[1][5] = -w1 * dvdw2 - (w3 * u + w2 * w3 * dudw2); d[2][5] = -w1 * dvdw3 - (w2 * u + w2 * w3 * dudw3);
+    /* third row S5:152-162 */
+    d[0][6] = -w2 * dvdw1 - (w3 * u + w1 * w3 * dudw1); d[1][6] = -(v + w2 * dvdw2) - w1 * w3 * dudw2; d[2][6] = -w2 * dvdw3 - (w1 * u + w1 * w3 * dudw3);
+    d[0][7] = (v + w1 * dvdw1) - w2 * w3 * dudw1; d[1][7] = w1 * dvdw2 - (w3 * u + w2 * w3 * dudw2); d[2][7] = w1 * dvdw3 - (w2 * u + w2 * w3 * dudw3);
+    d[0][8] = 2 * w1 * u + (w12 + w22) * dudw1; d[1][8] = 2 * w2 * u + (w12 + w22) * dudw2; d[2][8] = (w22 + w32) * dudw3;   /* S5:162 as written */
+}
+
+static void project_one(const rot_t* R, const double* dp, const svo_stereo_camera* cam, const double* X, float* pix, double* J)
+{
+    const double* r = R->r;
+    const double X1p = X[0], Y1p = X[1], Z1p = X[2];
+    const double X1c = r[0] * X1p + r[1] * Y1p + r[2] * Z1p + dp[3];                /* S5:180-182 */
+    const double Y1c = r[3] * X1p + r[4] * Y1p + r[5] * Z1p + dp[4];
+    const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + dp[5];
+    const double X2c = X1c - cam->baseline;                                         /* S5:185 */
+    pix[0] = (float)(cam->l_fx * X1c / Z1c + cam->l_cx);                            /* S5:189-193: stored as float */
+    pix[1] = (float)(cam->l_fy * Y1c / Z1c + cam->l_cy);
+    pix[2] = (float)(cam->r_fx * X2c / Z1c + cam->r_cx);
+    pix[3] = (float)(cam->r_fy * Y1c / Z1c + cam->r_cy);
+    for (int j = 0; j < 6; j++) {                                                   /* S5:201-255 */
+        double X1cd, Y1cd, Z1cd;
+        if (j < 3) {
+            if (R->small) {
+                if (j == 0) { X1cd = 0; Y1cd = -Z1p; Z1cd = Y1p; }
+                else if (j == 1) { X1cd = Z1p; Y1cd = 0; Z1cd = -X1p; }
+                else { X1cd = -Y1p; Y1cd = X1p; Z1cd = 0; }
+            } else {
+                const double* d = R->dr[j];
+                X1cd = d[0] * X1p + d[1] * Y1p + d[2] * Z1p;
+                Y1cd = d[3] * X1p + d[4] * Y1p + d[5] * Z1p;
+                Z1cd = d[6] * X1p + d[7] * Y1p + d[8] * Z1p;
+            }
+        } else { X1cd = j == 3; Y1cd = j == 4; Z1cd = j == 5; }
+        J[0 * 6 + j] = cam->l_fx * (X1cd * Z1c - X1c * Z1cd) / (Z1c * Z1c);         /* S5:251-254 */
+        J[1 * 6 + j] = cam->l_fy * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
+        J[2 * 6 + j] = cam->r_fx * (X1cd * Z1c - X2c * Z1cd) / (Z1c * Z1c);
+        J[3 * 6 + j] = cam->r_fy * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
+    }
+}
+
+void svo_oracle_project(const double* lmks3, int n, const svo_stereo_camera* cam, const double* delta6, float* pix, double* jac)
+{
+    rot_t R; rodrigues_with_derivs(delta6, &R);
+    for (int i = 0; i < n; i++) project_one(&R, delta6, cam, lmks3 + 3 * i, pix + 4 * i, jac + 24 * i);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* 6x6 solve  [frozen]  (Eigen::JacobiSVD(H).solve(g) + condition number; S5:375-388)               */
+/* ------------------------------------------------------------------------------------------------ */
+/* H is symmetric positive semi-definite, so its singular values are |eigenvalues|: cyclic Jacobi
+ * eigen-decomposition, pseudo-inverse with Eigen's default rank threshold (6*eps*sigma_max). */
+static int solve_sym6(const double* Hin, const double* g, double* x)
+{
+    double A[36], V[36];
+    memcpy(A, Hin, sizeof(A));
+    for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, dg = 0;
+        for (int p = 0; p < 6; p++) { dg += A[p * 7] * A[p * 7]; for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q]; }
+        if (!(off > 1e-32 * dg)) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[p * 6 + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; k++) { const double akp = A[k * 6 + p], akq = A[k * 6 + q]; A[k * 6 + p] = c * akp - s * akq; A[k * 6 + q] = s * akp + c * akq; }
+                for (int k = 0; k < 6; k++) { const double apk = A[p * 6 + k], aqk = A[q * 6 + k]; A[p * 6 + k] = c * apk - s * aqk; A[q * 6 + k] = s * apk + c * aqk; }
+                for (int k = 0; k < 6; k++) { const double vkp = V[k * 6 + p], vkq = V[k * 6 + q]; V[k * 6 + p] = c * vkp - s * vkq; V[k * 6 + q] = s * vkp + c * vkq; }
+            }
+    }
+    double smax = 0, smin = DBL_MAX; int has_nan = 0;
+    for (int i = 0; i < 6; i++) { const double s = fabs(A[i * 7]); if (isnan(s)) has_nan = 1; if (s > smax) smax = s; if (s < smin) smin = s; }
+    const double cond = smax / smin;                                                /* S5:379 */
+    if (has_nan || isnan(cond)) return 0;                                           /* S5:380-386 */
+    const double thr = 6.0 * DBL_EPSILON * smax;
+    for (int i = 0; i < 6; i++) x[i] = 0;
+    for (int i = 0; i < 6; i++) {
+        const double lam = A[i * 7];
+        if (!(fabs(lam) > thr)) continue;
+        double dot = 0;
+        for (int k = 0; k < 6; k++) dot += V[k * 6 + i] * g[k];
+        const double coef = dot / lam;
+        for (int k = 0; k < 6; k++) x[k] += coef * V[k * 6 + i];
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* pose conversion  [frozen]  (CPose3D(CPose3DRotVec(delta).getInverse()); S5:717-718)              */
+/* ------------------------------------------------------------------------------------------------ */
+void svo_oracle_delta_to_pose(const double* dp, double* pose)
+{
+    const double w1 = dp[0], w2 = dp[1], w3 = dp[2];
+    const double th = sqrt(w1 * w1 + w2 * w2 + w3 * w3);
+    double R[9];
+    if (th < 1e-10) {
+        R[0] = 1; R[1] = -w3; R[2] = w2; R[3] = w3; R[4] = 1; R[5] = -w1; R[6] = -w2; R[7] = w1; R[8] = 1;
+    } else {
+        const double a = sin(th) / th, b = (1.0 - cos(th)) / (th * th);
+        R[0] = 1 - b * (w2 * w2 + w3 * w3); R[1] = -a * w3 + b * w1 * w2; R[2] = a * w2 + b * w1 * w3;
+        R[3] = a * w3 + b * w1 * w2; R[4] = 1 - b * (w1 * w1 + w3 * w3); R[5] = -a * w1 + b * w2 * w3;
+        R[6] = -a * w2 + b * w1 * w3; R[7] = a * w1 + b * w2 * w3; R[8] = 1 - b * (w1 * w1 + w2 * w2);
+    }
+    /* inverse: Ri = R^T, ti = -R^T t */
+    double Ri[9] = { R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8] };
+    pose[0] = -(Ri[0] * dp[3] + Ri[1] * dp[4] + Ri[2] * dp[5]);
+    pose[1] = -(Ri[3] * dp[3] + Ri[4] * dp[4] + Ri[5] * dp[5]);
+    pose[2] = -(Ri[6] * dp[3] + Ri[7] * dp[4] + Ri[8] * dp[5]);
+    /* yaw-pitch-roll of R = Rz(yaw) Ry(pitch) Rx(roll) */
+    const double pitch = atan2(-Ri[6], hypot(Ri[0], Ri[3]));
+    double yaw, roll;
+    if (fabs(Ri[7]) + fabs(Ri[8]) < 10 * DBL_EPSILON) {   /* gimbal lock */
+        roll = 0.0;
+        yaw = pitch > 0 ? atan2(Ri[5], Ri[2]) : atan2(-Ri[5], -Ri[2]);
+    } else { roll = atan2(Ri[7], Ri[8]); yaw = atan2(Ri[3], Ri[0]); }
+    pose[3] = yaw; pose[4] = pitch; pose[5] = roll;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* estimator state                                                                                   */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct { svo_keypoint* kps; uint8_t* desc; int n; int64_t* row_index; int rows; } feat_set;
+typedef struct { svo_dmatch* m; int n; int64_t* row_index; int rows; int64_t* ids; int n_ids; } pairing_t;
+typedef struct { int present; int n_oct; int w[MAXOCT], h[MAXOCT]; feat_set f[2][MAXOCT]; pairing_t pr[MAXOCT]; } pair_data;
+
+struct svo_oracle {
+    svo_params p;
+    int m_current_fast_th, m_current_orb_th;        /* C:35-36 */
+    int m_error;                                    /* C:38 */
+    int m_reset;                                    /* C:32 */
+    int64_t m_last_match_ID, m_last_kf_max_id;      /* C:33 (m_last_kf_max_id uninitialised in the reference; 0 here) */
+    int m_num_tracked_last_frame, m_num_tracked_last_kf;
+    double m_last_computed_pose[6];                 /* C:49 */
+    unsigned m_it_counter;
+    pair_data* cur, *prev;
+    svo_index_pair* tracked[MAXOCT]; int n_tracked[MAXOCT];
+    double* residual; int n_residual;
+    int32_t* outliers; int n_outliers;
+};
+
+static void free_pair(pair_data* d)
+{
+    if (!d) return;
+    for (int o = 0; o < MAXOCT; o++) {
+        for (int s = 0; s < 2; s++) { free(d->f[s][o].kps); free(d->f[s][o].desc); free(d->f[s][o].row_index); }
+        free(d->pr[o].m); free(d->pr[o].row_index); free(d->pr[o].ids);
+    }
+    free(d);
+}
+
+svo_oracle* svo_oracle_create(void)
+{
+    svo_oracle* o = (svo_oracle*)xcalloc(1, sizeof(*o));
+    svo_oracle_params_defaults(&o->p);
+    o->m_current_fast_th = 20; o->m_current_orb_th = 60;    /* C:35-36 */
+    o->m_error = SVO_VOEC_NONE;
+    return o;
+}
+
+void svo_oracle_destroy(svo_oracle* o)
+{
+    if (!o) return;
+    if (o->prev != o->cur) free_pair(o->prev);
+    free_pair(o->cur);
+    for (int i = 0; i < MAXOCT; i++) free(o->tracked[i]);
+    free(o->residual); free(o->outliers); free(o);
+}
+
+void svo_oracle_set_params(svo_oracle* o, const svo_params* p)
+{
+    o->p = *p;
+    o->m_current_fast_th = p->initial_FAST_threshold;       /* H:532, H:661 */
+    o->m_current_orb_th = (int)p->orb_max_distance;         /* H:539, H:662 */
+}
+void svo_oracle_get_params(const svo_oracle* o, svo_params* p) { *p = o->p; }
+void svo_oracle_set_fast_threshold(svo_oracle* o, int v) { int lo = o->p.fast_min_th, hi = o->p.fast_max_th; int m = v > lo ? v : lo; o->m_current_fast_th = hi < m ? hi : m; }
+void svo_oracle_set_orb_threshold(svo_oracle* o, int v) { int lo = o->p.orb_min_th, hi = o->p.orb_max_th; int m = v > lo ? v : lo; o->m_current_orb_th = hi < m ? hi : m; }
+int svo_oracle_get_fast_threshold(const svo_oracle* o) { return o->m_current_fast_th; }
+int svo_oracle_get_orb_threshold(const svo_oracle* o) { return o->m_current_orb_th; }
+void svo_oracle_reset_ids(svo_oracle* o) { o->m_reset = 1; }
+void svo_oracle_set_this_frame_as_kf(svo_oracle* o)
+{
+    if (!o->cur || o->cur->pr[0].n_ids <= 0) return;
+    int64_t mx = o->cur->pr[0].ids[0];
+    for (int i = 1; i < o->cur->pr[0].n_ids; i++) if (o->cur->pr[0].ids[i] > mx) mx = o->cur->pr[0].ids[i];
+    o->m_last_kf_max_id = mx;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* stage 2 driver  (S2:385-671)                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+static int stage2_detect(svo_oracle* o, pair_data* d, int side, const uint8_t* const* oct_img, const int* oct_stride)
+{
+    const svo_params* p = &o->p;
+    const int nOct = d->n_oct;
+    size_t kps_to_detect[MAXOCT];
+    kps_to_detect[0] = (size_t)((double)(size_t)p->orb_nfeats * (double)(2 * nOct) / (pow(2, nOct) - 1));   /* S2:405 */
+    for (int oc = 1; oc < nOct; oc++) kps_to_detect[oc] = (size_t)round((double)kps_to_detect[0] / pow(2, oc));   /* S2:407 */
+    for (int oc = 0; oc < nOct; oc++) {
+        const int W = d->w[oc], H = d->h[oc];
+        int cap; svo_keypoint* kv; uint8_t* dv; int n;
+        if (p->detect_method == SVO_DM_ORB) {                                       /* S2:458-497 */
+            const size_t nfe = p->non_maximal_suppression ? (size_t)(1.5 * (double)(size_t)p->orb_nfeats) : (size_t)p->orb_nfeats;   /* S2:461-464 */
+            cap = (int)nfe + 16;
+            kv = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)cap); dv = (uint8_t*)xmalloc((size_t)cap * 32);
+            n = svo_oracle_orb_detect(oct_img[oc], W, H, oct_stride[oc], (int)nfe, p->orb_nlevels, o->m_current_fast_th, kv, dv, cap);
+        } else if (p->detect_method == SVO_DM_FAST_ORB) {                           /* S2:502-515 */
+            cap = W * H / 9 + 16;
+            kv = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)cap); dv = (uint8_t*)xmalloc((size_t)cap * 32);
+            n = svo_oracle_fast_orb_detect(oct_img[oc], W, H, oct_stride[oc], o->m_current_fast_th, kv, dv, cap);
+        } else return -2;                                                           /* S2:578 (KLT/FASTER out of scope) */
+        feat_set* fs = &d->f[side][oc];
+        int32_t* order = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        int nk = n;
+        if (p->non_maximal_suppression) {                                           /* S2:583-610 */
+            if (p->nmsMethod != SVO_NMS_STANDARD) { free(order); free(kv); free(dv); return -2; }   /* adaptive: out of scope */
+            nk = svo_oracle_nms_copy(kv, n, p->min_distance, W, H, (int)kps_to_detect[oc], order);
+        } else for (int i = 0; i < n; i++) order[i] = i;                            /* S2:613-614 */
+        svo_keypoint* k2 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nk > 0 ? nk : 1));
+        uint8_t* d2 = (uint8_t*)xmalloc((size_t)(nk > 0 ? nk : 1) * 32);
+        for (int i = 0; i < nk; i++) { k2[i] = kv[order[i]]; memcpy(d2 + (size_t)i * 32, dv + (size_t)order[i] * 32, 32); }
+        free(kv); free(dv);
+        /* S2:618 m_update_indexes(order = true) */
+        int32_t* ro = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(nk > 0 ? nk : 1));
+        fs->row_index = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)H); fs->rows = H;
+        svo_oracle_row_sort_index(k2, nk, H, ro, fs->row_index);
+        fs->kps = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nk > 0 ? nk : 1));
+        fs->desc = (uint8_t*)xmalloc((size_t)(nk > 0 ? nk : 1) * 32);
+        for (int i = 0; i < nk; i++) { fs->kps[i] = k2[ro[i]]; memcpy(fs->desc + (size_t)i * 32, d2 + (size_t)ro[i] * 32, 32); }
+        fs->n = nk;
+        free(k2); free(d2); free(ro); free(order);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* stage 5  (S5:392-736)                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct { const svo_keypoint* l1, *r1, *l2, *r2; } lists_t;
+
+/* m_evalRGN (S5:275-390) */
+static int eval_rgn(const svo_params* P, const svo_keypoint* l2, const svo_keypoint* r2, int nL, const uint8_t* mask,
+                    const double* lmks, int n_non_masked, const double* deltaPose, const svo_stereo_camera* cam,
+                    double* out_newPose, double* out_gradient, double* out_residual, int* residual_init, double* out_cost, int* out_error_code)
+{
+    (void)n_non_masked;
+    if (!*residual_init) { for (int i = 0; i < nL; i++) out_residual[i] = DBL_MAX; *residual_init = 1; }   /* S5:296 */
+    *out_cost = 0; *out_error_code = SVO_VOEC_NONE;
+    double g[6] = { 0 }, H[36] = { 0 };
+    rot_t R; rodrigues_with_derivs(deltaPose, &R);                                  /* S5:313 */
+    const double b2 = P->use_robust_kernel ? P->kernel_param * P->kernel_param : 0; /* S5:316 */
+    const double b2_1 = P->use_robust_kernel ? 1. / b2 : 0;                         /* S5:317 */
+    for (int m = 0, i = 0; m < nL; ++m) {                                           /* S5:318 */
+        if (!mask[m]) continue;
+        float pix[4]; double J[24];
+        project_one(&R, deltaPose, cam, lmks + 3 * i, pix, J);
+        int good = 1;
+        for (int k = 0; k < 24; k++) if (isnan(J[k]) || isinf(J[k])) good = 0;      /* S5:322, H:919-928 */
+        if (!good) { ++i; continue; }
+        const double rlx = (double)(l2[m].x - pix[0]);                              /* S5:335-338: float subtraction */
+        const double rly = (double)(l2[m].y - pix[1]);
+        const double rrx = (double)(r2[m].x - pix[2]);
+        const double rry = (double)(r2[m].y - pix[3]);
+        const double ri[4] = { rlx, rly, rrx, rry };
+        const double s = rlx * rlx + rly * rly + rrx * rrx + rry * rry;             /* S5:344 */
+        out_residual[m] = s;                                                        /* S5:345 */
+        double rho_p = 1, fi;
+        if (P->use_robust_kernel) { const double nn = sqrt(1 + (s * b2_1)); rho_p = 1 / nn; fi = b2 * (nn - 1); }   /* S5:351-356 */
+        else fi = 0.5 * s;                                                          /* S5:359 */
+        *out_cost += fi;
+        for (int a = 0; a < 6; a++) {                                               /* S5:364-369: H NOT weighted by rho_p */
+            double jr = 0;
+            for (int k = 0; k < 4; k++) jr += J[k * 6 + a] * ri[k];
+            g[a] += rho_p * jr;
+            for (int b = 0; b < 6; b++) { double h = 0; for (int k = 0; k < 4; k++) h += J[k * 6 + a] * J[k * 6 + b]; H[a * 6 + b] += h; }
+        }
+        ++i;
+    }
+    memcpy(out_gradient, g, sizeof(g));
+    if (!solve_sym6(H, g, out_newPose)) { *out_error_code = SVO_VOEC_BAD_COND_NUMBER; return 0; }   /* S5:375-388 */
+    return 1;
+}
+
+static void triangulate(const svo_keypoint* l1, const svo_keypoint* r1, int nL, const uint8_t* surv, const svo_stereo_camera* cam, double* lmks)
+{
+    const double cul = cam->l_cx, cvl = cam->l_cy, fl = cam->l_fx, cur = cam->r_cx, fr = cam->r_fx, baseline = cam->baseline;   /* S5:510-515 */
+    for (int m = 0, i = 0; m < nL; ++m) {                                           /* S5:530-544 */
+        if (!surv[m]) continue;
+        const double ul = l1[m].x, vl = l1[m].y, ur = r1[m].x;
+        const double b_d = baseline / (fl * (cur - ur) + fr * (ul - cul));
+        lmks[3 * i] = b_d * fr * (ul - cul); lmks[3 * i + 1] = b_d * fr * (vl - cvl); lmks[3 * i + 2] = b_d * fl * fr;
+        ++i;
+    }
+}
+
+/* stage5_optimize on gathered lists.  cur_match_idx[i] = tracked_pairs[..].second of point i */
+static void stage5_core(svo_oracle* o, const svo_keypoint* l1, const svo_keypoint* r1, const svo_keypoint* l2, const svo_keypoint* r2,
+                        const int32_t* cur_match_idx, int nL, int img_w, int img_h, const svo_stereo_camera* cam,
+                        const double* initial_estimation, svo_result* result, double** res_out, int* nres_out, int32_t** outl_out, int* noutl_out)
+{
+    const svo_params* P = &o->p;
+    uint8_t* survivors = (uint8_t*)xcalloc((size_t)(nL > 0 ? nL : 1), 1);
+    svo_oracle_nms_mask(l1, nL, P->min_distance, img_w, img_h, nL, survivors);      /* S5:465-474 */
+    double* out_residual = (double*)xmalloc(sizeof(double) * (size_t)(nL > 0 ? nL : 1));
+    int residual_init = 0, n_res = 0;
+    int32_t* outliers = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(nL > 0 ? nL : 1));
+    int n_outliers = 0;
+    double pCost = 0, cCost = 0; int done = 0, abort_ = 0;
+    double deltaPose[6] = { 0, 0, 0, 0, 0, 0 }, out_newPose[6] = { 0 }, out_grad[6];
+    if (P->use_custom_initial_pose) { if (initial_estimation) memcpy(deltaPose, initial_estimation, sizeof(deltaPose)); }   /* S5:504-505 */
+    else if (P->use_previous_pose_as_initial) memcpy(deltaPose, o->m_last_computed_pose, sizeof(deltaPose));   /* S5:506-507 */
+    double* lmks = (double*)xmalloc(sizeof(double) * 3 * (size_t)(nL > 0 ? nL : 1));
+    int n_non_masked = 0;
+    for (int i = 0; i < nL; i++) n_non_masked += survivors[i];                      /* S5:520 */
+    if (n_non_masked < 8) { result->valid = 0; goto finish; }                        /* S5:521-526 */
+    triangulate(l1, r1, nL, survivors, cam, lmks);                                  /* S5:529-544 */
+    {
+        unsigned timesInc = 0; int out_error_code;
+        result->num_it = 0;
+        while (result->num_it < P->initial_max_iters && !done && !abort_) {         /* S5:549 */
+            pCost = cCost;
+            int cond = eval_rgn(P, l2, r2, nL, survivors, lmks, n_non_masked, deltaPose, cam, out_newPose, out_grad, out_residual, &residual_init, &cCost, &result->error_code);
+            n_res = nL;
+            if (!cond) { o->m_error = result->error_code; result->valid = 0; n_res = 0; goto finish; }   /* S5:569-573 (residual not swapped out) */
+            for (int k = 0; k < 6; k++) deltaPose[k] += out_newPose[k];             /* S5:576-577 */
+            if (result->num_it > 0) {                                               /* S5:580-596 */
+                double m = 0; for (int c = 0; c < 6; c++) m += out_newPose[c] * out_newPose[c];
+                done = sqrt(m) < P->min_mod_out_vector;
+                if (pCost < cCost) { if (++timesInc > (unsigned)P->max_incr_cost) { result->error_code = SVO_VOEC_INCR_FUNC_COST_STG1; abort_ = 1; } }
+            }
+            result->num_it++;
+        }
+        for (int i = 0; i < n_res; ++i) {                                           /* S5:601-611 */
+            if (out_residual[i] > P->residual_threshold) survivors[i] = 0;
+            else outliers[n_outliers++] = cur_match_idx[i];                         /* "outliers" holds inliers */
+        }
+        n_non_masked = 0; for (int i = 0; i < nL; i++) n_non_masked += survivors[i];   /* S5:615 */
+        if (n_non_masked < 8) { result->valid = 0; goto finish; }                    /* S5:616-621 */
+        triangulate(l1, r1, nL, survivors, cam, lmks);                              /* S5:623-638 */
+        done = 0; abort_ = 0;                                                       /* S5:645 */
+        result->num_it_final = 0;
+        while (result->num_it_final < P->max_iters && !done && !abort_) {           /* S5:650 */
+            pCost = cCost;
+            int cond = eval_rgn(P, l2, r2, nL, survivors, lmks, n_non_masked, deltaPose, cam, out_newPose, out_grad, out_residual, &residual_init, &cCost, &out_error_code);
+            n_res = nL;
+            if (!cond) { o->m_error = SVO_VOEC_BAD_COND_NUMBER; result->valid = 0; goto finish; }   /* S5:670-675; m_error set at S5:384 */
+            for (int k = 0; k < 6; k++) deltaPose[k] += out_newPose[k];
+            if (result->num_it_final > 0) {                                         /* S5:682-698 */
+                double m = 0; for (int c = 0; c < 6; c++) m += out_newPose[c] * out_newPose[c];
+                done = sqrt(m) < P->min_mod_out_vector;
+                if (pCost < cCost) { if (++timesInc > (unsigned)P->max_incr_cost) { abort_ = 1; result->error_code = SVO_VOEC_INCR_FUNC_COST_STG2; } }
+            }
+            result->num_it_final++;
+        }
+        memcpy(result->delta, deltaPose, sizeof(deltaPose));
+        svo_oracle_delta_to_pose(deltaPose, result->outPose);                       /* S5:717-718 */
+        if (!P->use_custom_initial_pose && P->use_previous_pose_as_initial) memcpy(o->m_last_computed_pose, deltaPose, sizeof(deltaPose));   /* S5:720-721 */
+        result->tracked_feats_from_last_frame = o->m_num_tracked_last_frame;        /* S5:724-725 */
+        result->tracked_feats_from_last_KF = o->m_num_tracked_last_kf;
+        result->valid = !abort_;                                                    /* S5:727 */
+    }
+finish:
+    free(lmks); free(survivors);
+    *res_out = out_residual; *nres_out = n_res; *outl_out = outliers; *noutl_out = n_outliers;
+    result->n_residual = n_res; result->n_outliers = n_outliers;
+}
+
+static void store_stage5_outputs(svo_oracle* o, double* res, int nres, int32_t* outl, int noutl)
+{
+    free(o->residual); free(o->outliers);
+    o->residual = res; o->n_residual = nres; o->outliers = outl; o->n_outliers = noutl;
+}
+
+int svo_oracle_change_in_pose(svo_oracle* o, const svo_index_pair* tracked, int n_tracked,
+                              const svo_dmatch* pre_m, const svo_dmatch* cur_m,
+                              const svo_keypoint* pre_l, const svo_keypoint* pre_r,
+                              const svo_keypoint* cur_l, const svo_keypoint* cur_r,
+                              const svo_stereo_camera* cam, const double* init6,
+                              svo_result* res, double* residual, int32_t* outliers)
+{
+    /* C:355-413: single octave, image size from the camera record (C:402-403) */
+    const int n = n_tracked;
+    svo_keypoint* l1 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(n ? n : 1)), *r1 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(n ? n : 1));
+    svo_keypoint* l2 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(n ? n : 1)), *r2 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(n ? n : 1));
+    int32_t* cmi = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+    for (int i = 0; i < n; i++) {                                                   /* S5:419-461, nOctaves == 1 */
+        l1[i] = pre_l[pre_m[tracked[i].first].queryIdx]; r1[i] = pre_r[pre_m[tracked[i].first].trainIdx];
+        l2[i] = cur_l[cur_m[tracked[i].second].queryIdx]; r2[i] = cur_r[cur_m[tracked[i].second].trainIdx];
+        cmi[i] = tracked[i].second;
+    }
+    memset(res, 0, sizeof(*res));
+    double* ro; int nro; int32_t* oo; int noo;
+    stage5_core(o, l1, r1, l2, r2, cmi, n, cam->ncols, cam->nrows, cam, init6, res, &ro, &nro, &oo, &noo);
+    if (residual) memcpy(residual, ro, sizeof(double) * (size_t)nro);
+    if (outliers) memcpy(outliers, oo, sizeof(int32_t) * (size_t)noo);
+    free(ro); free(oo); free(l1); free(r1); free(l2); free(r2); free(cmi);
+    return res->valid;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* processNewImagePair  (P:41-385)                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+int svo_oracle_process(svo_oracle* o, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                       const svo_stereo_camera* cam, int repeat, svo_result* result)
+{
+    const svo_params* p = &o->p;
+    memset(result, 0, sizeof(*result));
+    result->error_code = SVO_VOEC_NONE;                                             /* P:50 */
+    if (p->detect_method < 0 || p->detect_method > 3) return -2;                    /* P:54-61 */
+    if (p->match_method < 0 || p->match_method > 2) return -2;                      /* P:62-68 */
+    if (p->ifm_method < 0 || p->ifm_method > 3) return -2;                          /* P:69-76 */
+    if (!left || !right) return -3;                                                 /* P:81 */
+    /* P:86-89 shift unless repeating or recovering from a tracking / conditioning failure */
+    if (!repeat && o->m_error != SVO_VOEC_BAD_TRACKING && o->m_error != SVO_VOEC_BAD_COND_NUMBER) {
+        if (o->prev && o->prev != o->cur) free_pair(o->prev);
+        o->prev = o->cur; o->cur = NULL;
+    }
+    o->m_error = SVO_VOEC_NONE;                                                     /* P:95 */
+    if (o->cur && o->cur != o->prev) free_pair(o->cur);
+    pair_data* cur = (pair_data*)xcalloc(1, sizeof(pair_data));                     /* P:100 */
+    o->cur = cur; cur->present = 1;
+    /* stage 1 substitute: inputs are rectified gray; build the octave pyramid (S1:80-83) */
+    const int nOct = p->detect_method == SVO_DM_ORB ? 1 : (p->nOctaves < 1 ? 1 : (p->nOctaves > MAXOCT ? MAXOCT : p->nOctaves));
+    cur->n_oct = nOct;
+    const uint8_t* oimg[2][MAXOCT]; int ostride[2][MAXOCT]; uint8_t* obuf[2][MAXOCT];
+    for (int s = 0; s < 2; s++) {
+        oimg[s][0] = s ? right : left; ostride[s][0] = stride; obuf[s][0] = NULL;
+        cur->w[0] = w; cur->h[0] = h;
+        for (int oc = 1; oc < nOct; oc++) {
+            cur->w[oc] = cur->w[oc - 1] / 2; cur->h[oc] = cur->h[oc - 1] / 2;
+            obuf[s][oc] = (uint8_t*)xmalloc((size_t)cur->w[oc] * cur->h[oc]);
+            svo_oracle_half_smooth(oimg[s][oc - 1], cur->w[oc - 1], cur->h[oc - 1], ostride[s][oc - 1], obuf[s][oc]);
+            oimg[s][oc] = obuf[s][oc]; ostride[s][oc] = cur->w[oc];
+        }
+    }
+    int rc = 0;
+    rc = stage2_detect(o, cur, 0, oimg[0], ostride[0]);                             /* P:166 */
+    if (!rc) rc = stage2_detect(o, cur, 1, oimg[1], ostride[1]);                    /* P:167 */
+    for (int s = 0; s < 2; s++) for (int oc = 1; oc < nOct; oc++) free(obuf[s][oc]);
+    if (rc) return rc;
+    result->n_octaves = nOct;
+    for (int oc = 0; oc < nOct; oc++) { result->detected_left[oc] = cur->f[0][oc].n; result->detected_right[oc] = cur->f[1][oc].n; }   /* P:171-176 */
+    /* P:254-267 reset of the match IDs */
+    if (o->m_reset) {
+        o->m_last_match_ID = 0;
+        if (o->prev) for (int oc = 0; oc < nOct; oc++) for (int m = 0; m < o->prev->pr[oc].n_ids; m++) o->prev->pr[oc].ids[m] = o->m_last_match_ID++;
+        o->m_reset = 0;
+        o->m_last_kf_max_id = o->m_last_match_ID - 1;
+    }
+    /* stage 3 (P:269) */
+    const int use_ids = p->vo_use_matches_ids && !(o->prev && o->prev->present);    /* S3:67 */
+    for (int oc = 0; oc < nOct; oc++) {
+        feat_set* fl = &cur->f[0][oc], *fr = &cur->f[1][oc];
+        pairing_t* pr = &cur->pr[oc];
+        pr->m = (svo_dmatch*)xmalloc(sizeof(svo_dmatch) * (size_t)(fl->n > 0 ? fl->n : 1));
+        pr->row_index = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)(cur->h[oc] + 1)); pr->rows = cur->h[oc] + 1;
+        int m = svo_oracle_match_lr(p, o->m_current_orb_th, fl->kps, fl->desc, fl->n, fl->row_index, fr->kps, fr->desc, fr->n, fr->row_index,
+                                    cur->w[oc], cur->h[oc], pr->m, fl->n, pr->row_index);
+        if (m < 0) return m;
+        pr->n = m;
+        pr->ids = (int64_t*)xcalloc((size_t)(m > 0 ? m : 1), sizeof(int64_t)); pr->n_ids = 0;
+        if (use_ids) { for (int i = 0; i < m; i++) pr->ids[i] = o->m_last_match_ID++; pr->n_ids = m; }   /* S3:172-173 */
+        result->stereo_matches[oc] = m;                                             /* P:274-276 */
+    }
+    for (int oc = 0; oc < MAXOCT; oc++) { free(o->tracked[oc]); o->tracked[oc] = NULL; o->n_tracked[oc] = 0; }
+    store_stage5_outputs(o, NULL, 0, NULL, 0);
+    if (o->prev && o->prev->present) {                                              /* P:305 */
+        pair_data* prev = o->prev;
+        o->m_num_tracked_last_frame = 0; o->m_num_tracked_last_kf = 0;              /* S4:743 */
+        for (int oc = 0; oc < nOct; oc++) {                                         /* P:314 stage4_track */
+            pairing_t* pp = &prev->pr[oc], *cp = &cur->pr[oc];
+            int cap = pp->n > 0 ? pp->n : 1;
+            if (cp->n > cap) cap = cp->n;
+            o->tracked[oc] = (svo_index_pair*)xmalloc(sizeof(svo_index_pair) * (size_t)cap);
+            int t = svo_oracle_track(p, o->m_current_orb_th,
+                                     prev->f[0][oc].kps, prev->f[0][oc].desc, prev->f[1][oc].kps, prev->f[1][oc].desc, pp->m, pp->n, pp->row_index,
+                                     cur->f[0][oc].kps, cur->f[0][oc].desc, cur->f[1][oc].kps, cur->f[1][oc].desc, cp->m, cp->n, cp->row_index,
+                                     cur->w[oc], cur->h[oc], o->tracked[oc], cap);
+            if (t < 0) return t;
+            o->n_tracked[oc] = t;
+            if (p->vo_use_matches_ids) {                                            /* S4:268-305 / 716-733 */
+                uint8_t* ct = (uint8_t*)xcalloc((size_t)(cp->n > 0 ? cp->n : 1), 1);
+                cp->n_ids = cp->n;
+                for (int k = 0; k < t; k++) {
+                    int pi = o->tracked[oc][k].first, ci = o->tracked[oc][k].second;
+                    cp->ids[ci] = pi < pp->n_ids ? pp->ids[pi] : 0; ct[ci] = 1;
+                }
+                for (int k = 0; k < cp->n; k++) if (!ct[k]) cp->ids[k] = o->m_last_match_ID++;
+                free(ct);
+            }
+            o->m_num_tracked_last_frame += t;                                       /* S4:746 */
+            for (int k = 0; k < cp->n_ids; k++) if (cp->ids[k] <= o->m_last_kf_max_id) o->m_num_tracked_last_kf++;   /* S4:747-751 */
+        }
+        if (o->m_num_tracked_last_frame < p->bad_tracking_th) {                     /* P:326-330 */
+            o->m_error = result->error_code = SVO_VOEC_BAD_TRACKING;
+        }
+        if (o->m_error != SVO_VOEC_BAD_TRACKING) {                                  /* P:332-341 stage5_optimize */
+            int nT = o->m_num_tracked_last_frame;
+            svo_keypoint* l1 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nT ? nT : 1)), *r1 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nT ? nT : 1));
+            svo_keypoint* l2 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nT ? nT : 1)), *r2 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nT ? nT : 1));
+            int32_t* cmi = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(nT ? nT : 1));
+            int pc = 0;
+            for (int oc = 0; oc < nOct; oc++) {                                     /* S5:419-461 */
+                const float scale_norm = (float)(size_t)(nOct > 1 ? pow(2, oc) : 1);
+                for (int i = 0; i < o->n_tracked[oc]; i++, pc++) {
+                    const svo_dmatch* pm = &prev->pr[oc].m[o->tracked[oc][i].first], *cm = &cur->pr[oc].m[o->tracked[oc][i].second];
+                    l1[pc] = prev->f[0][oc].kps[pm->queryIdx]; r1[pc] = prev->f[1][oc].kps[pm->trainIdx];
+                    l2[pc] = cur->f[0][oc].kps[cm->queryIdx]; r2[pc] = cur->f[1][oc].kps[cm->trainIdx];
+                    if (nOct > 1) { l1[pc].x *= scale_norm; l1[pc].y *= scale_norm; r1[pc].x *= scale_norm; r1[pc].y *= scale_norm;
+                                    l2[pc].x *= scale_norm; l2[pc].y *= scale_norm; r2[pc].x *= scale_norm; r2[pc].y *= scale_norm; }
+                    cmi[pc] = o->tracked[oc][i].second;
+                }
+            }
+            double* ro; int nro; int32_t* oo; int noo;
+            stage5_core(o, l1, r1, l2, r2, cmi, nT, prev->w[0], prev->h[0], cam, NULL, result, &ro, &nro, &oo, &noo);   /* S5:465-468 */
+            store_stage5_outputs(o, ro, nro, oo, noo);
+            free(l1); free(r1); free(l2); free(r2); free(cmi);
+        }
+    } else {
+        result->error_code = SVO_VOEC_FIRST_ITERATION; result->valid = 0;           /* P:348-352 */
+    }
+    if (!repeat) ++o->m_it_counter;                                                 /* P:380-381 */
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* getters                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+static const pair_data* pick(const svo_oracle* o, int which) { return which ? o->prev : o->cur; }
+
+int svo_oracle_get_keypoints(const svo_oracle* o, int which, int side, int octave, svo_keypoint* kps, uint8_t* desc, int cap)
+{
+    const pair_data* d = pick(o, which); if (!d || octave >= d->n_oct) return 0;
+    const feat_set* f = &d->f[side][octave]; int n = f->n < cap ? f->n : cap;
+    if (kps) memcpy(kps, f->kps, sizeof(svo_keypoint) * (size_t)n);
+    if (desc) memcpy(desc, f->desc, (size_t)n * 32);
+    return f->n;
+}
+int svo_oracle_get_row_index(const svo_oracle* o, int which, int side, int octave, int64_t* idx, int cap)
+{
+    const pair_data* d = pick(o, which); if (!d || octave >= d->n_oct) return 0;
+    const feat_set* f = &d->f[side][octave]; int n = f->rows < cap ? f->rows : cap;
+    if (idx) memcpy(idx, f->row_index, sizeof(int64_t) * (size_t)n);
+    return f->rows;
+}
+int svo_oracle_get_matches(const svo_oracle* o, int which, int octave, svo_dmatch* m, int cap)
+{
+    const pair_data* d = pick(o, which); if (!d || octave >= d->n_oct) return 0;
+    int n = d->pr[octave].n < cap ? d->pr[octave].n : cap;
+    if (m) memcpy(m, d->pr[octave].m, sizeof(svo_dmatch) * (size_t)n);
+    return d->pr[octave].n;
+}
+int svo_oracle_get_matches_row_index(const svo_oracle* o, int which, int octave, int64_t* idx, int cap)
+{
+    const pair_data* d = pick(o, which); if (!d || octave >= d->n_oct) return 0;
+    int n = d->pr[octave].rows < cap ? d->pr[octave].rows : cap;
+    if (idx) memcpy(idx, d->pr[octave].row_index, sizeof(int64_t) * (size_t)n);
+    return d->pr[octave].rows;
+}
+int svo_oracle_get_match_ids(const svo_oracle* o, int which, int octave, int64_t* ids, int cap)
+{
+    const pair_data* d = pick(o, which); if (!d || octave >= d->n_oct) return 0;
+    int n = d->pr[octave].n_ids < cap ? d->pr[octave].n_ids : cap;
+    if (ids) memcpy(ids, d->pr[octave].ids, sizeof(int64_t) * (size_t)n);
+    return d->pr[octave].n_ids;
+}
+int svo_oracle_get_tracked(const svo_oracle* o, int octave, svo_index_pair* t, int cap)
+{
+    if (octave >= MAXOCT) return 0;
+    int n = o->n_tracked[octave] < cap ? o->n_tracked[octave] : cap;
+    if (t && n > 0) memcpy(t, o->tracked[octave], sizeof(svo_index_pair) * (size_t)n);
+    return o->n_tracked[octave];
+}
+int svo_oracle_get_residuals(const svo_oracle* o, double* r, int cap)
+{
+    int n = o->n_residual < cap ? o->n_residual : cap;
+    if (r && n > 0) memcpy(r, o->residual, sizeof(double) * (size_t)n);
+    return o->n_residual;
+}
+int svo_oracle_get_outliers(const svo_oracle* o, int32_t* idx, int cap)
+{
+    int n = o->n_outliers < cap ? o->n_outliers : cap;
+    if (idx && n > 0) memcpy(idx, o->outliers, sizeof(int32_t) * (size_t)n);
+    return o->n_outliers;
+}

@@ -1,0 +1,112 @@
+/* svo_oracle.h -- CPU oracle for the stereo-VO hot path (stages 2-5 of
+ * rso::CStereoOdometryEstimator::processNewImagePair, libstereo-odometry/src/process_new_image_pair.cpp:41).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product path (stereo_vo_amd/) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" for everything that the reference delegates to OpenCV / MRPT / Eigen
+ * (ORB detect+describe, BFMatcher tie-breaking, findFundamentalMat, JacobiSVD solve, CPose3D conversion):
+ * none of those libraries exists in /root/reference, in this image or on the GPU box, and the reference's
+ * only live test (tests/computeSAD8_unittest.cpp:20-41) pins compute_SAD8 alone, which is restated and
+ * checked here as a toolchain known-answer.  The reference's OWN logic (row index, grid NMS, match filters,
+ * collision filter, consistency check, stereo projection + Jacobian, robust Gauss-Newton, control flow,
+ * recovery rule) is restated line by line with file:line citations in svo_oracle.c.
+ */
+#ifndef SVO_ORACLE_H
+#define SVO_ORACLE_H
+#include "../include/svo_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svo_oracle svo_oracle;
+
+void svo_oracle_params_defaults(svo_params* p);
+
+svo_oracle* svo_oracle_create(void);
+void svo_oracle_destroy(svo_oracle* o);
+/* mirrors loadParamsFromConfigFile: stores params then resetFASTThreshold()/resetORBThreshold() (H:661-662) */
+void svo_oracle_set_params(svo_oracle* o, const svo_params* p);
+void svo_oracle_get_params(const svo_oracle* o, svo_params* p);
+void svo_oracle_set_fast_threshold(svo_oracle* o, int v);   /* H:531 (clamped) */
+void svo_oracle_set_orb_threshold(svo_oracle* o, int v);    /* H:538 (clamped) */
+int  svo_oracle_get_fast_threshold(const svo_oracle* o);
+int  svo_oracle_get_orb_threshold(const svo_oracle* o);
+void svo_oracle_reset_ids(svo_oracle* o);                   /* H:684 */
+void svo_oracle_set_this_frame_as_kf(svo_oracle* o);        /* H:675-683 */
+
+/* processNewImagePair (P:41-385) on already-rectified 8-bit gray images. Returns 0, or <0 on a hard error. */
+int svo_oracle_process(svo_oracle* o, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                       const svo_stereo_camera* cam, int repeat, svo_result* res);
+
+/* which: 0 = current frame, 1 = previous frame; side: 0 = left, 1 = right */
+int svo_oracle_get_keypoints(const svo_oracle* o, int which, int side, int octave, svo_keypoint* kps,
+                             uint8_t* desc, int cap);
+int svo_oracle_get_row_index(const svo_oracle* o, int which, int side, int octave, int64_t* idx, int cap);
+int svo_oracle_get_matches(const svo_oracle* o, int which, int octave, svo_dmatch* m, int cap);
+int svo_oracle_get_matches_row_index(const svo_oracle* o, int which, int octave, int64_t* idx, int cap);
+int svo_oracle_get_match_ids(const svo_oracle* o, int which, int octave, int64_t* ids, int cap);
+int svo_oracle_get_tracked(const svo_oracle* o, int octave, svo_index_pair* t, int cap);
+int svo_oracle_get_residuals(const svo_oracle* o, double* r, int cap);
+int svo_oracle_get_outliers(const svo_oracle* o, int32_t* idx, int cap);
+
+/* ---- stage-level entry points (unit tests and golden vectors) ---- */
+
+/* cv::ORB::detectAndCompute stand-in (S2:482-493). Returns number of keypoints written (<= cap). */
+int svo_oracle_orb_detect(const uint8_t* img, int w, int h, int stride, int nfeatures, int nlevels,
+                          int fast_th, svo_keypoint* kps, uint8_t* desc, int cap);
+/* cv::FastFeatureDetector::detect + cv::ORB::compute stand-in (S2:510-512) */
+int svo_oracle_fast_orb_detect(const uint8_t* img, int w, int h, int stride, int fast_th,
+                               svo_keypoint* kps, uint8_t* desc, int cap);
+/* FAST-9/16 corner score map of one image (0 = not a corner at threshold th). */
+void svo_oracle_fast_score_map(const uint8_t* img, int w, int h, int stride, int th, uint8_t* score);
+/* pyramid level sizes and bilinear x1/1.2 chain; level buffers are tightly packed (stride == width). */
+int svo_oracle_pyramid_sizes(int w, int h, int nlevels, int* lw, int* lh, float* scale);
+void svo_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh);
+void svo_oracle_half_smooth(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst); /* MRPT x1/2 */
+/* m_non_max_sup copying overload (S2:296-370): returns number kept; out_order[i] = input index */
+int svo_oracle_nms_copy(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h,
+                        int num_out_points, int32_t* out_order);
+/* m_non_max_sup mask overload (S2:225-283) */
+void svo_oracle_nms_mask(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h,
+                         int num_out_points, uint8_t* survivors);
+/* m_update_indexes (S2:65-130): order[i] = input index of i-th output; idx has img_h entries */
+void svo_oracle_row_sort_index(const svo_keypoint* kps, int n, int img_h, int32_t* order, int64_t* idx);
+/* cv::BFMatcher(NORM_HAMMING,false).match stand-in (S3:88-94): first minimum */
+void svo_oracle_hamming_bf(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist);
+/* stage 3 on caller data (BF or RbR per params); returns M */
+int svo_oracle_match_lr(const svo_params* p, int orb_th, const svo_keypoint* kl, const uint8_t* dl, int nl,
+                        const int64_t* idxl, const svo_keypoint* kr, const uint8_t* dr, int nr,
+                        const int64_t* idxr, int img_w, int img_h, svo_dmatch* out, int cap,
+                        int64_t* row_index /* img_h+1 */);
+/* cv::findFundamentalMat(FM_RANSAC,1.0,0.99) stand-in. Returns inlier count; mask has n entries (all 0 if n<8) */
+int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9,
+                                  int* best_hyp, int* n_hyp_used);
+/* stage 4 on caller data; returns T */
+int svo_oracle_track(const svo_params* p, int orb_th,
+                     const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr,
+                     const svo_dmatch* pm, int npm, const int64_t* pri,
+                     const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr,
+                     const svo_dmatch* cm, int ncm, const int64_t* cri,
+                     int img_w, int img_h, svo_index_pair* out, int cap);
+/* getChangeInPose (C:355-413): stage 5 on caller data. init6 may be NULL. residual has n_tracked entries,
+ * outliers capacity n_tracked. State (m_last_computed_pose) lives in `o`. Returns result.valid. */
+int svo_oracle_change_in_pose(svo_oracle* o, const svo_index_pair* tracked, int n_tracked,
+                              const svo_dmatch* pre_m, const svo_dmatch* cur_m,
+                              const svo_keypoint* pre_l, const svo_keypoint* pre_r,
+                              const svo_keypoint* cur_l, const svo_keypoint* cur_r,
+                              const svo_stereo_camera* cam, const double* init6,
+                              svo_result* res, double* residual, int32_t* outliers);
+/* m_pinhole_stereo_projection (S5:35-257): pix = n x 4 floats (uL vL uR vR), jac = n x 24 doubles (row-major 4x6) */
+void svo_oracle_project(const double* lmks3, int n, const svo_stereo_camera* cam, const double* delta6,
+                        float* pix, double* jac);
+/* CPose3D( CPose3DRotVec(delta).getInverse() ) -> x y z yaw pitch roll (S5:717-718) */
+void svo_oracle_delta_to_pose(const double* delta6, double* pose6);
+/* compute_SAD8 (compute_SAD8.cpp:71-98) -- toolchain known-answer only */
+uint32_t svo_oracle_sad8(const uint8_t* l, const uint8_t* r, size_t stride, int lx, int ly, int rx, int ry);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+"""Deterministic synthetic stereo sequences: textured planes seen by a rectified pinhole pair.
+
+Plays the role of the image source of the reference's demo (demo-stereo-odometry/demo-main.cpp:200-220,
+mrpt CCameraSensor) on inputs that can be generated on the GPU box from this repository alone.
+Rendering uses torch so that it runs on the CPU here and on cuda:0 in bench.py; every random quantity comes
+from a seeded xorshift64* so that a (seed, frame) pair always names the same scene and motion.
+"""
+import math
+import numpy as np
+import torch
+
+from .abi import StereoCamera
+
+MASK64 = (1 << 64) - 1
+
+
+class XorShift64Star:
+    def __init__(self, seed):
+        self.s = (seed & MASK64) or 0x9E3779B97F4A7C15
+
+    def next(self):
+        x = self.s
+        x ^= x >> 12
+        x ^= (x << 25) & MASK64
+        x ^= x >> 27
+        self.s = x
+        return (x * 0x2545F4914F6CDD1D) & MASK64
+
+    def uniform(self, a=0.0, b=1.0):
+        return a + (b - a) * ((self.next() >> 11) / float(1 << 53))
+
+    def randint(self, a, b):  # inclusive
+        return a + int(self.next() % (b - a + 1))
+
+
+def _manhattan_texture(rng, size, n_rect):
+    """Axis-aligned rectangles 4..40 texels with intensities U{16..240} over a mid-gray canvas."""
+    tex = np.full((size, size), 128, np.uint8)
+    for _ in range(n_rect):
+        rw, rh = rng.randint(4, 40), rng.randint(4, 40)
+        x0, y0 = rng.randint(0, size - rw), rng.randint(0, size - rh)
+        tex[y0:y0 + rh, x0:x0 + rw] = rng.randint(16, 240)
+    # fine detail so that corner neighbourhoods are distinctive (small rectangles 2..8 texels)
+    for _ in range(3 * n_rect):
+        rw, rh = rng.randint(2, 8), rng.randint(2, 8)
+        x0, y0 = rng.randint(0, size - rw), rng.randint(0, size - rh)
+        tex[y0:y0 + rh, x0:x0 + rw] = rng.randint(16, 240)
+    return tex
+
+
+def _rot_zyx(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+class SyntheticStereoWorld:
+    """A static world of textured planes and a camera trajectory.
+
+    Camera frame: x right, y down, z forward.  World frame = frame of the left camera at t = 0.
+    pose[t] is the 4x4 camera-to-world transform of the left camera at frame t; the right camera sits at
+    +baseline along the left camera's x axis (S5:185: X2c = X1c - baseline).
+    """
+
+    def __init__(self, width, height, focal, baseline=0.12, seed=0, n_frames=20, device="cpu",
+                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048):
+        self.w, self.h, self.f, self.B = int(width), int(height), float(focal), float(baseline)
+        self.cx = (self.w - 1) / 2.0 if cx is None else float(cx)
+        self.cy = (self.h - 1) / 2.0 if cy is None else float(cy)
+        self.seed = int(seed)
+        self.n_frames = int(n_frames)
+        self.device = torch.device(device)
+        self.noise_sigma = float(noise_sigma)
+        rng = XorShift64Star(0x5EED0000 + self.seed)
+        # planes: (point, normal, e_u, e_v, (umin, umax, vmin, vmax), metres per texel)
+        planes = []
+        # far wall
+        planes.append((np.array([0, 0, 26.0]), np.array([0, 0, -1.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), (-60, 60, -40, 40), 0.06))
+        # ground
+        planes.append((np.array([0, 1.7, 0]), np.array([0, -1.0, 0]), np.array([1.0, 0, 0]), np.array([0, 0, 1.0]), (-40, 40, 0.5, 80), 0.04))
+        # a few nearer facades with small random tilt
+        n_fac = 3 + rng.randint(0, 1)
+        for k in range(n_fac):
+            z = rng.uniform(7.0, 16.0)
+            xc = rng.uniform(-7.0, 7.0)
+            half = rng.uniform(1.2, 3.0)
+            tilt = rng.uniform(-0.35, 0.35)
+            n = np.array([math.sin(tilt), 0, -math.cos(tilt)])
+            eu = np.array([math.cos(tilt), 0, math.sin(tilt)])
+            ev = np.array([0, 1.0, 0])
+            planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), 0.012 + 0.002 * k))
+        self.planes = planes
+        self.textures = [torch.from_numpy(_manhattan_texture(rng, tex_size, 5000)).to(self.device).float() for _ in planes]
+        self.tex_size = tex_size
+        # trajectory
+        self.poses = [np.eye(4)]
+        self.deltas = [np.eye(4)]
+        for t in range(1, self.n_frames):
+            fwd = rng.uniform(0.05, 0.3)
+            yaw_cam = math.radians(rng.uniform(-0.5, 0.5))      # rotation about the camera's y (vertical) axis
+            pitch_cam = math.radians(rng.uniform(-0.1, 0.1))
+            roll_cam = math.radians(rng.uniform(-0.1, 0.1))
+            # axes in camera convention: "yaw" about y-down, "pitch" about x, "roll" about z
+            cyw, syw = math.cos(yaw_cam), math.sin(yaw_cam)
+            Ry = np.array([[cyw, 0, syw], [0, 1, 0], [-syw, 0, cyw]])
+            cpt, spt = math.cos(pitch_cam), math.sin(pitch_cam)
+            Rx = np.array([[1, 0, 0], [0, cpt, -spt], [0, spt, cpt]])
+            crl, srl = math.cos(roll_cam), math.sin(roll_cam)
+            Rz = np.array([[crl, -srl, 0], [srl, crl, 0], [0, 0, 1]])
+            D = np.eye(4)
+            D[:3, :3] = Ry @ Rx @ Rz
+            D[:3, 3] = [rng.uniform(-0.01, 0.01), rng.uniform(-0.005, 0.005), fwd]
+            self.deltas.append(D)
+            self.poses.append(self.poses[-1] @ D)
+        ys, xs = torch.meshgrid(torch.arange(self.h, device=self.device, dtype=torch.float32),
+                                torch.arange(self.w, device=self.device, dtype=torch.float32), indexing="ij")
+        self._ray = torch.stack([(xs - self.cx) / self.f, (ys - self.cy) / self.f, torch.ones_like(xs)], dim=-1)  # h,w,3
+
+    def camera(self) -> StereoCamera:
+        return StereoCamera.simple(self.f, self.cx, self.cy, self.B, self.w, self.h)
+
+    def gt_delta(self, t):
+        """4x4 pose of frame t with respect to frame t-1 (what result.outPose estimates, S5:715-718)."""
+        return self.deltas[t]
+
+    def _render_eye(self, T, gen_seed):
+        dev = self.device
+        R = torch.tensor(T[:3, :3], dtype=torch.float32, device=dev)
+        o = torch.tensor(T[:3, 3], dtype=torch.float32, device=dev)
+        d = self._ray @ R.T                                        # h,w,3 world directions
+        best_s = torch.full((self.h, self.w), float("inf"), device=dev)
+        img = torch.full((self.h, self.w), 90.0, device=dev)
+        for (P, n, eu, ev, ext, mpt), tex in zip(self.planes, self.textures):
+            Pt = torch.tensor(P, dtype=torch.float32, device=dev)
+            nt = torch.tensor(n, dtype=torch.float32, device=dev)
+            eut = torch.tensor(eu, dtype=torch.float32, device=dev)
+            evt = torch.tensor(ev, dtype=torch.float32, device=dev)
+            denom = d @ nt
+            s = torch.dot(nt, Pt - o) / denom
+            X = o + s.unsqueeze(-1) * d - Pt
+            a, b = X @ eut, X @ evt
+            ok = (s > 0.05) & (s < best_s) & (a >= ext[0]) & (a <= ext[1]) & (b >= ext[2]) & (b <= ext[3]) & torch.isfinite(s)
+            tu = a / mpt + self.tex_size / 2.0
+            tv = b / mpt + self.tex_size / 2.0
+            # wrap the texture so that large planes stay textured everywhere
+            tu = torch.remainder(tu, self.tex_size - 1.0)
+            tv = torch.remainder(tv, self.tex_size - 1.0)
+            x0 = tu.floor().clamp(0, self.tex_size - 2).long()
+            y0 = tv.floor().clamp(0, self.tex_size - 2).long()
+            fx, fy = tu - x0, tv - y0
+            v = (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy)
+                 + tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
+            img = torch.where(ok, v, img)
+            best_s = torch.where(ok, s, best_s)
+        if self.noise_sigma > 0:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(gen_seed)
+            noise = torch.randn((self.h, self.w), generator=g, dtype=torch.float32) * self.noise_sigma
+            img = img + noise.to(dev)
+        return img.round().clamp(0, 255).to(torch.uint8)
+
+    def render(self, t):
+        """(left, right) uint8 [h, w] tensors on self.device for frame t."""
+        T = self.poses[t]
+        Tr = T.copy()
+        Tr[:3, 3] = T[:3, 3] + T[:3, :3] @ np.array([self.B, 0, 0])
+        base = (self.seed * 100003 + t) * 2
+        return self._render_eye(T, base + 1), self._render_eye(Tr, base + 2)
+
+
+def pose6_to_matrix(p):
+    """x y z yaw pitch roll (R = Rz(yaw) Ry(pitch) Rx(roll)) -> 4x4."""
+    M = np.eye(4)
+    M[:3, :3] = _rot_zyx(p[3], p[4], p[5])
+    M[:3, 3] = p[:3]
+    return M
+
+
+def pose_error(A, B):
+    """(rotation angle [rad], translation norm) between two 4x4 transforms."""
+    dR = A[:3, :3].T @ B[:3, :3]
+    c = max(-1.0, min(1.0, (np.trace(dR) - 1.0) / 2.0))
+    return math.acos(c), float(np.linalg.norm(A[:3, 3] - B[:3, 3]))

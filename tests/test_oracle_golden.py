@@ -1,0 +1,84 @@
+"""The oracle against its own frozen vectors (tests/golden/oracle_small_seq.npz) and against ground truth."""
+import os
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stereo_vo_amd.abi import StereoCamera, north_star_params
+from stereo_vo_amd.synth import SyntheticStereoWorld, pose6_to_matrix, pose_error
+
+
+def load_small_seq(golden_dir):
+    g = np.load(os.path.join(golden_dir, "oracle_small_seq.npz"))
+    cam = StereoCamera.simple(float(g["F"]), float(g["cx"]), float(g["cy"]), float(g["baseline"]), int(g["W"]), int(g["H"]))
+    p = north_star_params(O.default_params(), orb_nfeats=int(g["orb_nfeats"]))
+    return g, cam, p
+
+
+def test_small_sequence_matches_frozen_vectors(golden_dir):
+    g, cam, p = load_small_seq(golden_dir)
+    o = O.Oracle(p)
+    for t in range(4):
+        r = o.process(g["L%d" % t], g["R%d" % t], cam)
+        for side in (0, 1):
+            k, d = o.keypoints(0, side)
+            assert k.tobytes() == g["kps%d_%d" % (side, t)].tobytes()
+            assert (d == g["desc%d_%d" % (side, t)]).all()
+            assert (o.row_index(0, side) == g["rowidx%d_%d" % (side, t)]).all()
+        assert o.matches(0).tobytes() == g["matches%d" % t].tobytes()
+        assert (o.matches_row_index(0) == g["mrow%d" % t]).all()
+        assert o.tracked().tobytes() == g["tracked%d" % t].tobytes()
+        assert (o.outliers() == g["outliers%d" % t]).all()
+        sc = g["scalars%d" % t]
+        assert [r.num_it, r.num_it_final, r.valid, r.error_code, r.tracked_feats_from_last_frame, r.detected_left[0],
+                r.detected_right[0], r.stereo_matches[0], r.n_outliers, r.n_residual] == sc.tolist()
+        assert np.allclose(np.array(r.outPose), g["pose%d" % t], atol=1e-12)
+        assert np.allclose(o.residuals(), g["residual%d" % t], rtol=1e-9, atol=1e-12)
+
+
+def test_first_frame_and_recovery_rule(golden_dir):
+    """a19 / P:86-95, 326-330, 348-352: first frame -> voecFirstIteration; after voecBadTracking the previous
+    frame is NOT replaced, so the next call tracks against the older frame."""
+    g, cam, p = load_small_seq(golden_dir)
+    o = O.Oracle(p)
+    r0 = o.process(g["L0"], g["R0"], cam)
+    assert r0.error_code == 4 and not r0.valid
+    k_prev0, _ = o.keypoints(0, 0)
+    blank = np.full_like(g["L0"], 128)
+    rb = o.process(blank, blank, cam)                      # nothing to track -> bad tracking
+    assert rb.error_code == 5 and not rb.valid and rb.detected_left[0] == 0
+    r2 = o.process(g["L1"], g["R1"], cam)                  # prev must still be frame 0
+    kp, _ = o.keypoints(1, 0)
+    assert kp.tobytes() == k_prev0.tobytes()
+    assert r2.valid and r2.tracked_feats_from_last_frame == int(g["scalars1"][4])
+    # repeat=True keeps prev as well (P:86, 91-92)
+    r3 = o.process(g["L2"], g["R2"], cam, repeat=True)
+    kp, _ = o.keypoints(1, 0)
+    assert kp.tobytes() == k_prev0.tobytes() and r3.error_code in (0, 5)
+
+
+def test_config1_plumbing_sequence_tracks_ground_truth():
+    """BASELINE.json configs[0]: 20-frame 640x480 synthetic sequence, CPU only; poses follow the generator's
+    ground truth and chain like the demo does (demo-main.cpp:235-242 with K = identity)."""
+    w = SyntheticStereoWorld(640, 480, 400.0, 0.12, seed=11, n_frames=20)
+    cam = w.camera()
+    o = O.Oracle(north_star_params(O.default_params(), orb_nfeats=500))
+    pose = np.eye(4)
+    n_valid = 0
+    errs = []
+    for t in range(20):
+        L, R = [x.numpy() for x in w.render(t)]
+        r = o.process(L, R, cam)
+        if t == 0:
+            assert r.error_code == 4
+            continue
+        if r.valid:
+            n_valid += 1
+            est = pose6_to_matrix(np.array(r.outPose))
+            errs.append(pose_error(est, w.gt_delta(t)))
+            pose = pose @ est
+    assert n_valid >= 18
+    errs = np.array(errs)
+    assert np.median(errs[:, 0]) < 3e-3 and np.median(errs[:, 1]) < 0.03
+    er, et = pose_error(pose, w.poses[19])
+    assert er < 0.03 and et < 0.35
