@@ -1,0 +1,146 @@
+/* svo_hip.h -- C-ABI of the MI355X (gfx950) stereo-VO hot path.  Shared library: stereo_vo_amd/libsvo_hip.so
+ *
+ * Drop-in boundary for stages 2-5 of rso::CStereoOdometryEstimator::processNewImagePair()
+ * (libstereo-odometry/src/process_new_image_pair.cpp:41-385, "P"; declarations in
+ * libstereo-odometry/include/libstereo-odometry.h, "H").  Plain pointers and sizes only; every call returns an
+ * int status (0 = ok, <0 = error, see svo_strerror) and never throws.  Out-buffers are caller-owned with their
+ * capacity passed in; device buffers are context-owned and persist across frames (the previous frame's
+ * keypoints / descriptors / pairings stay in HBM).
+ *
+ * One context drives `n_lanes` INDEPENDENT estimator streams ("lanes") through every kernel launch together:
+ * a lane is what one rso::CStereoOdometryEstimator instance is in the reference (all of its state is
+ * per-instance, H:732-831), and batching lanes per launch is how a 256-CU device is filled by a workload whose
+ * single-stream form is launch-latency bound.  A context with n_lanes = 1 is exactly one
+ * estimator.  There is no CPU fallback: without a HIP device svo_create fails.
+ */
+#ifndef SVO_HIP_H
+#define SVO_HIP_H
+#include "svo_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_MAX_LANES 64
+#define SVO_MAX_LEVELS 8
+
+/* status codes */
+enum {
+    SVO_OK = 0, SVO_ERR_HIP = -1, SVO_ERR_ARG = -2, SVO_ERR_UNSUPPORTED = -3, SVO_ERR_NO_DEVICE = -4,
+    SVO_ERR_CAPACITY = -5, SVO_ERR_STATE = -6
+};
+
+/* svo_process flags */
+enum {
+    SVO_RUN_DETECT = 1,     /* stage 2  (P:166-167 -> stage2_detect_features, H:1017)  */
+    SVO_RUN_MATCH = 2,      /* stage 3  (P:269 -> stage3_match_left_right, H:1025)     */
+    SVO_RUN_TRACK = 4,      /* stage 4  (P:314 -> stage4_track, H:1033)                */
+    SVO_RUN_OPTIMIZE = 8,   /* stage 5  (P:338 -> stage5_optimize, H:1041)             */
+    SVO_RUN_ALL = 15,
+    SVO_FLAG_REPEAT = 16,   /* request_data.repeat (H:221, P:86-92)                    */
+    SVO_FLAG_NO_SHIFT = 32, /* do not run the prev/cur shift of P:86-100 (staged tests and the
+                               precomputed-data bypass of P:131-162 / P:219-251 after svo_put_*) */
+    SVO_FLAG_DEVICE_IMAGES = 64  /* svo_image.data are device pointers (already resident in HBM) */
+};
+
+typedef struct svo_ctx svo_ctx;
+
+typedef struct svo_config {
+    int32_t device;         /* HIP device ordinal */
+    int32_t n_lanes;        /* 1..SVO_MAX_LANES independent estimator streams per launch */
+    int32_t max_w, max_h;   /* largest image the context will see */
+    int32_t max_kps;        /* capacity of every keypoint / pairing list (power of two, <= 8192) */
+    int32_t max_cand;       /* capacity of the per-level FAST candidate list at level 0 (scaled by area above) */
+    int32_t kernel_times;   /* 1: bracket every kernel with HIP events (svo_kernel_times) */
+    int32_t _pad;
+    void*   stream;         /* hipStream_t to run on; NULL = the context creates its own */
+} svo_config;
+
+/* 8-bit gray, row-major (what stage 1 hands to stage 2: S1:47-85 is outside this library) */
+typedef struct svo_image {
+    const uint8_t* data;
+    int32_t w, h;
+    int64_t stride;         /* bytes between rows */
+} svo_image;
+
+typedef struct svo_frame {  /* one lane's rectified stereo pair (request_data.stereo_imgs, H:208) */
+    svo_image left, right;
+} svo_frame;
+
+void svo_config_defaults(svo_config* c);
+void svo_params_defaults(svo_params* p);          /* reference defaults, north-star selectors (svo_types.h) */
+
+int  svo_create(const svo_config* cfg, svo_ctx** out);
+void svo_destroy(svo_ctx* ctx);
+const char* svo_strerror(int status);
+const char* svo_last_error(const svo_ctx* ctx);   /* text of the last HIP failure */
+
+/* loadParamsFromConfigFile (H:554-663): stores the record, then resetFASTThreshold / resetORBThreshold */
+int svo_set_params(svo_ctx* ctx, const svo_params* p);
+int svo_get_params(const svo_ctx* ctx, svo_params* p);
+int svo_set_fast_threshold(svo_ctx* ctx, int v);  /* setFASTThreshold, clamped (H:531) */
+int svo_set_orb_threshold(svo_ctx* ctx, int v);   /* setORBThreshold, clamped (H:538) */
+int svo_get_fast_threshold(const svo_ctx* ctx);
+int svo_get_orb_threshold(const svo_ctx* ctx);
+/* request_data.stereo_cam (H:211), per lane; lane = -1 sets every lane */
+int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam);
+/* forget both frames and the warm start of one lane (a freshly constructed estimator, C:28-50); -1 = all */
+int svo_reset(svo_ctx* ctx, int lane);
+
+/* processNewImagePair for every lane (P:41-385): ENQUEUES the whole frame on the context's stream and
+ * returns; frames[lane] for lane in [0,n_lanes).  Nothing is copied back until svo_wait/svo_get_*. */
+int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags);
+/* block until every enqueued frame has finished */
+int svo_wait(svo_ctx* ctx);
+/* TStereoOdometryResult of the last frame, per lane (H:235-264); implies svo_wait */
+int svo_get_result(svo_ctx* ctx, int lane, svo_result* res);
+int svo_get_results(svo_ctx* ctx, svo_result* res /* n_lanes entries */);
+
+/* getValues (H:704-724) and friends.  which: 0 = current frame, 1 = previous frame; side: 0 left, 1 right.
+ * Each returns the list length (possibly > cap; only min(len,cap) entries are written) or <0. */
+int svo_get_keypoints(svo_ctx* ctx, int lane, int which, int side, svo_keypoint* kps, uint8_t* desc, int cap);
+int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* m, int cap);
+int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int cap);          /* tracked_pairs[0] (H:823) */
+int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap);                /* result.out_residual */
+int svo_get_outliers(svo_ctx* ctx, int lane, int32_t* idx, int cap);              /* result.outliers */
+
+/* the precomputed-data bypass (request_data.use_precomputed_data, H:214-218, P:131-162, P:219-251):
+ * load caller-supplied features / pairings into a lane's current (which=0) or previous (which=1) frame. */
+int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keypoint* kps, const uint8_t* desc, int n,
+                     int img_w, int img_h);
+int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n);
+int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n);
+
+/* getChangeInPose (H:162-172, C:355-413): stage 5 alone on caller arrays, lane 0 of the context.
+ * residual: n_tracked doubles; outliers: n_tracked int32 (holds INLIER cur-match indices, S5:603-610).
+ * init6 may be NULL.  Returns result.valid (0/1) or <0. */
+int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, int n_tracked,
+                       const svo_dmatch* pre_matches, int n_pre, const svo_dmatch* cur_matches, int n_cur,
+                       const svo_keypoint* pre_left, int n_pl, const svo_keypoint* pre_right, int n_pr,
+                       const svo_keypoint* cur_left, int n_cl, const svo_keypoint* cur_right, int n_cr,
+                       const svo_stereo_camera* cam, const double* init6,
+                       svo_result* res, double* residual, int32_t* outliers);
+
+/* cv::BFMatcher(NORM_HAMMING,false).match stand-in (S3:88-94, S4:141-142) on caller arrays (host pointers):
+ * for each of nq 32-byte query rows the FIRST minimum-distance train row.  idx = -1 when nt == 0. */
+int svo_hamming_match(svo_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                      int32_t* idx, int32_t* dist);
+
+/* debugging / parity probes */
+int svo_debug_get_level(svo_ctx* ctx, int lane, int side, int level, uint8_t* out, int cap, int* w, int* h);
+int svo_debug_get_raw_keypoints(svo_ctx* ctx, int lane, int side, svo_keypoint* kps, uint8_t* desc, int cap);
+int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w);   /* capacity-overflow bits */
+
+/* per-kernel HIP-event timing (svo_config.kernel_times = 1): names[i] points to static storage.
+ * total_ms[i] / calls[i] accumulate since the last svo_kernel_times_reset. Returns number of kernels. */
+int svo_kernel_times(svo_ctx* ctx, const char** names, double* total_ms, int64_t* calls, int cap);
+int svo_kernel_times_reset(svo_ctx* ctx);
+
+/* sizeof() of the ABI records as this library was compiled: out[0..5] = keypoint, dmatch, stereo_camera,
+ * params, result, config.  Lets a binding verify its mirror of svo_types.h. */
+void svo_abi_sizes(int32_t* out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,525 @@
+// k_detect.hip -- stage 2 on the device: pyramid, FAST-9/16 + 3x3 NMS, per-level top-K, Harris, orientation,
+// steered BRIEF-256, then the reference's own grid NMS and row sort.
+//
+// Replaces cv::ORB::detectAndCompute as called at libstereo-odometry/src/stage2_detect.cpp:482-493 and the
+// reference's m_non_max_sup (stage2_detect.cpp:296-370) + m_update_indexes (stage2_detect.cpp:65-130).
+// Every formula is the one frozen in oracle/svo_oracle.c; integer work is bit-exact by construction and the few
+// float expressions are written one IEEE operation per operator (compiled with -ffp-contract=off).
+#include "svo_device.h"
+#include "svo_kernels.h"
+#include "../../include/svo_orb_tables.h"
+
+// device copies of the frozen tables
+__constant__ int c_umax[16];
+__constant__ int c_gauss7[7];
+__device__ __attribute__((aligned(16))) int8_t g_brief_rot[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS * 4];
+
+hipError_t svo_upload_tables()
+{
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_umax), svo_umax, sizeof(svo_umax));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_gauss7), svo_gauss7, sizeof(svo_gauss7));
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_brief_rot), svo_brief_rot, sizeof(svo_brief_rot));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// begin_frame: publish the level-0 pointers, clear the per-frame counters, and apply the prev/cur shift with
+// the reference's recovery rule (process_new_image_pair.cpp:86-100): the previous frame is replaced by the
+// current one unless this is a repeat or the last call ended in voecBadTracking / voecBadCondNumber.
+// ------------------------------------------------------------------------------------------------------------
+struct ImgPtrs { const uint8_t* p[2 * SVO_MAX_LANES]; };
+
+__global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool detect = flags & SVO_RUN_DETECT, do_shift = !(flags & SVO_FLAG_NO_SHIFT), repeat = flags & SVO_FLAG_REPEAT;
+    if (detect) {
+        if (t < c.n_img) { c.img0[t] = ptrs.p[t]; c.raw_n[t] = 0; }
+        if (t < c.n_img * SVO_MAX_LEVELS) { c.cand_cnt[t] = 0; c.lvl_n[t] = 0; }
+    }
+    if (t < c.n_lanes) {
+        LaneState& s = c.lane[t];
+        if (do_shift) {
+            if (!repeat && s.m_error != SVO_VOEC_BAD_TRACKING && s.m_error != SVO_VOEC_BAD_COND_NUMBER) {
+                if (s.has_cur) { s.prev_slot = 1 - s.prev_slot; s.has_prev = 1; }     // m_prev_imgpair = m_current_imgpair (P:86-89)
+            }
+            s.m_error = SVO_VOEC_NONE;                                                 // P:95
+            s.has_cur = 1;                                                             // P:100
+            const int cur = 1 - s.prev_slot;
+            c.n_kps[feat_cnt_idx(t, cur, 0)] = 0; c.n_kps[feat_cnt_idx(t, cur, 1)] = 0;
+            c.n_matches[t * 2 + cur] = 0;
+            if (!repeat) s.it_counter++;                                               // P:380-381
+        }
+        if (flags & SVO_RUN_TRACK) c.n_tracked[t] = 0;
+        if (detect) c.status[t] = 0;
+        svo_result& r = c.results[t];
+        r.error_code = SVO_VOEC_NONE;                                                  // P:50
+        r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = 1;
+        r.tracked_feats_from_last_frame = 0; r.tracked_feats_from_last_KF = 0;
+        for (int k = 0; k < 6; k++) { r.outPose[k] = 0; r.delta[k] = 0; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1: one pyramid level from the previous one, bilinear with the frozen 11-bit integer tables.
+// HBM-bound: reads ~1.44 source bytes and writes 1 byte per output pixel.  Each thread produces 4 adjacent
+// pixels and stores them as one dword (rows are 64-byte aligned).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
+{
+    const int img = blockIdx.z;
+    const LevelGeom& d = c.lv[level];
+    const LevelGeom& s = c.lv[level - 1];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x4 >= d.w || y >= d.h) return;
+    int spitch; const uint8_t* src = level_ptr(c, img, level - 1, spitch);
+    uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
+    const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
+    const int y0 = yi[y], ay = yf[y], y1 = y0 + 1 < s.h ? y0 + 1 : s.h - 1;
+    const uint8_t* r0 = src + (long long)y0 * spitch, *r1 = src + (long long)y1 * spitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        if (x < d.w) {
+            const int x0 = xi[x], ax = xf[x], x1 = x0 + 1 < s.w ? x0 + 1 : s.w - 1;
+            const int v = r0[x0] * (2048 - ax) * (2048 - ay) + r0[x1] * ax * (2048 - ay) + r1[x0] * (2048 - ax) * ay + r1[x1] * ax * ay;
+            out |= (uint32_t)((v + (1 << 21)) >> 22) << (8 * k);
+        }
+    }
+    *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64 and >= w rounded up to 4
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
+// Tile = 64x16 interior pixels; the 72x24 source window (3 px circle radius + 1 px NMS halo) is staged in LDS
+// with coalesced row loads, scores of the 66x18 window go to LDS, then the interior is suppressed and the
+// survivors are appended to the level's candidate list (the compiler aggregates the atomic per wave).
+// ------------------------------------------------------------------------------------------------------------
+#define FT_W 64
+#define FT_H 16
+#define FT_LW (FT_W + 8)
+#define FT_LH (FT_H + 8)
+#define FT_SW (FT_W + 2)
+#define FT_SH (FT_H + 2)
+
+__device__ __forceinline__ int fast_score_lds(const uint8_t* p, int th)
+{
+    // p points at the centre pixel inside the LDS tile (row pitch FT_LW)
+    const int c = p[0];
+    int d[16];
+    d[0] = p[-3 * FT_LW]; d[1] = p[-3 * FT_LW + 1]; d[2] = p[-2 * FT_LW + 2]; d[3] = p[-FT_LW + 3];
+    d[4] = p[3]; d[5] = p[FT_LW + 3]; d[6] = p[2 * FT_LW + 2]; d[7] = p[3 * FT_LW + 1];
+    d[8] = p[3 * FT_LW]; d[9] = p[3 * FT_LW - 1]; d[10] = p[2 * FT_LW - 2]; d[11] = p[FT_LW - 3];
+    d[12] = p[-3]; d[13] = p[-FT_LW - 3]; d[14] = p[-2 * FT_LW - 2]; d[15] = p[-3 * FT_LW - 1];
+    unsigned bright = 0, dark = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { d[i] -= c; bright |= (unsigned)(d[i] > th) << i; dark |= (unsigned)(-d[i] > th) << i; }
+    unsigned rb = bright | (bright << 16), rd = dark | (dark << 16);
+    unsigned xb = rb & (rb >> 1); xb &= xb >> 2; xb &= xb >> 4; xb &= rb >> 8;
+    unsigned xd = rd & (rd >> 1); xd &= xd >> 2; xd &= xd >> 4; xd &= rd >> 8;
+    if (!((xb | xd) & 0xFFFFu)) return 0;
+    // score: max over the 16 arcs of the min one-sided difference (log-step min over 2,4,8 then the 9th)
+    int best = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        int v[16], a[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = pass ? -d[i] : d[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = min(v[i], v[(i + 1) & 15]);
+        int b[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) b[i] = min(a[i], a[(i + 2) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = min(b[i], b[(i + 4) & 15]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) best = max(best, min(a[i], v[(i + 8) & 15]));
+    }
+    return best - 1;
+}
+
+__global__ void __launch_bounds__(256) k_fast(DevCtx c)
+{
+    __shared__ uint8_t tile[FT_LH * FT_LW];
+    __shared__ uint8_t score[FT_SH * FT_SW];
+    const int img = blockIdx.y;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && (int)blockIdx.x >= c.lv[l].tile_off) level = l;
+    const LevelGeom& g = c.lv[level];
+    const int t = blockIdx.x - g.tile_off;
+    const int tx = t % g.tiles_x, ty = t / g.tiles_x;
+    const int x0 = SVO_EDGE + tx * FT_W, y0 = SVO_EDGE + ty * FT_H;      // interior origin
+    int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
+    // stage the window [x0-4, x0+68) x [y0-4, y0+20); always inside the image because EDGE >= 4 on the low side,
+    // clamped on the high side (clamped pixels only feed positions that are masked out below)
+    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += blockDim.x) {
+        const int r = i / (FT_LW / 4), q = i % (FT_LW / 4);
+        const int yy = min(y0 - 4 + r, g.h - 1);
+        const int xx = x0 - 4 + q * 4;
+        const uint8_t* rp = src + (long long)yy * pitch;
+        uint32_t w;
+        if (xx + 3 < g.w) { w = rp[xx] | (rp[xx + 1] << 8) | (rp[xx + 2] << 16) | ((uint32_t)rp[xx + 3] << 24); }
+        else { w = 0; for (int k = 0; k < 4; k++) w |= (uint32_t)rp[min(xx + k, g.w - 1)] << (8 * k); }
+        *(uint32_t*)&tile[r * FT_LW + q * 4] = w;
+    }
+    __syncthreads();
+    // scores on the 66x18 window = interior + 1 px halo; only positions in [EDGE-1, w-EDGE+1) are evaluated
+    for (int i = threadIdx.x; i < FT_SH * FT_SW; i += blockDim.x) {
+        const int r = i / FT_SW, q = i % FT_SW;
+        const int x = x0 - 1 + q, y = y0 - 1 + r;
+        int s = 0;
+        if (x < g.w - SVO_EDGE + 1 && y < g.h - SVO_EDGE + 1) s = fast_score_lds(&tile[(r + 3) * FT_LW + (q + 3)], c.fast_th);
+        score[i] = (uint8_t)s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FT_H * FT_W; i += blockDim.x) {
+        const int r = i / FT_W, q = i % FT_W;
+        const int x = x0 + q, y = y0 + r;
+        const uint8_t* s = &score[(r + 1) * FT_SW + (q + 1)];
+        const int v = s[0];
+        const bool keep = v && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE &&
+            v > s[-1] && v > s[1] && v > s[-FT_SW - 1] && v > s[-FT_SW] && v > s[-FT_SW + 1] && v > s[FT_SW - 1] && v > s[FT_SW] && v > s[FT_SW + 1];
+        if (keep) {
+            const uint32_t slot = atomicAdd(&c.cand_cnt[img * SVO_MAX_LEVELS + level], 1u);
+            if (slot < (uint32_t)g.cand_cap)
+                c.cand_keys[(long long)img * c.cand_total + g.cand_off + slot] = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
+            else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3: per (image, level): keep the best 2*quota corners by (FAST score desc, position asc) with a 4-pass radix
+// select on the unique 32-bit keys, compute the Harris response of each, sort by (response desc, position asc)
+// and keep the best quota.  One 512-thread block per (image, level).
+// ------------------------------------------------------------------------------------------------------------
+#define SEL_MAX 2048     // >= 2 * quota[0]
+
+__device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x, int y)
+{
+    int a = 0, b = 0, cc = 0;
+    for (int dy = -3; dy <= 3; dy++) {
+        const uint8_t* pm = img + (long long)(y + dy - 1) * pitch + x, *p0 = pm + pitch, *pp = p0 + pitch;
+#pragma unroll
+        for (int dx = -3; dx <= 3; dx++) {
+            const int Ix = ((int)p0[dx + 1] - (int)p0[dx - 1]) * 2 + ((int)pm[dx + 1] - (int)pm[dx - 1]) + ((int)pp[dx + 1] - (int)pp[dx - 1]);
+            const int Iy = ((int)pp[dx] - (int)pm[dx]) * 2 + ((int)pp[dx - 1] - (int)pm[dx - 1]) + ((int)pp[dx + 1] - (int)pm[dx + 1]);
+            a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
+        }
+    }
+    const float s = 1.0f / (4.0f * 7.0f * 255.0f);
+    const float s2 = s * s;
+    const float s4 = s2 * s2;
+    const float fa = (float)a, fb = (float)b, fc = (float)cc;
+    const float det = fa * fb - fc * fc;
+    const float tr = fa + fb;
+    const float k = 0.04f * (tr * tr);
+    return (det - k) * s4;
+}
+
+__global__ void __launch_bounds__(512) k_select(DevCtx c)
+{
+    __shared__ unsigned long long keys[SEL_MAX];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need, s_sel;
+    const int level = blockIdx.x, img = blockIdx.y;
+    const LevelGeom& g = c.lv[level];
+    const int tid = threadIdx.x;
+    unsigned nc = c.cand_cnt[img * SVO_MAX_LEVELS + level];
+    if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
+    const unsigned K = min(nc, (unsigned)(2 * g.quota));
+    if (K == 0 || g.quota <= 0) { if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; return; }
+    const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
+    // radix select: find the K-th largest key
+    unsigned prefix = 0, mask = 0, need = K;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u); }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0; int b = 255;
+            for (; b > 0; b--) { if (acc + hist[b] >= need) break; acc += hist[b]; }
+            s_prefix = prefix | ((unsigned)b << shift); s_need = need - acc;
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need; mask |= 255u << shift;
+        __syncthreads();
+    }
+    const uint32_t cutoff = prefix;     // exactly K keys are >= cutoff (keys are unique)
+    if (tid == 0) s_sel = 0;
+    for (int i = tid; i < SEL_MAX; i += blockDim.x) keys[i] = 0;
+    __syncthreads();
+    int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
+    for (unsigned i = tid; i < nc; i += blockDim.x) {
+        const uint32_t k = ck[i];
+        if (k >= cutoff) {
+            const unsigned slot = atomicAdd(&s_sel, 1u);
+            const uint32_t pos = 0xFFFFFFu - (k & 0xFFFFFFu);
+            const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
+            const float r = harris_at(lim, pitch, x, y);
+            if (slot < SEL_MAX) keys[slot] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
+        }
+    }
+    __syncthreads();
+    int P = 64; while (P < (int)K) P <<= 1;
+    bitonic_sort_lds<true>(keys, P);
+    const int nout = min((int)K, g.quota);
+    for (int i = tid; i < nout; i += blockDim.x) {
+        const unsigned long long k = keys[i];
+        c.lvl_pos[(long long)img * c.raw_cap + g.slot_off + i] = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+        c.lvl_resp[(long long)img * c.raw_cap + g.slot_off + i] = inv_ord32((uint32_t)(k >> 32));
+    }
+    if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = nout;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x37 window:
+// 7x7 sigma-2 integer Gaussian of the 31x31 patch, 256 pair tests packed with wave ballots.  One wave per
+// keypoint slot, 4 waves per block.
+// ------------------------------------------------------------------------------------------------------------
+#define DP_W 40      // LDS row pitch of the raw 37x37 window
+
+__device__ __forceinline__ float atan2_deg(float y, float x)
+{
+    const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, cq, c2;
+    if (ax >= ay) {
+        cq = ay / (ax + 2.220446e-16f);
+        c2 = cq * cq;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cq;
+    } else {
+        cq = ax / (ay + 2.220446e-16f);
+        c2 = cq * cq;
+        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cq;
+    }
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
+__global__ void __launch_bounds__(256) k_describe(DevCtx c)
+{
+    __shared__ uint8_t raw[4][37 * DP_W];
+    __shared__ unsigned short hb[4][37 * 32];    // horizontal pass, 31 valid columns
+    __shared__ uint8_t bl[4][31 * 32];           // blurred 31x31 patch
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wid;       // position in the level-segmented arrays
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
+    const LevelGeom& g = c.lv[level];
+    const int rank = slot - g.slot_off;
+    // wave-uniform predicate; idle waves still take part in the block barriers below
+    const bool active = slot < c.n_slots && rank < c.lvl_n[img * SVO_MAX_LEVELS + level];
+    int x = SVO_EDGE, y = SVO_EDGE;
+    if (active) { const uint32_t pos = c.lvl_pos[(long long)img * c.raw_cap + slot]; x = (int)(pos % (uint32_t)g.w); y = (int)(pos / (uint32_t)g.w); }
+    int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
+    uint8_t* R = raw[wid];
+    if (active)
+        for (int i = lane; i < 37 * 37; i += 64) {
+            const int r = i / 37, q = i - r * 37;
+            R[r * DP_W + q] = lim[(long long)(y - 18 + r) * pitch + (x - 18 + q)];
+        }
+    __syncthreads();
+    // moments over the radius-15 disc: lane = column u (31 lanes), loop over rows
+    int m10 = 0, m01 = 0;
+    if (active && lane < 31) {
+        const int u = lane - 15;
+        for (int v = -15; v <= 15; v++) {
+            const int um = c_umax[v < 0 ? -v : v];
+            if (u >= -um && u <= um) { const int I = R[(v + 18) * DP_W + (u + 18)]; m10 += u * I; m01 += v * I; }
+        }
+    }
+    m10 = wave_reduce_sum_i32(m10); m01 = wave_reduce_sum_i32(m01);
+    const float angle = atan2_deg((float)m01, (float)m10);
+    int bin = (int)(angle * (1.0f / 12.0f) + 0.5f);
+    if (bin >= SVO_BRIEF_NBINS) bin -= SVO_BRIEF_NBINS;
+    // separable integer Gaussian
+    unsigned short* Hb = hb[wid];
+    if (active)
+        for (int i = lane; i < 37 * 31; i += 64) {
+            const int r = i / 31, q = i - r * 31;
+            const uint8_t* p = &R[r * DP_W + q];      // columns q .. q+6 <-> patch column q-15 +- 3
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) s += c_gauss7[k] * p[k];
+            Hb[r * 32 + q] = (unsigned short)s;
+        }
+    __syncthreads();
+    uint8_t* B = bl[wid];
+    if (active)
+        for (int i = lane; i < 31 * 31; i += 64) {
+            const int r = i / 31, q = i - r * 31;
+            int s = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) s += c_gauss7[k] * Hb[(r + k) * 32 + q];
+            B[r * 32 + q] = (uint8_t)((s + 32768) >> 16);
+        }
+    __syncthreads();
+    if (!active) return;
+    const int8_t* pat = g_brief_rot + bin * (SVO_BRIEF_NPAIRS * 4);
+    unsigned long long bits[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = k * 64 + lane;
+        const int pr = *(const int*)(pat + i * 4);
+        const int ax = (int8_t)(pr & 0xFF), ay = (int8_t)((pr >> 8) & 0xFF), bx = (int8_t)((pr >> 16) & 0xFF), by = (int8_t)((pr >> 24) & 0xFF);
+        const int a = B[(ay + 15) * 32 + (ax + 15)], b = B[(by + 15) * 32 + (bx + 15)];
+        bits[k] = __ballot(a < b);
+    }
+    if (lane == 0) {
+        const long long o = (long long)img * c.raw_cap + slot;
+        unsigned long long* d = (unsigned long long*)(c.raw_desc + o * 32);
+        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+        svo_keypoint k;
+        k.x = (float)x * g.scale; k.y = (float)y * g.scale; k.size = 31.0f * g.scale; k.angle = angle;
+        k.response = c.lvl_resp[o]; k.octave = level; k.class_id = -1;
+        c.raw_kps[o] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K6: the reference's own post-processing of the detector output, one 1024-thread block per image:
+//   m_non_max_sup (stage2_detect.cpp:296-370): visit in (response desc, index asc) order, greedy grid occupancy;
+//   m_update_indexes(order=true) (stage2_detect.cpp:65-130): re-sort by (pt.y asc, rank asc).
+// Writes the final keypoints + descriptors of the lane's current slot.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int num_out_points, int NS_MAX)
+{
+    // dynamic LDS only (G17): keys[NS_MAX] u64 | hash[2*NS_MAX] u32 | acc_idx[NS_MAX] u16 | s_nacc
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NS_HASH = 2 * NS_MAX;
+    unsigned long long* keys = (unsigned long long*)smem;
+    uint32_t* hash = (uint32_t*)(keys + NS_MAX);
+    unsigned short* acc_idx = (unsigned short*)(hash + NS_HASH);          // raw index of the i-th survivor
+    int* s_nacc_p = (int*)(acc_idx + NS_MAX);
+#define s_nacc (*s_nacc_p)
+    const int img = blockIdx.x, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
+    const svo_keypoint* rk = c.raw_kps + (long long)img * c.raw_cap;
+    // compact the level-segmented winners into raw order: level 0 first, each level by Harris rank
+    int lvl_base[SVO_MAX_LEVELS + 1];
+    lvl_base[0] = 0;
+    for (int l = 0; l < SVO_MAX_LEVELS; l++) lvl_base[l + 1] = lvl_base[l] + (l < c.n_levels ? c.lvl_n[img * SVO_MAX_LEVELS + l] : 0);
+    const int n = lvl_base[c.n_levels];
+    for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = 0;
+    for (int i = tid; i < NS_HASH; i += blockDim.x) hash[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    // key = (response desc, raw index asc); the payload is the raw index, the slot is recovered from it
+    for (int l = 0; l < c.n_levels; l++) {
+        const int nl = lvl_base[l + 1] - lvl_base[l];
+        for (int i = tid; i < nl; i += blockDim.x) {
+            const int raw_i = lvl_base[l] + i;
+            const float resp = rk[c.lv[l].slot_off + i].response;
+            keys[raw_i] = ((unsigned long long)ord32(resp) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)raw_i);
+        }
+    }
+    __syncthreads();
+    int P = 64; while (P < n) P <<= 1;
+    if (do_nms) bitonic_sort_lds<true>(keys, P);
+    auto slot_of = [&](int raw_i) { int l = 0; for (int q = 1; q < SVO_MAX_LEVELS; q++) if (q < c.n_levels && raw_i >= lvl_base[q]) l = q; return c.lv[l].slot_off + (raw_i - lvl_base[l]); };
+    if (tid == 0) s_nacc = 0;
+    __syncthreads();
+    int nacc;
+    if (do_nms) {
+        const unsigned cell = (unsigned)((double)min_distance / 2.0);
+        const float inv = 1.0f / (float)cell;
+        const unsigned glx = (unsigned)(1 + (float)c.W * inv), gly = (unsigned)(1 + (float)c.H * inv);
+        if (tid < 64) {
+            const int r = grid_nms_wave(n, num_out_points, gly, hash, NS_HASH,
+                [&](int i, int& sx, int& sy) {
+                    const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+                    const svo_keypoint& k = rk[slot_of(raw_i)];
+                    const size_t ux = (size_t)(k.x * inv), uy = (size_t)(k.y * inv);
+                    sx = (int)ux; sy = (int)uy;
+                    return ux < glx && uy < gly;
+                },
+                [&](int i, int out) { acc_idx[out] = (unsigned short)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull)); });
+            if (tid == 0) s_nacc = r;
+        }
+        __syncthreads();
+        nacc = s_nacc;
+    } else {
+        for (int i = tid; i < n; i += blockDim.x) acc_idx[i] = (unsigned short)i;
+        nacc = n;
+        __syncthreads();
+    }
+    if (nacc > c.max_kps) { nacc = c.max_kps; if (tid == 0) atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); }
+    // row sort: (pt.y asc, survivor rank asc)
+    for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = ~0ull;
+    __syncthreads();
+    for (int i = tid; i < nacc; i += blockDim.x) keys[i] = ((unsigned long long)ord32(rk[slot_of(acc_idx[i])].y) << 32) | (unsigned)i;
+    __syncthreads();
+    P = 64; while (P < nacc) P <<= 1;
+    bitonic_sort_lds<false>(keys, P);
+    const int cur = 1 - c.lane[lane_id].prev_slot;
+    const long long ob = feat_base(c, lane_id, cur, side);
+    for (int i = tid; i < nacc; i += blockDim.x) {
+        const int s = slot_of(acc_idx[(int)(keys[i] & 0xFFFFFFFFull)]);
+        c.kps[ob + i] = rk[s];
+        const uint4* sd = (const uint4*)(c.raw_desc + ((long long)img * c.raw_cap + s) * 32);
+        uint4* dd = (uint4*)(c.desc + (ob + i) * 32);
+        dd[0] = sd[0]; dd[1] = sd[1];
+    }
+    if (tid == 0) {
+        c.n_kps[feat_cnt_idx(lane_id, cur, side)] = nacc;
+        c.raw_n[img] = n;
+        if (side == 0) c.results[lane_id].detected_left[0] = nacc; else c.results[lane_id].detected_right[0] = nacc;
+    }
+}
+#undef s_nacc
+
+// ------------------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------------------
+void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned flags, hipStream_t st)
+{
+    ImgPtrs ip;
+    for (int i = 0; i < 2 * SVO_MAX_LANES; i++) ip.p[i] = (ptrs && i < c.n_img) ? ptrs[i] : nullptr;
+    const int n = c.n_img * SVO_MAX_LEVELS;
+    hipLaunchKernelGGL(k_begin_frame, dim3((n + 255) / 256), dim3(256), 0, st, c, ip, flags);
+}
+
+void launch_resize(const DevCtx& c, int level, hipStream_t st)
+{
+    const LevelGeom& d = c.lv[level];
+    const int tx = (d.w + 3) / 4;
+    hipLaunchKernelGGL(k_resize, dim3((tx + 255) / 256, d.h, c.n_img), dim3(256), 0, st, c, level);
+}
+
+void launch_fast(const DevCtx& c, hipStream_t st)
+{
+    if (c.n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_fast, dim3(c.n_tiles, c.n_img), dim3(256), 0, st, c);
+}
+
+void launch_select(const DevCtx& c, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_select, dim3(c.n_levels, c.n_img), dim3(512), 0, st, c);
+}
+
+void launch_describe(const DevCtx& c, hipStream_t st)
+{
+    if (c.n_slots <= 0) return;
+    hipLaunchKernelGGL(k_describe, dim3((c.n_slots + 3) / 4, c.n_img), dim3(256), 0, st, c);
+}
+
+static int nms_pmax(const DevCtx& c) { int p = 64; while (p < c.raw_cap) p <<= 1; return p; }
+static size_t nms_rowsort_smem(int pmax) { return (size_t)pmax * (8 + 8 + 2) + 16; }
+
+hipError_t configure_nms_rowsort(const DevCtx& c)
+{
+    return hipFuncSetAttribute((const void*)k_nms_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(nms_pmax(c)));
+}
+
+void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int num_out_points, hipStream_t st)
+{
+    const int pmax = nms_pmax(c);
+    hipLaunchKernelGGL(k_nms_rowsort, dim3(c.n_img), dim3(1024), nms_rowsort_smem(pmax), st, c, do_nms, min_distance, num_out_points, pmax);
+}

@@ -1,0 +1,404 @@
+// k_gn.hip -- stage 5 on the device: one persistent 256-thread workgroup per lane runs the whole optimiser
+// (gather, grid-NMS mask, triangulation, both Gauss-Newton phases, residual gating, pose inverse) in ONE launch
+// with no host round trip.
+//
+// Replaces stage5_optimize (libstereo-odometry/src/stage5_optimization.cpp:392-736), m_evalRGN (:275-390) and
+// m_pinhole_stereo_projection (:35-257).  Double precision throughout, like the reference.  The 28 sums of one
+// iteration (21 of J^T J, 6 of J^T r, cost) are reduced with wavefront shuffles and a 4-wave LDS step: the
+// Jacobian block is 4T x 6 with a 6x6 output, far too thin for an MFMA tile.
+// The reduction order differs from the reference's sequential loop, so results agree with the oracle to rounding
+// (tests: 1e-4 rad / 1e-3 m), not bit for bit.
+#include "svo_device.h"
+#include "svo_kernels.h"
+#include <float.h>
+
+struct Rot { double r[9]; double dr[3][9]; int small_angle; };
+
+// S5:45-163 (formulas kept as written, including the (w2^2+w3^2) factor of dr22dw3 at S5:162)
+__device__ void rodrigues_with_derivs(const double* dp, Rot& R)
+{
+    const double w1 = dp[0], w2 = dp[1], w3 = dp[2];
+    const double w12 = w1 * w1, w22 = w2 * w2, w32 = w3 * w3;
+    const double tt = sqrt(w1 * w1 + w2 * w2 + w3 * w3);
+    const double tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt;
+    const double sin_tt = sin(tt), cos_tt = cos(tt);
+    double* r = R.r;
+    for (int i = 0; i < 9; i++) { R.dr[0][i] = 0; R.dr[1][i] = 0; R.dr[2][i] = 0; }
+    if (tt < 1e-5) {
+        R.small_angle = 1;
+        r[0] = 1; r[1] = -w3; r[2] = w2; r[3] = w3; r[4] = 1; r[5] = -w1; r[6] = -w2; r[7] = w1; r[8] = 1;
+        return;
+    }
+    R.small_angle = 0;
+    const double u = (cos_tt - 1) / tt2;
+    const double dudw1 = ((-sin_tt * w1 / tt) * tt2 - (cos_tt - 1) * 2 * w1) / tt4;
+    const double dudw2 = ((-sin_tt * w2 / tt) * tt2 - (cos_tt - 1) * 2 * w2) / tt4;
+    const double dudw3 = ((-sin_tt * w3 / tt) * tt2 - (cos_tt - 1) * 2 * w3) / tt4;
+    const double v = sin_tt / tt;
+    const double dvdw1 = w1 * (tt * cos_tt - sin_tt) / tt3;
+    const double dvdw2 = w2 * (tt * cos_tt - sin_tt) / tt3;
+    const double dvdw3 = w3 * (tt * cos_tt - sin_tt) / tt3;
+    r[0] = (w22 + w32) * u + 1; r[1] = -w3 * v - w1 * w2 * u; r[2] = w2 * v - w1 * w3 * u;
+    r[3] = w3 * v - w1 * w2 * u; r[4] = (w12 + w32) * u + 1; r[5] = -w1 * v - w2 * w3 * u;
+    r[6] = -w2 * v - w1 * w3 * u; r[7] = w1 * v - w2 * w3 * u; r[8] = (w12 + w22) * u + 1;
+    double (*d)[9] = R.dr;
+    d[0][0] = (w22 + w32) * dudw1; d[1][0] = 2 * w2 * u + (w22 + w32) * dudw2; d[2][0] = 2 * w3 * u + (w22 + w32) * dudw3;
+    d[0][1] = -w3 * dvdw1 - (w2 * u + w1 * w2 * dudw1); d[1][1] = -w3 * dvdw2 - (w1 * u + w1 * w2 * dudw2); d[2][1] = -(v + w3 * dvdw3) - w1 * w2 * dudw3;
+    d[0][2] = w2 * dvdw1 - (w3 * u + w1 * w3 * dudw1); d[1][2] = (v + w2 * dvdw2) - w1 * w3 * dudw2; d[2][2] = w2 * dvdw3 - (w1 * u + w1 * w3 * dudw3);
+    d[0][3] = w3 * dvdw1 - (w2 * u + w1 * w2 * dudw1); d[1][3] = w3 * dvdw2 - (w1 * u + w1 * w2 * dudw2); d[2][3] = (v + w3 * dvdw3) - w1 * w2 * dudw3;
+    d[0][4] = 2 * w1 * u + (w12 + w32) * dudw1; d[1][4] = (w12 + w32) * dudw2; d[2][4] = 2 * w3 * u + (w12 + w32) * dudw3;
+    d[0][5] = -(v + w1 * dvdw1) - w2 * w3 * dudw1; d[1][5] = -w1 * dvdw2 - (w3 * u + w2 * w3 * dudw2); d[2][5] = -w1 * dvdw3 - (w2 * u + w2 * w3 * dudw3);
+    d[0][6] = -w2 * dvdw1 - (w3 * u + w1 * w3 * dudw1); d[1][6] = -(v + w2 * dvdw2) - w1 * w3 * dudw2; d[2][6] = -w2 * dvdw3 - (w1 * u + w1 * w3 * dudw3);
+    d[0][7] = (v + w1 * dvdw1) - w2 * w3 * dudw1; d[1][7] = w1 * dvdw2 - (w3 * u + w2 * w3 * dudw2); d[2][7] = w1 * dvdw3 - (w2 * u + w2 * w3 * dudw3);
+    d[0][8] = 2 * w1 * u + (w12 + w22) * dudw1; d[1][8] = 2 * w2 * u + (w12 + w22) * dudw2; d[2][8] = (w22 + w32) * dudw3;
+}
+
+// 6x6 symmetric solve (Eigen::JacobiSVD(H).solve(g) stand-in, S5:375-388).  Well-conditioned systems go through
+// a Cholesky factorisation; anything else falls back to the oracle's Jacobi pseudo-inverse with Eigen's rank
+// threshold.  Returns 0 when the condition number would be NaN (voecBadCondNumber).
+__device__ int solve_sym6(const double* H, const double* g, double* x)
+{
+    double dmax = 0; bool bad = false;
+    for (int i = 0; i < 36; i++) if (isnan(H[i]) || isinf(H[i])) bad = true;
+    for (int i = 0; i < 6; i++) { if (isnan(g[i])) bad = true; dmax = fmax(dmax, fabs(H[i * 7])); }
+    if (bad) return 0;
+    double L[36];
+    bool spd = dmax > 0;
+    if (spd) {
+        for (int j = 0; j < 6 && spd; j++) {
+            double s = H[j * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[j * 6 + k] * L[j * 6 + k];
+            if (!(s > 1e-13 * dmax)) { spd = false; break; }
+            const double ljj = sqrt(s);
+            L[j * 6 + j] = ljj;
+            for (int i = j + 1; i < 6; i++) {
+                double t = H[i * 6 + j];
+                for (int k = 0; k < j; k++) t -= L[i * 6 + k] * L[j * 6 + k];
+                L[i * 6 + j] = t / ljj;
+            }
+        }
+    }
+    if (spd) {
+        double y[6];
+        for (int i = 0; i < 6; i++) { double t = g[i]; for (int k = 0; k < i; k++) t -= L[i * 6 + k] * y[k]; y[i] = t / L[i * 6 + i]; }
+        for (int i = 5; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < 6; k++) t -= L[k * 6 + i] * x[k]; x[i] = t / L[i * 6 + i]; }
+        return 1;
+    }
+    // rank-deficient or indefinite: cyclic Jacobi eigen-decomposition + pseudo-inverse (oracle's solve_sym6)
+    double A[36], V[36];
+    for (int i = 0; i < 36; i++) { A[i] = H[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, dg = 0;
+        for (int p = 0; p < 6; p++) { dg += A[p * 7] * A[p * 7]; for (int q = p + 1; q < 6; q++) off += A[p * 6 + q] * A[p * 6 + q]; }
+        if (!(off > 1e-32 * dg)) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[p * 6 + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 6; k++) { const double akp = A[k * 6 + p], akq = A[k * 6 + q]; A[k * 6 + p] = cs * akp - sn * akq; A[k * 6 + q] = sn * akp + cs * akq; }
+                for (int k = 0; k < 6; k++) { const double apk = A[p * 6 + k], aqk = A[q * 6 + k]; A[p * 6 + k] = cs * apk - sn * aqk; A[q * 6 + k] = sn * apk + cs * aqk; }
+                for (int k = 0; k < 6; k++) { const double vkp = V[k * 6 + p], vkq = V[k * 6 + q]; V[k * 6 + p] = cs * vkp - sn * vkq; V[k * 6 + q] = sn * vkp + cs * vkq; }
+            }
+    }
+    double smax = 0, smin = DBL_MAX;
+    for (int i = 0; i < 6; i++) { const double s = fabs(A[i * 7]); if (s > smax) smax = s; if (s < smin) smin = s; }
+    const double cond = smax / smin;
+    if (isnan(cond)) return 0;
+    const double thr = 6.0 * DBL_EPSILON * smax;
+    for (int i = 0; i < 6; i++) x[i] = 0;
+    for (int i = 0; i < 6; i++) {
+        const double lam = A[i * 7];
+        if (!(fabs(lam) > thr)) continue;
+        double dot = 0;
+        for (int k = 0; k < 6; k++) dot += V[k * 6 + i] * g[k];
+        const double coef = dot / lam;
+        for (int k = 0; k < 6; k++) x[k] += coef * V[k * 6 + i];
+    }
+    return 1;
+}
+
+// CPose3D(CPose3DRotVec(delta).getInverse()) -> x y z yaw pitch roll (S5:717-718; oracle's svo_oracle_delta_to_pose)
+__device__ void delta_to_pose(const double* dp, double* pose)
+{
+    const double w1 = dp[0], w2 = dp[1], w3 = dp[2];
+    const double th = sqrt(w1 * w1 + w2 * w2 + w3 * w3);
+    double R[9];
+    if (th < 1e-10) { R[0] = 1; R[1] = -w3; R[2] = w2; R[3] = w3; R[4] = 1; R[5] = -w1; R[6] = -w2; R[7] = w1; R[8] = 1; }
+    else {
+        const double a = sin(th) / th, b = (1.0 - cos(th)) / (th * th);
+        R[0] = 1 - b * (w2 * w2 + w3 * w3); R[1] = -a * w3 + b * w1 * w2; R[2] = a * w2 + b * w1 * w3;
+        R[3] = a * w3 + b * w1 * w2; R[4] = 1 - b * (w1 * w1 + w3 * w3); R[5] = -a * w1 + b * w2 * w3;
+        R[6] = -a * w2 + b * w1 * w3; R[7] = a * w1 + b * w2 * w3; R[8] = 1 - b * (w1 * w1 + w2 * w2);
+    }
+    const double Ri[9] = { R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8] };
+    pose[0] = -(Ri[0] * dp[3] + Ri[1] * dp[4] + Ri[2] * dp[5]);
+    pose[1] = -(Ri[3] * dp[3] + Ri[4] * dp[4] + Ri[5] * dp[5]);
+    pose[2] = -(Ri[6] * dp[3] + Ri[7] * dp[4] + Ri[8] * dp[5]);
+    const double pitch = atan2(-Ri[6], hypot(Ri[0], Ri[3]));
+    double yaw, roll;
+    if (fabs(Ri[7]) + fabs(Ri[8]) < 10 * DBL_EPSILON) { roll = 0.0; yaw = pitch > 0 ? atan2(Ri[5], Ri[2]) : atan2(-Ri[5], -Ri[2]); }
+    else { roll = atan2(Ri[7], Ri[8]); yaw = atan2(Ri[3], Ri[0]); }
+    pose[3] = yaw; pose[4] = pitch; pose[5] = roll;
+}
+
+#define GN_NSUM 28
+struct GnShared {
+    double part[4][GN_NSUM];
+    double step[6];
+    double cost;
+    int ok;
+    int n_non_masked;
+};
+
+// one m_evalRGN (S5:275-390).  Every thread returns the same (ok, cost, step) through `sh`.
+__device__ void eval_rgn(const DevCtx& c, const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
+                         const double* lmk, const float* obs, double* residual, bool first_call, const double* delta, GnShared& sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    Rot R; rodrigues_with_derivs(delta, R);
+    const double b2 = P.use_robust_kernel ? P.kernel_param * P.kernel_param : 0;
+    const double b2_1 = P.use_robust_kernel ? 1. / b2 : 0;
+    double acc[GN_NSUM];
+#pragma unroll
+    for (int i = 0; i < GN_NSUM; i++) acc[i] = 0;
+    for (int m = tid; m < T; m += blockDim.x) {
+        if (first_call) residual[m] = DBL_MAX;                                  // S5:296
+        if (!mask[m]) continue;
+        const double X1p = lmk[3 * m], Y1p = lmk[3 * m + 1], Z1p = lmk[3 * m + 2];
+        const double* r = R.r;
+        const double X1c = r[0] * X1p + r[1] * Y1p + r[2] * Z1p + delta[3];
+        const double Y1c = r[3] * X1p + r[4] * Y1p + r[5] * Z1p + delta[4];
+        const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + delta[5];
+        const double X2c = X1c - cam.baseline;
+        const float pl_x = (float)(cam.l_fx * X1c / Z1c + cam.l_cx), pl_y = (float)(cam.l_fy * Y1c / Z1c + cam.l_cy);
+        const float pr_x = (float)(cam.r_fx * X2c / Z1c + cam.r_cx), pr_y = (float)(cam.r_fy * Y1c / Z1c + cam.r_cy);
+        double J[4][6];
+        bool good = true;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double X1cd, Y1cd, Z1cd;
+            if (j < 3) {
+                if (R.small_angle) {
+                    if (j == 0) { X1cd = 0; Y1cd = -Z1p; Z1cd = Y1p; }
+                    else if (j == 1) { X1cd = Z1p; Y1cd = 0; Z1cd = -X1p; }
+                    else { X1cd = -Y1p; Y1cd = X1p; Z1cd = 0; }
+                } else {
+                    const double* d = R.dr[j];
+                    X1cd = d[0] * X1p + d[1] * Y1p + d[2] * Z1p;
+                    Y1cd = d[3] * X1p + d[4] * Y1p + d[5] * Z1p;
+                    Z1cd = d[6] * X1p + d[7] * Y1p + d[8] * Z1p;
+                }
+            } else { X1cd = j == 3; Y1cd = j == 4; Z1cd = j == 5; }
+            J[0][j] = cam.l_fx * (X1cd * Z1c - X1c * Z1cd) / (Z1c * Z1c);
+            J[1][j] = cam.l_fy * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
+            J[2][j] = cam.r_fx * (X1cd * Z1c - X2c * Z1cd) / (Z1c * Z1c);
+            J[3][j] = cam.r_fy * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
+            if (isnan(J[0][j]) || isinf(J[0][j]) || isnan(J[1][j]) || isinf(J[1][j]) || isnan(J[2][j]) || isinf(J[2][j]) || isnan(J[3][j]) || isinf(J[3][j])) good = false;
+        }
+        if (!good) continue;                                                   // S5:322
+        const float* o = obs + 8 * (long long)m;
+        const double ri[4] = { (double)(o[4] - pl_x), (double)(o[5] - pl_y), (double)(o[6] - pr_x), (double)(o[7] - pr_y) };   // float subtraction, S5:335-338
+        const double s = ri[0] * ri[0] + ri[1] * ri[1] + ri[2] * ri[2] + ri[3] * ri[3];
+        residual[m] = s;                                                        // S5:345
+        double rho_p = 1, fi;
+        if (P.use_robust_kernel) { const double nn = sqrt(1 + (s * b2_1)); rho_p = 1 / nn; fi = b2 * (nn - 1); }
+        else fi = 0.5 * s;
+        acc[27] += fi;
+        int h = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double jr = J[0][a] * ri[0] + J[1][a] * ri[1] + J[2][a] * ri[2] + J[3][a] * ri[3];
+            acc[21 + a] += rho_p * jr;                                          // gradient weighted ...
+#pragma unroll
+            for (int b = a; b < 6; b++) { acc[h] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b] + J[3][a] * J[3][b]; h++; }   // ... Hessian NOT (S5:364-369)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GN_NSUM; i++) { const double v = wave_reduce_sum_f64(acc[i]); if (lane == 0) sh.part[wid][i] = v; }
+    __syncthreads();
+    if (tid == 0) {
+        double tot[GN_NSUM];
+        for (int i = 0; i < GN_NSUM; i++) tot[i] = ((sh.part[0][i] + sh.part[1][i]) + sh.part[2][i]) + sh.part[3][i];
+        double H[36], g[6], x[6] = { 0, 0, 0, 0, 0, 0 };
+        int h = 0;
+        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { H[a * 6 + b] = tot[h]; H[b * 6 + a] = tot[h]; h++; }
+        for (int a = 0; a < 6; a++) g[a] = tot[21 + a];
+        sh.ok = solve_sym6(H, g, x);
+        sh.cost = tot[27];
+        for (int a = 0; a < 6; a++) sh.step[a] = x[a];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PM = P.pmax;                                        // power of two >= max_kps
+    unsigned long long* keys = (unsigned long long*)smem;         // PM
+    uint32_t* hash = (uint32_t*)(keys + PM);                      // 2*PM
+    unsigned char* mask = (unsigned char*)(hash + 2 * PM);        // PM
+    int* scan = (int*)(mask + PM);                                // 32
+    GnShared* shp = (GnShared*)(scan + 32);
+    GnShared& sh = *shp;
+    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    LaneState& ls = c.lane[lane_id];
+    svo_result& res = c.results[lane_id];
+    if (!P.standalone && (!ls.has_prev || ls.m_error == SVO_VOEC_BAD_TRACKING)) return;      // P:305, P:332
+    const svo_stereo_camera cam = c.cams[lane_id];
+    const int T = c.n_tracked[lane_id];
+    const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
+    const svo_index_pair* trk = c.tracked + (long long)lane_id * c.max_kps;
+    const svo_dmatch* pm = c.matches + match_base(c, lane_id, prev), *cm = c.matches + match_base(c, lane_id, cur);
+    const svo_keypoint* pkl = c.kps + feat_base(c, lane_id, prev, 0), *pkr = c.kps + feat_base(c, lane_id, prev, 1);
+    const svo_keypoint* ckl = c.kps + feat_base(c, lane_id, cur, 0), *ckr = c.kps + feat_base(c, lane_id, cur, 1);
+    float* obs = c.gn_obs + (long long)lane_id * c.max_kps * 8;
+    double* lmk = c.gn_lmk + (long long)lane_id * c.max_kps * 3;
+    double* residual = c.residual + (long long)lane_id * c.max_kps;
+    int* outl = c.outliers + (long long)lane_id * c.max_kps;
+    // ---- gather the four keypoint lists (S5:419-461, single octave) and the NMS sort keys ----
+    for (int i = tid; i < PM; i += blockDim.x) { keys[i] = 0; mask[i] = 0; }
+    for (int i = tid; i < 2 * PM; i += blockDim.x) hash[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int i = tid; i < T; i += blockDim.x) {
+        const svo_dmatch a = pm[trk[i].first], b = cm[trk[i].second];
+        const svo_keypoint l1 = pkl[a.queryIdx], r1 = pkr[a.trainIdx], l2 = ckl[b.queryIdx], r2 = ckr[b.trainIdx];
+        float* o = obs + 8 * (long long)i;
+        o[0] = l1.x; o[1] = l1.y; o[2] = r1.x; o[3] = r1.y; o[4] = l2.x; o[5] = l2.y; o[6] = r2.x; o[7] = r2.y;
+        keys[i] = ((unsigned long long)ord32(l1.response) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+    }
+    __syncthreads();
+    // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283) ----
+    int Pn = 64; while (Pn < T) Pn <<= 1;
+    bitonic_sort_lds<true>(keys, Pn);
+    {
+        const unsigned cell = (unsigned)((double)P.min_distance / 2.0);
+        const float inv = 1.0f / (float)cell;
+        const unsigned glx = (unsigned)(1 + (float)P.img_w * inv), gly = (unsigned)(1 + (float)P.img_h * inv);
+        if (tid < 64) {
+            const int r = grid_nms_wave(T, T, gly, hash, 2 * PM,
+                [&](int i, int& sx, int& sy) {
+                    const int m = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+                    const size_t ux = (size_t)(obs[8 * (long long)m] * inv), uy = (size_t)(obs[8 * (long long)m + 1] * inv);
+                    sx = (int)ux; sy = (int)uy;
+                    return ux < glx && uy < gly;
+                },
+                [&](int i, int) { mask[(int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull))] = 1; });
+            if (tid == 0) sh.n_non_masked = r;
+        }
+    }
+    __syncthreads();
+    int n_non_masked = sh.n_non_masked;
+    if (n_non_masked < 8) { if (tid == 0) { res.valid = 0; res.n_residual = 0; res.n_outliers = 0; } return; }       // S5:521-526
+    // ---- triangulation (S5:529-544) ----
+    const double cul = cam.l_cx, cvl = cam.l_cy, fl = cam.l_fx, cur_ = cam.r_cx, fr = cam.r_fx, baseline = cam.baseline;
+    auto triangulate = [&]() {
+        for (int m = tid; m < T; m += blockDim.x) {
+            if (!mask[m]) continue;
+            const double ul = obs[8 * (long long)m], vl = obs[8 * (long long)m + 1], ur = obs[8 * (long long)m + 2];
+            const double b_d = baseline / (fl * (cur_ - ur) + fr * (ul - cul));
+            lmk[3 * m] = b_d * fr * (ul - cul); lmk[3 * m + 1] = b_d * fr * (vl - cvl); lmk[3 * m + 2] = b_d * fl * fr;
+        }
+    };
+    triangulate();
+    __threadfence_block();
+    __syncthreads();
+    double delta[6] = { 0, 0, 0, 0, 0, 0 };
+    if (P.use_custom_initial_pose) { for (int k = 0; k < 6; k++) delta[k] = P.init[k]; }                             // S5:504-505
+    else if (P.use_previous_pose_as_initial) { for (int k = 0; k < 6; k++) delta[k] = ls.last_pose[k]; }             // S5:506-507
+    double pCost = 0, cCost = 0; bool done = false, abort_ = false;
+    unsigned timesInc = 0; int num_it = 0, num_it_final = 0, err_code = res.error_code;
+    bool first = true;
+    // ---- phase 1 (S5:549-598) ----
+    while (num_it < P.initial_max_iters && !done && !abort_) {
+        pCost = cCost;
+        eval_rgn(c, P, cam, T, mask, lmk, obs, residual, first, delta, sh);
+        first = false;
+        err_code = SVO_VOEC_NONE;                                                                                    // S5:299
+        cCost = sh.cost;
+        if (!sh.ok) {                                                                                                // S5:380-386, 569-573
+            if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.error_code = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.n_residual = 0; res.n_outliers = 0; }
+            return;
+        }
+        double m2 = 0;
+        for (int k = 0; k < 6; k++) { delta[k] += sh.step[k]; m2 += sh.step[k] * sh.step[k]; }
+        if (num_it > 0) {
+            done = sqrt(m2) < P.min_mod_out_vector;
+            if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { err_code = SVO_VOEC_INCR_FUNC_COST_STG1; abort_ = true; } }
+        }
+        num_it++;
+        __syncthreads();
+    }
+    // ---- keep only the inliers (S5:601-611); "outliers" receives the INLIER cur-match indices ----
+    const int n_res = first ? 0 : T;
+    int n_out = 0;
+    for (int base = 0; base < n_res; base += blockDim.x) {
+        const int i = base + tid;
+        int keep = 0;
+        if (i < n_res) { if (residual[i] > P.residual_threshold) mask[i] = 0; else keep = 1; }
+        int tot;
+        const int off = block_exclusive_scan(keep, scan, &tot);
+        if (keep) outl[n_out + off] = trk[i].second;
+        n_out += tot;
+        __syncthreads();
+    }
+    {
+        int cnt = 0;
+        for (int m = tid; m < T; m += blockDim.x) cnt += mask[m];
+        int tot; block_exclusive_scan(cnt, scan, &tot);
+        n_non_masked = tot;
+        __syncthreads();
+    }
+    if (n_non_masked < 8) {                                                                                          // S5:616-621
+        if (tid == 0) { res.valid = 0; res.num_it = num_it; res.error_code = err_code; res.n_residual = n_res; res.n_outliers = n_out; }
+        return;
+    }
+    triangulate();                                                                                                   // S5:623-638
+    __threadfence_block();
+    __syncthreads();
+    done = false; abort_ = false;
+    // ---- phase 2 (S5:650-700): timesInc, pCost, cCost carry over ----
+    while (num_it_final < P.max_iters && !done && !abort_) {
+        pCost = cCost;
+        eval_rgn(c, P, cam, T, mask, lmk, obs, residual, first, delta, sh);
+        first = false;
+        cCost = sh.cost;
+        if (!sh.ok) {                                                                                                // S5:670-675 (result.error_code untouched)
+            if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }
+            return;
+        }
+        double m2 = 0;
+        for (int k = 0; k < 6; k++) { delta[k] += sh.step[k]; m2 += sh.step[k] * sh.step[k]; }
+        if (num_it_final > 0) {
+            done = sqrt(m2) < P.min_mod_out_vector;
+            if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { abort_ = true; err_code = SVO_VOEC_INCR_FUNC_COST_STG2; } }
+        }
+        num_it_final++;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double pose[6];
+        delta_to_pose(delta, pose);                                                                                  // S5:717-718
+        for (int k = 0; k < 6; k++) { res.outPose[k] = pose[k]; res.delta[k] = delta[k]; }
+        if (!P.use_custom_initial_pose && P.use_previous_pose_as_initial) for (int k = 0; k < 6; k++) ls.last_pose[k] = delta[k];   // S5:720-721
+        res.tracked_feats_from_last_frame = T;                                                                       // S5:724
+        res.tracked_feats_from_last_KF = 0;
+        res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code;
+        res.n_residual = T; res.n_outliers = n_out;
+        res.valid = !abort_;                                                                                         // S5:727
+    }
+}
+
+static size_t gn_smem(int pmax) { return (size_t)pmax * (8 + 8 + 1) + sizeof(int) * 32 + sizeof(GnShared) + 16; }
+
+hipError_t configure_gauss_newton(int pmax)
+{
+    return hipFuncSetAttribute((const void*)k_gauss_newton, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+}
+
+void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P);
+}

@@ -1,0 +1,478 @@
+// k_match.hip -- stages 3 and 4 on the device: brute-force Hamming matching with 256-bit descriptor tiles in LDS,
+// the reference's left-right filters, the sequential joint collision filter of the tracker, the fundamental-matrix
+// RANSAC and the final consistency check.
+//
+// Replaces stage3_match_left_right (libstereo-odometry/src/stage3_match_left_right.cpp:83-178, smDescBF) and
+// stage4_track (libstereo-odometry/src/stage4_match_consecutive.cpp:88-329, ifmDescBF).  cv::BFMatcher and
+// cv::findFundamentalMat are replaced by the algorithms frozen in oracle/svo_oracle.c; all index lists come out
+// bit-exact, the RANSAC arithmetic is IEEE double in the oracle's operation order (-ffp-contract=off).
+#include "svo_device.h"
+#include "svo_kernels.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// K7: Hamming brute force, first minimum.  mode 0: current left -> current right (stage 3).  mode 1: previous
+// pairings -> current pairings, blockIdx.z & 1 = side (left-left / right-right), rows addressed through the
+// DMatch lists (the descriptor gather of S4:105-131 is folded into the loads).
+// Each thread owns one query descriptor in registers (4 x u64); train descriptors stream through LDS in tiles of
+// 256 x 32 B and are read as wave-wide broadcasts; distance and train index are packed (dist << 16 | idx) so that
+// min() is the first-minimum rule of cv::BFMatcher, and partial results of the train splits merge by atomicMin.
+// ------------------------------------------------------------------------------------------------------------
+#define HM_TILE 256
+
+__global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long tile[HM_TILE * 4];
+    const int lane_id = blockIdx.y;
+    const int side = mode ? (blockIdx.z / nsplit) : 0, split = blockIdx.z % nsplit;
+    const LaneState& ls = c.lane[lane_id];
+    const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
+    int nq, nt; const uint8_t* qd, *td; const svo_dmatch* qm = nullptr, *tm = nullptr;
+    if (mode == 0) {
+        nq = c.n_kps[feat_cnt_idx(lane_id, cur, 0)]; nt = c.n_kps[feat_cnt_idx(lane_id, cur, 1)];
+        qd = c.desc + feat_base(c, lane_id, cur, 0) * 32; td = c.desc + feat_base(c, lane_id, cur, 1) * 32;
+    } else {
+        if (!ls.has_prev) return;
+        nq = c.n_matches[lane_id * 2 + prev]; nt = c.n_matches[lane_id * 2 + cur];
+        qd = c.desc + feat_base(c, lane_id, prev, side) * 32; td = c.desc + feat_base(c, lane_id, cur, side) * 32;
+        qm = c.matches + match_base(c, lane_id, prev); tm = c.matches + match_base(c, lane_id, cur);
+    }
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)(blockIdx.x * blockDim.x) >= nq || nt <= 0) return;            // block-uniform
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (q < nq) {
+        const int row = mode ? (side ? qm[q].trainIdx : qm[q].queryIdx) : q;
+        const ulonglong2* p = (const ulonglong2*)(qd + (long long)row * 32);
+        const ulonglong2 a = p[0], b = p[1];
+        q0 = a.x; q1 = a.y; q2 = b.x; q3 = b.y;
+    }
+    // this block's share of the train rows, in whole tiles
+    const int tiles = (nt + HM_TILE - 1) / HM_TILE;
+    const int t_per = (tiles + nsplit - 1) / nsplit;
+    const int t_begin = split * t_per, t_end = min(tiles, t_begin + t_per);
+    unsigned best = 0xFFFFFFFFu;
+    for (int t = t_begin; t < t_end; t++) {
+        const int j0 = t * HM_TILE, jn = min(HM_TILE, nt - j0);
+        __syncthreads();
+        if ((int)threadIdx.x < jn) {
+            const int j = j0 + threadIdx.x;
+            const int row = mode ? (side ? tm[j].trainIdx : tm[j].queryIdx) : j;
+            const ulonglong2* p = (const ulonglong2*)(td + (long long)row * 32);
+            ((ulonglong2*)tile)[threadIdx.x * 2] = p[0];
+            ((ulonglong2*)tile)[threadIdx.x * 2 + 1] = p[1];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < jn; j++) {
+            const ulonglong2 a = ((const ulonglong2*)tile)[j * 2], b = ((const ulonglong2*)tile)[j * 2 + 1];
+            const unsigned d = __popcll(q0 ^ a.x) + __popcll(q1 ^ a.y) + __popcll(q2 ^ b.x) + __popcll(q3 ^ b.y);
+            best = min(best, (d << 16) | (unsigned)(j0 + j));
+        }
+    }
+    if (q < nq && best != 0xFFFFFFFFu) {
+        unsigned* out = (unsigned*)c.bf_idx + ((long long)lane_id * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
+        if (nsplit > 1) atomicMin(out, best); else *out = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8a: stage-3 filters (S3:124-175), one 1024-thread block per lane.
+//   1-to-1: per right feature keep the left with the smallest (distance, left index)   [S3:127-147]
+//   epipolar / threshold / disparity with the reference's int truncations                [S3:159-168]
+// then an order-preserving compaction (pairings stay in ascending left index = ascending row).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_one, double max_y_diff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* right_best = (unsigned*)smem;              // max_kps
+    int* scan = (int*)(right_best + c.max_kps);          // 32
+    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    const LaneState& ls = c.lane[lane_id];
+    const int cur = 1 - ls.prev_slot;
+    const int nl = c.n_kps[feat_cnt_idx(lane_id, cur, 0)], nr = c.n_kps[feat_cnt_idx(lane_id, cur, 1)];
+    const svo_keypoint* kl = c.kps + feat_base(c, lane_id, cur, 0), *kr = c.kps + feat_base(c, lane_id, cur, 1);
+    const unsigned* packed = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 0) * c.max_kps;
+    svo_dmatch* out = c.matches + match_base(c, lane_id, cur);
+    for (int j = tid; j < nr; j += blockDim.x) right_best[j] = 0xFFFFFFFFu;
+    __syncthreads();
+    const bool any = nl > 0 && nr > 0;
+    if (any && one_to_one)
+        for (int i = tid; i < nl; i += blockDim.x) { const unsigned p = packed[i]; atomicMin(&right_best[p & 0xFFFFu], (p & 0xFFFF0000u) | (unsigned)i); }
+    __syncthreads();
+    int m_total = 0;
+    const int n_iter = any ? (nl + (int)blockDim.x - 1) / (int)blockDim.x : 0;
+    for (int it = 0; it < n_iter; it++) {
+        const int i = it * blockDim.x + tid;
+        int keep = 0; unsigned p = 0;
+        if (i < nl) {
+            p = packed[i];
+            const int j = (int)(p & 0xFFFFu);
+            const float distance = (float)(p >> 16);
+            keep = 1;
+            if (one_to_one && (int)(right_best[j] & 0xFFFFu) != i) keep = 0;
+            const int diff = (int)(kl[i].y - kr[j].y);                                   // S3:162
+            const int disp = (int)(kl[i].x - kr[j].x);                                   // S3:163
+            if ((double)abs(diff) > max_y_diff || distance > (float)c.orb_th || (double)disp < 1.0 || (double)disp > (double)c.W) keep = 0;
+        }
+        int tot;
+        const int off = block_exclusive_scan(keep, scan, &tot);
+        if (keep) { svo_dmatch d; d.queryIdx = i; d.trainIdx = (int)(p & 0xFFFFu); d.imgIdx = 0; d.distance = (float)(p >> 16); out[m_total + off] = d; }
+        m_total += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { c.n_matches[lane_id * 2 + cur] = m_total; c.results[lane_id].stereo_matches[0] = m_total; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8b: the tracker's joint sequential filter (S4:145-160), exact, one wave per lane.
+// k is kept iff dL <= th and dR <= th and neither its left nor its right train index was taken by an EARLIER
+// KEPT k.  Earlier chunks of 64 are remembered in two LDS bitmaps; inside a chunk the chain is resolved in rank
+// order with ballot masks (same scheme as grid_nms_wave).  Also gathers the pixel pairs for the two RANSACs
+// (S4:181-189, 216-224).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* ltaken = (unsigned*)smem;                 // max_kps/32 words
+    unsigned* rtaken = ltaken + c.max_kps / 32;
+    const int lane_id = blockIdx.x, lane = threadIdx.x;
+    const LaneState& ls = c.lane[lane_id];
+    if (!ls.has_prev) { if (lane == 0) c.trk_nk[lane_id] = 0; return; }
+    const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
+    const int npm = c.n_matches[lane_id * 2 + prev], ncm = c.n_matches[lane_id * 2 + cur];
+    if (npm <= 0 || ncm <= 0) { if (lane == 0) c.trk_nk[lane_id] = 0; return; }
+    for (int i = lane; i < c.max_kps / 32; i += 64) { ltaken[i] = 0; rtaken[i] = 0; }
+    __syncthreads();
+    const unsigned* pL = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 1) * c.max_kps;
+    const unsigned* pR = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 2) * c.max_kps;
+    const svo_dmatch* pm = c.matches + match_base(c, lane_id, prev), *cm = c.matches + match_base(c, lane_id, cur);
+    const svo_keypoint* pkl = c.kps + feat_base(c, lane_id, prev, 0), *pkr = c.kps + feat_base(c, lane_id, prev, 1);
+    const svo_keypoint* ckl = c.kps + feat_base(c, lane_id, cur, 0), *ckr = c.kps + feat_base(c, lane_id, cur, 1);
+    int* kq = c.trk_kq + (long long)lane_id * c.max_kps;
+    float* ptsL = c.trk_pts + ((long long)lane_id * 2 + 0) * c.max_kps * 4, *ptsR = c.trk_pts + ((long long)lane_id * 2 + 1) * c.max_kps * 4;
+    int nk = 0;
+    for (int base = 0; base < npm; base += 64) {
+        const int k = base + lane;
+        int tl = -1 - lane, tr = -1 - lane;     // distinct dummies so that idle lanes never "conflict"
+        bool pass = false;
+        if (k < npm) {
+            const unsigned a = pL[k], b = pR[k];
+            tl = (int)(a & 0xFFFFu); tr = (int)(b & 0xFFFFu);
+            pass = !((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th);
+            if (pass && (((ltaken[tl >> 5] >> (tl & 31)) & 1u) || ((rtaken[tr >> 5] >> (tr & 31)) & 1u))) pass = false;
+        }
+        unsigned long long conf = 0;
+        for (int j = 0; j < 63; j++) {
+            const int ol = __shfl(tl, j, 64), orr = __shfl(tr, j, 64);
+            if (j < lane && (ol == tl || orr == tr)) conf |= 1ull << j;
+        }
+        bool undecided = pass;
+        unsigned long long acc_mask = 0;
+        for (;;) {
+            const unsigned long long und = __ballot(undecided);
+            if (!und) break;
+            bool acc_now = false;
+            if (undecided) {
+                if (conf & acc_mask) undecided = false;
+                else if (!(conf & und)) { acc_now = true; undecided = false; }
+            }
+            acc_mask |= __ballot(acc_now);
+        }
+        if ((acc_mask >> lane) & 1ull) {
+            atomicOr(&ltaken[tl >> 5], 1u << (tl & 31)); atomicOr(&rtaken[tr >> 5], 1u << (tr & 31));
+            const int o = nk + __popcll(acc_mask & ((1ull << lane) - 1ull));
+            kq[o] = k;
+            const svo_keypoint a = pkl[pm[k].queryIdx], b = ckl[cm[tl].queryIdx];
+            ptsL[o * 4] = a.x; ptsL[o * 4 + 1] = a.y; ptsL[o * 4 + 2] = b.x; ptsL[o * 4 + 3] = b.y;
+            const svo_keypoint e = pkr[pm[k].trainIdx], f = ckr[cm[tr].trainIdx];
+            ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
+        }
+        nk += __popcll(acc_mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) c.trk_nk[lane_id] = nk;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K9: fundamental-matrix RANSAC (cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) stand-in; S4:202, 237).
+// Fixed schedule of SVO_RANSAC_HYP seeded samples evaluated in parallel; the adaptive stop of a sequential
+// RANSAC is emulated afterwards by scanning the inlier counts in hypothesis order.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31);
+}
+__device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
+{
+    unsigned long long x = s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; s = x; return x * 0x2545F4914F6CDD1DULL;
+}
+
+// one thread per hypothesis: sample 8 pairs, normalised linear 8-point solution through the null vector of the
+// 8x9 system (Gauss-Jordan, full pivoting).  The 8x9 matrix lives in LDS, one column of doubles per thread slot.
+__global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c)
+{
+    __shared__ double As[72][64];     // As[r*9+col][thread]: conflict-free (consecutive threads, consecutive banks)
+    const int h = blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, lane_id = blockIdx.z, tx = threadIdx.x;
+    const int n = c.trk_nk[lane_id];
+    if (n < 8) return;
+    const float* pts = c.trk_pts + ((long long)lane_id * 2 + side) * c.max_kps * 4;
+    int s[8];
+    {
+        unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
+        if (!st) st = 1;
+        for (int j = 0; j < 8; j++) {
+            int v; bool dup;
+            do { v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false; for (int k = 0; k < j; k++) if (s[k] == v) dup = true; } while (dup);
+            s[j] = v;
+        }
+    }
+    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+    for (int i = 0; i < 8; i++) { const float4 p = ((const float4*)pts)[s[i]]; c1x += (double)p.x; c1y += (double)p.y; c2x += (double)p.z; c2y += (double)p.w; }
+    c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
+    double d1 = 0, d2 = 0;
+    for (int i = 0; i < 8; i++) {
+        const float4 p = ((const float4*)pts)[s[i]];
+        const double ax = (double)p.x - c1x, ay = (double)p.y - c1y, bx = (double)p.z - c2x, by = (double)p.w - c2y;
+        d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
+    }
+    const double s1 = 11.313708498984761 / d1, s2 = 11.313708498984761 / d2;
+#define A(r, cc) As[(r) * 9 + (cc)][tx]
+    for (int i = 0; i < 8; i++) {
+        const float4 p = ((const float4*)pts)[s[i]];
+        const double x1 = ((double)p.x - c1x) * s1, y1 = ((double)p.y - c1y) * s1, x2 = ((double)p.z - c2x) * s2, y2 = ((double)p.w - c2y) * s2;
+        A(i, 0) = x2 * x1; A(i, 1) = x2 * y1; A(i, 2) = x2; A(i, 3) = y2 * x1; A(i, 4) = y2 * y1; A(i, 5) = y2; A(i, 6) = x1; A(i, 7) = y1; A(i, 8) = 1.0;
+    }
+    int perm[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) perm[j] = j;
+    for (int k = 0; k < 8; k++) {
+        double best = -1.0; int pi = k, pj = k;
+        for (int i = k; i < 8; i++) for (int j = k; j < 9; j++) { const double v = fabs(A(i, j)); if (v > best) { best = v; pi = i; pj = j; } }
+        if (pi != k) for (int j = 0; j < 9; j++) { const double t = A(k, j); A(k, j) = A(pi, j); A(pi, j) = t; }
+        if (pj != k) {
+            for (int i = 0; i < 8; i++) { const double t = A(i, k); A(i, k) = A(i, pj); A(i, pj) = t; }
+            // perm[k] <-> perm[pj] without dynamic register indexing
+            int pk = 0, pp = 0;
+#pragma unroll
+            for (int j = 0; j < 9; j++) { if (j == k) pk = perm[j]; if (j == pj) pp = perm[j]; }
+#pragma unroll
+            for (int j = 0; j < 9; j++) { if (j == k) perm[j] = pp; else if (j == pj) perm[j] = pk; }
+        }
+        const double piv = A(k, k);
+        for (int j = k; j < 9; j++) A(k, j) = A(k, j) / piv;
+        for (int i = 0; i < 8; i++) { if (i == k) continue; const double f = A(i, k); for (int j = k; j < 9; j++) A(i, j) = A(i, j) - f * A(k, j); }
+    }
+    double f[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        double v = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) if (perm[i] == j) v = (i == 8) ? 1.0 : -A(i, 8);
+        f[j] = v;
+    }
+#undef A
+    const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
+    double M[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
+        M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
+    }
+    double* F = c.rs_F + (((long long)lane_id * 2 + side) * SVO_RANSAC_HYP + h) * 9;
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+        F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
+        F[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+    }
+}
+
+__device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, float fx2, float fy2)
+{
+    const double x1 = (double)fx1, y1 = (double)fy1, x2 = (double)fx2, y2 = (double)fy2;
+    double a = (F[0] * x1 + F[1] * y1) + F[2], b = (F[3] * x1 + F[4] * y1) + F[5], cc = (F[6] * x1 + F[7] * y1) + F[8];
+    const double sB = 1.0 / (a * a + b * b), dB = (x2 * a + y2 * b) + cc;
+    a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; cc = (F[2] * x2 + F[5] * y2) + F[8];
+    const double sA = 1.0 / (a * a + b * b), dA = (x1 * a + y1 * b) + cc;
+    const double eA = (dA * dA) * sA, eB = (dB * dB) * sB;
+    const double e = eA > eB ? eA : eB;
+    return e <= 1.0;
+}
+
+// inlier counts: 16 hypotheses per 256-thread block, F matrices broadcast from LDS, points streamed once per thread
+#define RC_HB 16
+__global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
+{
+    __shared__ double Fs[RC_HB][9];
+    __shared__ int cnt_s[RC_HB];
+    const int side = blockIdx.y, lane_id = blockIdx.z, h0 = blockIdx.x * RC_HB, tid = threadIdx.x;
+    const int n = c.trk_nk[lane_id];
+    if (n < 8) return;
+    const float4* pts = (const float4*)(c.trk_pts + ((long long)lane_id * 2 + side) * c.max_kps * 4);
+    const double* F = c.rs_F + (((long long)lane_id * 2 + side) * SVO_RANSAC_HYP + h0) * 9;
+    if (tid < RC_HB * 9) Fs[tid / 9][tid % 9] = F[tid];
+    if (tid < RC_HB) cnt_s[tid] = 0;
+    __syncthreads();
+    int cnt[RC_HB];
+#pragma unroll
+    for (int h = 0; h < RC_HB; h++) cnt[h] = 0;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const float4 p = pts[i];
+#pragma unroll
+        for (int h = 0; h < RC_HB; h++) cnt[h] += fm_inlier(Fs[h], p.x, p.y, p.z, p.w);
+    }
+#pragma unroll
+    for (int h = 0; h < RC_HB; h++) { const int v = wave_reduce_sum_i32(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
+    __syncthreads();
+    if (tid < RC_HB) c.rs_cnt[((long long)lane_id * 2 + side) * SVO_RANSAC_HYP + h0 + tid] = cnt_s[tid];
+}
+
+// pick the model a sequential RANSAC with the 0.99-confidence stop would have returned, apply both masks
+// (S4:243-255), the consistency check (S4:282), and write tracked_pairs; then the bad-tracking gate (P:326-330)
+// and the first-frame rule (P:348-352).
+__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracking_th)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* in_l = smem;                         // max_kps
+    unsigned char* in_r = in_l + c.max_kps;             // max_kps
+    int* scan = (int*)(in_r + c.max_kps);               // 32
+    __shared__ int s_best[2], s_cnt[2];
+    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    LaneState& ls = c.lane[lane_id];
+    svo_result& res = c.results[lane_id];
+    if (!ls.has_prev) {
+        if (tid == 0) { res.error_code = SVO_VOEC_FIRST_ITERATION; res.valid = 0; c.n_tracked[lane_id] = 0; }
+        return;
+    }
+    const int n = c.trk_nk[lane_id];
+    if (tid == 0 || tid == 64) {
+        const int side = tid >> 6;
+        int best_k = -1, best_cnt = 0;
+        if (n >= 8) {
+            const int* cnts = c.rs_cnt + ((long long)lane_id * 2 + side) * SVO_RANSAC_HYP;
+            int niters = SVO_RANSAC_HYP;
+            for (int k = 0; k < niters; k++) {
+                const int cnt = cnts[k];
+                if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
+                    best_cnt = cnt; best_k = k;
+                    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
+                    double acc = 1.0; int K = 0;
+                    while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
+                    niters = K;
+                }
+            }
+        }
+        s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
+    }
+    __syncthreads();
+    const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
+    const bool use_f = goodFL && goodFR;                             // S4:243
+    if (use_f) {
+        const double* FL = c.rs_F + (((long long)lane_id * 2 + 0) * SVO_RANSAC_HYP + s_best[0]) * 9;
+        const double* FR = c.rs_F + (((long long)lane_id * 2 + 1) * SVO_RANSAC_HYP + s_best[1]) * 9;
+        double fl[9], fr[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { fl[i] = FL[i]; fr[i] = FR[i]; }
+        const float4* pl = (const float4*)(c.trk_pts + ((long long)lane_id * 2 + 0) * c.max_kps * 4);
+        const float4* pr = (const float4*)(c.trk_pts + ((long long)lane_id * 2 + 1) * c.max_kps * 4);
+        for (int i = tid; i < n; i += blockDim.x) {
+            const float4 a = pl[i], b = pr[i];
+            in_l[i] = (unsigned char)fm_inlier(fl, a.x, a.y, a.z, a.w);
+            in_r[i] = (unsigned char)fm_inlier(fr, b.x, b.y, b.z, b.w);
+        }
+    }
+    __syncthreads();
+    const unsigned* pL = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 1) * c.max_kps;
+    const unsigned* pR = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 2) * c.max_kps;
+    const int* kq = c.trk_kq + (long long)lane_id * c.max_kps;
+    svo_index_pair* out = c.tracked + (long long)lane_id * c.max_kps;
+    int t_total = 0;
+    const int n_iter = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (int it = 0; it < n_iter; it++) {
+        const int i = it * blockDim.x + tid;
+        int keep = 0, k = 0, tl = 0;
+        if (i < n) {
+            k = kq[i];
+            tl = (int)(pL[k] & 0xFFFFu);
+            const int tr = (int)(pR[k] & 0xFFFFu);
+            keep = 1;
+            if (use_f && (in_l[i] == 0 || in_r[i] == 0)) keep = 0;
+            if (tl != tr) keep = 0;                                   // S4:282
+        }
+        int tot;
+        const int off = block_exclusive_scan(keep, scan, &tot);
+        if (keep) { svo_index_pair p; p.first = k; p.second = tl; out[t_total + off] = p; }
+        t_total += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        c.n_tracked[lane_id] = t_total;                                // m_num_tracked_pairs_from_last_frame (S4:743-752)
+        if (t_total < bad_tracking_th) { ls.m_error = SVO_VOEC_BAD_TRACKING; res.error_code = SVO_VOEC_BAD_TRACKING; }   // P:326-330
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------------------
+void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_hamming, dim3((c.max_kps + 255) / 256, c.n_lanes, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
+}
+
+void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)
+{
+    const size_t sm = sizeof(unsigned) * c.max_kps + sizeof(int) * 32;
+    hipLaunchKernelGGL(k_match_lr_filter, dim3(c.n_lanes), dim3(1024), sm, st, c, one_to_one, max_y_diff);
+}
+
+void launch_track_filter(const DevCtx& c, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned), st, c);
+}
+void launch_ransac_hyp(const DevCtx& c, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ransac_hyp, dim3(SVO_RANSAC_HYP / 64, 2, c.n_lanes), dim3(64), 0, st, c);
+}
+void launch_ransac_count(const DevCtx& c, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ransac_count, dim3(SVO_RANSAC_HYP / RC_HB, 2, c.n_lanes), dim3(256), 0, st, c);
+}
+void launch_track_finalize(const DevCtx& c, int bad_tracking_th, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c, bad_tracking_th);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// standalone brute-force matcher on caller arrays (svo_hamming_match): same inner loop, plain row addressing
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hamming_plain(const uint8_t* qd, int nq, const uint8_t* td, int nt, unsigned* out, int nsplit)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long tile[HM_TILE * 4];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, split = blockIdx.y;
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (q < nq) { const ulonglong2* p = (const ulonglong2*)(qd + (long long)q * 32); const ulonglong2 a = p[0], b = p[1]; q0 = a.x; q1 = a.y; q2 = b.x; q3 = b.y; }
+    const int tiles = (nt + HM_TILE - 1) / HM_TILE, t_per = (tiles + nsplit - 1) / nsplit;
+    const int t_begin = split * t_per, t_end = min(tiles, t_begin + t_per);
+    unsigned best = 0xFFFFFFFFu;
+    for (int t = t_begin; t < t_end; t++) {
+        const int j0 = t * HM_TILE, jn = min(HM_TILE, nt - j0);
+        __syncthreads();
+        if ((int)threadIdx.x < jn) {
+            const ulonglong2* p = (const ulonglong2*)(td + (long long)(j0 + threadIdx.x) * 32);
+            ((ulonglong2*)tile)[threadIdx.x * 2] = p[0]; ((ulonglong2*)tile)[threadIdx.x * 2 + 1] = p[1];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < jn; j++) {
+            const ulonglong2 a = ((const ulonglong2*)tile)[j * 2], b = ((const ulonglong2*)tile)[j * 2 + 1];
+            const unsigned d = __popcll(q0 ^ a.x) + __popcll(q1 ^ a.y) + __popcll(q2 ^ b.x) + __popcll(q3 ^ b.y);
+            best = min(best, (d << 16) | (unsigned)(j0 + j));
+        }
+    }
+    if (q < nq && best != 0xFFFFFFFFu) { if (nsplit > 1) atomicMin(&out[q], best); else out[q] = best; }
+}
+
+void launch_hamming_plain(const uint8_t* q, int nq, const uint8_t* t, int nt, unsigned* out, int nsplit, hipStream_t st)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_hamming_plain, dim3((nq + 255) / 256, nsplit), dim3(256), 0, st, q, nq, t, nt, out, nsplit);
+}

@@ -1,0 +1,692 @@
+// svo_api.hip -- the C-ABI of include/svo_hip.h: context, geometry, frame pipeline, getters.
+//
+// svo_process enqueues one frame of every lane on the context's stream as a fixed sequence of ~20 kernel
+// launches; every data-dependent size (keypoint, pairing, track counts) stays in device memory, so there is no
+// host synchronisation inside a frame and frames can be enqueued back to back.
+#include "svo_device.h"
+#include "svo_kernels.h"
+#include <math.h>
+#include <string.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#define HIPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); return SVO_ERR_HIP; } } while (0)
+
+enum { KT_BEGIN, KT_RESIZE, KT_FAST, KT_SELECT, KT_DESCRIBE, KT_NMS, KT_HAM_LR, KT_LR_FILTER, KT_HAM_TRK, KT_TRK_FILTER,
+       KT_RANSAC_HYP, KT_RANSAC_CNT, KT_TRK_FINAL, KT_GN, KT_COUNT };
+static const char* kt_names[KT_COUNT] = { "begin_frame", "resize", "fast", "select", "describe", "nms_rowsort", "hamming_lr",
+    "match_lr_filter", "hamming_track", "track_filter", "ransac_hyp", "ransac_count", "track_finalize", "gauss_newton" };
+
+struct TimedSpan { int id; hipEvent_t a, b; };
+
+struct svo_ctx {
+    svo_config cfg;
+    svo_params params;
+    int fast_th, orb_th;
+    hipStream_t stream; bool own_stream;
+    DevCtx dc;
+    bool geom_ready; int geom_w, geom_h, geom_nfe, geom_nlevels;
+    uint8_t* d_img0; int img0_pitch_internal;
+    long long pyr_bytes_alloc; int cand_total_alloc, rtab_alloc;
+    std::vector<void*> allocs;
+    std::string last_error;
+    std::vector<TimedSpan> spans; std::vector<hipEvent_t> free_events;
+    double kt_total[KT_COUNT]; long long kt_calls[KT_COUNT];
+    unsigned* d_ham_out; uint8_t* d_ham_q, *d_ham_t; int ham_cap_q, ham_cap_t;
+};
+
+static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+extern "C" void svo_config_defaults(svo_config* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->device = 0; c->n_lanes = 1; c->max_w = 1280; c->max_h = 960; c->max_kps = 4096; c->max_cand = 1 << 17; c->kernel_times = 0; c->stream = nullptr;
+}
+
+extern "C" void svo_params_defaults(svo_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->nOctaves = 3;                                   // stage1_rectify.cpp:27-30
+    p->detect_method = SVO_DM_ORB;                     // north-star selector (reference default dmFASTER, stage2_detect.cpp:45)
+    p->non_maximal_suppression = 1; p->nmsMethod = SVO_NMS_STANDARD; p->min_distance = 3;   // stage2_detect.cpp:49-51
+    p->orb_nfeats = 500; p->orb_nlevels = 8; p->minimum_ORB_response = 0.0;                 // stage2_detect.cpp:52-54
+    p->fast_min_th = 5; p->fast_max_th = 30; p->initial_FAST_threshold = 20;                // stage2_detect.cpp:55-56
+    p->match_method = SVO_SM_DESC_BF;                  // north-star selector (reference default smSAD, stage3:47)
+    p->orb_max_distance = 40; p->orb_min_th = 30; p->orb_max_th = 100;                      // stage3_match_left_right.cpp:50-51
+    p->enable_robust_1to1_match = 0; p->max_y_diff = 0;                                     // stage3_match_left_right.cpp:52-54
+    p->ifm_method = SVO_IFM_DESC_BF; p->ifm_win_w = 16; p->ifm_win_h = 16; p->filter_fund_matrix = 0;   // H:610; no reference defaults (common.cpp:84)
+    p->use_robust_kernel = 1; p->kernel_param = 3.0; p->max_iters = 100; p->initial_max_iters = 10;     // common.cpp:69-82
+    p->min_mod_out_vector = 1e-3; p->max_incr_cost = 3; p->residual_threshold = 10.0; p->bad_tracking_th = 5;
+    p->use_previous_pose_as_initial = 1; p->use_custom_initial_pose = 0;
+    p->vo_use_matches_ids = 0;                         // process_new_image_pair.cpp:35
+}
+
+extern "C" const char* svo_strerror(int s)
+{
+    switch (s) {
+        case SVO_OK: return "ok";
+        case SVO_ERR_HIP: return "HIP runtime error (see svo_last_error)";
+        case SVO_ERR_ARG: return "invalid argument";
+        case SVO_ERR_UNSUPPORTED: return "configuration outside the supported hot path";
+        case SVO_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case SVO_ERR_CAPACITY: return "context capacity exceeded";
+        case SVO_ERR_STATE: return "call not valid in the current state";
+        default: return "unknown status";
+    }
+}
+extern "C" const char* svo_last_error(const svo_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" void svo_abi_sizes(int32_t* out)
+{
+    out[0] = sizeof(svo_keypoint); out[1] = sizeof(svo_dmatch); out[2] = sizeof(svo_stereo_camera);
+    out[3] = sizeof(svo_params); out[4] = sizeof(svo_result); out[5] = sizeof(svo_config);
+}
+
+template <typename T>
+static hipError_t dev_alloc(svo_ctx* ctx, T** p, size_t n)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
+    if (e != hipSuccess) return e;
+    e = hipMemset(q, 0, n * sizeof(T) + 256);
+    if (e != hipSuccess) return e;
+    ctx->allocs.push_back(q);
+    *p = (T*)q;
+    return hipSuccess;
+}
+
+static void level_sizes(int w, int h, int nlevels, int* lw, int* lh, float* sc)
+{
+    for (int l = 0; l < nlevels; l++) {                      // same expression as oracle svo_oracle_pyramid_sizes
+        const float sf = (float)pow(1.2, (double)l);
+        sc[l] = sf; lw[l] = (int)lrintf((float)w / sf); lh[l] = (int)lrintf((float)h / sf);
+    }
+}
+
+static long long pyramid_bytes(int w, int h, int nlevels)
+{
+    int lw[SVO_MAX_LEVELS], lh[SVO_MAX_LEVELS]; float sc[SVO_MAX_LEVELS];
+    level_sizes(w, h, nlevels, lw, lh, sc);
+    long long b = 0;
+    for (int l = 1; l < nlevels; l++) b += (long long)align_up(lw[l], 64) * lh[l];
+    return align_up((int)((b + 255) & ~255LL), 256);
+}
+
+extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
+{
+    if (!cfg || !out) return SVO_ERR_ARG;
+    *out = nullptr;
+    if (cfg->n_lanes < 1 || cfg->n_lanes > SVO_MAX_LANES || cfg->max_w < 64 || cfg->max_h < 64) return SVO_ERR_ARG;
+    if (cfg->max_kps < 64 || cfg->max_kps > 8192 || (cfg->max_kps & (cfg->max_kps - 1))) return SVO_ERR_ARG;
+    if ((long long)cfg->max_w * cfg->max_h >= (1 << 24)) return SVO_ERR_UNSUPPORTED;      // position packs into 24 bits
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return SVO_ERR_NO_DEVICE;
+    svo_ctx* ctx = new svo_ctx();
+    ctx->cfg = *cfg;
+    svo_params_defaults(&ctx->params);
+    ctx->fast_th = 20; ctx->orb_th = 60;                  // common.cpp:35-36
+    ctx->geom_ready = false;
+    ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
+    for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
+    *out = ctx;                                           // so that the caller can read last_error and destroy
+    HIPCHECK(hipSetDevice(cfg->device));
+    if (cfg->stream) { ctx->stream = (hipStream_t)cfg->stream; ctx->own_stream = false; }
+    else { HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    HIPCHECK(svo_upload_tables());
+    DevCtx& d = ctx->dc;
+    memset(&d, 0, sizeof(d));
+    const int L = cfg->n_lanes, NI = 2 * L, MK = cfg->max_kps;
+    d.n_lanes = L; d.n_img = NI; d.max_kps = MK; d.n_levels = SVO_MAX_LEVELS;
+    ctx->pyr_bytes_alloc = pyramid_bytes(cfg->max_w, cfg->max_h, SVO_MAX_LEVELS);
+    ctx->cand_total_alloc = (int)((long long)cfg->max_cand * 33 / 10) + 8 * 1024;
+    ctx->rtab_alloc = 2 * (cfg->max_w + cfg->max_h) * SVO_MAX_LEVELS;
+    ctx->img0_pitch_internal = align_up(cfg->max_w, 64);
+    HIPCHECK(dev_alloc(ctx, &ctx->d_img0, (size_t)NI * ctx->img0_pitch_internal * cfg->max_h));
+    HIPCHECK(dev_alloc(ctx, (uint8_t***)&d.img0, (size_t)NI));
+    HIPCHECK(dev_alloc(ctx, &d.pyr, (size_t)NI * ctx->pyr_bytes_alloc));
+    HIPCHECK(dev_alloc(ctx, &d.rtab, (size_t)ctx->rtab_alloc));
+    HIPCHECK(dev_alloc(ctx, &d.cand_keys, (size_t)NI * ctx->cand_total_alloc));
+    HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS));
+    HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * MK));
+    HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * MK));
+    HIPCHECK(dev_alloc(ctx, &d.lvl_n, (size_t)NI * SVO_MAX_LEVELS));
+    HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * MK));
+    HIPCHECK(dev_alloc(ctx, &d.raw_desc, (size_t)NI * MK * 32));
+    HIPCHECK(dev_alloc(ctx, &d.raw_n, (size_t)NI));
+    HIPCHECK(dev_alloc(ctx, &d.kps, (size_t)L * 4 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.desc, (size_t)L * 4 * MK * 32));
+    HIPCHECK(dev_alloc(ctx, &d.n_kps, (size_t)L * 4));
+    HIPCHECK(dev_alloc(ctx, &d.matches, (size_t)L * 2 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.n_matches, (size_t)L * 2));
+    HIPCHECK(dev_alloc(ctx, &d.bf_idx, (size_t)L * 3 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.trk_kq, (size_t)L * MK));
+    HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.trk_pts, (size_t)L * 2 * MK * 4));
+    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)L * 2 * SVO_RANSAC_HYP * 9));
+    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)L * 2 * SVO_RANSAC_HYP));
+    HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)L * MK));
+    HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.gn_lmk, (size_t)L * MK * 3));
+    HIPCHECK(dev_alloc(ctx, &d.gn_obs, (size_t)L * MK * 8));
+    HIPCHECK(dev_alloc(ctx, &d.residual, (size_t)L * MK));
+    HIPCHECK(dev_alloc(ctx, &d.outliers, (size_t)L * MK));
+    HIPCHECK(dev_alloc(ctx, &d.cams, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.lane, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.results, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.status, (size_t)L));
+    d.bf_dist = nullptr;
+    HIPCHECK(configure_gauss_newton(MK));
+    return SVO_OK;
+}
+
+extern "C" void svo_destroy(svo_ctx* ctx)
+{
+    if (!ctx) return;
+    hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->allocs) hipFree(p);
+    if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
+    if (ctx->d_ham_q) hipFree(ctx->d_ham_q);
+    if (ctx->d_ham_t) hipFree(ctx->d_ham_t);
+    for (auto& s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto e : ctx->free_events) hipEventDestroy(e);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int svo_set_params(svo_ctx* ctx, const svo_params* p)
+{
+    if (!ctx || !p) return SVO_ERR_ARG;
+    ctx->params = *p;
+    ctx->fast_th = p->initial_FAST_threshold;            // resetFASTThreshold (H:532, 661)
+    ctx->orb_th = (int)p->orb_max_distance;              // resetORBThreshold (H:539, 662)
+    ctx->geom_ready = false;
+    return SVO_OK;
+}
+extern "C" int svo_get_params(const svo_ctx* ctx, svo_params* p) { if (!ctx || !p) return SVO_ERR_ARG; *p = ctx->params; return SVO_OK; }
+extern "C" int svo_set_fast_threshold(svo_ctx* ctx, int v)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    const int lo = ctx->params.fast_min_th, hi = ctx->params.fast_max_th, m = v > lo ? v : lo;
+    ctx->fast_th = hi < m ? hi : m;
+    return SVO_OK;
+}
+extern "C" int svo_set_orb_threshold(svo_ctx* ctx, int v)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    const int lo = ctx->params.orb_min_th, hi = ctx->params.orb_max_th, m = v > lo ? v : lo;
+    ctx->orb_th = hi < m ? hi : m;
+    return SVO_OK;
+}
+extern "C" int svo_get_fast_threshold(const svo_ctx* ctx) { return ctx ? ctx->fast_th : SVO_ERR_ARG; }
+extern "C" int svo_get_orb_threshold(const svo_ctx* ctx) { return ctx ? ctx->orb_th : SVO_ERR_ARG; }
+
+extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam)
+{
+    if (!ctx || !cam || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < ctx->cfg.n_lanes; l++)
+        if (lane < 0 || lane == l) HIPCHECK(hipMemcpy(ctx->dc.cams + l, cam, sizeof(*cam), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
+extern "C" int svo_reset(svo_ctx* ctx, int lane)
+{
+    if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < ctx->cfg.n_lanes; l++)
+        if (lane < 0 || lane == l) {
+            HIPCHECK(hipMemset(ctx->dc.lane + l, 0, sizeof(LaneState)));
+            HIPCHECK(hipMemset(ctx->dc.n_kps + l * 4, 0, 4 * sizeof(int)));
+            HIPCHECK(hipMemset(ctx->dc.n_matches + l * 2, 0, 2 * sizeof(int)));
+            HIPCHECK(hipMemset(ctx->dc.n_tracked + l, 0, sizeof(int)));
+            HIPCHECK(hipMemset(ctx->dc.results + l, 0, sizeof(svo_result)));
+        }
+    return SVO_OK;
+}
+
+// cv::ORB per-level feature budget (oracle: orb_level_quota)
+static void level_quota(int nfeatures, int nlevels, int* q)
+{
+    const float factor = (float)(1.0 / 1.2);
+    float nd = (float)nfeatures * (1.0f - factor) / (1.0f - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { q[l] = (int)lrintf(nd); sum += q[l]; nd *= factor; }
+    q[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+}
+
+static void resize_table(int src, int dst, int* idx, int* frac)
+{
+    for (int d = 0; d < dst; d++) {                          // oracle: resize_table
+        const long long num = (long long)(2 * d + 1) * src - dst, den = 2LL * dst;
+        long long q = num >= 0 ? num / den : -((-num + den - 1) / den);
+        const long long r = num - q * den;
+        int f = (int)((r * 2048 + den / 2) / den);
+        if (q < 0) { q = 0; f = 0; }
+        if (q >= src - 1) { q = src - 1; f = 0; }
+        idx[d] = (int)q; frac[d] = f;
+    }
+}
+
+static int ensure_geometry(svo_ctx* ctx, int w, int h)
+{
+    const svo_params& p = ctx->params;
+    const int nfe = p.non_maximal_suppression ? (int)(size_t)(1.5 * (double)(size_t)p.orb_nfeats) : p.orb_nfeats;   // stage2_detect.cpp:461-464
+    int nlev = p.orb_nlevels; if (nlev < 1) nlev = 1;
+    if (ctx->geom_ready && ctx->geom_w == w && ctx->geom_h == h && ctx->geom_nfe == nfe && ctx->geom_nlevels == nlev) return SVO_OK;
+    if (w > ctx->cfg.max_w || h > ctx->cfg.max_h || w < 64 || h < 64) return SVO_ERR_CAPACITY;
+    if (nlev > SVO_MAX_LEVELS) return SVO_ERR_UNSUPPORTED;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    DevCtx& d = ctx->dc;
+    int lw[SVO_MAX_LEVELS], lh[SVO_MAX_LEVELS], quota[SVO_MAX_LEVELS]; float sc[SVO_MAX_LEVELS];
+    level_sizes(w, h, nlev, lw, lh, sc);
+    level_quota(nfe, nlev, quota);
+    d.W = w; d.H = h; d.n_levels = nlev;
+    long long off = 0; int tile_off = 0, slot_off = 0, cand_off = 0, rt_off = 0;
+    std::vector<int> rtab;
+    for (int l = 0; l < nlev; l++) {
+        LevelGeom& g = d.lv[l];
+        g.w = lw[l]; g.h = lh[l]; g.pitch = align_up(lw[l], 64); g.scale = sc[l];
+        g.offset = off; if (l >= 1) off += (long long)g.pitch * g.h;
+        const int iw = g.w - 2 * SVO_EDGE, ih = g.h - 2 * SVO_EDGE;
+        const bool live = iw > 0 && ih > 0 && quota[l] > 0;
+        g.tiles_x = live ? (iw + 63) / 64 : 0; g.tiles_y = live ? (ih + 15) / 16 : 0;
+        g.tile_off = tile_off; tile_off += g.tiles_x * g.tiles_y;
+        g.quota = live ? quota[l] : 0; g.slot_off = slot_off; slot_off += g.quota;
+        long long cc = (long long)ctx->cfg.max_cand * ((long long)g.w * g.h) / ((long long)lw[0] * lh[0]);
+        if (cc < 1024) cc = 1024;
+        g.cand_cap = (int)cc; g.cand_off = cand_off; cand_off += g.cand_cap;
+        g.rtab_off = rt_off;
+        if (l >= 1) {
+            std::vector<int> xi(g.w), xf(g.w), yi(g.h), yf(g.h);
+            resize_table(lw[l - 1], g.w, xi.data(), xf.data());
+            resize_table(lh[l - 1], g.h, yi.data(), yf.data());
+            rtab.insert(rtab.end(), xi.begin(), xi.end()); rtab.insert(rtab.end(), xf.begin(), xf.end());
+            rtab.insert(rtab.end(), yi.begin(), yi.end()); rtab.insert(rtab.end(), yf.begin(), yf.end());
+            rt_off += 2 * (g.w + g.h);
+        }
+        if (2 * g.quota > 2048) return SVO_ERR_UNSUPPORTED;           // k_select LDS budget (SEL_MAX)
+    }
+    for (int l = nlev; l < SVO_MAX_LEVELS; l++) { memset(&d.lv[l], 0, sizeof(LevelGeom)); d.lv[l].tile_off = tile_off; d.lv[l].slot_off = slot_off; }
+    d.pyr_bytes = ctx->pyr_bytes_alloc;
+    if (off > ctx->pyr_bytes_alloc || cand_off > ctx->cand_total_alloc || (int)rtab.size() > ctx->rtab_alloc || slot_off > d.max_kps) return SVO_ERR_CAPACITY;
+    d.n_tiles = tile_off; d.n_slots = slot_off; d.raw_cap = d.max_kps; d.cand_total = ctx->cand_total_alloc;
+    if (!rtab.empty()) HIPCHECK(hipMemcpy(d.rtab, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHECK(configure_nms_rowsort(d));
+    ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = nfe; ctx->geom_nlevels = nlev;
+    return SVO_OK;
+}
+
+// ---- kernel timing ------------------------------------------------------------------------------------------
+static hipEvent_t get_event(svo_ctx* ctx)
+{
+    if (!ctx->free_events.empty()) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct Span {
+    svo_ctx* ctx; int id; hipEvent_t a, b; bool on;
+    Span(svo_ctx* c, int i) : ctx(c), id(i), on(c->cfg.kernel_times != 0) { if (on) { a = get_event(ctx); b = get_event(ctx); hipEventRecord(a, ctx->stream); } }
+    ~Span() { if (on) { hipEventRecord(b, ctx->stream); ctx->spans.push_back({ id, a, b }); } }
+};
+static void collect_spans(svo_ctx* ctx)
+{
+    for (auto& s : ctx->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { ctx->kt_total[s.id] += ms; ctx->kt_calls[s.id] += 1; }
+        ctx->free_events.push_back(s.a); ctx->free_events.push_back(s.b);
+    }
+    ctx->spans.clear();
+}
+
+extern "C" int svo_wait(svo_ctx* ctx)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    collect_spans(ctx);
+    return SVO_OK;
+}
+
+extern "C" int svo_kernel_times(svo_ctx* ctx, const char** names, double* total_ms, int64_t* calls, int cap)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    for (int i = 0; i < KT_COUNT && i < cap; i++) { if (names) names[i] = kt_names[i]; if (total_ms) total_ms[i] = ctx->kt_total[i]; if (calls) calls[i] = ctx->kt_calls[i]; }
+    return KT_COUNT;
+}
+extern "C" int svo_kernel_times_reset(svo_ctx* ctx)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
+    return SVO_OK;
+}
+
+static int hamming_splits(const svo_ctx* ctx) { return ctx->cfg.n_lanes >= 16 ? 2 : (ctx->cfg.n_lanes >= 4 ? 4 : 8); }
+
+// ---- processNewImagePair ---------------------------------------------------------------------------------
+extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    const svo_params& p = ctx->params;
+    // P:54-76: invalid selectors are hard errors; the variants outside the hot path are refused explicitly
+    if (p.detect_method < 0 || p.detect_method > 3 || p.match_method < 0 || p.match_method > 2 || p.ifm_method < 0 || p.ifm_method > 3) return SVO_ERR_ARG;
+    if ((flags & SVO_RUN_DETECT) && p.detect_method != SVO_DM_ORB) return SVO_ERR_UNSUPPORTED;
+    if ((flags & SVO_RUN_MATCH) && p.match_method != SVO_SM_DESC_BF) return SVO_ERR_UNSUPPORTED;
+    if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF) return SVO_ERR_UNSUPPORTED;
+    if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD) return SVO_ERR_UNSUPPORTED;
+    if (p.min_distance < 2) return SVO_ERR_ARG;            // cell size 0 divides by zero in the reference (S2:331-332)
+    DevCtx& d = ctx->dc;
+    const hipStream_t st = ctx->stream;
+    const uint8_t* ptrs[2 * SVO_MAX_LANES];
+    if (flags & SVO_RUN_DETECT) {
+        if (!frames) return SVO_ERR_ARG;                    // P:81
+        const int w = frames[0].left.w, h = frames[0].left.h;
+        for (int l = 0; l < d.n_lanes; l++) {
+            const svo_frame& f = frames[l];
+            if (!f.left.data || !f.right.data || f.left.w != w || f.left.h != h || f.right.w != w || f.right.h != h) return SVO_ERR_ARG;
+        }
+        int rc = ensure_geometry(ctx, w, h); if (rc) return rc;
+        if (flags & SVO_FLAG_DEVICE_IMAGES) {
+            const long long stride = frames[0].left.stride;
+            for (int l = 0; l < d.n_lanes; l++) {
+                if (frames[l].left.stride != stride || frames[l].right.stride != stride) return SVO_ERR_ARG;
+                ptrs[2 * l] = frames[l].left.data; ptrs[2 * l + 1] = frames[l].right.data;
+            }
+            d.img0_pitch = (int)stride;
+        } else {
+            const int pitch = ctx->img0_pitch_internal;
+            for (int l = 0; l < d.n_lanes; l++)
+                for (int s = 0; s < 2; s++) {
+                    const svo_image& im = s ? frames[l].right : frames[l].left;
+                    uint8_t* dst = ctx->d_img0 + (size_t)(2 * l + s) * pitch * ctx->cfg.max_h;
+                    HIPCHECK(hipMemcpy2DAsync(dst, pitch, im.data, (size_t)im.stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
+                    ptrs[2 * l + s] = dst;
+                }
+            d.img0_pitch = pitch;
+        }
+    } else if (!ctx->geom_ready) return SVO_ERR_STATE;
+    d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
+    { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); }
+    if (flags & SVO_RUN_DETECT) {
+        { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
+        { Span s(ctx, KT_FAST); launch_fast(d, st); }
+        { Span s(ctx, KT_SELECT); launch_select(d, st); }
+        { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
+        // kps_to_detect[0] for a single octave = 2 * orb_nfeats (stage2_detect.cpp:405)
+        const int num_out = (int)(size_t)((double)(size_t)p.orb_nfeats * 2.0 / (pow(2, 1) - 1));
+        { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression, p.min_distance, num_out, st); }
+    }
+    const int nsplit = hamming_splits(ctx);
+    if (flags & SVO_RUN_MATCH) {
+        HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * 3 * d.max_kps * sizeof(int), st));
+        { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
+        { Span s(ctx, KT_LR_FILTER); launch_match_lr_filter(d, p.enable_robust_1to1_match, p.max_y_diff, st); }
+    }
+    if (flags & SVO_RUN_TRACK) {
+        if (!(flags & SVO_RUN_MATCH)) HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * 3 * d.max_kps * sizeof(int), st));
+        { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
+        { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
+        { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, st); }
+        { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, st); }
+        { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, st); }
+    }
+    if (flags & SVO_RUN_OPTIMIZE) {
+        GNParams g; memset(&g, 0, sizeof(g));
+        g.use_robust_kernel = p.use_robust_kernel; g.max_iters = p.max_iters; g.initial_max_iters = p.initial_max_iters; g.max_incr_cost = p.max_incr_cost;
+        g.use_previous_pose_as_initial = p.use_previous_pose_as_initial; g.use_custom_initial_pose = 0;   // processNewImagePair passes no initial estimate (P:338)
+        g.min_distance = p.min_distance; g.img_w = d.W; g.img_h = d.H; g.pmax = d.max_kps; g.standalone = 0;
+        g.kernel_param = p.kernel_param; g.min_mod_out_vector = p.min_mod_out_vector; g.residual_threshold = p.residual_threshold;
+        if (p.use_custom_initial_pose) g.use_custom_initial_pose = 1;        // deltaPose = initial_estimation = zeros (S5:504-505, default argument H:1045)
+        { Span s(ctx, KT_GN); launch_gauss_newton(d, g, st); }
+    }
+    HIPCHECK(hipGetLastError());
+    return SVO_OK;
+}
+
+// ---- getters ------------------------------------------------------------------------------------------------
+static int lane_state(svo_ctx* ctx, int lane, LaneState* s)
+{
+    int rc = svo_wait(ctx); if (rc) return rc;
+    HIPCHECK(hipMemcpy(s, ctx->dc.lane + lane, sizeof(LaneState), hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+static int slot_of(const LaneState& s, int which) { return which ? s.prev_slot : 1 - s.prev_slot; }
+
+extern "C" int svo_get_results(svo_ctx* ctx, svo_result* res)
+{
+    if (!ctx || !res) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    HIPCHECK(hipMemcpy(res, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+extern "C" int svo_get_result(svo_ctx* ctx, int lane, svo_result* res)
+{
+    if (!ctx || !res || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    HIPCHECK(hipMemcpy(res, ctx->dc.results + lane, sizeof(svo_result), hipMemcpyDeviceToHost));
+    return SVO_OK;
+}
+
+extern "C" int svo_get_keypoints(svo_ctx* ctx, int lane, int which, int side, svo_keypoint* kps, uint8_t* desc, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1) return SVO_ERR_ARG;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    if (which ? !s.has_prev : !s.has_cur) return 0;
+    const int slot = slot_of(s, which);
+    int n = 0;
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_kps + (lane * 2 + slot) * 2 + side, sizeof(int), hipMemcpyDeviceToHost));
+    const int m = n < cap ? n : cap;
+    const long long base = (((long long)lane * 2 + slot) * 2 + side) * ctx->dc.max_kps;
+    if (kps && m > 0) HIPCHECK(hipMemcpy(kps, ctx->dc.kps + base, sizeof(svo_keypoint) * m, hipMemcpyDeviceToHost));
+    if (desc && m > 0) HIPCHECK(hipMemcpy(desc, ctx->dc.desc + base * 32, (size_t)32 * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* mm, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1) return SVO_ERR_ARG;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    if (which ? !s.has_prev : !s.has_cur) return 0;
+    const int slot = slot_of(s, which);
+    int n = 0;
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_matches + lane * 2 + slot, sizeof(int), hipMemcpyDeviceToHost));
+    const int m = n < cap ? n : cap;
+    if (mm && m > 0) HIPCHECK(hipMemcpy(mm, ctx->dc.matches + ((long long)lane * 2 + slot) * ctx->dc.max_kps, sizeof(svo_dmatch) * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    int n = 0;
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_tracked + lane, sizeof(int), hipMemcpyDeviceToHost));
+    const int m = n < cap ? n : cap;
+    if (t && m > 0) HIPCHECK(hipMemcpy(t, ctx->dc.tracked + (long long)lane * ctx->dc.max_kps, sizeof(svo_index_pair) * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    svo_result res; int rc = svo_get_result(ctx, lane, &res); if (rc) return rc;
+    const int n = res.n_residual, m = n < cap ? n : cap;
+    if (r && m > 0) HIPCHECK(hipMemcpy(r, ctx->dc.residual + (long long)lane * ctx->dc.max_kps, sizeof(double) * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int svo_get_outliers(svo_ctx* ctx, int lane, int32_t* idx, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    svo_result res; int rc = svo_get_result(ctx, lane, &res); if (rc) return rc;
+    const int n = res.n_outliers, m = n < cap ? n : cap;
+    if (idx && m > 0) HIPCHECK(hipMemcpy(idx, ctx->dc.outliers + (long long)lane * ctx->dc.max_kps, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+// ---- precomputed-data bypass ----------------------------------------------------------------------------------
+static int mark_present(svo_ctx* ctx, int lane, int which)
+{
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    if (which) s.has_prev = 1; else s.has_cur = 1;
+    HIPCHECK(hipMemcpy(ctx->dc.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
+extern "C" int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keypoint* kps, const uint8_t* desc, int n, int img_w, int img_h)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || n < 0 || (n > 0 && !kps)) return SVO_ERR_ARG;
+    if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
+    int rc = ensure_geometry(ctx, img_w, img_h); if (rc) return rc;
+    LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    const int slot = slot_of(s, which);
+    const long long base = (((long long)lane * 2 + slot) * 2 + side) * ctx->dc.max_kps;
+    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.kps + base, kps, sizeof(svo_keypoint) * n, hipMemcpyHostToDevice));
+    if (n > 0 && desc) HIPCHECK(hipMemcpy(ctx->dc.desc + base * 32, desc, (size_t)32 * n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_kps + (lane * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice));
+    return mark_present(ctx, lane, which);
+}
+
+extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !m)) return SVO_ERR_ARG;
+    if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    const int slot = slot_of(s, which);
+    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.matches + ((long long)lane * 2 + slot) * ctx->dc.max_kps, m, sizeof(svo_dmatch) * n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_matches + lane * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
+    return mark_present(ctx, lane, which);
+}
+
+extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || n < 0 || (n > 0 && !t)) return SVO_ERR_ARG;
+    if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.tracked + (long long)lane * ctx->dc.max_kps, t, sizeof(svo_index_pair) * n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_tracked + lane, &n, sizeof(int), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
+// ---- getChangeInPose (common.cpp:355-413) -------------------------------------------------------------------
+extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, int n_tracked,
+                                  const svo_dmatch* pre_matches, int n_pre, const svo_dmatch* cur_matches, int n_cur,
+                                  const svo_keypoint* pre_left, int n_pl, const svo_keypoint* pre_right, int n_pr,
+                                  const svo_keypoint* cur_left, int n_cl, const svo_keypoint* cur_right, int n_cr,
+                                  const svo_stereo_camera* cam, const double* init6,
+                                  svo_result* res, double* residual, int32_t* outliers)
+{
+    if (!ctx || !cam || !res || n_tracked < 0) return SVO_ERR_ARG;
+    if (cam->ncols < 1 || cam->nrows < 1) return SVO_ERR_ARG;
+    const svo_params& p = ctx->params;
+    DevCtx& d = ctx->dc;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    if (!ctx->geom_ready) { d.W = cam->ncols; d.H = cam->nrows; }
+    const int lane = 0;
+    HIPCHECK(hipMemcpy(d.cams + lane, cam, sizeof(*cam), hipMemcpyHostToDevice));
+    LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    s.has_prev = 1; s.has_cur = 1;
+    HIPCHECK(hipMemcpy(d.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
+    auto put_k = [&](int which, int side, const svo_keypoint* k, int n) -> int {
+        if (n > d.max_kps) return SVO_ERR_CAPACITY;
+        const int slot = slot_of(s, which);
+        const long long base = (((long long)lane * 2 + slot) * 2 + side) * d.max_kps;
+        if (n > 0 && hipMemcpy(d.kps + base, k, sizeof(svo_keypoint) * n, hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
+        if (hipMemcpy(d.n_kps + (lane * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
+        return SVO_OK;
+    };
+    if ((rc = put_k(1, 0, pre_left, n_pl)) || (rc = put_k(1, 1, pre_right, n_pr)) || (rc = put_k(0, 0, cur_left, n_cl)) || (rc = put_k(0, 1, cur_right, n_cr))) return rc;
+    if ((rc = svo_put_matches(ctx, lane, 1, pre_matches, n_pre)) || (rc = svo_put_matches(ctx, lane, 0, cur_matches, n_cur))) return rc;
+    launch_begin_frame(d, nullptr, SVO_FLAG_NO_SHIFT, ctx->stream);
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if ((rc = svo_put_tracked(ctx, lane, tracked, n_tracked))) return rc;
+    GNParams g; memset(&g, 0, sizeof(g));
+    g.use_robust_kernel = p.use_robust_kernel; g.max_iters = p.max_iters; g.initial_max_iters = p.initial_max_iters; g.max_incr_cost = p.max_incr_cost;
+    g.use_previous_pose_as_initial = p.use_previous_pose_as_initial; g.use_custom_initial_pose = p.use_custom_initial_pose;
+    g.min_distance = p.min_distance; g.img_w = cam->ncols; g.img_h = cam->nrows;      // common.cpp:402-403
+    g.pmax = d.max_kps; g.standalone = 1;
+    g.kernel_param = p.kernel_param; g.min_mod_out_vector = p.min_mod_out_vector; g.residual_threshold = p.residual_threshold;
+    for (int k = 0; k < 6; k++) g.init[k] = init6 ? init6[k] : 0.0;
+    // only lane 0 carries data; the other lanes see n_tracked == 0 and return invalid
+    { Span sp(ctx, KT_GN); launch_gauss_newton(d, g, ctx->stream); }
+    if ((rc = svo_get_result(ctx, lane, res))) return rc;
+    if (residual && res->n_residual > 0) HIPCHECK(hipMemcpy(residual, d.residual, sizeof(double) * res->n_residual, hipMemcpyDeviceToHost));
+    if (outliers && res->n_outliers > 0) HIPCHECK(hipMemcpy(outliers, d.outliers, sizeof(int32_t) * res->n_outliers, hipMemcpyDeviceToHost));
+    return res->valid;
+}
+
+// ---- standalone brute-force matcher -------------------------------------------------------------------------
+extern "C" int svo_hamming_match(svo_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt, int32_t* idx, int32_t* dist)
+{
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!query || !idx || !dist)) || (nt > 0 && !train)) return SVO_ERR_ARG;
+    if (nt > 65535) return SVO_ERR_UNSUPPORTED;            // train index packs into 16 bits
+    if (nq == 0) return SVO_OK;
+    if (nt == 0) { for (int i = 0; i < nq; i++) { idx[i] = -1; dist[i] = 0; } return SVO_OK; }
+    if (nq > ctx->ham_cap_q) {
+        if (ctx->d_ham_q) hipFree(ctx->d_ham_q); if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
+        ctx->d_ham_q = nullptr; ctx->d_ham_out = nullptr; ctx->ham_cap_q = 0;
+        HIPCHECK(hipMalloc((void**)&ctx->d_ham_q, (size_t)nq * 32)); HIPCHECK(hipMalloc((void**)&ctx->d_ham_out, (size_t)nq * 4)); ctx->ham_cap_q = nq;
+    }
+    if (nt > ctx->ham_cap_t) {
+        if (ctx->d_ham_t) hipFree(ctx->d_ham_t);
+        ctx->d_ham_t = nullptr; ctx->ham_cap_t = 0;
+        HIPCHECK(hipMalloc((void**)&ctx->d_ham_t, (size_t)nt * 32)); ctx->ham_cap_t = nt;
+    }
+    const hipStream_t st = ctx->stream;
+    HIPCHECK(hipMemcpyAsync(ctx->d_ham_q, query, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(ctx->d_ham_t, train, (size_t)nt * 32, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemsetAsync(ctx->d_ham_out, 0xFF, (size_t)nq * 4, st));
+    const int tiles = (nt + 255) / 256;
+    int nsplit = 1; while (nsplit < 16 && nsplit * 2 <= tiles && ((nq + 255) / 256) * nsplit < 1024) nsplit *= 2;
+    launch_hamming_plain(ctx->d_ham_q, nq, ctx->d_ham_t, nt, ctx->d_ham_out, nsplit, st);
+    std::vector<unsigned> out((size_t)nq);
+    HIPCHECK(hipMemcpyAsync(out.data(), ctx->d_ham_out, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < nq; i++) { idx[i] = (int)(out[i] & 0xFFFFu); dist[i] = (int)(out[i] >> 16); }
+    return SVO_OK;
+}
+
+// ---- probes ------------------------------------------------------------------------------------------------
+extern "C" int svo_debug_get_level(svo_ctx* ctx, int lane, int side, int level, uint8_t* out, int cap, int* w, int* h)
+{
+    if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || level < 0 || level >= ctx->dc.n_levels) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    const LevelGeom& g = ctx->dc.lv[level];
+    if (w) *w = g.w; if (h) *h = g.h;
+    if (!out) return g.w * g.h;
+    if (cap < g.w * g.h) return SVO_ERR_CAPACITY;
+    const int img = lane * 2 + side;
+    const uint8_t* src; int pitch;
+    if (level == 0) { const uint8_t* p0 = nullptr; HIPCHECK(hipMemcpy(&p0, ctx->dc.img0 + img, sizeof(p0), hipMemcpyDeviceToHost)); src = p0; pitch = ctx->dc.img0_pitch; if (!src) return SVO_ERR_STATE; }
+    else { src = ctx->dc.pyr + (long long)img * ctx->dc.pyr_bytes + g.offset; pitch = g.pitch; }
+    HIPCHECK(hipMemcpy2D(out, (size_t)g.w, src, (size_t)pitch, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost));
+    return g.w * g.h;
+}
+
+extern "C" int svo_debug_get_raw_keypoints(svo_ctx* ctx, int lane, int side, svo_keypoint* kps, uint8_t* desc, int cap)
+{
+    if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    const DevCtx& d = ctx->dc;
+    const int img = lane * 2 + side;
+    int ln[SVO_MAX_LEVELS];
+    HIPCHECK(hipMemcpy(ln, d.lvl_n + img * SVO_MAX_LEVELS, sizeof(ln), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int l = 0; l < d.n_levels; l++) {
+        for (int i = 0; i < ln[l]; i++, n++) {
+            if (n >= cap) continue;
+            const long long o = (long long)img * d.raw_cap + d.lv[l].slot_off + i;
+            if (kps) HIPCHECK(hipMemcpy(kps + n, d.raw_kps + o, sizeof(svo_keypoint), hipMemcpyDeviceToHost));
+            if (desc) HIPCHECK(hipMemcpy(desc + (size_t)n * 32, d.raw_desc + o * 32, 32, hipMemcpyDeviceToHost));
+        }
+    }
+    return n;
+}
+
+extern "C" int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w)
+{
+    if (!ctx || !w || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    HIPCHECK(hipMemcpy(w, ctx->dc.status + lane, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SVO_OK;
+}

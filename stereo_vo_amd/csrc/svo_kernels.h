@@ -1,0 +1,32 @@
+// svo_kernels.h -- host-side launchers of the HIP kernels (defined in k_detect.hip, k_match.hip, k_gn.hip)
+#pragma once
+#include "svo_device.h"
+
+struct GNParams {
+    int use_robust_kernel, max_iters, initial_max_iters, max_incr_cost;
+    int use_previous_pose_as_initial, use_custom_initial_pose;
+    int min_distance, img_w, img_h;      // grid of the stage-5 NMS mask (S5:465-468)
+    int pmax;                            // power of two >= max_kps (LDS carve)
+    int standalone;                      // 1: getChangeInPose entry (no prev/bad-tracking gate)
+    int pad;
+    double kernel_param, min_mod_out_vector, residual_threshold;
+    double init[6];
+};
+
+hipError_t svo_upload_tables();
+void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned flags, hipStream_t st);
+void launch_resize(const DevCtx& c, int level, hipStream_t st);
+void launch_fast(const DevCtx& c, hipStream_t st);
+void launch_select(const DevCtx& c, hipStream_t st);
+void launch_describe(const DevCtx& c, hipStream_t st);
+hipError_t configure_nms_rowsort(const DevCtx& c);
+void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int num_out_points, hipStream_t st);
+void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st);
+void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st);
+void launch_track_filter(const DevCtx& c, hipStream_t st);
+void launch_ransac_hyp(const DevCtx& c, hipStream_t st);
+void launch_ransac_count(const DevCtx& c, hipStream_t st);
+void launch_track_finalize(const DevCtx& c, int bad_tracking_th, hipStream_t st);
+void launch_hamming_plain(const uint8_t* q, int nq, const uint8_t* t, int nt, unsigned* out, int nsplit, hipStream_t st);
+hipError_t configure_gauss_newton(int pmax);
+void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st);

@@ -1,0 +1,288 @@
+"""ctypes binding of the HIP C-ABI (include/svo_hip.h -> stereo_vo_amd/libsvo_hip.so).
+
+This is the product path.  There is no CPU fallback: `lib()` raises if the shared library is missing and
+`Context()` raises if no HIP device is present.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .abi import Params, Result, StereoCamera, keypoint_dtype, dmatch_dtype, index_pair_dtype
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvo_hip.so")
+_LIB = None
+
+MAX_LANES = 64
+RUN_DETECT, RUN_MATCH, RUN_TRACK, RUN_OPTIMIZE, RUN_ALL = 1, 2, 4, 8, 15
+FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES = 16, 32, 64
+
+# every entry point include/svo_hip.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "svo_config_defaults", "svo_params_defaults", "svo_create", "svo_destroy", "svo_strerror", "svo_last_error",
+    "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
+    "svo_get_orb_threshold", "svo_set_camera", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results",
+    "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
+    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_change_in_pose", "svo_hamming_match",
+    "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
+    "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_lanes", C.c_int32), ("max_w", C.c_int32), ("max_h", C.c_int32),
+                ("max_kps", C.c_int32), ("max_cand", C.c_int32), ("kernel_times", C.c_int32), ("_pad", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("stride", C.c_int64)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("left", Image), ("right", Image)]
+
+
+class SvoError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvoError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.svo_strerror.restype = C.c_char_p
+        L.svo_last_error.restype = C.c_char_p
+        L.svo_last_error.argtypes = [C.c_void_p]
+        for n in ("svo_destroy", "svo_config_defaults", "svo_params_defaults", "svo_abi_sizes"):
+            getattr(L, n).restype = None
+        L.svo_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def default_params() -> Params:
+    p = Params()
+    lib().svo_params_defaults(C.byref(p))
+    return p
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """n_lanes independent rso::CStereoOdometryEstimator streams driven through the HIP kernels together."""
+
+    def __init__(self, n_lanes=1, max_w=1280, max_h=960, max_kps=4096, max_cand=1 << 17, device=0, kernel_times=False, stream=None):
+        self.L = lib()
+        cfg = Config()
+        self.L.svo_config_defaults(C.byref(cfg))
+        cfg.device, cfg.n_lanes, cfg.max_w, cfg.max_h, cfg.max_kps, cfg.max_cand = device, n_lanes, max_w, max_h, max_kps, max_cand
+        cfg.kernel_times = int(kernel_times)
+        cfg.stream = stream
+        self.n_lanes, self.max_kps = n_lanes, max_kps
+        h = C.c_void_p()
+        rc = self.L.svo_create(C.byref(cfg), C.byref(h))
+        self.h = h
+        if rc != 0:
+            msg = self._err(rc)
+            if h:
+                self.L.svo_destroy(h)
+            self.h = None
+            raise SvoError("svo_create failed: " + msg)
+        self._keep = None
+
+    def _err(self, rc):
+        s = self.L.svo_strerror(rc).decode()
+        if self.h:
+            le = self.L.svo_last_error(self.h)
+            if le:
+                s += " [" + le.decode() + "]"
+        return s
+
+    def _ck(self, rc, what):
+        if rc < 0:
+            raise SvoError("%s: %s" % (what, self._err(rc)))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.svo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters ------------------------------------------------------------------------------------
+    def set_params(self, p: Params):
+        self._ck(self.L.svo_set_params(self.h, C.byref(p)), "svo_set_params")
+
+    def set_camera(self, cam: StereoCamera, lane=-1):
+        self._ck(self.L.svo_set_camera(self.h, lane, C.byref(cam)), "svo_set_camera")
+
+    def set_fast_threshold(self, v):
+        self._ck(self.L.svo_set_fast_threshold(self.h, int(v)), "svo_set_fast_threshold")
+
+    def set_orb_threshold(self, v):
+        self._ck(self.L.svo_set_orb_threshold(self.h, int(v)), "svo_set_orb_threshold")
+
+    def fast_threshold(self):
+        return self.L.svo_get_fast_threshold(self.h)
+
+    def orb_threshold(self):
+        return self.L.svo_get_orb_threshold(self.h)
+
+    def reset(self, lane=-1):
+        self._ck(self.L.svo_reset(self.h, lane), "svo_reset")
+
+    # -- frames ----------------------------------------------------------------------------------------
+    def process_host(self, pairs, flags=RUN_ALL):
+        """pairs: list of (left, right) uint8 numpy arrays [h, w], one per lane."""
+        assert len(pairs) == self.n_lanes
+        fr = (Frame * self.n_lanes)()
+        keep = []
+        for i, (l, r) in enumerate(pairs):
+            l = np.ascontiguousarray(l, np.uint8)
+            r = np.ascontiguousarray(r, np.uint8)
+            keep += [l, r]
+            h, w = l.shape
+            fr[i].left = Image(l.ctypes.data, w, h, l.strides[0])
+            fr[i].right = Image(r.ctypes.data, w, h, r.strides[0])
+        self._keep = keep
+        self._ck(self.L.svo_process(self.h, fr, C.c_uint32(flags & ~FLAG_DEVICE_IMAGES)), "svo_process")
+
+    def process_device(self, ptr_pairs, w, h, stride, flags=RUN_ALL):
+        """ptr_pairs: list of (left_ptr, right_ptr) device addresses (e.g. torch tensor.data_ptr()), one per lane."""
+        assert len(ptr_pairs) == self.n_lanes
+        fr = (Frame * self.n_lanes)()
+        for i, (l, r) in enumerate(ptr_pairs):
+            fr[i].left = Image(l, w, h, stride)
+            fr[i].right = Image(r, w, h, stride)
+        self._ck(self.L.svo_process(self.h, fr, C.c_uint32(flags | FLAG_DEVICE_IMAGES)), "svo_process")
+
+    def run_stages(self, flags):
+        """Run stages on data already in the context (svo_put_* / previous svo_process), no prev/cur shift."""
+        self._ck(self.L.svo_process(self.h, None, C.c_uint32((flags | FLAG_NO_SHIFT) & ~RUN_DETECT)), "svo_process")
+
+    def wait(self):
+        self._ck(self.L.svo_wait(self.h), "svo_wait")
+
+    def result(self, lane=0) -> Result:
+        r = Result()
+        self._ck(self.L.svo_get_result(self.h, lane, C.byref(r)), "svo_get_result")
+        return r
+
+    def results(self):
+        arr = (Result * self.n_lanes)()
+        self._ck(self.L.svo_get_results(self.h, arr), "svo_get_results")
+        return list(arr)
+
+    # -- lists -----------------------------------------------------------------------------------------
+    def keypoints(self, lane=0, which=0, side=0):
+        n = self._ck(self.L.svo_get_keypoints(self.h, lane, which, side, None, None, 0), "svo_get_keypoints")
+        k = np.zeros(n, keypoint_dtype)
+        d = np.zeros((n, 32), np.uint8)
+        if n:
+            self._ck(self.L.svo_get_keypoints(self.h, lane, which, side, _vp(k), _vp(d), n), "svo_get_keypoints")
+        return k, d
+
+    def raw_keypoints(self, lane=0, side=0):
+        n = self._ck(self.L.svo_debug_get_raw_keypoints(self.h, lane, side, None, None, 0), "svo_debug_get_raw_keypoints")
+        k = np.zeros(n, keypoint_dtype)
+        d = np.zeros((n, 32), np.uint8)
+        if n:
+            self._ck(self.L.svo_debug_get_raw_keypoints(self.h, lane, side, _vp(k), _vp(d), n), "svo_debug_get_raw_keypoints")
+        return k, d
+
+    def level(self, lane, side, level):
+        w, h = C.c_int(0), C.c_int(0)
+        n = self._ck(self.L.svo_debug_get_level(self.h, lane, side, level, None, 0, C.byref(w), C.byref(h)), "svo_debug_get_level")
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._ck(self.L.svo_debug_get_level(self.h, lane, side, level, _vp(out), n, C.byref(w), C.byref(h)), "svo_debug_get_level")
+        return out
+
+    def status_word(self, lane=0):
+        w = C.c_uint32(0)
+        self._ck(self.L.svo_debug_get_status_word(self.h, lane, C.byref(w)), "svo_debug_get_status_word")
+        return w.value
+
+    def matches(self, lane=0, which=0):
+        n = self._ck(self.L.svo_get_matches(self.h, lane, which, None, 0), "svo_get_matches")
+        m = np.zeros(n, dmatch_dtype)
+        if n:
+            self._ck(self.L.svo_get_matches(self.h, lane, which, _vp(m), n), "svo_get_matches")
+        return m
+
+    def tracked(self, lane=0):
+        n = self._ck(self.L.svo_get_tracked(self.h, lane, None, 0), "svo_get_tracked")
+        t = np.zeros(n, index_pair_dtype)
+        if n:
+            self._ck(self.L.svo_get_tracked(self.h, lane, _vp(t), n), "svo_get_tracked")
+        return t
+
+    def residuals(self, lane=0):
+        n = self._ck(self.L.svo_get_residuals(self.h, lane, None, 0), "svo_get_residuals")
+        r = np.zeros(n, np.float64)
+        if n:
+            self._ck(self.L.svo_get_residuals(self.h, lane, _vp(r), n), "svo_get_residuals")
+        return r
+
+    def outliers(self, lane=0):
+        n = self._ck(self.L.svo_get_outliers(self.h, lane, None, 0), "svo_get_outliers")
+        r = np.zeros(n, np.int32)
+        if n:
+            self._ck(self.L.svo_get_outliers(self.h, lane, _vp(r), n), "svo_get_outliers")
+        return r
+
+    # -- precomputed-data bypass -------------------------------------------------------------------------
+    def put_features(self, lane, which, side, kps, desc, img_w, img_h):
+        kps = np.ascontiguousarray(kps)
+        desc = None if desc is None else np.ascontiguousarray(desc, np.uint8)
+        self._ck(self.L.svo_put_features(self.h, lane, which, side, _vp(kps), _vp(desc), len(kps), img_w, img_h), "svo_put_features")
+
+    def put_matches(self, lane, which, m):
+        m = np.ascontiguousarray(m)
+        self._ck(self.L.svo_put_matches(self.h, lane, which, _vp(m), len(m)), "svo_put_matches")
+
+    def put_tracked(self, lane, t):
+        t = np.ascontiguousarray(t)
+        self._ck(self.L.svo_put_tracked(self.h, lane, _vp(t), len(t)), "svo_put_tracked")
+
+    def change_in_pose(self, tracked, pre_m, cur_m, pre_l, pre_r, cur_l, cur_r, cam, init6=None):
+        n = len(tracked)
+        res = Result()
+        residual = np.zeros(max(n, 1), np.float64)
+        outl = np.zeros(max(n, 1), np.int32)
+        init = None if init6 is None else np.ascontiguousarray(init6, np.float64)
+        arrs = [np.ascontiguousarray(a) for a in (tracked, pre_m, cur_m, pre_l, pre_r, cur_l, cur_r)]
+        rc = self.L.svo_change_in_pose(self.h, _vp(arrs[0]), n, _vp(arrs[1]), len(pre_m), _vp(arrs[2]), len(cur_m),
+                                       _vp(arrs[3]), len(pre_l), _vp(arrs[4]), len(pre_r), _vp(arrs[5]), len(cur_l), _vp(arrs[6]), len(cur_r),
+                                       C.byref(cam), _vp(init), C.byref(res), _vp(residual), _vp(outl))
+        self._ck(rc, "svo_change_in_pose")
+        return bool(rc), res, residual[:res.n_residual], outl[:res.n_outliers]
+
+    def hamming_match(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.zeros(max(len(q), 1), np.int32)
+        dist = np.zeros(max(len(q), 1), np.int32)
+        self._ck(self.L.svo_hamming_match(self.h, _vp(q), len(q), _vp(t), len(t), _vp(idx), _vp(dist)), "svo_hamming_match")
+        return idx[:len(q)], dist[:len(q)]
+
+    # -- timing ----------------------------------------------------------------------------------------
+    def kernel_times(self):
+        names = (C.c_char_p * 32)()
+        tot = (C.c_double * 32)()
+        calls = (C.c_int64 * 32)()
+        n = self._ck(self.L.svo_kernel_times(self.h, names, tot, calls, 32), "svo_kernel_times")
+        return {names[i].decode(): (tot[i], calls[i]) for i in range(n)}
+
+    def kernel_times_reset(self):
+        self._ck(self.L.svo_kernel_times_reset(self.h), "svo_kernel_times_reset")
