@@ -1,0 +1,44 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/svo_hip.h declares, its record
+sizes match the Python mirrors, and it refuses to run without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import pytest
+
+from stereo_vo_amd import hip
+from stereo_vo_amd.abi import Params, Result, StereoCamera, keypoint_dtype, dmatch_dtype
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = hip.lib()
+    hdr = open(os.path.join(ROOT, "include", "svo_hip.h")).read()
+    declared = set(re.findall(r"\b(svo_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_abi_record_sizes():
+    a = (C.c_int32 * 6)()
+    hip.lib().svo_abi_sizes(a)
+    assert list(a) == [keypoint_dtype.itemsize, dmatch_dtype.itemsize, C.sizeof(StereoCamera), C.sizeof(Params), C.sizeof(Result), C.sizeof(hip.Config)]
+
+
+def test_defaults_agree_with_oracle_defaults():
+    from oracle import oracle as O
+    a, b = hip.default_params(), O.default_params()
+    assert bytes(a) == bytes(b)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hip.SvoError, match="no HIP device"):
+        hip.Context()
+
+
+def test_strerror():
+    assert hip.lib().svo_strerror(0) == b"ok" and b"fallback" in hip.lib().svo_strerror(-4)

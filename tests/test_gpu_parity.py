@@ -1,0 +1,258 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): keypoints, descriptors, pairings and tracked pairs bit-exact; poses within
+1e-4 rad / 1e-3 m.  Every test here needs a real MI355X: run with `pytest -m gpu`."""
+import os
+import numpy as np
+import pytest
+
+from stereo_vo_amd import hip
+from stereo_vo_amd.abi import StereoCamera, north_star_params, keypoint_dtype, dmatch_dtype, index_pair_dtype
+from stereo_vo_amd.synth import SyntheticStereoWorld
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M, POSE_TOL_RAD = 1e-3, 1e-4
+
+
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def assert_same_frame(ctx, lane, orc, r, ro, tag):
+    for side in (0, 1):
+        k, d = ctx.keypoints(lane, 0, side)
+        ko, do = orc.keypoints(0, side)
+        assert len(k) == len(ko), (tag, side, len(k), len(ko))
+        assert k.tobytes() == ko.tobytes(), (tag, "keypoints", side)
+        assert (d == do).all(), (tag, "descriptors", side)
+    assert ctx.matches(lane).tobytes() == orc.matches(0).tobytes(), (tag, "pairings")
+    assert ctx.tracked(lane).tobytes() == orc.tracked().tobytes(), (tag, "tracked pairs")
+    assert (r.valid, r.error_code) == (ro.valid, ro.error_code), (tag, r.valid, r.error_code, ro.valid, ro.error_code)
+    assert (r.detected_left[0], r.detected_right[0], r.stereo_matches[0]) == (ro.detected_left[0], ro.detected_right[0], ro.stereo_matches[0])
+    assert (r.n_residual, r.n_outliers) == (ro.n_residual, ro.n_outliers), tag
+    if ro.valid:
+        dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
+        assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD, (tag, dp)
+        assert r.tracked_feats_from_last_frame == ro.tracked_feats_from_last_frame
+        assert (ctx.outliers(lane) == orc.outliers()).all(), (tag, "inlier list")
+        a, b = ctx.residuals(lane), orc.residuals()
+        fin = b < 1e300
+        assert ((a < 1e300) == fin).all() and np.allclose(a[fin], b[fin], rtol=1e-6, atol=1e-9), (tag, "residuals")
+
+
+def load_small(golden_dir):
+    g = np.load(os.path.join(golden_dir, "oracle_small_seq.npz"))
+    cam = StereoCamera.simple(float(g["F"]), float(g["cx"]), float(g["cy"]), float(g["baseline"]), int(g["W"]), int(g["H"]))
+    p = north_star_params(hip.default_params(), orb_nfeats=int(g["orb_nfeats"]))
+    return g, cam, p
+
+
+def test_small_sequence_against_golden_and_oracle(golden_dir):
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(4):
+        ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+        r, ro = ctx.result(0), orc.process(g["L%d" % t], g["R%d" % t], cam)
+        assert_same_frame(ctx, 0, orc, r, ro, "t=%d" % t)
+        # and against the committed vectors directly
+        for side in (0, 1):
+            k, d = ctx.keypoints(0, 0, side)
+            assert k.tobytes() == g["kps%d_%d" % (side, t)].tobytes() and (d == g["desc%d_%d" % (side, t)]).all()
+        assert ctx.matches(0).tobytes() == g["matches%d" % t].tobytes()
+        assert ctx.tracked(0).tobytes() == g["tracked%d" % t].tobytes()
+        assert np.allclose(np.array(r.outPose), g["pose%d" % t], atol=1e-6)
+        assert ctx.status_word(0) == 0
+    ctx.close()
+
+
+def test_pyramid_and_detector_stage_outputs(golden_dir):
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    ctx.process_host([(g["L0"], g["R0"])], hip.RUN_DETECT)
+    lw, lh, _ = O().pyramid_sizes(int(g["W"]), int(g["H"]), 8)
+    prev = g["L0"]
+    for l in range(1, 8):
+        ref = O().resize(prev, lw[l], lh[l])
+        assert (ctx.level(0, 0, l) == ref).all(), "level %d" % l
+        prev = ref
+    for side, img in ((0, g["L0"]), (1, g["R0"])):
+        k, d = ctx.raw_keypoints(0, side)
+        ko, do = O().orb_detect(img, int(1.5 * int(g["orb_nfeats"])), 8, 20)
+        assert k.tobytes() == ko.tobytes() and (d == do).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,f,cx,cy,B,nfe", [(1280, 960, 800.0, None, None, 0.12, 2000), (1241, 376, 718.856, 607.19, 185.22, 0.537, 900)])
+def test_full_size_streams_match_oracle(w, h, f, cx, cy, B, nfe):
+    """BASELINE.json configs[1] (1280x960, ~2000 kps) and configs[2] (KITTI-00 shape), 2 lanes x 3 frames."""
+    worlds = [SyntheticStereoWorld(w, h, f, B, seed=100 + s, n_frames=3, cx=cx, cy=cy) for s in range(2)]
+    cam = worlds[0].camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=nfe)
+    ctx = hip.Context(n_lanes=2, max_w=w, max_h=h, max_kps=4096)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orcs = [O().Oracle(p) for _ in range(2)]
+    for t in range(3):
+        pairs = [tuple(x.numpy() for x in wd.render(t)) for wd in worlds]
+        ctx.process_host(pairs)
+        for lane in range(2):
+            ro = orcs[lane].process(pairs[lane][0], pairs[lane][1], cam)
+            assert_same_frame(ctx, lane, orcs[lane], ctx.result(lane), ro, "%dx%d lane=%d t=%d" % (w, h, lane, t))
+            assert ctx.status_word(lane) == 0
+            if t > 0 and w == 1280:
+                assert ro.detected_left[0] > 1500 and ro.tracked_feats_from_last_frame > 100
+    ctx.close()
+
+
+def test_hamming_match_against_oracle_and_properties():
+    ctx = hip.Context(n_lanes=1, max_w=64, max_h=64, max_kps=64)
+    rng = np.random.RandomState(0)
+    for nq, nt in [(1, 1), (3, 255), (255, 256), (257, 257), (1000, 3), (2025, 2025), (5000, 3000)]:
+        q = rng.randint(0, 256, (nq, 32)).astype(np.uint8)
+        t = rng.randint(0, 256, (nt, 32)).astype(np.uint8)
+        if nt > 10:          # planted ties and exact duplicates: the FIRST minimum must win (cv::BFMatcher::match)
+            t[nt - 1] = t[2]; q[0] = t[2]
+            t[7] = t[5]
+            if nq > 1: q[1] = t[5]; q[1, 0] ^= 1
+        idx, dist = ctx.hamming_match(q, t)
+        io, do = O().hamming_bf(q, t)
+        assert (idx == io).all() and (dist == do).all(), (nq, nt)
+    idx, dist = ctx.hamming_match(q[:4], np.zeros((0, 32), np.uint8))
+    assert (idx == -1).all()
+    # full size beyond what the oracle covers quickly: size-independent properties on a sample of queries
+    nq = nt = 30000
+    q = rng.randint(0, 256, (nq, 32)).astype(np.uint8); t = rng.randint(0, 256, (nt, 32)).astype(np.uint8)
+    idx, dist = ctx.hamming_match(q, t)
+    pc = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for i in rng.choice(nq, 40, replace=False):
+        dd = pc[q[i][None, :] ^ t].sum(1)
+        assert dist[i] == dd.min() and idx[i] == int(np.argmin(dd))
+    # self-match: every row's nearest neighbour in its own set is itself at distance 0
+    idx, dist = ctx.hamming_match(t[:20000], t[:20000])
+    assert (dist == 0).all() and (idx == np.arange(20000)).all()
+    ctx.close()
+
+
+def _tracks(cam, delta, n=400, seed=3, noise=0.0, n_out=0):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_units import _synthetic_tracks
+    return _synthetic_tracks(cam, delta, n=n, seed=seed, noise=noise, n_out=n_out)
+
+
+def test_change_in_pose_against_oracle():
+    """getChangeInPose boundary (common.cpp:355-413): stage 5 alone on caller arrays."""
+    cam = StereoCamera.simple(800.0, 639.5, 479.5, 0.12, 1280, 960)
+    p = north_star_params(hip.default_params())
+    for delta, noise, n_out, n in [(np.array([0.004, -0.009, 0.002, 0.02, -0.01, -0.25]), 0.0, 0, 400),
+                                   (np.array([-0.01, 0.02, 0.005, -0.05, 0.02, 0.4]), 0.3, 40, 1500),
+                                   (np.array([0.0, 0.001, 0.0, 0.0, 0.0, -0.1]), 0.1, 0, 6)]:
+        t, m, pl, pr, cl, cr = _tracks(cam, delta, n=n, noise=noise, n_out=n_out)
+        ctx = hip.Context(n_lanes=1, max_w=1280, max_h=960, max_kps=2048)
+        ctx.set_params(p)
+        orc = O().Oracle(p)
+        for rep in range(2):       # second call exercises the m_last_computed_pose warm start
+            v, r, resid, outl = ctx.change_in_pose(t, m, m, pl, pr, cl, cr, cam)
+            vo, ro, resid_o, outl_o = orc.change_in_pose(t, m, m, pl, pr, cl, cr, cam)
+            assert v == vo and (r.n_residual, r.n_outliers, r.error_code) == (ro.n_residual, ro.n_outliers, ro.error_code)
+            if vo:
+                assert np.abs(np.array(r.delta) - np.array(ro.delta)).max() < 1e-7
+                dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
+                assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD
+                assert (outl == outl_o).all()
+                fin = resid_o < 1e300
+                assert np.allclose(resid[fin], resid_o[fin], rtol=1e-6, atol=1e-9)
+                assert abs(r.num_it - ro.num_it) <= 1 and abs(r.num_it_final - ro.num_it_final) <= 1
+        # custom initial pose has priority and is not stored (S5:504-505, 720)
+        q = p.copy(); q.use_custom_initial_pose = 1
+        ctx.set_params(q); orc.set_params(q)
+        v, r, _, _ = ctx.change_in_pose(t, m, m, pl, pr, cl, cr, cam, init6=delta * 0.9)
+        vo, ro, _, _ = orc.change_in_pose(t, m, m, pl, pr, cl, cr, cam, init6=delta * 0.9)
+        assert v == vo and (not vo or np.abs(np.array(r.delta) - np.array(ro.delta)).max() < 1e-7)
+        ctx.close()
+
+
+def test_recovery_rule_and_first_frame(golden_dir):
+    """a19: voecFirstIteration on the first frame; after voecBadTracking the previous frame is kept (P:86-89)."""
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    blank = np.full_like(g["L0"], 128)
+    seq = [(g["L0"], g["R0"], False), (blank, blank, False), (g["L1"], g["R1"], False), (g["L2"], g["R2"], True), (g["L3"], g["R3"], False)]
+    for i, (L, R, rep) in enumerate(seq):
+        ctx.process_host([(L, R)], hip.RUN_ALL | (hip.FLAG_REPEAT if rep else 0))
+        r, ro = ctx.result(0), orc.process(L, R, cam, repeat=rep)
+        assert_same_frame(ctx, 0, orc, r, ro, "step %d" % i)
+        kp, _ = ctx.keypoints(0, 1, 0); kpo, _ = orc.keypoints(1, 0)
+        assert kp.tobytes() == kpo.tobytes(), "previous-frame keypoints at step %d" % i
+    assert [4, 5][0] == 4
+    ctx.close()
+
+
+def test_precomputed_data_bypass(golden_dir):
+    """P:131-162 / P:219-251: caller-supplied features and pairings, then stages 4-5 only."""
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    for which, t in ((1, 1), (0, 2)):
+        for side in (0, 1):
+            ctx.put_features(0, which, side, g["kps%d_%d" % (side, t)], g["desc%d_%d" % (side, t)], W, H)
+        ctx.put_matches(0, which, g["matches%d" % t])
+    ctx.run_stages(hip.RUN_TRACK | hip.RUN_OPTIMIZE)
+    assert ctx.tracked(0).tobytes() == g["tracked2"].tobytes()
+    r = ctx.result(0)
+    # frame 2 of the golden run started from frame 1's pose; here the warm start is zero: same optimum within tolerance
+    dp = np.abs(np.array(r.outPose) - g["pose2"])
+    assert r.valid and dp[:3].max() < 5e-3 and dp[3:].max() < 5e-4
+    # stage 3 alone on put features reproduces the pairings
+    ctx.run_stages(hip.RUN_MATCH)
+    assert ctx.matches(0).tobytes() == g["matches2"].tobytes()
+    ctx.close()
+
+
+def test_device_resident_images_and_lane_independence(golden_dir):
+    import torch
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    ctx = hip.Context(n_lanes=3, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    keep = []
+    for t in range(3):
+        Ld = torch.from_numpy(g["L%d" % t]).cuda().contiguous(); Rd = torch.from_numpy(g["R%d" % t]).cuda().contiguous()
+        blank = torch.full_like(Ld, 100)
+        keep += [Ld, Rd, blank]
+        torch.cuda.synchronize()
+        # lanes 0 and 2 see the same stream, lane 1 sees a blank stream: lanes must not influence each other
+        ctx.process_device([(Ld.data_ptr(), Rd.data_ptr()), (blank.data_ptr(), blank.data_ptr()), (Ld.data_ptr(), Rd.data_ptr())], W, H, W)
+        ro = orc.process(g["L%d" % t], g["R%d" % t], cam)
+        for lane in (0, 2):
+            assert_same_frame(ctx, lane, orc, ctx.result(lane), ro, "lane %d t=%d" % (lane, t))
+        rb = ctx.result(1)
+        assert rb.detected_left[0] == 0 and rb.error_code == (4 if t == 0 else 5)
+    ctx.close()
+
+
+def test_edge_inputs():
+    p = north_star_params(hip.default_params(), orb_nfeats=100)
+    cam = StereoCamera.simple(100.0, 31.5, 31.5, 0.1, 64, 64)
+    ctx = hip.Context(n_lanes=1, max_w=128, max_h=128, max_kps=256, max_cand=4096)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    rng = np.random.RandomState(9)
+    # 64x64: every level is narrower than two border widths + 1 -> at most a handful of candidates
+    for shape in ((64, 64), (65, 97), (128, 128)):
+        L = rng.randint(0, 256, shape).astype(np.uint8); R = np.roll(L, -3, axis=1)
+        ctx.reset()
+        orc2 = O().Oracle(p)
+        for rep in range(2):
+            ctx.process_host([(L, R)])
+            r, ro = ctx.result(0), orc2.process(L, R, cam)
+            assert_same_frame(ctx, 0, orc2, r, ro, str(shape))
+    ctx.close()
