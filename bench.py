@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/sec of the HIP hot path (stages 2-5 of processNewImagePair) on synthetic streams.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run, one rank per GPU.  A "step" advances every lane (independent stereo stream) of every rank by
+one frame: value = N * lanes * K / t, t = max over ranks of the barrier-bracketed wall time of the K steps.
+All frames are rendered and resident in HBM before the timed region; nothing is copied host->device inside it.
+Workload at N=1: BASELINE.json configs[1] -- 1280x960 synthetic stereo streams, ~2000 ORB keypoints per image
+(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton.
+Streams shard by independent stream across ranks with no data-path collective ("weak" scaling); the per-frame
+result records are all-gathered over RCCL as in configs[3] (512 B-class, latency only).
+
+Rank 0 prints ONE JSON line with the `roofline` of the dominant kernel (HIP events recorded around every kernel on
+the stream it runs on) and the `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from stereo_vo_amd import hip  # noqa: E402
+from stereo_vo_amd.abi import Result, north_star_params  # noqa: E402
+from stereo_vo_amd.synth import SyntheticStereoWorld  # noqa: E402
+
+import ctypes as C  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def lane_seeds(rank, world_size, lanes):
+    """Stream ids owned by `rank`: stream s -> rank s // lanes (contiguous blocks), SURVEY.md 8e."""
+    assert 0 <= rank < world_size
+    return [rank * lanes + i for i in range(lanes)]
+
+
+def frame_schedule(step, n_frames):
+    """Ping-pong 0..F-1..0.. so that consecutive steps are always consecutive poses of the trajectory."""
+    if n_frames <= 1:
+        return 0
+    period = 2 * (n_frames - 1)
+    k = step % period
+    return k if k < n_frames else period - k
+
+
+def gather_records(local, world_size):
+    """All-gather of the per-rank result records (uint8 tensor [lanes, sizeof(svo_result)]) -> [world*lanes, ...]."""
+    if world_size == 1:
+        return local
+    import torch.distributed as dist
+    parts = [torch.empty_like(local) for _ in range(world_size)]
+    dist.all_gather(parts, local)
+    return torch.cat(parts, dim=0)
+
+
+def reduce_max(value, device, world_size):
+    if world_size == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def algorithmic_bytes(kernel, n_img, lv, n_kps, n_match, n_track):
+    """ALGORITHMIC bytes one launch of `kernel` must move (SURVEY.md 8d split per kernel).
+    lv = [(w, h)] per pyramid level."""
+    px = [w * h for (w, h) in lv]
+    if kernel == "fast":            # read every level once, 4 B per emitted corner
+        return n_img * sum(px)
+    if kernel == "resize":          # per launch (one level): read level l-1 + write level l; averaged over the 7 launches
+        return n_img * sum(px[l - 1] + px[l] for l in range(1, len(px))) / max(1, len(px) - 1)
+    if kernel == "describe":        # 37x37 window read + 28 B keypoint + 32 B descriptor written per keypoint slot
+        return n_img * n_kps * 1.5 * (37 * 37 + 60)
+    if kernel == "select":
+        return n_img * n_kps * 3 * (4 + 81)
+    if kernel == "nms_rowsort":
+        return n_img * n_kps * 1.5 * 2 * 60
+    if kernel == "hamming_lr":      # both descriptor sets read once, one packed word written per query
+        return (n_img // 2) * (2 * n_kps * 32 + n_kps * 4)
+    if kernel == "hamming_track":
+        return (n_img // 2) * 2 * (2 * n_match * 32 + n_match * 4)
+    if kernel == "gauss_newton":    # 40 B per tracked pair per iteration, ~12 iterations
+        return (n_img // 2) * n_track * 40 * 12
+    return (n_img // 2) * (n_match * 16 + n_track * 8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--lanes", type=int, default=16, help="independent stereo streams per GPU")
+    ap.add_argument("--frames", type=int, default=6, help="distinct frames rendered per stream (played ping-pong)")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=960)
+    ap.add_argument("--orb-nfeats", type=int, default=2000)
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of one stream timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    W, H, B, F = args.width, args.height, args.lanes, args.frames
+    focal = 800.0 * W / 1280.0
+    seeds = lane_seeds(rank, world, B)
+    # four scenes shared by the streams (textures are the slow part to mint), one trajectory per stream
+    worlds = [SyntheticStereoWorld(W, H, focal, 0.12, seed=s, n_frames=F, device=dev, scene_seed=s % 4) for s in seeds]
+    frames = [[w.render(t) for t in range(F)] for w in worlds]          # [lane][t] -> (L, R) uint8 on device
+    cam = worlds[0].camera()
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream(dev)
+    p = north_star_params(hip.default_params(), orb_nfeats=args.orb_nfeats)
+    ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=4096, device=local_rank, kernel_times=True, stream=stream.cuda_stream)
+    ctx.set_params(p)
+    ctx.set_camera(cam)
+    rec = torch.zeros((B, C.sizeof(Result)), dtype=torch.uint8, device=dev)
+
+    def step(i):
+        t = frame_schedule(i, F)
+        ctx.process_device([(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)], W, H, W)
+        ctx.copy_results_async(rec.data_ptr(), rec.numel())
+        return gather_records(rec, world)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.wait()
+    ctx.kernel_times_reset()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    allrec = None
+    for i in range(args.steps):
+        allrec = step(args.warmup + i)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    dt = reduce_max(dt, dev, world)
+
+    kt = ctx.kernel_times()
+    results = ctx.results()
+    n_valid = sum(1 for r in results if r.valid)
+    mean_kps = float(np.mean([r.detected_left[0] for r in results]))
+    mean_match = float(np.mean([r.stereo_matches[0] for r in results]))
+    mean_track = float(np.mean([r.tracked_feats_from_last_frame for r in results]))
+    assert allrec is not None and allrec.shape[0] == world * B
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt
+        lw, lh = [], []
+        for l in range(8):
+            sf = np.float32(1.2 ** l)
+            lw.append(int(np.rint(np.float32(W) / sf))); lh.append(int(np.rint(np.float32(H) / sf)))
+        lv = list(zip(lw, lh))
+        per_kernel = {k: {"ms_per_launch": v[0] / max(1, v[1]) / (7 if k == "resize" else 1), "ms_per_step": v[0] / max(1, v[1]), "launches": int(v[1]) * (7 if k == "resize" else 1)}
+                      for k, v in kt.items() if v[1] > 0}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
+        abytes = algorithmic_bytes(dom, 2 * B, lv, mean_kps, mean_match, mean_track)
+        achieved = abytes / (per_kernel[dom]["ms_per_launch"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4)}
+        # end-to-end algorithmic traffic of the whole path (SURVEY.md 8d formula), for the DESIGN.md table
+        P = sum(a * b for a, b in lv) / float(W * H)
+        pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
+        cpu_baseline = None
+        if world == 1 and args.cpu_frames > 0:
+            from oracle import oracle as O      # checker / baseline only; never on the product path
+            orc = O.Oracle(p)
+            host = [(frames[0][t][0].cpu().numpy(), frames[0][t][1].cpu().numpy()) for t in range(F)]
+            orc.process(host[0][0], host[0][1], cam)
+            c0 = time.perf_counter()
+            for i in range(args.cpu_frames):
+                t = frame_schedule(1 + i, F)
+                orc.process(host[t][0], host[t][1], cam)
+            cdt = time.perf_counter() - c0
+            cpu_baseline = {"value": round(args.cpu_frames / cdt, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                            "sample": "%d frames of stream 0 (%dx%d, orb_nfeats=%d) on the single-threaded C oracle, host has %d cores"
+                                      % (args.cpu_frames, W, H, args.orb_nfeats, os.cpu_count() or 0)}
+        line = {
+            "metric": "stereo pairs/sec @1280x960", "value": round(value, 2), "unit": "stereo pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic stereo streams, ORB %d feats x 8 levels (~%d kps/image after NMS), BF match, BF track, robust GN; %d independent streams per GPU, one frame per stream per step"
+                                   % (W, H, args.orb_nfeats, int(mean_kps), B),
+                       "lanes_per_gpu": B, "frames_per_stream": F, "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "path_hbm_frac": round(pair_bytes * value / 1e9 / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_pair": int(pair_bytes),
+            "valid_last_step": "%d/%d" % (n_valid, B),
+            "mean_kps": round(mean_kps, 1), "mean_matches": round(mean_match, 1), "mean_tracked": round(mean_track, 1),
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in per_kernel.items()},
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,9 @@ int svo_wait(svo_ctx* ctx);
 /* TStereoOdometryResult of the last frame, per lane (H:235-264); implies svo_wait */
 int svo_get_result(svo_ctx* ctx, int lane, svo_result* res);
 int svo_get_results(svo_ctx* ctx, svo_result* res /* n_lanes entries */);
+/* enqueue a device-to-device copy of the n_lanes result records into caller-owned device memory (e.g. the send
+ * buffer of an RCCL all-gather of poses) on the context's stream; no host synchronisation */
+int svo_copy_results_async(svo_ctx* ctx, void* dst_device, size_t bytes);
 
 /* getValues (H:704-724) and friends.  which: 0 = current frame, 1 = previous frame; side: 0 left, 1 right.
  * Each returns the list length (possibly > cap; only min(len,cap) entries are written) or <0. */

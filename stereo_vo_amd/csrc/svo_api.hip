@@ -459,6 +459,12 @@ extern "C" int svo_get_results(svo_ctx* ctx, svo_result* res)
     HIPCHECK(hipMemcpy(res, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToHost));
     return SVO_OK;
 }
+extern "C" int svo_copy_results_async(svo_ctx* ctx, void* dst, size_t bytes)
+{
+    if (!ctx || !dst || bytes < sizeof(svo_result) * (size_t)ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    HIPCHECK(hipMemcpyAsync(dst, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SVO_OK;
+}
 extern "C" int svo_get_result(svo_ctx* ctx, int lane, svo_result* res)
 {
     if (!ctx || !res || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;

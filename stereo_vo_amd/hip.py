@@ -21,7 +21,7 @@ FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES = 16, 32, 64
 EXPORTS = [
     "svo_config_defaults", "svo_params_defaults", "svo_create", "svo_destroy", "svo_strerror", "svo_last_error",
     "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
-    "svo_get_orb_threshold", "svo_set_camera", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results",
+    "svo_get_orb_threshold", "svo_set_camera", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_change_in_pose", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
@@ -183,6 +183,9 @@ class Context:
         arr = (Result * self.n_lanes)()
         self._ck(self.L.svo_get_results(self.h, arr), "svo_get_results")
         return list(arr)
+
+    def copy_results_async(self, dst_ptr, nbytes):
+        self._ck(self.L.svo_copy_results_async(self.h, C.c_void_p(dst_ptr), C.c_size_t(nbytes)), "svo_copy_results_async")
 
     # -- lists -----------------------------------------------------------------------------------------
     def keypoints(self, lane=0, which=0, side=0):

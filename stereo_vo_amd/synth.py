@@ -64,8 +64,10 @@ class SyntheticStereoWorld:
     +baseline along the left camera's x axis (S5:185: X2c = X1c - baseline).
     """
 
+    _scene_cache = {}
+
     def __init__(self, width, height, focal, baseline=0.12, seed=0, n_frames=20, device="cpu",
-                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048):
+                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048, scene_seed=None):
         self.w, self.h, self.f, self.B = int(width), int(height), float(focal), float(baseline)
         self.cx = (self.w - 1) / 2.0 if cx is None else float(cx)
         self.cy = (self.h - 1) / 2.0 if cy is None else float(cy)
@@ -73,7 +75,23 @@ class SyntheticStereoWorld:
         self.n_frames = int(n_frames)
         self.device = torch.device(device)
         self.noise_sigma = float(noise_sigma)
-        rng = XorShift64Star(0x5EED0000 + self.seed)
+        # scene (planes + textures) and trajectory have separate seeds so that many independent streams can share
+        # one scene's textures (they are the slow part to mint); by default both follow `seed`.
+        self.scene_seed = self.seed if scene_seed is None else int(scene_seed)
+        self._build_scene(tex_size)
+        self._build_trajectory()
+        ys, xs = torch.meshgrid(torch.arange(self.h, device=self.device, dtype=torch.float32),
+                                torch.arange(self.w, device=self.device, dtype=torch.float32), indexing="ij")
+        self._ray = torch.stack([(xs - self.cx) / self.f, (ys - self.cy) / self.f, torch.ones_like(xs)], dim=-1)  # h,w,3
+
+    def _build_scene(self, tex_size):
+        key = (self.scene_seed, tex_size)
+        if key in SyntheticStereoWorld._scene_cache:
+            self.planes, texs = SyntheticStereoWorld._scene_cache[key]
+            self.textures = [torch.from_numpy(t).to(self.device).float() for t in texs]
+            self.tex_size = tex_size
+            return
+        rng = XorShift64Star(0x5EED0000 + self.scene_seed)
         # planes: (point, normal, e_u, e_v, (umin, umax, vmin, vmax), metres per texel)
         planes = []
         # far wall
@@ -92,9 +110,13 @@ class SyntheticStereoWorld:
             ev = np.array([0, 1.0, 0])
             planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), 0.012 + 0.002 * k))
         self.planes = planes
-        self.textures = [torch.from_numpy(_manhattan_texture(rng, tex_size, 5000)).to(self.device).float() for _ in planes]
+        texs = [_manhattan_texture(rng, tex_size, 5000) for _ in planes]
+        SyntheticStereoWorld._scene_cache[key] = (planes, texs)
+        self.textures = [torch.from_numpy(t).to(self.device).float() for t in texs]
         self.tex_size = tex_size
-        # trajectory
+
+    def _build_trajectory(self):
+        rng = XorShift64Star(0x7AA70000 + self.seed)
         self.poses = [np.eye(4)]
         self.deltas = [np.eye(4)]
         for t in range(1, self.n_frames):
@@ -114,9 +136,6 @@ class SyntheticStereoWorld:
             D[:3, 3] = [rng.uniform(-0.01, 0.01), rng.uniform(-0.005, 0.005), fwd]
             self.deltas.append(D)
             self.poses.append(self.poses[-1] @ D)
-        ys, xs = torch.meshgrid(torch.arange(self.h, device=self.device, dtype=torch.float32),
-                                torch.arange(self.w, device=self.device, dtype=torch.float32), indexing="ij")
-        self._ray = torch.stack([(xs - self.cx) / self.f, (ys - self.cy) / self.f, torch.ones_like(xs)], dim=-1)  # h,w,3
 
     def camera(self) -> StereoCamera:
         return StereoCamera.simple(self.f, self.cx, self.cy, self.B, self.w, self.h)

@@ -1,0 +1,62 @@
+"""The N>1 path of bench.py on CPU: two gloo ranks shard the streams, all-gather their result records and reduce
+the step time with MAX, exactly as the RCCL path does on GPUs (streams are independent, the only
+collective is the gather of the fixed-size result records)."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, lanes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from stereo_vo_amd.abi import Result
+    seeds = bench.lane_seeds(rank, world, lanes)
+    rec = torch.zeros((lanes, C.sizeof(Result)), dtype=torch.uint8)
+    for i, s in enumerate(seeds):                       # fake result records: pose x = stream id
+        r = Result(); r.outPose[0] = float(s); r.valid = 1; r.tracked_feats_from_last_frame = 100 + s
+        rec[i] = torch.frombuffer(bytearray(bytes(r)), dtype=torch.uint8)
+    allrec = bench.gather_records(rec, world)
+    tmax = bench.reduce_max(0.5 + rank, torch.device("cpu"), world)
+    q.put((rank, seeds, allrec.numpy().tobytes(), tmax))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather():
+    world, lanes = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lanes, q)) for r in range(world)]
+    for p in procs: p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    from stereo_vo_amd.abi import Result
+    outs.sort()
+    assert outs[0][1] == [0, 1, 2] and outs[1][1] == [3, 4, 5]          # disjoint, contiguous stream blocks
+    assert outs[0][2] == outs[1][2]                                      # every rank sees the same gathered records
+    sz = C.sizeof(Result)
+    recs = [Result.from_buffer_copy(outs[0][2][i * sz:(i + 1) * sz]) for i in range(world * lanes)]
+    assert [r.outPose[0] for r in recs] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]  # ordered by stream id = rank-major
+    assert [r.tracked_feats_from_last_frame for r in recs] == [100, 101, 102, 103, 104, 105]
+    assert outs[0][3] == outs[1][3] == 1.5                               # MAX over ranks of the step time
+
+
+def test_frame_schedule_is_ping_pong():
+    import bench
+    assert [bench.frame_schedule(i, 4) for i in range(9)] == [0, 1, 2, 3, 2, 1, 0, 1, 2]
+    assert all(abs(bench.frame_schedule(i + 1, 6) - bench.frame_schedule(i, 6)) == 1 for i in range(40))
+    assert bench.frame_schedule(5, 1) == 0
