@@ -94,16 +94,21 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 
 // ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
-// Tile = 64x16 interior pixels; the 72x24 source window (3 px circle radius + 1 px NMS halo) is staged in LDS
-// with coalesced row loads, scores of the 66x18 window go to LDS, then the interior is suppressed and the
-// survivors are appended to the level's candidate list (the compiler aggregates the atomic per wave).
+// Tile = 64x32 interior pixels.  The 80x40 source window (3 px circle radius + 1 px NMS halo, start aligned to
+// 8 bytes) is staged in LDS with coalesced dword loads.  A three-step cascade keeps the expensive work dense:
+//   (1) every position of the 66x34 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
+//       contains two ADJACENT compass points, so a corner needs two adjacent compass pixels both brighter than
+//       c+t or both darker than c-t; survivors are compacted into an LDS list with wave ballots;
+//   (2) only the listed positions run the 16-pixel bit-mask test and, if they pass, the arc-min score;
+//   (3) the interior is suppressed 3x3 from the LDS score map and survivors are appended to the level's list.
 // ------------------------------------------------------------------------------------------------------------
 #define FT_W 64
-#define FT_H 16
-#define FT_LW (FT_W + 8)
-#define FT_LH (FT_H + 8)
+#define FT_H 32
+#define FT_LW 80              // LDS window pitch; window x origin = x0 - 7 (a multiple of 8 + 0: x0 = 31 + 64*tx)
+#define FT_LH (FT_H + 8)      // window y origin = y0 - 4
 #define FT_SW (FT_W + 2)
 #define FT_SH (FT_H + 2)
+#define FT_SP 68              // score map pitch
 
 __device__ __forceinline__ int fast_score_lds(const uint8_t* p, int th)
 {
@@ -141,54 +146,107 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* p, int th)
     return best - 1;
 }
 
+// cardinal-pair test on the LDS window; p = centre
+__device__ __forceinline__ bool fast_quick(const uint8_t* p, int th)
+{
+    const int c = p[0];
+    const int n = (int)p[-3 * FT_LW] - c, e = (int)p[3] - c, s = (int)p[3 * FT_LW] - c, w = (int)p[-3] - c;
+    const bool bn = n > th, be = e > th, bs = s > th, bw = w > th;
+    const bool dn = -n > th, de = -e > th, ds = -s > th, dw = -w > th;
+    return (bn & be) | (be & bs) | (bs & bw) | (bw & bn) | (dn & de) | (de & ds) | (ds & dw) | (dw & dn);
+}
+
 __global__ void __launch_bounds__(256) k_fast(DevCtx c)
 {
-    __shared__ uint8_t tile[FT_LH * FT_LW];
-    __shared__ uint8_t score[FT_SH * FT_SW];
-    const int img = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
+    __shared__ uint8_t score[FT_SH * FT_SP];
+    __shared__ unsigned short list[FT_SH * FT_SW];
+    __shared__ unsigned s_count;
+    const int img = blockIdx.y, tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     int level = 0;
 #pragma unroll
     for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && (int)blockIdx.x >= c.lv[l].tile_off) level = l;
     const LevelGeom& g = c.lv[level];
     const int t = blockIdx.x - g.tile_off;
-    const int tx = t % g.tiles_x, ty = t / g.tiles_x;
-    const int x0 = SVO_EDGE + tx * FT_W, y0 = SVO_EDGE + ty * FT_H;      // interior origin
+    const int bx = t % g.tiles_x, by = t / g.tiles_x;
+    const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
     int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
-    // stage the window [x0-4, x0+68) x [y0-4, y0+20); always inside the image because EDGE >= 4 on the low side,
-    // clamped on the high side (clamped pixels only feed positions that are masked out below)
-    for (int i = threadIdx.x; i < FT_LH * (FT_LW / 4); i += blockDim.x) {
-        const int r = i / (FT_LW / 4), q = i % (FT_LW / 4);
-        const int yy = min(y0 - 4 + r, g.h - 1);
-        const int xx = x0 - 4 + q * 4;
-        const uint8_t* rp = src + (long long)yy * pitch;
-        uint32_t w;
-        if (xx + 3 < g.w) { w = rp[xx] | (rp[xx + 1] << 8) | (rp[xx + 2] << 16) | ((uint32_t)rp[xx + 3] << 24); }
-        else { w = 0; for (int k = 0; k < 4; k++) w |= (uint32_t)rp[min(xx + k, g.w - 1)] << (8 * k); }
-        *(uint32_t*)&tile[r * FT_LW + q * 4] = w;
+    if (tid == 0) s_count = 0;
+    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+36) ----
+    if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
+        for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
+            const int r = i / (FT_LW / 4), q = i - r * (FT_LW / 4);
+            const int yy = min(y0 - 4 + r, g.h - 1);
+            const int xx = min(x0 - 7 + q * 4, pitch - 4);           // rows are readable up to the pitch
+            *(uint32_t*)&tile[r * FT_LW + q * 4] = *(const uint32_t*)(src + (long long)yy * pitch + xx);
+        }
+    } else {                                                          // unaligned caller image: byte loads
+        for (int i = tid; i < FT_LH * FT_LW; i += 256) {
+            const int r = i / FT_LW, q = i - r * FT_LW;
+            tile[i] = src[(long long)min(y0 - 4 + r, g.h - 1) * pitch + min(x0 - 7 + q, g.w - 1)];
+        }
     }
     __syncthreads();
-    // scores on the 66x18 window = interior + 1 px halo; only positions in [EDGE-1, w-EDGE+1) are evaluated
-    for (int i = threadIdx.x; i < FT_SH * FT_SW; i += blockDim.x) {
-        const int r = i / FT_SW, q = i % FT_SW;
+    if (c.debug_mode == 1) return;
+    // ---- (1) cardinal test on the 66x34 window (interior + 1 px halo); positions beyond [.., dim-EDGE+1) are skipped ----
+    const int xlim = g.w - SVO_EDGE + 1, ylim = g.h - SVO_EDGE + 1;
+    auto quick_at = [&](int r, int q, bool live) {
         const int x = x0 - 1 + q, y = y0 - 1 + r;
-        int s = 0;
-        if (x < g.w - SVO_EDGE + 1 && y < g.h - SVO_EDGE + 1) s = fast_score_lds(&tile[(r + 3) * FT_LW + (q + 3)], c.fast_th);
-        score[i] = (uint8_t)s;
+        bool pass = false;
+        if (live && x < xlim && y < ylim) pass = fast_quick(&tile[(r + 3) * FT_LW + (q + 6)], c.fast_th);
+        if (live) score[r * FT_SP + q] = 0;
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            unsigned base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if ((tid & 63) == leader) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (pass) list[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)(r * FT_SP + q);
+        }
+    };
+    for (int r = ty; r < FT_SH; r += 4) quick_at(r, tx, r < FT_SH);
+    { const int r = tid >> 1; quick_at(r < FT_SH ? r : 0, 64 + (tid & 1), r < FT_SH); }      // the two extra columns
+    __syncthreads();
+    if (c.debug_mode == 2) return;
+    // ---- (2) full test + score on the survivors only ----
+    const int ns = (int)s_count;
+    for (int i = tid; i < ns; i += 256) {
+        const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
+        score[pos] = (uint8_t)fast_score_lds(&tile[(r + 3) * FT_LW + (q + 6)], c.fast_th);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < FT_H * FT_W; i += blockDim.x) {
-        const int r = i / FT_W, q = i % FT_W;
-        const int x = x0 + q, y = y0 + r;
-        const uint8_t* s = &score[(r + 1) * FT_SW + (q + 1)];
+    if (c.debug_mode == 3) return;
+    // ---- (3) 3x3 NMS on the interior; survivors are collected in LDS and appended to the level's list with ONE
+    //      global atomic per workgroup (a per-corner returning atomic on the few hot counters cost 2.8 ms) ----
+    __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
+    __shared__ unsigned s_nout, s_base;
+    if (tid == 0) s_nout = 0;
+    __syncthreads();
+    for (int r = ty; r < FT_H; r += 4) {
+        const int q = tx, x = x0 + q, y = y0 + r;
+        const uint8_t* s = &score[(r + 1) * FT_SP + (q + 1)];
         const int v = s[0];
         const bool keep = v && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE &&
-            v > s[-1] && v > s[1] && v > s[-FT_SW - 1] && v > s[-FT_SW] && v > s[-FT_SW + 1] && v > s[FT_SW - 1] && v > s[FT_SW] && v > s[FT_SW + 1];
-        if (keep) {
-            const uint32_t slot = atomicAdd(&c.cand_cnt[img * SVO_MAX_LEVELS + level], 1u);
-            if (slot < (uint32_t)g.cand_cap)
-                c.cand_keys[(long long)img * c.cand_total + g.cand_off + slot] = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
-            else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
+            v > s[-1] && v > s[1] && v > s[-FT_SP - 1] && v > s[-FT_SP] && v > s[-FT_SP + 1] && v > s[FT_SP - 1] && v > s[FT_SP] && v > s[FT_SP + 1];
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            unsigned base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (tx == leader) base = atomicAdd(&s_nout, (unsigned)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (keep) out_keys[base + __popcll(m & ((1ull << tx) - 1ull))] = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
         }
+    }
+    __syncthreads();
+    const unsigned nout = s_nout;
+    if (nout == 0 || c.debug_mode == 4) return;
+    if (tid == 0) s_base = atomicAdd(&c.cand_cnt[img * SVO_MAX_LEVELS + level], nout);
+    __syncthreads();
+    const unsigned gbase = s_base;
+    uint32_t* dst = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
+    for (unsigned i = tid; i < nout; i += 256) {
+        if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
+        else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
     }
 }
 

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -176,6 +177,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.results, (size_t)L));
     HIPCHECK(dev_alloc(ctx, &d.status, (size_t)L));
     d.bf_dist = nullptr;
+    { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
     HIPCHECK(configure_gauss_newton(MK));
     return SVO_OK;
 }
@@ -290,7 +292,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
         g.offset = off; if (l >= 1) off += (long long)g.pitch * g.h;
         const int iw = g.w - 2 * SVO_EDGE, ih = g.h - 2 * SVO_EDGE;
         const bool live = iw > 0 && ih > 0 && quota[l] > 0;
-        g.tiles_x = live ? (iw + 63) / 64 : 0; g.tiles_y = live ? (ih + 15) / 16 : 0;
+        g.tiles_x = live ? (iw + 63) / 64 : 0; g.tiles_y = live ? (ih + 31) / 32 : 0;     // k_fast tile = 64 x 32
         g.tile_off = tile_off; tile_off += g.tiles_x * g.tiles_y;
         g.quota = live ? quota[l] : 0; g.slot_off = slot_off; slot_off += g.quota;
         long long cc = (long long)ctx->cfg.max_cand * ((long long)g.w * g.h) / ((long long)lw[0] * lh[0]);
@@ -404,7 +406,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
                 }
             d.img0_pitch = pitch;
         }
-    } else if (!ctx->geom_ready) return SVO_ERR_STATE;
+    } else if (!ctx->geom_ready && (flags & (SVO_RUN_MATCH | SVO_RUN_OPTIMIZE))) return SVO_ERR_STATE;
     d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
     { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); }
     if (flags & SVO_RUN_DETECT) {

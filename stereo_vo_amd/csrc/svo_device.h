@@ -48,6 +48,7 @@ struct DevCtx {
     int img0_pitch;
     int max_kps, raw_cap, cand_total, n_tiles, n_slots;
     int fast_th, orb_th;
+    int debug_mode;           // SVO_DEBUG_MODE env (kernel ablations while tuning; 0 in production)
     long long pyr_bytes;
     LevelGeom lv[SVO_MAX_LEVELS];
     // buffers

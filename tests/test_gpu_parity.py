@@ -256,3 +256,33 @@ def test_edge_inputs():
             r, ro = ctx.result(0), orc2.process(L, R, cam)
             assert_same_frame(ctx, 0, orc2, r, ro, str(shape))
     ctx.close()
+
+
+def test_cpp_estimator_demo_matches_oracle_chain(tmp_path):
+    """The C++ host mirror (rso::CStereoOdometryEstimator over the C-ABI) driven like the reference's demo
+    (demo-main.cpp:210-253) on BASELINE.json configs[0] (20-frame 640x480), against the oracle chained in Python."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from make_sequence import write_sequence
+    from stereo_vo_amd.synth import pose6_to_matrix
+    seq, out = str(tmp_path / "seq.svoseq"), str(tmp_path / "camera_pose.txt")
+    world = write_sequence(seq, 640, 480, 400.0, 0.12, seed=11, n_frames=20)
+    exe = os.path.join(root, "tools", "demo_stereo_odometry")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    subprocess.check_call([exe, seq, out, "500"])
+    got = np.loadtxt(out)
+    orc = O().Oracle(north_star_params(hip.default_params(), orb_nfeats=500))
+    pose = np.eye(4); rows = []
+    from stereo_vo_amd.synth import _rot_zyx
+    for t in range(20):
+        L, R = [x.numpy() for x in world.render(t)]
+        r = orc.process(L, R, world.camera())
+        if r.valid:
+            pose = pose @ pose6_to_matrix(np.array(r.outPose))
+        pitch = np.arctan2(-pose[2, 0], np.hypot(pose[0, 0], pose[1, 0]))
+        rows.append([pose[0, 3], pose[1, 3], pose[2, 3], np.arctan2(pose[1, 0], pose[0, 0]), pitch, np.arctan2(pose[2, 1], pose[2, 2])])
+    want = np.array(rows)
+    assert got.shape == want.shape == (20, 6)
+    assert np.abs(got - want).max() < 2e-3      # the file keeps 3 decimals (D:251)
+    assert np.abs(got[-1, :3] - world.poses[19][:3, 3]).max() < 0.35   # and the chain follows the generator's ground truth
