@@ -451,14 +451,17 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int num_out_points, int NS_MAX)
 {
-    // dynamic LDS only (G17): keys[NS_MAX] u64 | hash[2*NS_MAX] u32 | acc_idx[NS_MAX] u16 | s_nacc
+    // dynamic LDS only (G17): keys[NS_MAX] u64 | hkey[2*NS_MAX] | hval[2*NS_MAX] | cellxy[NS_MAX] | acc_idx[NS_MAX] u16 | state[NS_MAX] u8 | scan[32] | flag
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NS_HASH = 2 * NS_MAX;
     unsigned long long* keys = (unsigned long long*)smem;
-    uint32_t* hash = (uint32_t*)(keys + NS_MAX);
-    unsigned short* acc_idx = (unsigned short*)(hash + NS_HASH);          // raw index of the i-th survivor
-    int* s_nacc_p = (int*)(acc_idx + NS_MAX);
-#define s_nacc (*s_nacc_p)
+    uint32_t* hkey = (uint32_t*)(keys + NS_MAX);
+    uint32_t* hval = hkey + NS_HASH;
+    uint32_t* cellxy = hval + NS_HASH;
+    unsigned short* acc_idx = (unsigned short*)(cellxy + NS_MAX);          // raw index of the i-th survivor
+    unsigned char* state = (unsigned char*)(acc_idx + NS_MAX);
+    int* scan = (int*)(state + NS_MAX);
+    int* flag = scan + 32;
     const int img = blockIdx.x, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
     const svo_keypoint* rk = c.raw_kps + (long long)img * c.raw_cap;
     // compact the level-segmented winners into raw order: level 0 first, each level by Harris rank
@@ -467,7 +470,6 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     for (int l = 0; l < SVO_MAX_LEVELS; l++) lvl_base[l + 1] = lvl_base[l] + (l < c.n_levels ? c.lvl_n[img * SVO_MAX_LEVELS + l] : 0);
     const int n = lvl_base[c.n_levels];
     for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = 0;
-    for (int i = tid; i < NS_HASH; i += blockDim.x) hash[i] = 0xFFFFFFFFu;
     __syncthreads();
     // key = (response desc, raw index asc); the payload is the raw index, the slot is recovered from it
     for (int l = 0; l < c.n_levels; l++) {
@@ -482,27 +484,30 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     int P = 64; while (P < n) P <<= 1;
     if (do_nms) bitonic_sort_lds<true>(keys, P);
     auto slot_of = [&](int raw_i) { int l = 0; for (int q = 1; q < SVO_MAX_LEVELS; q++) if (q < c.n_levels && raw_i >= lvl_base[q]) l = q; return c.lv[l].slot_off + (raw_i - lvl_base[l]); };
-    if (tid == 0) s_nacc = 0;
-    __syncthreads();
-    int nacc;
+    int nacc = 0;
     if (do_nms) {
-        const unsigned cell = (unsigned)((double)min_distance / 2.0);
-        const float inv = 1.0f / (float)cell;
-        const unsigned glx = (unsigned)(1 + (float)c.W * inv), gly = (unsigned)(1 + (float)c.H * inv);
-        if (tid < 64) {
-            const int r = grid_nms_wave(n, num_out_points, gly, hash, NS_HASH,
-                [&](int i, int& sx, int& sy) {
-                    const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
-                    const svo_keypoint& k = rk[slot_of(raw_i)];
-                    const size_t ux = (size_t)(k.x * inv), uy = (size_t)(k.y * inv);
-                    sx = (int)ux; sy = (int)uy;
-                    return ux < glx && uy < gly;
-                },
-                [&](int i, int out) { acc_idx[out] = (unsigned short)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull)); });
-            if (tid == 0) s_nacc = r;
+        const unsigned cell = (unsigned)((double)min_distance / 2.0);            // S2:331
+        const float inv = 1.0f / (float)cell;                                    // S2:332
+        const unsigned glx = (unsigned)(1 + (float)c.W * inv), gly = (unsigned)(1 + (float)c.H * inv);   // S2:334-335
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+            const svo_keypoint& k = rk[slot_of(raw_i)];
+            const size_t ux = (size_t)(k.x * inv), uy = (size_t)(k.y * inv);     // S2:348-349
+            cellxy[i] = (ux < glx && uy < gly) ? (((uint32_t)ux << 16) | (uint32_t)uy) : 0xFFFFFFFFu;
         }
         __syncthreads();
-        nacc = s_nacc;
+        grid_nms_block(n, gly, cellxy, hkey, hval, NS_HASH, state, flag);
+        // survivors in rank order, at most num_out_points of them (S2:342)
+        for (int base = 0; base < n && nacc < num_out_points; base += blockDim.x) {
+            const int i = base + tid;
+            const int keep = (i < n && state[i] == 1) ? 1 : 0;
+            int tot;
+            const int off = block_exclusive_scan(keep, scan, &tot);
+            if (keep && nacc + off < num_out_points) acc_idx[nacc + off] = (unsigned short)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+            nacc += tot;
+            __syncthreads();
+        }
+        if (nacc > num_out_points) nacc = num_out_points;
     } else {
         for (int i = tid; i < n; i += blockDim.x) acc_idx[i] = (unsigned short)i;
         nacc = n;
@@ -510,6 +515,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     }
     if (nacc > c.max_kps) { nacc = c.max_kps; if (tid == 0) atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); }
     // row sort: (pt.y asc, survivor rank asc)
+    __syncthreads();
     for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = ~0ull;
     __syncthreads();
     for (int i = tid; i < nacc; i += blockDim.x) keys[i] = ((unsigned long long)ord32(rk[slot_of(acc_idx[i])].y) << 32) | (unsigned)i;
@@ -531,7 +537,6 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         if (side == 0) c.results[lane_id].detected_left[0] = nacc; else c.results[lane_id].detected_right[0] = nacc;
     }
 }
-#undef s_nacc
 
 // ------------------------------------------------------------------------------------------------------------
 // host launchers
@@ -569,7 +574,7 @@ void launch_describe(const DevCtx& c, hipStream_t st)
 }
 
 static int nms_pmax(const DevCtx& c) { int p = 64; while (p < c.raw_cap) p <<= 1; return p; }
-static size_t nms_rowsort_smem(int pmax) { return (size_t)pmax * (8 + 8 + 2) + 16; }
+static size_t nms_rowsort_smem(int pmax) { return (size_t)pmax * (8 + 8 + 8 + 4 + 2 + 1) + 4 * 40; }
 
 hipError_t configure_nms_rowsort(const DevCtx& c)
 {

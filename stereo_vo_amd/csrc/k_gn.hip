@@ -147,31 +147,71 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 #define GN_NSUM 28
 struct GnShared {
     double part[4][GN_NSUM];
+    double tot[GN_NSUM];
     double step[6];
+    double delta[6];
     double cost;
+    Rot R;
     int ok;
     int n_non_masked;
 };
 
-// one m_evalRGN (S5:275-390).  Every thread returns the same (ok, cost, step) through `sh`.
-__device__ void eval_rgn(const DevCtx& c, const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
-                         const double* lmk, const float* obs, double* residual, bool first_call, const double* delta, GnShared& sh)
+// Cholesky solve of the 6x6 normal equations with every index static (registers, no scratch).  Returns false when a
+// pivot is not safely positive; the caller then takes the general path (solve_sym6).
+__device__ __forceinline__ bool chol6(const double* H, const double* g, double dmax, double* x)
+{
+    double L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double s = H[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+        ok = ok && (s > 1e-13 * dmax);
+        const double ljj = sqrt(s);
+        L[j][j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double t = H[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+            L[i][j] = t / ljj;
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double t = g[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
+        y[i] = t / L[i][i]; }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { double t = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) t -= L[k][i] * x[k];
+        x[i] = t / L[i][i]; }
+    return ok;
+}
+
+// one m_evalRGN (S5:275-390) with the rotation taken from sh.R / sh.delta (prepared by thread 0).  On return every
+// thread sees sh.ok, sh.cost, sh.step, and sh.delta / sh.R already advanced by the step (S5:576-577).
+__device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
+                         const double* lmk, const float* obs, double* residual, GnShared& sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    Rot R; rodrigues_with_derivs(delta, R);
     const double b2 = P.use_robust_kernel ? P.kernel_param * P.kernel_param : 0;
     const double b2_1 = P.use_robust_kernel ? 1. / b2 : 0;
+    const double t1 = sh.delta[3], t2 = sh.delta[4], t3 = sh.delta[5];
+    const bool small_angle = sh.R.small_angle != 0;
     double acc[GN_NSUM];
 #pragma unroll
     for (int i = 0; i < GN_NSUM; i++) acc[i] = 0;
     for (int m = tid; m < T; m += blockDim.x) {
-        if (first_call) residual[m] = DBL_MAX;                                  // S5:296
         if (!mask[m]) continue;
         const double X1p = lmk[3 * m], Y1p = lmk[3 * m + 1], Z1p = lmk[3 * m + 2];
-        const double* r = R.r;
-        const double X1c = r[0] * X1p + r[1] * Y1p + r[2] * Z1p + delta[3];
-        const double Y1c = r[3] * X1p + r[4] * Y1p + r[5] * Z1p + delta[4];
-        const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + delta[5];
+        const double* r = sh.R.r;
+        const double X1c = r[0] * X1p + r[1] * Y1p + r[2] * Z1p + t1;
+        const double Y1c = r[3] * X1p + r[4] * Y1p + r[5] * Z1p + t2;
+        const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + t3;
         const double X2c = X1c - cam.baseline;
         const float pl_x = (float)(cam.l_fx * X1c / Z1c + cam.l_cx), pl_y = (float)(cam.l_fy * Y1c / Z1c + cam.l_cy);
         const float pr_x = (float)(cam.r_fx * X2c / Z1c + cam.r_cx), pr_y = (float)(cam.r_fy * Y1c / Z1c + cam.r_cy);
@@ -181,12 +221,12 @@ __device__ void eval_rgn(const DevCtx& c, const GNParams& P, const svo_stereo_ca
         for (int j = 0; j < 6; j++) {
             double X1cd, Y1cd, Z1cd;
             if (j < 3) {
-                if (R.small_angle) {
+                if (small_angle) {
                     if (j == 0) { X1cd = 0; Y1cd = -Z1p; Z1cd = Y1p; }
                     else if (j == 1) { X1cd = Z1p; Y1cd = 0; Z1cd = -X1p; }
                     else { X1cd = -Y1p; Y1cd = X1p; Z1cd = 0; }
                 } else {
-                    const double* d = R.dr[j];
+                    const double* d = sh.R.dr[j];
                     X1cd = d[0] * X1p + d[1] * Y1p + d[2] * Z1p;
                     Y1cd = d[3] * X1p + d[4] * Y1p + d[5] * Z1p;
                     Z1cd = d[6] * X1p + d[7] * Y1p + d[8] * Z1p;
@@ -219,30 +259,49 @@ __device__ void eval_rgn(const DevCtx& c, const GNParams& P, const svo_stereo_ca
 #pragma unroll
     for (int i = 0; i < GN_NSUM; i++) { const double v = wave_reduce_sum_f64(acc[i]); if (lane == 0) sh.part[wid][i] = v; }
     __syncthreads();
+    if (tid < GN_NSUM) sh.tot[tid] = ((sh.part[0][tid] + sh.part[1][tid]) + sh.part[2][tid]) + sh.part[3][tid];
+    __syncthreads();
     if (tid == 0) {
-        double tot[GN_NSUM];
-        for (int i = 0; i < GN_NSUM; i++) tot[i] = ((sh.part[0][i] + sh.part[1][i]) + sh.part[2][i]) + sh.part[3][i];
         double H[36], g[6], x[6] = { 0, 0, 0, 0, 0, 0 };
-        int h = 0;
-        for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { H[a * 6 + b] = tot[h]; H[b * 6 + a] = tot[h]; h++; }
-        for (int a = 0; a < 6; a++) g[a] = tot[21 + a];
-        sh.ok = solve_sym6(H, g, x);
-        sh.cost = tot[27];
-        for (int a = 0; a < 6; a++) sh.step[a] = x[a];
+        {
+            int h = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int b = a; b < 6; b++) { const double v = sh.tot[h]; H[a * 6 + b] = v; H[b * 6 + a] = v; h++; }
+            }
+        }
+        double dmax = 0; bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 6; a++) { g[a] = sh.tot[21 + a]; bad = bad || isnan(g[a]); dmax = fmax(dmax, fabs(H[a * 7])); }
+#pragma unroll
+        for (int i = 0; i < 36; i++) bad = bad || isnan(H[i]) || isinf(H[i]);
+        int ok;
+        if (bad) ok = 0;
+        else if (dmax > 0 && chol6(H, g, dmax, x)) ok = 1;
+        else ok = solve_sym6(H, g, x);                                          // rank-deficient: pseudo-inverse path
+        sh.ok = ok;
+        sh.cost = sh.tot[27];
+#pragma unroll
+        for (int a = 0; a < 6; a++) { sh.step[a] = x[a]; sh.delta[a] += x[a]; }
+        if (ok) { double d6[6]; for (int a = 0; a < 6; a++) d6[a] = sh.delta[a]; rodrigues_with_derivs(d6, sh.R); }
     }
     __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
 {
+    // dynamic LDS: keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int PM = P.pmax;                                        // power of two >= max_kps
-    unsigned long long* keys = (unsigned long long*)smem;         // PM
-    uint32_t* hash = (uint32_t*)(keys + PM);                      // 2*PM
-    unsigned char* mask = (unsigned char*)(hash + 2 * PM);        // PM
-    int* scan = (int*)(mask + PM);                                // 32
-    GnShared* shp = (GnShared*)(scan + 32);
-    GnShared& sh = *shp;
+    const int PM = P.pmax;
+    unsigned long long* keys = (unsigned long long*)smem;
+    uint32_t* hkey = (uint32_t*)(keys + PM);
+    uint32_t* hval = hkey + 2 * PM;
+    uint32_t* cellxy = hval + 2 * PM;
+    unsigned char* state = (unsigned char*)(cellxy + PM);
+    unsigned char* mask = state + PM;
+    int* scan = (int*)(mask + PM);
+    GnShared& sh = *(GnShared*)(scan + 40);
     const int lane_id = blockIdx.x, tid = threadIdx.x;
     LaneState& ls = c.lane[lane_id];
     svo_result& res = c.results[lane_id];
@@ -258,9 +317,10 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     double* lmk = c.gn_lmk + (long long)lane_id * c.max_kps * 3;
     double* residual = c.residual + (long long)lane_id * c.max_kps;
     int* outl = c.outliers + (long long)lane_id * c.max_kps;
+    int Pn = 64; while (Pn < T) Pn <<= 1;
     // ---- gather the four keypoint lists (S5:419-461, single octave) and the NMS sort keys ----
-    for (int i = tid; i < PM; i += blockDim.x) { keys[i] = 0; mask[i] = 0; }
-    for (int i = tid; i < 2 * PM; i += blockDim.x) hash[i] = 0xFFFFFFFFu;
+    for (int i = tid; i < Pn; i += blockDim.x) keys[i] = 0;
+    for (int i = tid; i < T; i += blockDim.x) mask[i] = 0;
     __syncthreads();
     for (int i = tid; i < T; i += blockDim.x) {
         const svo_dmatch a = pm[trk[i].first], b = cm[trk[i].second];
@@ -269,27 +329,27 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
         o[0] = l1.x; o[1] = l1.y; o[2] = r1.x; o[3] = r1.y; o[4] = l2.x; o[5] = l2.y; o[6] = r2.x; o[7] = r2.y;
         keys[i] = ((unsigned long long)ord32(l1.response) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
     }
-    __syncthreads();
-    // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283) ----
-    int Pn = 64; while (Pn < T) Pn <<= 1;
+    __threadfence_block();
+    // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283); cap = T ----
     bitonic_sort_lds<true>(keys, Pn);
     {
         const unsigned cell = (unsigned)((double)P.min_distance / 2.0);
         const float inv = 1.0f / (float)cell;
         const unsigned glx = (unsigned)(1 + (float)P.img_w * inv), gly = (unsigned)(1 + (float)P.img_h * inv);
-        if (tid < 64) {
-            const int r = grid_nms_wave(T, T, gly, hash, 2 * PM,
-                [&](int i, int& sx, int& sy) {
-                    const int m = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
-                    const size_t ux = (size_t)(obs[8 * (long long)m] * inv), uy = (size_t)(obs[8 * (long long)m + 1] * inv);
-                    sx = (int)ux; sy = (int)uy;
-                    return ux < glx && uy < gly;
-                },
-                [&](int i, int) { mask[(int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull))] = 1; });
-            if (tid == 0) sh.n_non_masked = r;
+        for (int i = tid; i < T; i += blockDim.x) {
+            const int m = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+            const size_t ux = (size_t)(obs[8 * (long long)m] * inv), uy = (size_t)(obs[8 * (long long)m + 1] * inv);
+            cellxy[i] = (ux < glx && uy < gly) ? (((uint32_t)ux << 16) | (uint32_t)uy) : 0xFFFFFFFFu;
         }
+        __syncthreads();
+        int hsz = 128; while (hsz < 2 * T) hsz <<= 1;
+        grid_nms_block(T, gly, cellxy, hkey, hval, hsz, state, scan + 32);
+        int cnt = 0;
+        for (int i = tid; i < T; i += blockDim.x) if (state[i] == 1) { mask[(int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull))] = 1; cnt++; }
+        int tot; block_exclusive_scan(cnt, scan, &tot);
+        if (tid == 0) sh.n_non_masked = tot;
+        __syncthreads();
     }
-    __syncthreads();
     int n_non_masked = sh.n_non_masked;
     if (n_non_masked < 8) { if (tid == 0) { res.valid = 0; res.n_residual = 0; res.n_outliers = 0; } return; }       // S5:521-526
     // ---- triangulation (S5:529-544) ----
@@ -303,19 +363,23 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
         }
     };
     triangulate();
+    if (tid == 0) {
+        double d6[6] = { 0, 0, 0, 0, 0, 0 };
+        if (P.use_custom_initial_pose) { for (int k = 0; k < 6; k++) d6[k] = P.init[k]; }                            // S5:504-505
+        else if (P.use_previous_pose_as_initial) { for (int k = 0; k < 6; k++) d6[k] = ls.last_pose[k]; }            // S5:506-507
+        for (int k = 0; k < 6; k++) sh.delta[k] = d6[k];
+        rodrigues_with_derivs(d6, sh.R);
+    }
     __threadfence_block();
     __syncthreads();
-    double delta[6] = { 0, 0, 0, 0, 0, 0 };
-    if (P.use_custom_initial_pose) { for (int k = 0; k < 6; k++) delta[k] = P.init[k]; }                             // S5:504-505
-    else if (P.use_previous_pose_as_initial) { for (int k = 0; k < 6; k++) delta[k] = ls.last_pose[k]; }             // S5:506-507
     double pCost = 0, cCost = 0; bool done = false, abort_ = false;
     unsigned timesInc = 0; int num_it = 0, num_it_final = 0, err_code = res.error_code;
     bool first = true;
     // ---- phase 1 (S5:549-598) ----
     while (num_it < P.initial_max_iters && !done && !abort_) {
         pCost = cCost;
-        eval_rgn(c, P, cam, T, mask, lmk, obs, residual, first, delta, sh);
-        first = false;
+        if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }                // S5:296
+        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh);
         err_code = SVO_VOEC_NONE;                                                                                    // S5:299
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:380-386, 569-573
@@ -323,7 +387,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
             return;
         }
         double m2 = 0;
-        for (int k = 0; k < 6; k++) { delta[k] += sh.step[k]; m2 += sh.step[k] * sh.step[k]; }
+        for (int k = 0; k < 6; k++) m2 += sh.step[k] * sh.step[k];
         if (num_it > 0) {
             done = sqrt(m2) < P.min_mod_out_vector;
             if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { err_code = SVO_VOEC_INCR_FUNC_COST_STG1; abort_ = true; } }
@@ -362,15 +426,15 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     // ---- phase 2 (S5:650-700): timesInc, pCost, cCost carry over ----
     while (num_it_final < P.max_iters && !done && !abort_) {
         pCost = cCost;
-        eval_rgn(c, P, cam, T, mask, lmk, obs, residual, first, delta, sh);
-        first = false;
+        if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }
+        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh);
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:670-675 (result.error_code untouched)
             if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }
             return;
         }
         double m2 = 0;
-        for (int k = 0; k < 6; k++) { delta[k] += sh.step[k]; m2 += sh.step[k] * sh.step[k]; }
+        for (int k = 0; k < 6; k++) m2 += sh.step[k] * sh.step[k];
         if (num_it_final > 0) {
             done = sqrt(m2) < P.min_mod_out_vector;
             if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { abort_ = true; err_code = SVO_VOEC_INCR_FUNC_COST_STG2; } }
@@ -379,19 +443,20 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
         __syncthreads();
     }
     if (tid == 0) {
-        double pose[6];
+        double pose[6], delta[6];
+        for (int k = 0; k < 6; k++) delta[k] = sh.delta[k];
         delta_to_pose(delta, pose);                                                                                  // S5:717-718
         for (int k = 0; k < 6; k++) { res.outPose[k] = pose[k]; res.delta[k] = delta[k]; }
         if (!P.use_custom_initial_pose && P.use_previous_pose_as_initial) for (int k = 0; k < 6; k++) ls.last_pose[k] = delta[k];   // S5:720-721
         res.tracked_feats_from_last_frame = T;                                                                       // S5:724
         res.tracked_feats_from_last_KF = 0;
         res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code;
-        res.n_residual = T; res.n_outliers = n_out;
+        res.n_residual = n_res > T ? n_res : T; res.n_outliers = n_out;
         res.valid = !abort_;                                                                                         // S5:727
     }
 }
 
-static size_t gn_smem(int pmax) { return (size_t)pmax * (8 + 8 + 1) + sizeof(int) * 32 + sizeof(GnShared) + 16; }
+static size_t gn_smem(int pmax) { return (size_t)pmax * (8 + 8 + 8 + 4 + 1 + 1) + sizeof(int) * 40 + sizeof(GnShared) + 16; }
 
 hipError_t configure_gauss_newton(int pmax)
 {

@@ -344,11 +344,16 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracki
         return;
     }
     const int n = c.trk_nk[lane_id];
+    __shared__ int cnt_lds[2 * SVO_RANSAC_HYP];
+    // the hypothesis scan below is serial and data dependent: stage the counts in LDS so that every step is an LDS
+    // read instead of a dependent global load
+    for (int i = tid; i < 2 * SVO_RANSAC_HYP; i += blockDim.x) cnt_lds[i] = n >= 8 ? c.rs_cnt[(long long)lane_id * 2 * SVO_RANSAC_HYP + i] : 0;
+    __syncthreads();
     if (tid == 0 || tid == 64) {
         const int side = tid >> 6;
         int best_k = -1, best_cnt = 0;
         if (n >= 8) {
-            const int* cnts = c.rs_cnt + ((long long)lane_id * 2 + side) * SVO_RANSAC_HYP;
+            const int* cnts = cnt_lds + side * SVO_RANSAC_HYP;
             int niters = SVO_RANSAC_HYP;
             for (int k = 0; k < niters; k++) {
                 const int cnt = cnts[k];

@@ -119,7 +119,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     if (!cfg || !out) return SVO_ERR_ARG;
     *out = nullptr;
     if (cfg->n_lanes < 1 || cfg->n_lanes > SVO_MAX_LANES || cfg->max_w < 64 || cfg->max_h < 64) return SVO_ERR_ARG;
-    if (cfg->max_kps < 64 || cfg->max_kps > 8192 || (cfg->max_kps & (cfg->max_kps - 1))) return SVO_ERR_ARG;
+    if (cfg->max_kps < 64 || cfg->max_kps > 4096 || (cfg->max_kps & (cfg->max_kps - 1))) return SVO_ERR_ARG;   // LDS budget of the NMS / GN kernels
     if ((long long)cfg->max_w * cfg->max_h >= (1 << 24)) return SVO_ERR_UNSUPPORTED;      // position packs into 24 bits
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return SVO_ERR_NO_DEVICE;

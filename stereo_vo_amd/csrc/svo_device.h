@@ -170,68 +170,83 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
     return base + inc - v;
 }
 
-// ---- the reference's greedy grid NMS (m_non_max_sup, stage2_detect.cpp:225-283 / 296-370), exact, wave-parallel ----
-// Keypoints are visited in `order` (response-descending ranks).  An accepted keypoint blocks its own cell and
-// the 4 neighbours; a keypoint is rejected iff an EARLIER ACCEPTED one lies within Manhattan cell distance 1.
-// One wave walks the list in chunks of 64: earlier chunks are looked up in an LDS hash set of accepted cells,
-// conflicts inside the chunk are resolved with ballot masks in rank order.  Must be called by exactly one full
-// wave (64 lanes).  hash: table of HSZ (power of two) u32 slots, pre-filled with 0xFFFFFFFF.
-// cellx/celly(i) give the grid cell of the i-th keypoint in rank order; accept(i, out_index) is called for
-// survivors.  Returns the number accepted (<= cap).
-template <typename CellFn, typename AcceptFn>
-__device__ __forceinline__ int grid_nms_wave(int n, int cap, unsigned gly, uint32_t* hash, int HSZ, CellFn cell, AcceptFn accept)
+// ---- the reference's greedy grid NMS (m_non_max_sup, stage2_detect.cpp:225-283 / 296-370), exact and block-parallel ----
+// Reference: visit keypoints in response-descending rank order; accept one iff its grid cell is unmarked, then mark
+// the cell and its 4 neighbours.  Equivalent parallel form used here:
+//   * only the lowest-rank keypoint of a cell (its "representative") can ever be accepted: if it is accepted the
+//     cell is marked for everybody behind it, and if it is rejected the accepted neighbour that rejected it marked
+//     the cell before any later keypoint of the same cell;
+//   * a representative is accepted iff no ACCEPTED representative of lower rank sits in one of the 4 neighbour
+//     cells.  That recurrence is resolved in rounds: an undecided representative is rejected as soon as a
+//     lower-rank neighbour is accepted, accepted as soon as all lower-rank neighbours are rejected.  The undecided
+//     representative of globally lowest rank always decides, so the loop terminates; chains are short in practice.
+// cellxy[i] = (sx << 16) | sy of the rank-i keypoint, 0xFFFFFFFF when outside the grid (such keypoints are skipped).
+// hkey/hval: LDS hash of HSZ (power of two >= 2n) slots; state[i] ends 1 (accepted) or 0.  All threads of the
+// block must call; `flag` is one LDS int.  The caller applies the num_out_points cap in rank order.
+#define SVO_NMS_UNDECIDED 2
+__device__ __forceinline__ uint32_t nms_hash_slot(uint32_t key, int HSZ) { return ((key * 2654435761u) >> 7) & (uint32_t)(HSZ - 1); }
+
+__device__ __forceinline__ uint32_t nms_lookup(const uint32_t* hkey, const uint32_t* hval, int HSZ, uint32_t key)
 {
-    const int lane = threadIdx.x & 63;
-    int n_acc = 0;
-    for (int base = 0; base < n && n_acc < cap; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < n;
-        int sx = -4, sy = -4;
-        bool in_grid = false;
-        if (valid) in_grid = cell(i, sx, sy);
-        // 1) blocked by a keypoint accepted in an earlier chunk?
-        bool blocked = false;
-        if (valid && in_grid) {
-#pragma unroll
-            for (int q = 0; q < 5; q++) {
-                const int cx = sx + (q == 1) - (q == 2), cy = sy + (q == 3) - (q == 4);
-                if (cx < 0 || cy < 0) continue;
-                const uint32_t key = (uint32_t)cx * gly + (uint32_t)cy;
-                uint32_t h = (key * 2654435761u) & (uint32_t)(HSZ - 1);
-                for (;;) { const uint32_t v = hash[h]; if (v == key) { blocked = true; break; } if (v == 0xFFFFFFFFu) break; h = (h + 1) & (uint32_t)(HSZ - 1); }
-            }
-        }
-        // 2) conflicts with earlier lanes of this chunk
-        unsigned long long conf = 0;
-        for (int j = 0; j < 63; j++) {
-            const int ox = __shfl(sx, j, 64), oy = __shfl(sy, j, 64);
-            const int d = abs(ox - sx) + abs(oy - sy);
-            if (j < lane && d <= 1) conf |= 1ull << j;
-        }
-        bool undecided = valid && in_grid && !blocked;
-        unsigned long long acc_mask = 0;
-        for (;;) {
-            const unsigned long long und = __ballot(undecided);
-            if (!und) break;
-            bool acc_now = false;
-            if (undecided) {
-                if (conf & acc_mask) undecided = false;                     // an earlier accepted keypoint blocks me
-                else if (!(conf & und)) { acc_now = true; undecided = false; }   // nobody earlier can still block me
-            }
-            acc_mask |= __ballot(acc_now);
-        }
-        // 3) commit in rank order, honouring the cap (the reference stops at num_out_points)
-        const bool is_acc = (acc_mask >> lane) & 1ull;
-        const int my = n_acc + __popcll(acc_mask & ((1ull << lane) - 1ull));
-        if (is_acc && my < cap) {
-            const uint32_t key = (uint32_t)sx * gly + (uint32_t)sy;
-            uint32_t h = (key * 2654435761u) & (uint32_t)(HSZ - 1);
-            for (;;) { const uint32_t old = atomicCAS(&hash[h], 0xFFFFFFFFu, key); if (old == 0xFFFFFFFFu || old == key) break; h = (h + 1) & (uint32_t)(HSZ - 1); }
-            accept(i, my);
-        }
-        n_acc += __popcll(acc_mask);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+    uint32_t h = nms_hash_slot(key, HSZ);
+    for (;;) {
+        const uint32_t k = hkey[h];
+        if (k == key) return hval[h];
+        if (k == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+        h = (h + 1) & (uint32_t)(HSZ - 1);
     }
-    return n_acc < cap ? n_acc : cap;
+}
+
+__device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32_t* cellxy, uint32_t* hkey, uint32_t* hval, int HSZ,
+                                               volatile unsigned char* state, volatile int* flag)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < HSZ; i += nt) { hkey[i] = 0xFFFFFFFFu; hval[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    // representative (minimum rank) of every occupied cell
+    for (int i = tid; i < n; i += nt) {
+        const uint32_t c = cellxy[i];
+        if (c == 0xFFFFFFFFu) continue;
+        const uint32_t key = (c >> 16) * gly + (c & 0xFFFFu);
+        uint32_t h = nms_hash_slot(key, HSZ);
+        for (;;) {
+            const uint32_t old = atomicCAS(&hkey[h], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { atomicMin(&hval[h], (uint32_t)i); break; }
+            h = (h + 1) & (uint32_t)(HSZ - 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        const uint32_t c = cellxy[i];
+        unsigned char st = 0;
+        if (c != 0xFFFFFFFFu && nms_lookup(hkey, hval, HSZ, (c >> 16) * gly + (c & 0xFFFFu)) == (uint32_t)i) st = SVO_NMS_UNDECIDED;
+        state[i] = st;
+    }
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        bool pending = false;
+        for (int i = tid; i < n; i += nt) {
+            if (state[i] != SVO_NMS_UNDECIDED) continue;
+            const uint32_t c = cellxy[i];
+            const int sx = (int)(c >> 16), sy = (int)(c & 0xFFFFu);
+            bool any_acc = false, any_und = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int cx = sx + (q == 0) - (q == 1), cy = sy + (q == 2) - (q == 3);
+                if (cx < 0 || cy < 0 || cy >= (int)gly) continue;      // (cx, gly) would alias the key of (cx+1, 0)
+                const uint32_t j = nms_lookup(hkey, hval, HSZ, (uint32_t)cx * gly + (uint32_t)cy);
+                if (j < (uint32_t)i) { const unsigned char sj = state[j]; any_acc |= sj == 1; any_und |= sj == SVO_NMS_UNDECIDED; }
+            }
+            if (any_acc) state[i] = 0;
+            else if (!any_und) state[i] = 1;
+            else pending = true;
+        }
+        if (pending) *flag = 1;
+        __syncthreads();
+        const int again = *flag;
+        __syncthreads();
+        if (!again) break;
+    }
 }
