@@ -13,6 +13,9 @@
 __constant__ int c_umax[16];
 __constant__ int c_gauss7[7];
 __device__ __attribute__((aligned(16))) int8_t g_brief_rot[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS * 4];
+// the 749 pixels of the radius-15 disc as (LDS byte offset in the 37x40 window) | u << 16 | v << 24, padded to 768
+#define SVO_DISC_N 768
+__device__ uint32_t g_disc[SVO_DISC_N];
 
 hipError_t svo_upload_tables()
 {
@@ -20,7 +23,16 @@ hipError_t svo_upload_tables()
     if (e != hipSuccess) return e;
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_gauss7), svo_gauss7, sizeof(svo_gauss7));
     if (e != hipSuccess) return e;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_brief_rot), svo_brief_rot, sizeof(svo_brief_rot));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_rot), svo_brief_rot, sizeof(svo_brief_rot));
+    if (e != hipSuccess) return e;
+    uint32_t disc[SVO_DISC_N];
+    int n = 0;
+    for (int v = -15; v <= 15; v++) {
+        const int um = svo_umax[v < 0 ? -v : v];
+        for (int u = -um; u <= um; u++) disc[n++] = (uint32_t)((v + 18) * 40 + (u + 18)) | ((uint32_t)(uint8_t)(int8_t)u << 16) | ((uint32_t)(uint8_t)(int8_t)v << 24);
+    }
+    while (n < SVO_DISC_N) disc[n++] = (uint32_t)(18 * 40 + 18);      // u = v = 0: contributes nothing
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_disc), disc, sizeof(disc));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -63,33 +75,74 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
 
 // ------------------------------------------------------------------------------------------------------------
 // K1: one pyramid level from the previous one, bilinear with the frozen 11-bit integer tables.
-// HBM-bound: reads ~1.44 source bytes and writes 1 byte per output pixel.  Each thread produces 4 adjacent
-// pixels and stores them as one dword (rows are 64-byte aligned).
+// HBM-bound by design: ~1.44 source bytes read and 1 byte written per output pixel.  A 256-thread block produces
+// a 128x32 destination tile (big enough that ~6 dword loads per thread are in flight, the kernel is latency-bound
+// otherwise): the <= 160x41 source window is staged in LDS with aligned dword loads, the tile's slice of the x/y
+// tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
 // ------------------------------------------------------------------------------------------------------------
+#define RZ_W 128
+#define RZ_H 32
+#define RZ_SP 160     // LDS window pitch in bytes (40 dwords >= 128 * 1.2 + 2 + 3)
+#define RZ_SH 41      // >= 32 * 1.2 + 2
+
 __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 {
-    const int img = blockIdx.z;
+    __shared__ __attribute__((aligned(16))) uint8_t win[RZ_SH * RZ_SP];
+    __shared__ uint32_t xtab[RZ_W], ytab[RZ_H];
+    const int img = blockIdx.z, tid = threadIdx.x;
     const LevelGeom& d = c.lv[level];
     const LevelGeom& s = c.lv[level - 1];
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    if (x4 >= d.w || y >= d.h) return;
+    const int dx0 = blockIdx.x * RZ_W, dy0 = blockIdx.y * RZ_H;
     int spitch; const uint8_t* src = level_ptr(c, img, level - 1, spitch);
     uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
     const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
-    const int y0 = yi[y], ay = yf[y], y1 = y0 + 1 < s.h ? y0 + 1 : s.h - 1;
-    const uint8_t* r0 = src + (long long)y0 * spitch, *r1 = src + (long long)y1 * spitch;
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = x4 + k;
-        if (x < d.w) {
-            const int x0 = xi[x], ax = xf[x], x1 = x0 + 1 < s.w ? x0 + 1 : s.w - 1;
-            const int v = r0[x0] * (2048 - ax) * (2048 - ay) + r0[x1] * ax * (2048 - ay) + r1[x0] * (2048 - ax) * ay + r1[x1] * ax * ay;
-            out |= (uint32_t)((v + (1 << 21)) >> 22) << (8 * k);
+    const int sx0 = xi[dx0] & ~3, sy0 = yi[dy0];                       // window origin (block-uniform)
+    if (tid < RZ_W) { const int x = min(dx0 + tid, d.w - 1); xtab[tid] = ((uint32_t)(xi[x] - sx0) << 16) | (uint32_t)xf[x]; }
+    else if (tid < RZ_W + RZ_H) { const int y = min(dy0 + tid - RZ_W, d.h - 1); ytab[tid - RZ_W] = ((uint32_t)(yi[y] - sy0) << 16) | (uint32_t)yf[y]; }
+    if (c.debug_mode == 5) { /* ablation: no staging */ }
+    else if ((((uintptr_t)src | (uintptr_t)spitch) & 3) == 0) {
+        for (int i = tid; i < RZ_SH * (RZ_SP / 4); i += 256) {
+            const int r = i / (RZ_SP / 4), q = i - r * (RZ_SP / 4);
+            const int yy = min(sy0 + r, s.h - 1), xx = min(sx0 + 4 * q, spitch - 4);
+            *(uint32_t*)&win[r * RZ_SP + 4 * q] = *(const uint32_t*)(src + (long long)yy * spitch + xx);
+        }
+    } else {
+        for (int i = tid; i < RZ_SH * RZ_SP; i += 256) {
+            const int r = i / RZ_SP, q = i - r * RZ_SP;
+            win[i] = src[(long long)min(sy0 + r, s.h - 1) * spitch + min(sx0 + q, s.w - 1)];
         }
     }
-    *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64 and >= w rounded up to 4
+    __syncthreads();
+    const int gx = (tid & 31) * 4, x4 = dx0 + gx;                       // 4 adjacent pixels per row, 4 rows per thread
+    if (x4 >= d.w || c.debug_mode == 6) return;
+    uint32_t tx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tx[k] = xtab[gx + k];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int gy = (tid >> 5) + 8 * j, y = dy0 + gy;
+        if (y >= d.h) continue;
+        const uint32_t ty = ytab[gy];
+        const int ry = (int)(ty >> 16), ay = (int)(ty & 0xFFFFu);
+        const uint32_t* r0 = (const uint32_t*)&win[ry * RZ_SP], *r1 = r0 + RZ_SP / 4;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rx = (int)(tx[k] >> 16), ax = (int)(tx[k] & 0xFFFFu);
+            // the two taps of a row are fetched as ALIGNED dwords and byte-aligned in registers: left to itself the
+            // compiler fuses the byte pair into one ds_read_u16 at an odd address, which the LDS replays lane by lane
+            const uint32_t t0 = __builtin_amdgcn_alignbyte(r0[(rx >> 2) + 1], r0[rx >> 2], rx & 3);
+            const uint32_t t1 = __builtin_amdgcn_alignbyte(r1[(rx >> 2) + 1], r1[rx >> 2], rx & 3);
+            // exact integer regrouping of p00*wx0*wy0 + p01*wx1*wy0 + p10*wx0*wy1 + p11*wx1*wy1 with 24-bit multiplies
+            // (v_mul_u32_u24 / v_mad_u32_u24 are full rate, the 32-bit v_mul_lo_u32 is not): operands < 2^24
+            const unsigned top = __umul24(t0 & 0xFFu, 2048 - ax) + __umul24((t0 >> 8) & 0xFFu, ax);
+            const unsigned bot = __umul24(t1 & 0xFFu, 2048 - ax) + __umul24((t1 >> 8) & 0xFFu, ax);
+            const unsigned v = __umul24(top, 2048 - ay) + __umul24(bot, ay);
+            out |= ((v + (1u << 21)) >> 22) << (8 * k);
+        }
+        if (c.debug_mode == 7 && out != 0x12345678u) continue;
+        *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64: the tail of the last dword is padding
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -336,11 +389,15 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x37 window:
-// 7x7 sigma-2 integer Gaussian of the 31x31 patch, 256 pair tests packed with wave ballots.  One wave per
-// keypoint slot, 4 waves per block.
+// K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x37 window.
+// One wave per keypoint slot, 4 independent waves per block (no block barriers: every wave owns its LDS region).
+//   A  the 37x40 window is fetched as aligned dwords and byte-aligned with v_alignbyte on the way into LDS;
+//   B  moments from a precomputed list of the 749 disc pixels (12 per lane);
+//   C  horizontal 7-tap pass: one lane = one row x 4 columns from three LDS dwords, 4 x u16 out as one b64;
+//   D  the vertical 7-tap pass is evaluated ONLY at the 512 sample points the 256 tests need (8 per lane);
+//   E  256 tests packed with four wave ballots.
 // ------------------------------------------------------------------------------------------------------------
-#define DP_W 40      // LDS row pitch of the raw 37x37 window
+#define DP_P 40      // LDS row pitch of the raw window (10 dwords)
 
 __device__ __forceinline__ float atan2_deg(float y, float x)
 {
@@ -361,67 +418,78 @@ __device__ __forceinline__ float atan2_deg(float y, float x)
     return a;
 }
 
+// make this wave's LDS writes visible to its own later reads (no s_barrier: waves do not share data here)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __global__ void __launch_bounds__(256) k_describe(DevCtx c)
 {
-    __shared__ uint8_t raw[4][37 * DP_W];
-    __shared__ unsigned short hb[4][37 * 32];    // horizontal pass, 31 valid columns
-    __shared__ uint8_t bl[4][31 * 32];           // blurred 31x31 patch
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10];
+    __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * 32];    // horizontal pass, 32 columns (31 used)
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int img = blockIdx.y;
     const int slot = blockIdx.x * 4 + wid;       // position in the level-segmented arrays
+    if (slot >= c.n_slots) return;
     int level = 0;
 #pragma unroll
     for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
     const LevelGeom& g = c.lv[level];
     const int rank = slot - g.slot_off;
-    // wave-uniform predicate; idle waves still take part in the block barriers below
-    const bool active = slot < c.n_slots && rank < c.lvl_n[img * SVO_MAX_LEVELS + level];
-    int x = SVO_EDGE, y = SVO_EDGE;
-    if (active) { const uint32_t pos = c.lvl_pos[(long long)img * c.raw_cap + slot]; x = (int)(pos % (uint32_t)g.w); y = (int)(pos / (uint32_t)g.w); }
+    if (rank >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
+    const uint32_t pos = c.lvl_pos[(long long)img * c.raw_cap + slot];
+    const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
-    uint8_t* R = raw[wid];
-    if (active)
-        for (int i = lane; i < 37 * 37; i += 64) {
-            const int r = i / 37, q = i - r * 37;
-            R[r * DP_W + q] = lim[(long long)(y - 18 + r) * pitch + (x - 18 + q)];
+    uint32_t* R32 = raw32[wid];
+    const uint8_t* R = (const uint8_t*)R32;
+    // ---- A: window rows y-18..y+18, columns x-18..x+21 ----
+    if ((((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0) {
+        const int xa = (x - 18) & ~3, sh = (x - 18) & 3;
+        for (int t = lane; t < 370; t += 64) {
+            const int r = t / 10, k = t - r * 10;
+            const uint32_t* p = (const uint32_t*)(lim + (long long)(y - 18 + r) * pitch + xa) + k;
+            R32[t] = __builtin_amdgcn_alignbyte(p[1], p[0], sh);
         }
-    __syncthreads();
-    // moments over the radius-15 disc: lane = column u (31 lanes), loop over rows
+    } else {
+        for (int t = lane; t < 370; t += 64) {
+            const int r = t / 10, k = t - r * 10;
+            const uint8_t* p = lim + (long long)(y - 18 + r) * pitch + (x - 18 + 4 * k);
+            R32[t] = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
+    }
+    wave_lds_sync();
+    // ---- B: moments ----
     int m10 = 0, m01 = 0;
-    if (active && lane < 31) {
-        const int u = lane - 15;
-        for (int v = -15; v <= 15; v++) {
-            const int um = c_umax[v < 0 ? -v : v];
-            if (u >= -um && u <= um) { const int I = R[(v + 18) * DP_W + (u + 18)]; m10 += u * I; m01 += v * I; }
-        }
+#pragma unroll
+    for (int i = 0; i < SVO_DISC_N / 64; i++) {
+        const uint32_t e = g_disc[i * 64 + lane];
+        const int I = R[e & 0xFFFFu];
+        m10 += __mul24((int)(int8_t)(e >> 16), I); m01 += __mul24((int)(int8_t)(e >> 24), I);
     }
     m10 = wave_reduce_sum_i32(m10); m01 = wave_reduce_sum_i32(m01);
     const float angle = atan2_deg((float)m01, (float)m10);
     int bin = (int)(angle * (1.0f / 12.0f) + 0.5f);
     if (bin >= SVO_BRIEF_NBINS) bin -= SVO_BRIEF_NBINS;
-    // separable integer Gaussian
+    // ---- C: horizontal pass; Hb[r][q] = sum_k g[k] * raw[r][q + k], q = 0..31 ----
+    const int G0 = c_gauss7[0], G1 = c_gauss7[1], G2 = c_gauss7[2], G3 = c_gauss7[3];
     unsigned short* Hb = hb[wid];
-    if (active)
-        for (int i = lane; i < 37 * 31; i += 64) {
-            const int r = i / 31, q = i - r * 31;
-            const uint8_t* p = &R[r * DP_W + q];      // columns q .. q+6 <-> patch column q-15 +- 3
-            int s = 0;
+    for (int t = lane; t < 37 * 8; t += 64) {
+        const int r = t >> 3, gq = t & 7;
+        const uint32_t w0 = R32[r * 10 + gq], w1 = R32[r * 10 + gq + 1], w2 = R32[r * 10 + gq + 2];
+        int pb[12];
 #pragma unroll
-            for (int k = 0; k < 7; k++) s += c_gauss7[k] * p[k];
-            Hb[r * 32 + q] = (unsigned short)s;
-        }
-    __syncthreads();
-    uint8_t* B = bl[wid];
-    if (active)
-        for (int i = lane; i < 31 * 31; i += 64) {
-            const int r = i / 31, q = i - r * 31;
-            int s = 0;
+        for (int k = 0; k < 4; k++) { pb[k] = (w0 >> (8 * k)) & 0xFF; pb[4 + k] = (w1 >> (8 * k)) & 0xFF; pb[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        uint32_t o[4];
 #pragma unroll
-            for (int k = 0; k < 7; k++) s += c_gauss7[k] * Hb[(r + k) * 32 + q];
-            B[r * 32 + q] = (uint8_t)((s + 32768) >> 16);
-        }
-    __syncthreads();
-    if (!active) return;
+        for (int j = 0; j < 4; j++) o[j] = (uint32_t)(__mul24(G0, pb[j] + pb[j + 6]) + __mul24(G1, pb[j + 1] + pb[j + 5]) + __mul24(G2, pb[j + 2] + pb[j + 4]) + __mul24(G3, pb[j + 3]));
+        uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
+        *(uint2*)&Hb[r * 32 + gq * 4] = pk;
+    }
+    wave_lds_sync();
+    // ---- D + E: vertical pass at the sample points only, then the tests ----
     const int8_t* pat = g_brief_rot + bin * (SVO_BRIEF_NPAIRS * 4);
     unsigned long long bits[4];
 #pragma unroll
@@ -429,7 +497,10 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
         const int i = k * 64 + lane;
         const int pr = *(const int*)(pat + i * 4);
         const int ax = (int8_t)(pr & 0xFF), ay = (int8_t)((pr >> 8) & 0xFF), bx = (int8_t)((pr >> 16) & 0xFF), by = (int8_t)((pr >> 24) & 0xFF);
-        const int a = B[(ay + 15) * 32 + (ax + 15)], b = B[(by + 15) * 32 + (bx + 15)];
+        const unsigned short* pa = &Hb[(ay + 15) * 32 + (ax + 15)], *pb2 = &Hb[(by + 15) * 32 + (bx + 15)];
+        const int sa = __mul24(G0, pa[0] + pa[6 * 32]) + __mul24(G1, pa[32] + pa[5 * 32]) + __mul24(G2, pa[2 * 32] + pa[4 * 32]) + __mul24(G3, pa[3 * 32]);
+        const int sb = __mul24(G0, pb2[0] + pb2[6 * 32]) + __mul24(G1, pb2[32] + pb2[5 * 32]) + __mul24(G2, pb2[2 * 32] + pb2[4 * 32]) + __mul24(G3, pb2[3 * 32]);
+        const int a = (sa + 32768) >> 16, b = (sb + 32768) >> 16;
         bits[k] = __ballot(a < b);
     }
     if (lane == 0) {
@@ -552,8 +623,7 @@ void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned fl
 void launch_resize(const DevCtx& c, int level, hipStream_t st)
 {
     const LevelGeom& d = c.lv[level];
-    const int tx = (d.w + 3) / 4;
-    hipLaunchKernelGGL(k_resize, dim3((tx + 255) / 256, d.h, c.n_img), dim3(256), 0, st, c, level);
+    hipLaunchKernelGGL(k_resize, dim3((d.w + RZ_W - 1) / RZ_W, (d.h + RZ_H - 1) / RZ_H, c.n_img), dim3(256), 0, st, c, level);
 }
 
 void launch_fast(const DevCtx& c, hipStream_t st)
