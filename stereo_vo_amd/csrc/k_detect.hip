@@ -48,7 +48,7 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
     const bool detect = flags & SVO_RUN_DETECT, do_shift = !(flags & SVO_FLAG_NO_SHIFT), repeat = flags & SVO_FLAG_REPEAT;
     if (detect) {
         if (t < c.n_img) { c.img0[t] = ptrs.p[t]; c.raw_n[t] = 0; }
-        if (t < c.n_img * SVO_MAX_LEVELS) { c.cand_cnt[t] = 0; c.lvl_n[t] = 0; }
+        if (t < c.n_img * SVO_MAX_LEVELS) { c.cand_cnt[t * SVO_CNT_STRIDE] = 0; c.lvl_n[t] = 0; }
     }
     if (t < c.n_lanes) {
         LaneState& s = c.lane[t];
@@ -163,9 +163,11 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 #define FT_SH (FT_H + 2)
 #define FT_SP 68              // score map pitch
 
-__device__ __forceinline__ int fast_score_lds(const uint8_t* p, int th)
+__device__ __forceinline__ int fast_score_lds(const uint8_t* pp, int th)
 {
-    // p points at the centre pixel inside the LDS tile (row pitch FT_LW)
+    // pp points at the centre pixel inside the LDS tile (row pitch FT_LW).  volatile: keeps the 16 byte reads separate
+    // (the compiler otherwise fuses neighbours into ds_read_u16 at odd addresses, which the LDS replays lane by lane)
+    const volatile uint8_t* p = pp;
     const int c = p[0];
     int d[16];
     d[0] = p[-3 * FT_LW]; d[1] = p[-3 * FT_LW + 1]; d[2] = p[-2 * FT_LW + 2]; d[3] = p[-FT_LW + 3];
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
     __shared__ uint8_t score[FT_SH * FT_SP];
     __shared__ unsigned short list[FT_SH * FT_SW];
-    __shared__ unsigned s_count;
+    __shared__ int scan_s[32];
     const int img = blockIdx.y, tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     int level = 0;
 #pragma unroll
@@ -224,7 +226,6 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     const int bx = t % g.tiles_x, by = t / g.tiles_x;
     const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
     int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
-    if (tid == 0) s_count = 0;
     // ---- stage the window [x0-7, x0+73) x [y0-4, y0+36) ----
     if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
         for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
@@ -241,63 +242,79 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     }
     __syncthreads();
     if (c.debug_mode == 1) return;
-    // ---- (1) cardinal test on the 66x34 window (interior + 1 px halo); positions beyond [.., dim-EDGE+1) are skipped ----
+    // ---- (1) cardinal test on the 66x34 window (interior + 1 px halo); positions beyond [.., dim-EDGE+1) are skipped.
+    //      Each thread tests column tx of rows ty, ty+4, ... (plus a share of the two extra columns) and remembers
+    //      the passes in a bit mask; one block scan then compacts them into the LDS list. ----
     const int xlim = g.w - SVO_EDGE + 1, ylim = g.h - SVO_EDGE + 1;
-    auto quick_at = [&](int r, int q, bool live) {
-        const int x = x0 - 1 + q, y = y0 - 1 + r;
-        bool pass = false;
-        if (live && x < xlim && y < ylim) pass = fast_quick(&tile[(r + 3) * FT_LW + (q + 6)], c.fast_th);
-        if (live) score[r * FT_SP + q] = 0;
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-            unsigned base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if ((tid & 63) == leader) base = atomicAdd(&s_count, (unsigned)__popcll(m));
-            base = __shfl(base, leader, 64);
-            if (pass) list[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)(r * FT_SP + q);
+    unsigned passmask = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int r = ty + 4 * k;
+        if (r < FT_SH) {
+            score[r * FT_SP + tx] = 0;
+            if (x0 - 1 + tx < xlim && y0 - 1 + r < ylim && fast_quick(&tile[(r + 3) * FT_LW + (tx + 6)], c.fast_th)) passmask |= 1u << k;
         }
-    };
-    for (int r = ty; r < FT_SH; r += 4) quick_at(r, tx, r < FT_SH);
-    { const int r = tid >> 1; quick_at(r < FT_SH ? r : 0, 64 + (tid & 1), r < FT_SH); }      // the two extra columns
+    }
+    const int er = tid >> 1, eq = 64 + (tid & 1);                 // the two extra columns: threads 0..67
+    if (er < FT_SH) {
+        score[er * FT_SP + eq] = 0;
+        if (x0 - 1 + eq < xlim && y0 - 1 + er < ylim && fast_quick(&tile[(er + 3) * FT_LW + (eq + 6)], c.fast_th)) passmask |= 1u << 9;
+    }
+    int ns;
+    {
+        int off = block_exclusive_scan(__popc(passmask), scan_s, &ns);
+#pragma unroll
+        for (int k = 0; k < 9; k++) if (passmask & (1u << k)) list[off++] = (unsigned short)((ty + 4 * k) * FT_SP + tx);
+        if (passmask & (1u << 9)) list[off++] = (unsigned short)(er * FT_SP + eq);
+    }
     __syncthreads();
     if (c.debug_mode == 2) return;
     // ---- (2) full test + score on the survivors only ----
-    const int ns = (int)s_count;
     for (int i = tid; i < ns; i += 256) {
         const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
         score[pos] = (uint8_t)fast_score_lds(&tile[(r + 3) * FT_LW + (q + 6)], c.fast_th);
     }
     __syncthreads();
     if (c.debug_mode == 3) return;
-    // ---- (3) 3x3 NMS on the interior; survivors are collected in LDS and appended to the level's list with ONE
-    //      global atomic per workgroup (a per-corner returning atomic on the few hot counters cost 2.8 ms) ----
+    // ---- (3) 3x3 NMS, again only on the listed positions (interior ones with a score); survivors are collected in LDS
+    //      and appended to the level's list with ONE global atomic per workgroup (a per-corner returning atomic on the
+    //      few hot counters cost 2.8 ms) ----
     __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
-    __shared__ unsigned s_nout, s_base;
+    __shared__ unsigned s_nout;
     if (tid == 0) s_nout = 0;
     __syncthreads();
-    for (int r = ty; r < FT_H; r += 4) {
-        const int q = tx, x = x0 + q, y = y0 + r;
-        const uint8_t* s = &score[(r + 1) * FT_SP + (q + 1)];
-        const int v = s[0];
-        const bool keep = v && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE &&
-            v > s[-1] && v > s[1] && v > s[-FT_SP - 1] && v > s[-FT_SP] && v > s[-FT_SP + 1] && v > s[FT_SP - 1] && v > s[FT_SP] && v > s[FT_SP + 1];
+    for (int base = 0; base < ns; base += 256) {
+        const int i = base + tid;
+        bool keep = false; uint32_t key = 0;
+        if (i < ns) {
+            const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
+            const uint8_t* sp = &score[pos];
+            const int v = sp[0];
+            const int x = x0 - 1 + q, y = y0 - 1 + r;
+            if (v && r >= 1 && r <= FT_H && q >= 1 && q <= FT_W && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE)
+                keep = v > sp[-1] && v > sp[1] && v > sp[-FT_SP - 1] && v > sp[-FT_SP] && v > sp[-FT_SP + 1] && v > sp[FT_SP - 1] && v > sp[FT_SP] && v > sp[FT_SP + 1];
+            key = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
+        }
         const unsigned long long m = __ballot(keep);
         if (m) {
-            unsigned base = 0;
+            unsigned b2 = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if (tx == leader) base = atomicAdd(&s_nout, (unsigned)__popcll(m));
-            base = __shfl(base, leader, 64);
-            if (keep) out_keys[base + __popcll(m & ((1ull << tx) - 1ull))] = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
+            if (tx == leader) b2 = atomicAdd(&s_nout, (unsigned)__popcll(m));
+            b2 = __shfl(b2, leader, 64);
+            if (keep) out_keys[b2 + __popcll(m & ((1ull << tx) - 1ull))] = key;
         }
     }
     __syncthreads();
+    // only the first wave publishes: the other three retire here, so the returning global atomic (a ~2-3 us round trip
+    // on a hot counter) stalls one wave per tile instead of the whole workgroup
+    if (tid >= 64) return;
     const unsigned nout = s_nout;
     if (nout == 0 || c.debug_mode == 4) return;
-    if (tid == 0) s_base = atomicAdd(&c.cand_cnt[img * SVO_MAX_LEVELS + level], nout);
-    __syncthreads();
-    const unsigned gbase = s_base;
+    unsigned gbase = 0;
+    if (tid == 0) gbase = atomicAdd(&c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE], nout);
+    gbase = __shfl(gbase, 0, 64);
     uint32_t* dst = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
-    for (unsigned i = tid; i < nout; i += 256) {
+    for (unsigned i = tid; i < nout; i += 64) {
         if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
         else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
     }
@@ -340,7 +357,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     const int level = blockIdx.x, img = blockIdx.y;
     const LevelGeom& g = c.lv[level];
     const int tid = threadIdx.x;
-    unsigned nc = c.cand_cnt[img * SVO_MAX_LEVELS + level];
+    unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
     if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
     const unsigned K = min(nc, (unsigned)(2 * g.quota));
     if (K == 0 || g.quota <= 0) { if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; return; }

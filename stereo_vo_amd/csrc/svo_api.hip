@@ -148,7 +148,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.pyr, (size_t)NI * ctx->pyr_bytes_alloc));
     HIPCHECK(dev_alloc(ctx, &d.rtab, (size_t)ctx->rtab_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_keys, (size_t)NI * ctx->cand_total_alloc));
-    HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS));
+    HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS * SVO_CNT_STRIDE));
     HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * MK));
     HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * MK));
     HIPCHECK(dev_alloc(ctx, &d.lvl_n, (size_t)NI * SVO_MAX_LEVELS));

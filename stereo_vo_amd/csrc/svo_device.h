@@ -16,6 +16,7 @@
 
 #define SVO_EDGE 31
 #define SVO_RANSAC_HYP 256
+#define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each
 #define SVO_RANSAC_SEED 0x5EEDF00DCAFE1234ULL
 
 // status-word bits (svo_debug_get_status_word)
@@ -56,7 +57,7 @@ struct DevCtx {
     uint8_t* pyr;
     int* rtab;                // resize tables: for level l: idx_x[w], frac_x[w], idx_y[h], frac_y[h]
     uint32_t* cand_keys;
-    uint32_t* cand_cnt;       // [n_img][SVO_MAX_LEVELS]
+    uint32_t* cand_cnt;       // [n_img][SVO_MAX_LEVELS] counters, ONE PER 128-BYTE LINE (atomics to one L2 line serialise)
     uint32_t* lvl_pos;
     float* lvl_resp;
     int* lvl_n;               // [n_img][SVO_MAX_LEVELS]
