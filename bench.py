@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--lanes", type=int, default=16, help="independent stereo streams per GPU")
+    ap.add_argument("--lanes", type=int, default=64, help="independent stereo streams per GPU")
     ap.add_argument("--frames", type=int, default=6, help="distinct frames rendered per stream (played ping-pong)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
