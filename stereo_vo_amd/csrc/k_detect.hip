@@ -147,77 +147,99 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 
 // ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
+// Integer VALU issue is what bounds this kernel (measured ~90 % VALU-busy), so the design minimises instructions:
 // Tile = 64x32 interior pixels.  The 80x40 source window (3 px circle radius + 1 px NMS halo, start aligned to
 // 8 bytes) is staged in LDS with coalesced dword loads.  A three-step cascade keeps the expensive work dense:
-//   (1) every position of the 66x34 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
+//   (1) every position of the score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
 //       contains two ADJACENT compass points, so a corner needs two adjacent compass pixels both brighter than
-//       c+t or both darker than c-t; survivors are compacted into an LDS list with wave ballots;
-//   (2) only the listed positions run the 16-pixel bit-mask test and, if they pass, the arc-min score;
-//   (3) the interior is suppressed 3x3 from the LDS score map and survivors are appended to the level's list.
+//       c+t or both darker than c-t.  It runs on FOUR positions per lane-op: the centre row / N / S come in as
+//       aligned LDS dwords, E / W by v_alignbyte, and the comparisons are saturating packed-16-bit subtractions
+//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  Survivors are compacted into an LDS list by one scan;
+//   (2) only the listed positions run the 16-pixel bit-mask test and, if they pass, the arc-min score (one sign-
+//       folded pass of the log-step min network unless both polarities hit);
+//   (3) the 3x3 NMS also walks the list; survivors are appended to the level's candidate list with one global
+//       atomic per tile, issued by a single wave.
+// The score window is 68 columns wide (x0-3 .. x0+64) so that groups of four positions sit on dword boundaries.
 // ------------------------------------------------------------------------------------------------------------
 #define FT_W 64
 #define FT_H 32
-#define FT_LW 80              // LDS window pitch; window x origin = x0 - 7 (a multiple of 8 + 0: x0 = 31 + 64*tx)
+#define FT_LW 80              // LDS window pitch; window x origin = x0 - 7 (x0 = 31 + 64*bx, so x0 - 7 is a multiple of 8)
 #define FT_LH (FT_H + 8)      // window y origin = y0 - 4
-#define FT_SW (FT_W + 2)
-#define FT_SH (FT_H + 2)
-#define FT_SP 68              // score map pitch
+#define FT_SW 68              // score window: x = x0 - 3 + q, q in [0, 68); interior q in [3, 67)
+#define FT_SH (FT_H + 2)      // y = y0 - 1 + r, r in [0, 34); interior r in [1, 33)
+#define FT_SP 72              // score map pitch
+#define FT_NG (FT_SW / 4)     // 17 groups of four positions per row
 
-__device__ __forceinline__ int fast_score_lds(const uint8_t* pp, int th)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// cardinal-pair test of the two positions packed in one register half (bytes 0,2 or 1,3 of the centre dword)
+__device__ __forceinline__ uint32_t quick_half(uint32_t c, uint32_t n, uint32_t e, uint32_t s, uint32_t w, u16x2 t2)
 {
-    // pp points at the centre pixel inside the LDS tile (row pitch FT_LW).  volatile: keeps the 16 byte reads separate
-    // (the compiler otherwise fuses neighbours into ds_read_u16 at odd addresses, which the LDS replays lane by lane)
-    const volatile uint8_t* p = pp;
-    const int c = p[0];
-    int d[16];
-    d[0] = p[-3 * FT_LW]; d[1] = p[-3 * FT_LW + 1]; d[2] = p[-2 * FT_LW + 2]; d[3] = p[-FT_LW + 3];
-    d[4] = p[3]; d[5] = p[FT_LW + 3]; d[6] = p[2 * FT_LW + 2]; d[7] = p[3 * FT_LW + 1];
-    d[8] = p[3 * FT_LW]; d[9] = p[3 * FT_LW - 1]; d[10] = p[2 * FT_LW - 2]; d[11] = p[FT_LW - 3];
-    d[12] = p[-3]; d[13] = p[-FT_LW - 3]; d[14] = p[-2 * FT_LW - 2]; d[15] = p[-3 * FT_LW - 1];
-    unsigned bright = 0, dark = 0;
+    const u16x2 cc = as_u16x2(c), hi = cc + t2, lo = __builtin_elementwise_sub_sat(cc, t2);
+    const u16x2 N = as_u16x2(n), E = as_u16x2(e), S = as_u16x2(s), W = as_u16x2(w);
+    // "two adjacent compass points bright" == (N or S bright) and (E or W bright): any N/S point is adjacent to any E/W point
+    const u16x2 bns = __builtin_elementwise_sub_sat(__builtin_elementwise_max(N, S), hi), bew = __builtin_elementwise_sub_sat(__builtin_elementwise_max(E, W), hi);
+    const u16x2 dns = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(N, S)), dew = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(E, W));
+    const u16x2 r = __builtin_elementwise_min(bns, bew) | __builtin_elementwise_min(dns, dew);
+    return as_u32(r);
+}
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// FAST-9 score of the pixel at byte offset `off` of the LDS window: the largest t for which it is still a corner
+// = max over the 16 arcs of 9 contiguous circle pixels of the min one-sided difference, minus 1; 0 when that is
+// below th.  Both polarities run through one log-step min network on packed signed 16-bit pairs: the 16 differences
+// live in 8 registers as (d[2k], d[2k+1]), so rotations by 2, 4 and 8 circle positions are register renames and
+// only the rotation by one position costs a v_alignbit.
+__device__ __forceinline__ int fast_score_lds(const uint8_t* win, int off, int th)
+{
+    // every byte read goes through its own laundered index: left alone the compiler fuses neighbouring bytes into
+    // ds_read_u16 at odd addresses, which the LDS replays lane by lane
+    auto rd = [&](int o) -> int { int a = off + o; asm volatile("" : "+v"(a)); return (int)win[a]; };
+    const int c = rd(0);
+    const int o16[16] = { -3 * FT_LW, -3 * FT_LW + 1, -2 * FT_LW + 2, -FT_LW + 3, 3, FT_LW + 3, 2 * FT_LW + 2, 3 * FT_LW + 1,
+                          3 * FT_LW, 3 * FT_LW - 1, 2 * FT_LW - 2, FT_LW - 3, -3, -FT_LW - 3, -2 * FT_LW - 2, -3 * FT_LW - 1 };
+    i16x2 v[8];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { d[i] -= c; bright |= (unsigned)(d[i] > th) << i; dark |= (unsigned)(-d[i] > th) << i; }
-    unsigned rb = bright | (bright << 16), rd = dark | (dark << 16);
-    unsigned xb = rb & (rb >> 1); xb &= xb >> 2; xb &= xb >> 4; xb &= rb >> 8;
-    unsigned xd = rd & (rd >> 1); xd &= xd >> 2; xd &= xd >> 4; xd &= rd >> 8;
-    if (!((xb | xd) & 0xFFFFu)) return 0;
-    // score: max over the 16 arcs of the min one-sided difference (log-step min over 2,4,8 then the 9th)
+    for (int k = 0; k < 8; k++) { v[k].x = (short)(rd(o16[2 * k]) - c); v[k].y = (short)(rd(o16[2 * k + 1]) - c); }
     int best = 0;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        int v[16], a[16];
+        i16x2 a[8], b[8];
+        if (pass) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = pass ? -d[i] : d[i];
+            for (int k = 0; k < 8; k++) v[k] = -v[k];
+        }
+        // a[k] = min over 2: (min(d2k, d2k+1), min(d2k+1, d2k+2)); the one-position rotation pairs v[k].y with v[k+1].x
 #pragma unroll
-        for (int i = 0; i < 16; i++) a[i] = min(v[i], v[(i + 1) & 15]);
-        int b[16];
+        for (int k = 0; k < 8; k++) {
+            const uint32_t lo = __builtin_bit_cast(uint32_t, v[k]), hi = __builtin_bit_cast(uint32_t, v[(k + 1) & 7]);
+            const i16x2 r1 = __builtin_bit_cast(i16x2, __builtin_amdgcn_alignbit(hi, lo, 16));      // (d2k+1, d2k+2)
+            a[k] = __builtin_elementwise_min(v[k], r1);
+        }
 #pragma unroll
-        for (int i = 0; i < 16; i++) b[i] = min(a[i], a[(i + 2) & 15]);
+        for (int k = 0; k < 8; k++) b[k] = __builtin_elementwise_min(a[k], a[(k + 1) & 7]);          // min over 4
 #pragma unroll
-        for (int i = 0; i < 16; i++) a[i] = min(b[i], b[(i + 4) & 15]);
+        for (int k = 0; k < 8; k++) a[k] = __builtin_elementwise_min(b[k], b[(k + 2) & 7]);          // min over 8
+        i16x2 m = __builtin_elementwise_min(a[0], v[4]);                                             // the 9th pixel: d[i+8]
 #pragma unroll
-        for (int i = 0; i < 16; i++) best = max(best, min(a[i], v[(i + 8) & 15]));
+        for (int k = 1; k < 8; k++) m = __builtin_elementwise_max(m, __builtin_elementwise_min(a[k], v[(k + 4) & 7]));
+        best = max(best, max((int)m.x, (int)m.y));
     }
-    return best - 1;
-}
-
-// cardinal-pair test on the LDS window; p = centre
-__device__ __forceinline__ bool fast_quick(const uint8_t* p, int th)
-{
-    const int c = p[0];
-    const int n = (int)p[-3 * FT_LW] - c, e = (int)p[3] - c, s = (int)p[3 * FT_LW] - c, w = (int)p[-3] - c;
-    const bool bn = n > th, be = e > th, bs = s > th, bw = w > th;
-    const bool dn = -n > th, de = -e > th, ds = -s > th, dw = -w > th;
-    return (bn & be) | (be & bs) | (bs & bw) | (bw & bn) | (dn & de) | (de & ds) | (ds & dw) | (dw & dn);
+    return best > th ? best - 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_fast(DevCtx c)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
-    __shared__ uint8_t score[FT_SH * FT_SP];
+    __shared__ __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP];
     __shared__ unsigned short list[FT_SH * FT_SW];
-    __shared__ int scan_s[32];
-    const int img = blockIdx.y, tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    __shared__ unsigned s_count;
+    __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
+    __shared__ unsigned s_nout;
+    const int img = blockIdx.y, tid = threadIdx.x;
     int level = 0;
 #pragma unroll
     for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && (int)blockIdx.x >= c.lv[l].tile_off) level = l;
@@ -226,7 +248,8 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     const int bx = t % g.tiles_x, by = t / g.tiles_x;
     const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
     int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
-    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+36) ----
+    if (tid == 0) { s_nout = 0; s_count = 0; }
+    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+36), clear the score map ----
     if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
         for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
             const int r = i / (FT_LW / 4), q = i - r * (FT_LW / 4);
@@ -240,49 +263,63 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
             tile[i] = src[(long long)min(y0 - 4 + r, g.h - 1) * pitch + min(x0 - 7 + q, g.w - 1)];
         }
     }
+    for (int i = tid; i < FT_SH * FT_SP / 4; i += 256) ((uint32_t*)score)[i] = 0;
     __syncthreads();
     if (c.debug_mode == 1) return;
-    // ---- (1) cardinal test on the 66x34 window (interior + 1 px halo); positions beyond [.., dim-EDGE+1) are skipped.
-    //      Each thread tests column tx of rows ty, ty+4, ... (plus a share of the two extra columns) and remembers
-    //      the passes in a bit mask; one block scan then compacts them into the LDS list. ----
-    const int xlim = g.w - SVO_EDGE + 1, ylim = g.h - SVO_EDGE + 1;
-    unsigned passmask = 0;
+    // ---- (1) packed cardinal test: 34 rows x 17 groups of four positions ----
+    const int xlim = g.w - SVO_EDGE + 1, ylim = g.h - SVO_EDGE + 1;     // scores exist on [EDGE-1, dim-EDGE+1)
+    const uint32_t* T32 = (const uint32_t*)tile;
+    const u16x2 t2 = { (unsigned short)c.fast_th, (unsigned short)c.fast_th };
+    unsigned passmask = 0;                                              // 4 bits per task, up to 3 tasks per thread
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int r = ty + 4 * k;
-        if (r < FT_SH) {
-            score[r * FT_SP + tx] = 0;
-            if (x0 - 1 + tx < xlim && y0 - 1 + r < ylim && fast_quick(&tile[(r + 3) * FT_LW + (tx + 6)], c.fast_th)) passmask |= 1u << k;
+    for (int k = 0; k < 3; k++) {
+        const int task = tid + 256 * k;
+        if (task < FT_SH * FT_NG) {
+            const int r = task / FT_NG, gq = task - r * FT_NG;
+            const uint32_t* row = T32 + (r + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
+            const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
+            const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3), W = __builtin_amdgcn_alignbyte(C, Cp, 1);
+            const uint32_t m8 = 0x00FF00FFu;
+            const uint32_t pe = quick_half(C & m8, N & m8, E & m8, S & m8, W & m8, t2);                                     // positions 0, 2
+            const uint32_t po = quick_half((C >> 8) & m8, (N >> 8) & m8, (E >> 8) & m8, (S >> 8) & m8, (W >> 8) & m8, t2);   // positions 1, 3
+            const int xb = x0 - 3 + 4 * gq;
+            unsigned m = 0;
+            if (y0 - 1 + r < ylim) {
+                if ((pe & 0xFFFFu) && xb < xlim) m |= 1u;
+                if ((po & 0xFFFFu) && xb + 1 < xlim) m |= 2u;
+                if ((pe >> 16) && xb + 2 < xlim) m |= 4u;
+                if ((po >> 16) && xb + 3 < xlim) m |= 8u;
+            }
+            passmask |= m << (4 * k);
         }
     }
-    const int er = tid >> 1, eq = 64 + (tid & 1);                 // the two extra columns: threads 0..67
-    if (er < FT_SH) {
-        score[er * FT_SP + eq] = 0;
-        if (x0 - 1 + eq < xlim && y0 - 1 + er < ylim && fast_quick(&tile[(er + 3) * FT_LW + (eq + 6)], c.fast_th)) passmask |= 1u << 9;
-    }
-    int ns;
-    {
-        int off = block_exclusive_scan(__popc(passmask), scan_s, &ns);
+    {   // compaction: wave-inclusive scan of the pass counts, one LDS atomic per wave (list order is irrelevant)
+        const int cnt = __popc(passmask), lane = tid & 63;
+        int inc = cnt;
 #pragma unroll
-        for (int k = 0; k < 9; k++) if (passmask & (1u << k)) list[off++] = (unsigned short)((ty + 4 * k) * FT_SP + tx);
-        if (passmask & (1u << 9)) list[off++] = (unsigned short)(er * FT_SP + eq);
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+        unsigned wbase = 0;
+        if (lane == 63 && inc) wbase = atomicAdd(&s_count, (unsigned)inc);
+        wbase = __shfl(wbase, 63, 64);
+        int off = (int)wbase + inc - cnt;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int task = tid + 256 * k, r = task / FT_NG, gq = task - r * FT_NG;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (passmask & (1u << (4 * k + j))) list[off++] = (unsigned short)(r * FT_SP + 4 * gq + j);
+        }
     }
     __syncthreads();
+    const int ns = (int)s_count;
     if (c.debug_mode == 2) return;
-    // ---- (2) full test + score on the survivors only ----
+    // ---- (2) score on the survivors only ----
     for (int i = tid; i < ns; i += 256) {
         const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
-        score[pos] = (uint8_t)fast_score_lds(&tile[(r + 3) * FT_LW + (q + 6)], c.fast_th);
+        score[pos] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), c.fast_th);
     }
     __syncthreads();
     if (c.debug_mode == 3) return;
-    // ---- (3) 3x3 NMS, again only on the listed positions (interior ones with a score); survivors are collected in LDS
-    //      and appended to the level's list with ONE global atomic per workgroup (a per-corner returning atomic on the
-    //      few hot counters cost 2.8 ms) ----
-    __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
-    __shared__ unsigned s_nout;
-    if (tid == 0) s_nout = 0;
-    __syncthreads();
+    // ---- (3) 3x3 NMS on the listed interior positions; one global atomic per tile ----
     for (int base = 0; base < ns; base += 256) {
         const int i = base + tid;
         bool keep = false; uint32_t key = 0;
@@ -290,8 +327,8 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
             const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
             const uint8_t* sp = &score[pos];
             const int v = sp[0];
-            const int x = x0 - 1 + q, y = y0 - 1 + r;
-            if (v && r >= 1 && r <= FT_H && q >= 1 && q <= FT_W && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE)
+            const int x = x0 - 3 + q, y = y0 - 1 + r;
+            if (v && r >= 1 && r <= FT_H && q >= 3 && q < 3 + FT_W && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE)
                 keep = v > sp[-1] && v > sp[1] && v > sp[-FT_SP - 1] && v > sp[-FT_SP] && v > sp[-FT_SP + 1] && v > sp[FT_SP - 1] && v > sp[FT_SP] && v > sp[FT_SP + 1];
             key = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
         }
@@ -299,14 +336,14 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
         if (m) {
             unsigned b2 = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if (tx == leader) b2 = atomicAdd(&s_nout, (unsigned)__popcll(m));
+            if ((tid & 63) == leader) b2 = atomicAdd(&s_nout, (unsigned)__popcll(m));
             b2 = __shfl(b2, leader, 64);
-            if (keep) out_keys[b2 + __popcll(m & ((1ull << tx) - 1ull))] = key;
+            if (keep) out_keys[b2 + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = key;
         }
     }
     __syncthreads();
-    // only the first wave publishes: the other three retire here, so the returning global atomic (a ~2-3 us round trip
-    // on a hot counter) stalls one wave per tile instead of the whole workgroup
+    // only the first wave publishes: the other three retire here, so the returning global atomic (a ~2-3 us round trip)
+    // stalls one wave per tile instead of the whole workgroup
     if (tid >= 64) return;
     const unsigned nout = s_nout;
     if (nout == 0 || c.debug_mode == 4) return;
@@ -349,10 +386,47 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x,
     return (det - k) * s4;
 }
 
+// Harris response from 27 aligned dword loads (9 rows x 12 bytes) instead of 81 byte loads; same integer sums and
+// float expression as harris_at (the oracle's harris_response)
+__device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int x, int y)
+{
+    const int xa = (x - 4) & ~3, o = (x - 4) & 3;
+    int px[9][9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        const uint32_t* p = (const uint32_t*)(img + (long long)(y - 4 + r) * pitch + xa);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        const uint32_t A = __builtin_amdgcn_alignbyte(w1, w0, o), B = __builtin_amdgcn_alignbyte(w2, w1, o), C = w2 >> (8 * o);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { px[r][k] = (A >> (8 * k)) & 0xFF; px[r][4 + k] = (B >> (8 * k)) & 0xFF; }
+        px[r][8] = C & 0xFF;
+    }
+    int a = 0, b = 0, cc = 0;
+#pragma unroll
+    for (int r = 1; r < 8; r++) {
+#pragma unroll
+        for (int q = 1; q < 8; q++) {
+            const int Ix = (px[r][q + 1] - px[r][q - 1]) * 2 + (px[r - 1][q + 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r + 1][q - 1]);
+            const int Iy = (px[r + 1][q] - px[r - 1][q]) * 2 + (px[r + 1][q - 1] - px[r - 1][q - 1]) + (px[r + 1][q + 1] - px[r - 1][q + 1]);
+            a += __mul24(Ix, Ix); b += __mul24(Iy, Iy); cc += __mul24(Ix, Iy);
+        }
+    }
+    const float s = 1.0f / (4.0f * 7.0f * 255.0f);
+    const float s2 = s * s;
+    const float s4 = s2 * s2;
+    const float fa = (float)a, fb = (float)b, fc = (float)cc;
+    const float det = fa * fb - fc * fc;
+    const float tr = fa + fb;
+    const float k = 0.04f * (tr * tr);
+    return (det - k) * s4;
+}
+
 __global__ void __launch_bounds__(512) k_select(DevCtx c)
 {
     __shared__ unsigned long long keys[SEL_MAX];
+    __shared__ uint32_t sel[SEL_MAX];
     __shared__ unsigned hist[256];
+    __shared__ int scan_s[32];
     __shared__ unsigned s_prefix, s_need, s_sel;
     const int level = blockIdx.x, img = blockIdx.y;
     const LevelGeom& g = c.lv[level];
@@ -362,36 +436,49 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     const unsigned K = min(nc, (unsigned)(2 * g.quota));
     if (K == 0 || g.quota <= 0) { if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; return; }
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
-    // radix select: find the K-th largest key
+    // ---- radix select: the K-th largest of the unique 32-bit keys, 8 bits per pass ----
     unsigned prefix = 0, mask = 0, need = K;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
         for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u); }
         __syncthreads();
-        if (tid == 0) {
-            unsigned acc = 0; int b = 255;
-            for (; b > 0; b--) { if (acc + hist[b] >= need) break; acc += hist[b]; }
-            s_prefix = prefix | ((unsigned)b << shift); s_need = need - acc;
-        }
+        // bins in DESCENDING order: thread t owns bin 255 - t; the bin where the running count first reaches `need`
+        const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+        int tot;
+        const int before = block_exclusive_scan(mine, scan_s, &tot);
+        if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { s_prefix = prefix | ((unsigned)(255 - tid) << shift); s_need = need - (unsigned)before; }
         __syncthreads();
         prefix = s_prefix; need = s_need; mask |= 255u << shift;
         __syncthreads();
     }
     const uint32_t cutoff = prefix;     // exactly K keys are >= cutoff (keys are unique)
+    // ---- compact the K winners, then compute their Harris responses densely ----
     if (tid == 0) s_sel = 0;
     for (int i = tid; i < SEL_MAX; i += blockDim.x) keys[i] = 0;
     __syncthreads();
-    int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
-    for (unsigned i = tid; i < nc; i += blockDim.x) {
-        const uint32_t k = ck[i];
-        if (k >= cutoff) {
-            const unsigned slot = atomicAdd(&s_sel, 1u);
-            const uint32_t pos = 0xFFFFFFu - (k & 0xFFFFFFu);
-            const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
-            const float r = harris_at(lim, pitch, x, y);
-            if (slot < SEL_MAX) keys[slot] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
+    for (unsigned base = 0; base < nc; base += blockDim.x) {
+        const unsigned i = base + tid;
+        uint32_t k = 0;
+        const bool take = i < nc && (k = ck[i]) >= cutoff;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            unsigned b0 = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if ((tid & 63) == leader) b0 = atomicAdd(&s_sel, (unsigned)__popcll(m));
+            b0 = __shfl(b0, leader, 64);
+            const unsigned slot = b0 + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+            if (take && slot < SEL_MAX) sel[slot] = k;
         }
+    }
+    __syncthreads();
+    int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
+    const bool aligned = (((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0;
+    for (unsigned i = tid; i < K; i += blockDim.x) {
+        const uint32_t pos = 0xFFFFFFu - (sel[i] & 0xFFFFFFu);
+        const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
+        const float r = aligned ? harris_at_dw(lim, pitch, x, y) : harris_at(lim, pitch, x, y);
+        keys[i] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
     }
     __syncthreads();
     int P = 64; while (P < (int)K) P <<= 1;

@@ -50,17 +50,25 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
     const int t_per = (tiles + nsplit - 1) / nsplit;
     const int t_begin = split * t_per, t_end = min(tiles, t_begin + t_per);
     unsigned best = 0xFFFFFFFFu;
+    // software pipeline: the next train tile is fetched into registers while the current one is compared, so the
+    // global-load latency of a tile hides behind ~10k cycles of popcount work
+    ulonglong2 pa = make_ulonglong2(0, 0), pb = make_ulonglong2(0, 0);
+    auto fetch = [&](int t) {
+        const int j = t * HM_TILE + (int)threadIdx.x;
+        if (t < t_end && j < nt) {
+            const int row = mode ? (side ? tm[j].trainIdx : tm[j].queryIdx) : j;
+            const ulonglong2* p = (const ulonglong2*)(td + (long long)row * 32);
+            pa = p[0]; pb = p[1];
+        }
+    };
+    fetch(t_begin);
     for (int t = t_begin; t < t_end; t++) {
         const int j0 = t * HM_TILE, jn = min(HM_TILE, nt - j0);
         __syncthreads();
-        if ((int)threadIdx.x < jn) {
-            const int j = j0 + threadIdx.x;
-            const int row = mode ? (side ? tm[j].trainIdx : tm[j].queryIdx) : j;
-            const ulonglong2* p = (const ulonglong2*)(td + (long long)row * 32);
-            ((ulonglong2*)tile)[threadIdx.x * 2] = p[0];
-            ((ulonglong2*)tile)[threadIdx.x * 2 + 1] = p[1];
-        }
+        ((ulonglong2*)tile)[threadIdx.x * 2] = pa;
+        ((ulonglong2*)tile)[threadIdx.x * 2 + 1] = pb;
         __syncthreads();
+        fetch(t + 1);
 #pragma unroll 4
         for (int j = 0; j < jn; j++) {
             const ulonglong2 a = ((const ulonglong2*)tile)[j * 2], b = ((const ulonglong2*)tile)[j * 2 + 1];

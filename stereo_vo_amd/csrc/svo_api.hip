@@ -363,7 +363,9 @@ extern "C" int svo_kernel_times_reset(svo_ctx* ctx)
     return SVO_OK;
 }
 
-static int hamming_splits(const svo_ctx* ctx) { return ctx->cfg.n_lanes >= 16 ? 2 : (ctx->cfg.n_lanes >= 4 ? 4 : 8); }
+// train-side splits of the brute-force matcher: enough workgroups for ~8 waves per SIMD (a ~2000 x 2000 problem is
+// 8 query blocks x 8 train tiles; with one split per lane a 16-lane launch keeps ONE wave per SIMD busy)
+static int hamming_splits(const svo_ctx* ctx) { int s = 2048 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 8 ? 8 : s); }
 
 // ---- processNewImagePair ---------------------------------------------------------------------------------
 extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags)

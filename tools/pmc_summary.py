@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Average rocprofv3 --pmc counters per svo kernel from a counter_collection.csv."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    n = r["Kernel_Name"].split("(")[0]
+    if not n.startswith("k_"): continue
+    acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = sorted({c for k in acc.values() for c in k})
+print("kernel," + ",".join(names))
+for k, d in acc.items():
+    print(k + "," + ",".join("%.4g" % (sum(d[c]) / len(d[c])) if c in d else "" for c in names))
