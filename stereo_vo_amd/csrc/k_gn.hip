@@ -30,14 +30,18 @@ __device__ void rodrigues_with_derivs(const double* dp, Rot& R)
         return;
     }
     R.small_angle = 0;
-    const double u = (cos_tt - 1) / tt2;
-    const double dudw1 = ((-sin_tt * w1 / tt) * tt2 - (cos_tt - 1) * 2 * w1) / tt4;
-    const double dudw2 = ((-sin_tt * w2 / tt) * tt2 - (cos_tt - 1) * 2 * w2) / tt4;
-    const double dudw3 = ((-sin_tt * w3 / tt) * tt2 - (cos_tt - 1) * 2 * w3) / tt4;
-    const double v = sin_tt / tt;
-    const double dvdw1 = w1 * (tt * cos_tt - sin_tt) / tt3;
-    const double dvdw2 = w2 * (tt * cos_tt - sin_tt) / tt3;
-    const double dvdw3 = w3 * (tt * cos_tt - sin_tt) / tt3;
+    // same expressions as S5:102-110 with the divisions by tt, tt2, tt3, tt4 folded into one reciprocal (an f64 divide
+    // is a ~15-instruction sequence and this runs on one thread, on the critical path of every iteration)
+    const double itt = 1.0 / tt, itt2 = itt * itt, itt3 = itt2 * itt, itt4 = itt2 * itt2;
+    const double u = (cos_tt - 1) * itt2;
+    const double dudw1 = ((-sin_tt * w1 * itt) * tt2 - (cos_tt - 1) * 2 * w1) * itt4;
+    const double dudw2 = ((-sin_tt * w2 * itt) * tt2 - (cos_tt - 1) * 2 * w2) * itt4;
+    const double dudw3 = ((-sin_tt * w3 * itt) * tt2 - (cos_tt - 1) * 2 * w3) * itt4;
+    const double v = sin_tt * itt;
+    const double dvdw1 = w1 * (tt * cos_tt - sin_tt) * itt3;
+    const double dvdw2 = w2 * (tt * cos_tt - sin_tt) * itt3;
+    const double dvdw3 = w3 * (tt * cos_tt - sin_tt) * itt3;
+    (void)tt3; (void)tt4;
     r[0] = (w22 + w32) * u + 1; r[1] = -w3 * v - w1 * w2 * u; r[2] = w2 * v - w1 * w3 * u;
     r[3] = w3 * v - w1 * w2 * u; r[4] = (w12 + w32) * u + 1; r[5] = -w1 * v - w2 * w3 * u;
     r[6] = -w2 * v - w1 * w3 * u; r[7] = w1 * v - w2 * w3 * u; r[8] = (w12 + w22) * u + 1;
@@ -145,6 +149,7 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 }
 
 #define GN_NSUM 28
+#define GN_RED_BYTES ((size_t)GN_NSUM * 256 * sizeof(double))
 struct GnShared {
     double part[4][GN_NSUM];
     double tot[GN_NSUM];
@@ -160,7 +165,7 @@ struct GnShared {
 // pivot is not safely positive; the caller then takes the general path (solve_sym6).
 __device__ __forceinline__ bool chol6(const double* H, const double* g, double dmax, double* x)
 {
-    double L[6][6];
+    double L[6][6], inv[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -170,12 +175,13 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
         ok = ok && (s > 1e-13 * dmax);
         const double ljj = sqrt(s);
         L[j][j] = ljj;
+        inv[j] = 1.0 / ljj;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double t = H[i * 6 + j];
 #pragma unroll
             for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-            L[i][j] = t / ljj;
+            L[i][j] = t * inv[j];
         }
     }
     double y[6];
@@ -183,19 +189,19 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
     for (int i = 0; i < 6; i++) { double t = g[i];
 #pragma unroll
         for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
-        y[i] = t / L[i][i]; }
+        y[i] = t * inv[i]; }
 #pragma unroll
     for (int i = 5; i >= 0; i--) { double t = y[i];
 #pragma unroll
         for (int k = i + 1; k < 6; k++) t -= L[k][i] * x[k];
-        x[i] = t / L[i][i]; }
+        x[i] = t * inv[i]; }
     return ok;
 }
 
 // one m_evalRGN (S5:275-390) with the rotation taken from sh.R / sh.delta (prepared by thread 0).  On return every
 // thread sees sh.ok, sh.cost, sh.step, and sh.delta / sh.R already advanced by the step (S5:576-577).
 __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
-                         const double* lmk, const float* obs, double* residual, GnShared& sh)
+                         const double* lmk, const float* obs, double* residual, GnShared& sh, double* red)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const double b2 = P.use_robust_kernel ? P.kernel_param * P.kernel_param : 0;
@@ -213,8 +219,10 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
         const double Y1c = r[3] * X1p + r[4] * Y1p + r[5] * Z1p + t2;
         const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + t3;
         const double X2c = X1c - cam.baseline;
-        const float pl_x = (float)(cam.l_fx * X1c / Z1c + cam.l_cx), pl_y = (float)(cam.l_fy * Y1c / Z1c + cam.l_cy);
-        const float pr_x = (float)(cam.r_fx * X2c / Z1c + cam.r_cx), pr_y = (float)(cam.r_fy * Y1c / Z1c + cam.r_cy);
+        // S5:189-193 and 251-254 with the 28 divisions by Z1c / Z1c^2 folded into two reciprocals
+        const double iz = 1.0 / Z1c, iz2 = iz * iz;
+        const float pl_x = (float)(cam.l_fx * X1c * iz + cam.l_cx), pl_y = (float)(cam.l_fy * Y1c * iz + cam.l_cy);
+        const float pr_x = (float)(cam.r_fx * X2c * iz + cam.r_cx), pr_y = (float)(cam.r_fy * Y1c * iz + cam.r_cy);
         double J[4][6];
         bool good = true;
 #pragma unroll
@@ -232,11 +240,9 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
                     Z1cd = d[6] * X1p + d[7] * Y1p + d[8] * Z1p;
                 }
             } else { X1cd = j == 3; Y1cd = j == 4; Z1cd = j == 5; }
-            J[0][j] = cam.l_fx * (X1cd * Z1c - X1c * Z1cd) / (Z1c * Z1c);
-            J[1][j] = cam.l_fy * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
-            J[2][j] = cam.r_fx * (X1cd * Z1c - X2c * Z1cd) / (Z1c * Z1c);
-            J[3][j] = cam.r_fy * (Y1cd * Z1c - Y1c * Z1cd) / (Z1c * Z1c);
-            if (isnan(J[0][j]) || isinf(J[0][j]) || isnan(J[1][j]) || isinf(J[1][j]) || isnan(J[2][j]) || isinf(J[2][j]) || isnan(J[3][j]) || isinf(J[3][j])) good = false;
+            const double ju = (X1cd * Z1c - X1c * Z1cd) * iz2, jv = (Y1cd * Z1c - Y1c * Z1cd) * iz2, jur = (X1cd * Z1c - X2c * Z1cd) * iz2;
+            J[0][j] = cam.l_fx * ju; J[1][j] = cam.l_fy * jv; J[2][j] = cam.r_fx * jur; J[3][j] = cam.r_fy * jv;
+            if (isnan(ju) || isinf(ju) || isnan(jv) || isinf(jv) || isnan(jur) || isinf(jur)) good = false;
         }
         if (!good) continue;                                                   // S5:322
         const float* o = obs + 8 * (long long)m;
@@ -256,11 +262,22 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
             for (int b = a; b < 6; b++) { acc[h] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b] + J[3][a] * J[3][b]; h++; }   // ... Hessian NOT (S5:364-369)
         }
     }
+    // block reduction of the 28 sums through LDS: red[i][tid], then 8 threads per sum add 32 entries each and finish
+    // with three shuffles (28 shuffle trees of 6 steps each cost ~5x more on this latency-bound kernel)
 #pragma unroll
-    for (int i = 0; i < GN_NSUM; i++) { const double v = wave_reduce_sum_f64(acc[i]); if (lane == 0) sh.part[wid][i] = v; }
+    for (int i = 0; i < GN_NSUM; i++) red[i * 256 + tid] = acc[i];
     __syncthreads();
-    if (tid < GN_NSUM) sh.tot[tid] = ((sh.part[0][tid] + sh.part[1][tid]) + sh.part[2][tid]) + sh.part[3][tid];
+    if (tid < GN_NSUM * 8) {
+        const int sidx = tid >> 3, part = tid & 7;
+        const double* rp = red + sidx * 256 + part;
+        double sum = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) sum += rp[8 * k];
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+        if (part == 0) sh.tot[sidx] = sum;
+    }
     __syncthreads();
+    (void)lane; (void)wid;
     if (tid == 0) {
         double H[36], g[6], x[6] = { 0, 0, 0, 0, 0, 0 };
         {
@@ -291,14 +308,16 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
 
 __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
 {
-    // dynamic LDS: keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
+    // dynamic LDS: { keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] } U red[28][256] f64 | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PM = P.pmax;
     unsigned long long* keys = (unsigned long long*)smem;
     uint32_t* hkey = (uint32_t*)(keys + PM);
     uint32_t* hval = hkey + 2 * PM;
     uint32_t* cellxy = hval + 2 * PM;
-    unsigned char* state = (unsigned char*)(cellxy + PM);
+    // the sort/hash arrays are dead once the NMS mask exists; the same bytes then hold the 28 x 256 reduction buffer
+    const size_t region = (size_t)PM * 28 > GN_RED_BYTES ? (size_t)PM * 28 : GN_RED_BYTES;
+    unsigned char* state = smem + region;
     unsigned char* mask = state + PM;
     int* scan = (int*)(mask + PM);
     GnShared& sh = *(GnShared*)(scan + 40);
@@ -372,14 +391,15 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     }
     __threadfence_block();
     __syncthreads();
+    if (c.debug_mode == 10) return;
     double pCost = 0, cCost = 0; bool done = false, abort_ = false;
     unsigned timesInc = 0; int num_it = 0, num_it_final = 0, err_code = res.error_code;
     bool first = true;
     // ---- phase 1 (S5:549-598) ----
-    while (num_it < P.initial_max_iters && !done && !abort_) {
+    while (num_it < P.initial_max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it >= 1)) {
         pCost = cCost;
         if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }                // S5:296
-        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh);
+        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, (double*)keys);
         err_code = SVO_VOEC_NONE;                                                                                    // S5:299
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:380-386, 569-573
@@ -424,10 +444,10 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     __syncthreads();
     done = false; abort_ = false;
     // ---- phase 2 (S5:650-700): timesInc, pCost, cCost carry over ----
-    while (num_it_final < P.max_iters && !done && !abort_) {
+    while (num_it_final < P.max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it_final >= 1)) {
         pCost = cCost;
         if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }
-        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh);
+        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, (double*)keys);
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:670-675 (result.error_code untouched)
             if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }
@@ -456,7 +476,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     }
 }
 
-static size_t gn_smem(int pmax) { return (size_t)pmax * (8 + 8 + 8 + 4 + 1 + 1) + sizeof(int) * 40 + sizeof(GnShared) + 16; }
+static size_t gn_smem(int pmax) { const size_t region = (size_t)pmax * 28 > GN_RED_BYTES ? (size_t)pmax * 28 : GN_RED_BYTES; return region + (size_t)pmax * 2 + sizeof(int) * 40 + sizeof(GnShared) + 16; }
 
 hipError_t configure_gauss_newton(int pmax)
 {

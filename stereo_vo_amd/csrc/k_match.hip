@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* ltaken = (unsigned*)smem;                 // max_kps/32 words
     unsigned* rtaken = ltaken + c.max_kps / 32;
+    __shared__ int chunk_tl[64], chunk_tr[64];
     const int lane_id = blockIdx.x, lane = threadIdx.x;
     const LaneState& ls = c.lane[lane_id];
     if (!ls.has_prev) { if (lane == 0) c.trk_nk[lane_id] = 0; return; }
@@ -149,9 +150,16 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
     const int npm = c.n_matches[lane_id * 2 + prev], ncm = c.n_matches[lane_id * 2 + cur];
     if (npm <= 0 || ncm <= 0) { if (lane == 0) c.trk_nk[lane_id] = 0; return; }
     for (int i = lane; i < c.max_kps / 32; i += 64) { ltaken[i] = 0; rtaken[i] = 0; }
+    // the walk below is sequential: stage the packed matcher results in LDS first so that no step of it waits on HBM
+    unsigned* pL = rtaken + c.max_kps / 32, *pR = pL + c.max_kps;
+    int* kq_l = (int*)(pR + c.max_kps);      // kept list, LDS copy: a global store inside the walk would make every
+                                             // workgroup-scope fence wait ~2 us for its write acknowledgement
+    {
+        const unsigned* gL = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 1) * c.max_kps;
+        const unsigned* gR = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 2) * c.max_kps;
+        for (int i = lane; i < npm; i += 64) { pL[i] = gL[i]; pR[i] = gR[i]; }
+    }
     __syncthreads();
-    const unsigned* pL = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 1) * c.max_kps;
-    const unsigned* pR = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 2) * c.max_kps;
     const svo_dmatch* pm = c.matches + match_base(c, lane_id, prev), *cm = c.matches + match_base(c, lane_id, cur);
     const svo_keypoint* pkl = c.kps + feat_base(c, lane_id, prev, 0), *pkr = c.kps + feat_base(c, lane_id, prev, 1);
     const svo_keypoint* ckl = c.kps + feat_base(c, lane_id, cur, 0), *ckr = c.kps + feat_base(c, lane_id, cur, 1);
@@ -168,9 +176,12 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
             pass = !((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th);
             if (pass && (((ltaken[tl >> 5] >> (tl & 31)) & 1u) || ((rtaken[tr >> 5] >> (tr & 31)) & 1u))) pass = false;
         }
+        // conflicts with earlier lanes of the chunk.  This kernel runs ONE wave per lane, so every LDS or cross-lane
+        // permute round trip is fully exposed; v_readlane into SGPRs keeps the 63 comparisons pure ALU
         unsigned long long conf = 0;
+#pragma unroll
         for (int j = 0; j < 63; j++) {
-            const int ol = __shfl(tl, j, 64), orr = __shfl(tr, j, 64);
+            const int ol = __builtin_amdgcn_readlane(tl, j), orr = __builtin_amdgcn_readlane(tr, j);
             if (j < lane && (ol == tl || orr == tr)) conf |= 1ull << j;
         }
         bool undecided = pass;
@@ -187,16 +198,24 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
         }
         if ((acc_mask >> lane) & 1ull) {
             atomicOr(&ltaken[tl >> 5], 1u << (tl & 31)); atomicOr(&rtaken[tr >> 5], 1u << (tr & 31));
-            const int o = nk + __popcll(acc_mask & ((1ull << lane) - 1ull));
-            kq[o] = k;
-            const svo_keypoint a = pkl[pm[k].queryIdx], b = ckl[cm[tl].queryIdx];
-            ptsL[o * 4] = a.x; ptsL[o * 4 + 1] = a.y; ptsL[o * 4 + 2] = b.x; ptsL[o * 4 + 3] = b.y;
-            const svo_keypoint e = pkr[pm[k].trainIdx], f = ckr[cm[tr].trainIdx];
-            ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
+            kq_l[nk + __popcll(acc_mask & ((1ull << lane) - 1ull))] = k;
         }
         nk += __popcll(acc_mask);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+    }
+    // the pixel pairs for the two RANSACs (S4:181-189, 216-224), gathered after the sequential walk so that the three
+    // levels of dependent global loads (match -> keypoint index -> keypoint) pipeline across all kept entries
+    __threadfence_block();
+    for (int o = lane; o < nk; o += 64) {
+        const int k = kq_l[o];
+        kq[o] = k;
+        const int tl = (int)(pL[k] & 0xFFFFu), tr = (int)(pR[k] & 0xFFFFu);
+        const svo_dmatch mp = pm[k];
+        const svo_keypoint a = pkl[mp.queryIdx], b = ckl[cm[tl].queryIdx];
+        ptsL[o * 4] = a.x; ptsL[o * 4 + 1] = a.y; ptsL[o * 4 + 2] = b.x; ptsL[o * 4 + 3] = b.y;
+        const svo_keypoint e = pkr[mp.trainIdx], f = ckr[cm[tr].trainIdx];
+        ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
     }
     if (lane == 0) c.trk_nk[lane_id] = nk;
 }
@@ -368,9 +387,14 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracki
                 if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
                     best_cnt = cnt; best_k = k;
                     const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
-                    double acc = 1.0; int K = 0;
-                    while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
-                    niters = K;
+                    // the oracle's stop is the sequential product below; when even x^256 (by squaring, with a 10 % margin
+                    // for the different rounding) stays above the bound the loop cannot stop early and is skipped
+                    double p256 = x; for (int sq = 0; sq < 8; sq++) p256 = p256 * p256;
+                    if (p256 <= 0.011) {
+                        double acc = 1.0; int K = 0;
+                        while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
+                        niters = K;
+                    }
                 }
             }
         }
@@ -439,7 +463,7 @@ void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, 
 
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned), st, c);
+    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 3 * sizeof(unsigned), st, c);
 }
 void launch_ransac_hyp(const DevCtx& c, hipStream_t st)
 {
