@@ -179,8 +179,18 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
         abytes = algorithmic_bytes(dom, 2 * B, lv, mean_kps, mean_match, mean_track)
         achieved = abytes / (per_kernel[dom]["ms_per_launch"] * 1e-3) / 1e9
+        # HBM traffic of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs: FETCH_SIZE, WRITE_SIZE),
+        # scaled from the profiled lane count to this run's; None when no profile matches the kernel
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
+            if (W, H) == (1280, 960) and kk in pm["fetch_kb"]:
+                traffic = int((pm["fetch_kb"][kk] + pm["write_kb"][kk]) * 1024 * B / pm["lanes"])
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4)}
         # end-to-end algorithmic traffic of the whole path (SURVEY.md 8d formula), for the DESIGN.md table
         P = sum(a * b for a, b in lv) / float(W * H)
