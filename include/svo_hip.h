@@ -52,7 +52,7 @@ typedef struct svo_config {
     int32_t max_kps;        /* capacity of every keypoint / pairing list (power of two, <= 4096) */
     int32_t max_cand;       /* capacity of the per-level FAST candidate list at level 0 (scaled by area above) */
     int32_t kernel_times;   /* 1: bracket every kernel with HIP events (svo_kernel_times) */
-    int32_t _pad;
+    int32_t max_octaves;    /* 1..4: octave lists per lane (params_rectify.nOctaves of the FAST+ORB mode); 1 suffices for ORB */
     void*   stream;         /* hipStream_t to run on; NULL = the context creates its own */
 } svo_config;
 
@@ -106,6 +106,13 @@ int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* m, int cap);
 int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int cap);          /* tracked_pairs[0] (H:823) */
 int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap);                /* result.out_residual */
 int svo_get_outliers(svo_ctx* ctx, int lane, int32_t* idx, int cap);              /* result.outliers */
+/* the same lists of one octave (the FAST+ORB mode keeps one list per x1/2 octave, H:760-764, H:799), the row table
+ * of m_update_indexes (pyr_feats_index, H:763; img_h entries) and matches_lr_row_index (H:789; img_h + 1 entries) */
+int svo_get_keypoints_oct(svo_ctx* ctx, int lane, int which, int side, int octave, svo_keypoint* kps, uint8_t* desc, int cap);
+int svo_get_matches_oct(svo_ctx* ctx, int lane, int which, int octave, svo_dmatch* m, int cap);
+int svo_get_tracked_oct(svo_ctx* ctx, int lane, int octave, svo_index_pair* t, int cap);
+int svo_get_row_index(svo_ctx* ctx, int lane, int which, int side, int octave, int32_t* idx, int cap);
+int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int octave, int32_t* idx, int cap);
 
 /* the precomputed-data bypass (request_data.use_precomputed_data, H:214-218, P:131-162, P:219-251):
  * load caller-supplied features / pairings into a lane's current (which=0) or previous (which=1) frame. */

@@ -59,15 +59,18 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
             s.m_error = SVO_VOEC_NONE;                                                 // P:95
             s.has_cur = 1;                                                             // P:100
             const int cur = 1 - s.prev_slot;
-            c.n_kps[feat_cnt_idx(t, cur, 0)] = 0; c.n_kps[feat_cnt_idx(t, cur, 1)] = 0;
-            c.n_matches[t * 2 + cur] = 0;
+            for (int o = 0; o < c.oct_cap; o++) {
+                const int vl = t * c.oct_cap + o;
+                c.n_kps[feat_cnt_idx(vl, cur, 0)] = 0; c.n_kps[feat_cnt_idx(vl, cur, 1)] = 0;
+                c.n_matches[vl * 2 + cur] = 0;
+            }
             if (!repeat) s.it_counter++;                                               // P:380-381
         }
-        if (flags & SVO_RUN_TRACK) c.n_tracked[t] = 0;
+        if (flags & SVO_RUN_TRACK) for (int o = 0; o < c.oct_cap; o++) c.n_tracked[t * c.oct_cap + o] = 0;
         if (detect) c.status[t] = 0;
         svo_result& r = c.results[t];
         r.error_code = SVO_VOEC_NONE;                                                  // P:50
-        r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = 1;
+        r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = c.n_oct;
         r.tracked_feats_from_last_frame = 0; r.tracked_feats_from_last_KF = 0;
         for (int k = 0; k < 6; k++) { r.outPose[k] = 0; r.delta[k] = 0; }
     }
@@ -612,8 +615,10 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
         unsigned long long* d = (unsigned long long*)(c.raw_desc + o * 32);
         d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
         svo_keypoint k;
-        k.x = (float)x * g.scale; k.y = (float)y * g.scale; k.size = 31.0f * g.scale; k.angle = angle;
-        k.response = c.lvl_resp[o]; k.octave = level; k.class_id = -1;
+        // ORB mode: level-0 coordinates, size 31*scale, octave = pyramid level.  FAST+ORB mode: cv::FAST keypoints
+        // (octave-image coordinates, size 7, octave 0) that cv::ORB::compute only orients and describes
+        k.x = (float)x * g.scale; k.y = (float)y * g.scale; k.size = c.fast_orb ? 7.0f : 31.0f * g.scale; k.angle = angle;
+        k.response = c.lvl_resp[o]; k.octave = c.fast_orb ? 0 : level; k.class_id = -1;
         c.raw_kps[o] = k;
     }
 }
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
 //   m_update_indexes(order=true) (stage2_detect.cpp:65-130): re-sort by (pt.y asc, rank asc).
 // Writes the final keypoints + descriptors of the lane's current slot.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int num_out_points, int NS_MAX)
+__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX)
 {
     // dynamic LDS only (G17): keys[NS_MAX] u64 | hkey[2*NS_MAX] | hval[2*NS_MAX] | cellxy[NS_MAX] | acc_idx[NS_MAX] u16 | state[NS_MAX] u8 | scan[32] | flag
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -637,17 +642,21 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     unsigned char* state = (unsigned char*)(acc_idx + NS_MAX);
     int* scan = (int*)(state + NS_MAX);
     int* flag = scan + 32;
-    const int img = blockIdx.x, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
+    const int img = blockIdx.x, oct = blockIdx.y, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
+    const int vl = lane_id * c.oct_cap + oct;
     const svo_keypoint* rk = c.raw_kps + (long long)img * c.raw_cap;
-    // compact the level-segmented winners into raw order: level 0 first, each level by Harris rank
+    // ORB mode (one octave): all pyramid levels are gathered, level 0 first, each level by Harris rank, and the
+    // reference's grid NMS runs here.  FAST+ORB mode: level == octave, the NMS already ran before the describe kernel
+    // (k_fastorb_nms), so only this octave's segment is taken, in its accepted (response-descending) order.
+    const int l_first = c.fast_orb ? oct : 0, l_last = c.fast_orb ? oct + 1 : c.n_levels;
     int lvl_base[SVO_MAX_LEVELS + 1];
-    lvl_base[0] = 0;
-    for (int l = 0; l < SVO_MAX_LEVELS; l++) lvl_base[l + 1] = lvl_base[l] + (l < c.n_levels ? c.lvl_n[img * SVO_MAX_LEVELS + l] : 0);
-    const int n = lvl_base[c.n_levels];
+    for (int l = 0; l <= SVO_MAX_LEVELS; l++) lvl_base[l] = 0;
+    for (int l = l_first; l < SVO_MAX_LEVELS; l++) lvl_base[l + 1] = lvl_base[l] + (l < l_last ? c.lvl_n[img * SVO_MAX_LEVELS + l] : 0);
+    const int n = lvl_base[l_last];
     for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = 0;
     __syncthreads();
     // key = (response desc, raw index asc); the payload is the raw index, the slot is recovered from it
-    for (int l = 0; l < c.n_levels; l++) {
+    for (int l = l_first; l < l_last; l++) {
         const int nl = lvl_base[l + 1] - lvl_base[l];
         for (int i = tid; i < nl; i += blockDim.x) {
             const int raw_i = lvl_base[l] + i;
@@ -658,12 +667,13 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     __syncthreads();
     int P = 64; while (P < n) P <<= 1;
     if (do_nms) bitonic_sort_lds<true>(keys, P);
-    auto slot_of = [&](int raw_i) { int l = 0; for (int q = 1; q < SVO_MAX_LEVELS; q++) if (q < c.n_levels && raw_i >= lvl_base[q]) l = q; return c.lv[l].slot_off + (raw_i - lvl_base[l]); };
+    auto slot_of = [&](int raw_i) { int l = l_first; for (int q = l_first + 1; q < SVO_MAX_LEVELS; q++) if (q < l_last && raw_i >= lvl_base[q]) l = q; return c.lv[l].slot_off + (raw_i - lvl_base[l]); };
+    const int W = c.ow[oct], H = c.oh[oct], num_out_points = c.kps_to_detect[oct];
     int nacc = 0;
     if (do_nms) {
         const unsigned cell = (unsigned)((double)min_distance / 2.0);            // S2:331
         const float inv = 1.0f / (float)cell;                                    // S2:332
-        const unsigned glx = (unsigned)(1 + (float)c.W * inv), gly = (unsigned)(1 + (float)c.H * inv);   // S2:334-335
+        const unsigned glx = (unsigned)(1 + (float)W * inv), gly = (unsigned)(1 + (float)H * inv);   // S2:334-335
         for (int i = tid; i < n; i += blockDim.x) {
             const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
             const svo_keypoint& k = rk[slot_of(raw_i)];
@@ -698,7 +708,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     P = 64; while (P < nacc) P <<= 1;
     bitonic_sort_lds<false>(keys, P);
     const int cur = 1 - c.lane[lane_id].prev_slot;
-    const long long ob = feat_base(c, lane_id, cur, side);
+    const long long ob = feat_base(c, vl, cur, side);
     for (int i = tid; i < nacc; i += blockDim.x) {
         const int s = slot_of(acc_idx[(int)(keys[i] & 0xFFFFFFFFull)]);
         c.kps[ob + i] = rk[s];
@@ -706,11 +716,209 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         uint4* dd = (uint4*)(c.desc + (ob + i) * 32);
         dd[0] = sd[0]; dd[1] = sd[1];
     }
-    if (tid == 0) {
-        c.n_kps[feat_cnt_idx(lane_id, cur, side)] = nacc;
-        c.raw_n[img] = n;
-        if (side == 0) c.results[lane_id].detected_left[0] = nacc; else c.results[lane_id].detected_right[0] = nacc;
+    // m_update_indexes row table (stage2_detect.cpp:103-129): idx[r] = #keypoints with (int)y <= r for
+    // first_row <= r < last_row, 0 elsewhere (the reference never fills the tail).  keys are sorted by y: binary search.
+    {
+        int* ridx = c.row_index + (long long)feat_cnt_idx(vl, cur, side) * c.max_h;
+        int first_row = 0, last_row = 0;
+        if (nacc > 0) { first_row = (int)inv_ord32((uint32_t)(keys[0] >> 32)); last_row = (int)inv_ord32((uint32_t)(keys[nacc - 1] >> 32)); }
+        for (int r = tid; r < H; r += blockDim.x) {
+            int v = 0;
+            if (nacc > 0 && r >= first_row && r < last_row) {
+                int lo = 0, hi = nacc;                                         // first index whose (int)y > r
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)inv_ord32((uint32_t)(keys[mid] >> 32)) <= r) lo = mid + 1; else hi = mid; }
+                v = lo;
+            }
+            ridx[r] = v;
+        }
     }
+    if (tid == 0) {
+        c.n_kps[feat_cnt_idx(vl, cur, side)] = nacc;
+        c.raw_n[img] = n;
+        if (side == 0) c.results[lane_id].detected_left[oct] = nacc; else c.results[lane_id].detected_right[oct] = nacc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// FAST+ORB mode (stage2_detect.cpp:502-515, configs[4]): the x1/2 octave pyramid of mrpt CImagePyramid (S1:82-83)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_half(DevCtx c, int level)
+{
+    const int img = blockIdx.z;
+    const LevelGeom& d = c.lv[level];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x4 >= d.w || y >= d.h) return;
+    int spitch; const uint8_t* src = level_ptr(c, img, level - 1, spitch);
+    uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
+    const uint8_t* r0 = src + (long long)(2 * y) * spitch + 2 * x4, *r1 = r0 + spitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x4 + k < d.w) out |= (uint32_t)(((int)r0[2 * k] + r0[2 * k + 1] + r1[2 * k] + r1[2 * k + 1] + 2) >> 2) << (8 * k);
+    *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;
+}
+
+// FAST+ORB: the reference's grid NMS (m_non_max_sup, S2:296-370, cap kps_to_detect[octave]) applied to ALL FAST corners
+// of one (image, octave) in (score desc, raster position asc) order -- exactly the descending order of the unique
+// candidate keys.  The corners are consumed in chunks of the NS_MAX largest remaining keys (radix select, bitonic sort,
+// block-parallel NMS).  Between chunks only the ACCEPTED cells survive (a compact list re-seeds the hash with the
+// marker FO_ACCEPTED, which every later candidate sees as "accepted, lower rank"); a cell whose representative was
+// rejected needs no memory: whatever rejected it still rejects every later candidate of that cell.
+// Survivors go to the level-segmented arrays that k_describe reads (describing only survivors gives the same
+// descriptors as the reference's describe-then-suppress order).
+#define FO_ACCEPTED 0xFFFFFFFEu
+__global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance, int do_nms, int NS_MAX, int ACC_MAX)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NS_HASH = 4 * NS_MAX;
+    unsigned long long* keys = (unsigned long long*)smem;                  // NS_MAX
+    uint32_t* hkey = (uint32_t*)(keys + NS_MAX);                           // 4*NS_MAX
+    uint32_t* hval = hkey + NS_HASH;                                       // 4*NS_MAX
+    uint32_t* cellxy = hval + NS_HASH;                                     // NS_MAX
+    uint32_t* acc_cells = cellxy + NS_MAX;                                 // ACC_MAX: cell keys of everything accepted so far
+    unsigned* hist = acc_cells + ACC_MAX;                                  // 256
+    int* scan = (int*)(hist + 256);                                        // 32
+    int* flag = scan + 32;
+    unsigned* sh = (unsigned*)(flag + 1);                                  // s_prefix, s_need, s_sel
+    unsigned char* state = (unsigned char*)(sh + 4);                       // NS_MAX
+    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& g = c.lv[level];
+    unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
+    if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
+    const int cap = min(min(c.kps_to_detect[level], g.quota), ACC_MAX);    // quota = slots reserved for this octave
+    const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
+    const unsigned cell = (unsigned)((double)min_distance / 2.0);
+    const float inv = 1.0f / (float)cell;
+    const unsigned glx = (unsigned)(1 + (float)g.w * inv), gly = (unsigned)(1 + (float)g.h * inv);
+    auto slot_of_key = [&](uint32_t key) {                                 // find-or-insert
+        uint32_t h = nms_hash_slot(key, NS_HASH);
+        for (;;) {
+            const uint32_t old = atomicCAS(&hkey[h], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) return h;
+            h = (h + 1) & (uint32_t)(NS_HASH - 1);
+        }
+    };
+    int nacc = 0;
+    uint32_t upper = 0xFFFFFFFFu;             // keys >= upper are already consumed
+    unsigned remaining = nc;
+    while (remaining > 0 && nacc < cap) {
+        const unsigned K = min(remaining, (unsigned)NS_MAX);
+        // ---- the K largest keys below `upper` (radix select on the unique keys) ----
+        unsigned prefix = 0, mask = 0, need = K;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if (k < upper && (k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u); }
+            __syncthreads();
+            const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+            int tot;
+            const int before = block_exclusive_scan(mine, scan, &tot);
+            if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { sh[0] = prefix | ((unsigned)(255 - tid) << shift); sh[1] = need - (unsigned)before; }
+            __syncthreads();
+            prefix = sh[0]; need = sh[1]; mask |= 255u << shift;
+            __syncthreads();
+        }
+        const uint32_t cutoff = prefix;
+        if (tid == 0) sh[2] = 0;
+        for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = 0;
+        __syncthreads();
+        for (unsigned base = 0; base < nc; base += blockDim.x) {
+            const unsigned i = base + tid;
+            uint32_t k = 0;
+            const bool take = i < nc && (k = ck[i]) >= cutoff && k < upper;
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                unsigned b0 = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if ((tid & 63) == leader) b0 = atomicAdd(&sh[2], (unsigned)__popcll(m));
+                b0 = __shfl(b0, leader, 64);
+                const unsigned slot = b0 + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+                if (take && slot < (unsigned)NS_MAX) keys[slot] = (unsigned long long)k;
+            }
+        }
+        __syncthreads();
+        int P = 64; while (P < (int)K) P <<= 1;
+        bitonic_sort_lds<true>(keys, P);                                   // rank order of this chunk
+        if (do_nms) {
+            // ---- re-seed the hash with the accepted cells, then the chunk's representatives ----
+            for (int i = tid; i < NS_HASH; i += blockDim.x) { hkey[i] = 0xFFFFFFFFu; hval[i] = 0xFFFFFFFFu; }
+            __syncthreads();
+            for (int i = tid; i < nacc; i += blockDim.x) hval[slot_of_key(acc_cells[i])] = FO_ACCEPTED;
+            __syncthreads();
+            for (int i = tid; i < (int)K; i += blockDim.x) {
+                const uint32_t pos = 0xFFFFFFu - ((uint32_t)keys[i] & 0xFFFFFFu);
+                const float fx = (float)(pos % (uint32_t)g.w), fy = (float)(pos / (uint32_t)g.w);
+                const size_t ux = (size_t)(fx * inv), uy = (size_t)(fy * inv);
+                const uint32_t cxy = (ux < glx && uy < gly) ? (((uint32_t)ux << 16) | (uint32_t)uy) : 0xFFFFFFFFu;
+                cellxy[i] = cxy;
+                if (cxy != 0xFFFFFFFFu) {
+                    const uint32_t h = slot_of_key((cxy >> 16) * gly + (cxy & 0xFFFFu));
+                    if (hval[h] != FO_ACCEPTED) atomicMin(&hval[h], (uint32_t)i);      // markers are only written before this phase
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < (int)K; i += blockDim.x) {
+                const uint32_t cxy = cellxy[i];
+                unsigned char st = 0;
+                if (cxy != 0xFFFFFFFFu && nms_lookup(hkey, hval, NS_HASH, (cxy >> 16) * gly + (cxy & 0xFFFFu)) == (uint32_t)i) st = SVO_NMS_UNDECIDED;
+                state[i] = st;                                             // non-representatives and already-accepted cells: rejected
+            }
+            __syncthreads();
+            for (;;) {
+                if (tid == 0) *flag = 0;
+                __syncthreads();
+                bool pending = false;
+                for (int i = tid; i < (int)K; i += blockDim.x) {
+                    if (((volatile unsigned char*)state)[i] != SVO_NMS_UNDECIDED) continue;
+                    const uint32_t cxy = cellxy[i];
+                    const int sx = (int)(cxy >> 16), sy = (int)(cxy & 0xFFFFu);
+                    bool any_acc = false, any_und = false;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int cx = sx + (q == 0) - (q == 1), cy = sy + (q == 2) - (q == 3);
+                        if (cx < 0 || cy < 0 || cy >= (int)gly) continue;
+                        const uint32_t j = nms_lookup(hkey, hval, NS_HASH, (uint32_t)cx * gly + (uint32_t)cy);
+                        if (j == FO_ACCEPTED) any_acc = true;
+                        else if (j < (uint32_t)i) { const unsigned char sj = ((volatile unsigned char*)state)[j]; any_acc |= sj == 1; any_und |= sj == SVO_NMS_UNDECIDED; }
+                    }
+                    if (any_acc) ((volatile unsigned char*)state)[i] = 0;
+                    else if (!any_und) ((volatile unsigned char*)state)[i] = 1;
+                    else pending = true;
+                }
+                if (pending) *flag = 1;
+                __syncthreads();
+                const int again = *flag;
+                __syncthreads();
+                if (!again) break;
+            }
+        } else {
+            for (int i = tid; i < (int)K; i += blockDim.x) state[i] = 1;
+            __syncthreads();
+        }
+        // ---- emit the chunk's survivors in rank order, up to the cap, and remember their cells ----
+        int chunk_acc = 0;
+        for (int base = 0; base < (int)K && nacc + chunk_acc < cap; base += blockDim.x) {
+            const int i = base + tid;
+            const int keep = (i < (int)K && state[i] == 1) ? 1 : 0;
+            int tot;
+            const int off = block_exclusive_scan(keep, scan, &tot);
+            const int o_idx = nacc + chunk_acc + off;
+            if (keep && o_idx < cap) {
+                const uint32_t k = (uint32_t)keys[i];
+                const long long o = (long long)img * c.raw_cap + g.slot_off + o_idx;
+                c.lvl_pos[o] = 0xFFFFFFu - (k & 0xFFFFFFu);
+                c.lvl_resp[o] = (float)(k >> 24);                          // cv::FAST response = score
+                if (do_nms) { const uint32_t cxy = cellxy[i]; acc_cells[o_idx] = (cxy >> 16) * gly + (cxy & 0xFFFFu); }
+            }
+            chunk_acc += tot;
+            __syncthreads();
+        }
+        nacc = min(nacc + chunk_acc, cap);
+        upper = cutoff;
+        remaining -= K;
+        __syncthreads();
+    }
+    if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = nacc;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -747,16 +955,37 @@ void launch_describe(const DevCtx& c, hipStream_t st)
     hipLaunchKernelGGL(k_describe, dim3((c.n_slots + 3) / 4, c.n_img), dim3(256), 0, st, c);
 }
 
-static int nms_pmax(const DevCtx& c) { int p = 64; while (p < c.raw_cap) p <<= 1; return p; }
+#define FO_PMAX 2048     // chunk size of k_fastorb_nms (LDS: 45 B per entry)
+static int nms_pmax(const DevCtx& c)
+{
+    // keys per block: ORB mode gathers every level of an image (n_slots), FAST+ORB mode one octave's quota
+    int n = 64;
+    if (c.fast_orb) { for (int l = 0; l < c.n_levels; l++) if (c.lv[l].quota > n) n = c.lv[l].quota; } else n = c.n_slots;
+    int p = 64; while (p < n) p <<= 1; return p;
+}
 static size_t nms_rowsort_smem(int pmax) { return (size_t)pmax * (8 + 8 + 8 + 4 + 2 + 1) + 4 * 40; }
+static size_t fastorb_nms_smem(int pmax, int accmax) { return (size_t)pmax * (8 + 16 + 16 + 4 + 1) + (size_t)accmax * 4 + 4 * (256 + 32 + 8) + 16; }
 
 hipError_t configure_nms_rowsort(const DevCtx& c)
 {
+    hipError_t e = hipFuncSetAttribute((const void*)k_fastorb_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fastorb_nms_smem(FO_PMAX, c.max_kps));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_nms_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(nms_pmax(c)));
 }
 
-void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int num_out_points, hipStream_t st)
+void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, hipStream_t st)
 {
     const int pmax = nms_pmax(c);
-    hipLaunchKernelGGL(k_nms_rowsort, dim3(c.n_img), dim3(1024), nms_rowsort_smem(pmax), st, c, do_nms, min_distance, num_out_points, pmax);
+    hipLaunchKernelGGL(k_nms_rowsort, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax);
+}
+
+void launch_half(const DevCtx& c, int level, hipStream_t st)
+{
+    const LevelGeom& d = c.lv[level];
+    hipLaunchKernelGGL(k_half, dim3(((d.w + 3) / 4 + 255) / 256, d.h, c.n_img), dim3(256), 0, st, c, level);
+}
+
+void launch_fastorb_nms(const DevCtx& c, int do_nms, int min_distance, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fastorb_nms, dim3(c.n_levels, c.n_img), dim3(1024), fastorb_nms_smem(FO_PMAX, c.max_kps), st, c, min_distance, do_nms, FO_PMAX, c.max_kps);
 }

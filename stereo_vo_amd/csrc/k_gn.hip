@@ -326,26 +326,36 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     svo_result& res = c.results[lane_id];
     if (!P.standalone && (!ls.has_prev || ls.m_error == SVO_VOEC_BAD_TRACKING)) return;      // P:305, P:332
     const svo_stereo_camera cam = c.cams[lane_id];
-    const int T = c.n_tracked[lane_id];
+    // tracked pairs of all octaves, concatenated octave by octave (S5:419-461); toff[o] = first flat index of octave o
     const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
-    const svo_index_pair* trk = c.tracked + (long long)lane_id * c.max_kps;
-    const svo_dmatch* pm = c.matches + match_base(c, lane_id, prev), *cm = c.matches + match_base(c, lane_id, cur);
-    const svo_keypoint* pkl = c.kps + feat_base(c, lane_id, prev, 0), *pkr = c.kps + feat_base(c, lane_id, prev, 1);
-    const svo_keypoint* ckl = c.kps + feat_base(c, lane_id, cur, 0), *ckr = c.kps + feat_base(c, lane_id, cur, 1);
+    int toff[SVO_MAX_OCTAVES + 1];
+    toff[0] = 0;
+    for (int o = 0; o < SVO_MAX_OCTAVES; o++) toff[o + 1] = toff[o] + (o < c.n_oct ? c.n_tracked[lane_id * c.oct_cap + o] : 0);
+    int T = toff[SVO_MAX_OCTAVES];
+    if (T > P.pmax) { T = P.pmax; if (tid == 0) atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); }
+    auto oct_of = [&](int i) { int o = 0; for (int q = 1; q < SVO_MAX_OCTAVES; q++) if (i >= toff[q] && q < c.n_oct) o = q; return o; };
     float* obs = c.gn_obs + (long long)lane_id * c.max_kps * 8;
     double* lmk = c.gn_lmk + (long long)lane_id * c.max_kps * 3;
     double* residual = c.residual + (long long)lane_id * c.max_kps;
     int* outl = c.outliers + (long long)lane_id * c.max_kps;
+    int* cur_idx = c.trk_kq + (long long)lane_id * c.oct_cap * c.max_kps;      // tracked[..].second per point (the kept list of stage 4 is dead by now)
+
     int Pn = 64; while (Pn < T) Pn <<= 1;
     // ---- gather the four keypoint lists (S5:419-461, single octave) and the NMS sort keys ----
     for (int i = tid; i < Pn; i += blockDim.x) keys[i] = 0;
     for (int i = tid; i < T; i += blockDim.x) mask[i] = 0;
     __syncthreads();
     for (int i = tid; i < T; i += blockDim.x) {
-        const svo_dmatch a = pm[trk[i].first], b = cm[trk[i].second];
-        const svo_keypoint l1 = pkl[a.queryIdx], r1 = pkr[a.trainIdx], l2 = ckl[b.queryIdx], r2 = ckr[b.trainIdx];
-        float* o = obs + 8 * (long long)i;
-        o[0] = l1.x; o[1] = l1.y; o[2] = r1.x; o[3] = r1.y; o[4] = l2.x; o[5] = l2.y; o[6] = r2.x; o[7] = r2.y;
+        const int o = oct_of(i), vl = lane_id * c.oct_cap + o;
+        const svo_index_pair tp = c.tracked[(long long)vl * c.max_kps + (i - toff[o])];
+        const svo_dmatch a = c.matches[match_base(c, vl, prev) + tp.first], b = c.matches[match_base(c, vl, cur) + tp.second];
+        const svo_keypoint l1 = c.kps[feat_base(c, vl, prev, 0) + a.queryIdx], r1 = c.kps[feat_base(c, vl, prev, 1) + a.trainIdx];
+        const svo_keypoint l2 = c.kps[feat_base(c, vl, cur, 0) + b.queryIdx], r2 = c.kps[feat_base(c, vl, cur, 1) + b.trainIdx];
+        const float sn = (float)(size_t)(c.n_oct > 1 ? (1 << o) : 1);            // scale_norm, S5:422 (applied only when nOctaves > 1)
+        float* ob = obs + 8 * (long long)i;
+        if (c.n_oct > 1) { ob[0] = l1.x * sn; ob[1] = l1.y * sn; ob[2] = r1.x * sn; ob[3] = r1.y * sn; ob[4] = l2.x * sn; ob[5] = l2.y * sn; ob[6] = r2.x * sn; ob[7] = r2.y * sn; }
+        else { ob[0] = l1.x; ob[1] = l1.y; ob[2] = r1.x; ob[3] = r1.y; ob[4] = l2.x; ob[5] = l2.y; ob[6] = r2.x; ob[7] = r2.y; }
+        cur_idx[i] = tp.second;
         keys[i] = ((unsigned long long)ord32(l1.response) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
     }
     __threadfence_block();
@@ -424,7 +434,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
         if (i < n_res) { if (residual[i] > P.residual_threshold) mask[i] = 0; else keep = 1; }
         int tot;
         const int off = block_exclusive_scan(keep, scan, &tot);
-        if (keep) outl[n_out + off] = trk[i].second;
+        if (keep) outl[n_out + off] = cur_idx[i];
         n_out += tot;
         __syncthreads();
     }

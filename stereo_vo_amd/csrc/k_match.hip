@@ -22,19 +22,20 @@
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long tile[HM_TILE * 4];
-    const int lane_id = blockIdx.y;
+    const int vl = blockIdx.y, lane_id = vl / c.oct_cap;
+    if (vl % c.oct_cap >= c.n_oct) return;
     const int side = mode ? (blockIdx.z / nsplit) : 0, split = blockIdx.z % nsplit;
     const LaneState& ls = c.lane[lane_id];
     const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
     int nq, nt; const uint8_t* qd, *td; const svo_dmatch* qm = nullptr, *tm = nullptr;
     if (mode == 0) {
-        nq = c.n_kps[feat_cnt_idx(lane_id, cur, 0)]; nt = c.n_kps[feat_cnt_idx(lane_id, cur, 1)];
-        qd = c.desc + feat_base(c, lane_id, cur, 0) * 32; td = c.desc + feat_base(c, lane_id, cur, 1) * 32;
+        nq = c.n_kps[feat_cnt_idx(vl, cur, 0)]; nt = c.n_kps[feat_cnt_idx(vl, cur, 1)];
+        qd = c.desc + feat_base(c, vl, cur, 0) * 32; td = c.desc + feat_base(c, vl, cur, 1) * 32;
     } else {
         if (!ls.has_prev) return;
-        nq = c.n_matches[lane_id * 2 + prev]; nt = c.n_matches[lane_id * 2 + cur];
-        qd = c.desc + feat_base(c, lane_id, prev, side) * 32; td = c.desc + feat_base(c, lane_id, cur, side) * 32;
-        qm = c.matches + match_base(c, lane_id, prev); tm = c.matches + match_base(c, lane_id, cur);
+        nq = c.n_matches[vl * 2 + prev]; nt = c.n_matches[vl * 2 + cur];
+        qd = c.desc + feat_base(c, vl, prev, side) * 32; td = c.desc + feat_base(c, vl, cur, side) * 32;
+        qm = c.matches + match_base(c, vl, prev); tm = c.matches + match_base(c, vl, cur);
     }
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if ((int)(blockIdx.x * blockDim.x) >= nq || nt <= 0) return;            // block-uniform
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
         }
     }
     if (q < nq && best != 0xFFFFFFFFu) {
-        unsigned* out = (unsigned*)c.bf_idx + ((long long)lane_id * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
+        unsigned* out = (unsigned*)c.bf_idx + ((long long)vl * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
         if (nsplit > 1) atomicMin(out, best); else *out = best;
     }
 }
@@ -93,13 +94,14 @@ __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_o
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* right_best = (unsigned*)smem;              // max_kps
     int* scan = (int*)(right_best + c.max_kps);          // 32
-    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, oct = vl % c.oct_cap, tid = threadIdx.x;
+    if (oct >= c.n_oct) return;
     const LaneState& ls = c.lane[lane_id];
     const int cur = 1 - ls.prev_slot;
-    const int nl = c.n_kps[feat_cnt_idx(lane_id, cur, 0)], nr = c.n_kps[feat_cnt_idx(lane_id, cur, 1)];
-    const svo_keypoint* kl = c.kps + feat_base(c, lane_id, cur, 0), *kr = c.kps + feat_base(c, lane_id, cur, 1);
-    const unsigned* packed = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 0) * c.max_kps;
-    svo_dmatch* out = c.matches + match_base(c, lane_id, cur);
+    const int nl = c.n_kps[feat_cnt_idx(vl, cur, 0)], nr = c.n_kps[feat_cnt_idx(vl, cur, 1)];
+    const svo_keypoint* kl = c.kps + feat_base(c, vl, cur, 0), *kr = c.kps + feat_base(c, vl, cur, 1);
+    const unsigned* packed = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 0) * c.max_kps;
+    svo_dmatch* out = c.matches + match_base(c, vl, cur);
     for (int j = tid; j < nr; j += blockDim.x) right_best[j] = 0xFFFFFFFFu;
     __syncthreads();
     const bool any = nl > 0 && nr > 0;
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_o
             if (one_to_one && (int)(right_best[j] & 0xFFFFu) != i) keep = 0;
             const int diff = (int)(kl[i].y - kr[j].y);                                   // S3:162
             const int disp = (int)(kl[i].x - kr[j].x);                                   // S3:163
-            if ((double)abs(diff) > max_y_diff || distance > (float)c.orb_th || (double)disp < 1.0 || (double)disp > (double)c.W) keep = 0;
+            if ((double)abs(diff) > max_y_diff || distance > (float)c.orb_th || (double)disp < 1.0 || (double)disp > (double)c.ow[oct]) keep = 0;
         }
         int tot;
         const int off = block_exclusive_scan(keep, scan, &tot);
@@ -127,7 +129,25 @@ __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_o
         m_total += tot;
         __syncthreads();
     }
-    if (tid == 0) { c.n_matches[lane_id * 2 + cur] = m_total; c.results[lane_id].stereo_matches[0] = m_total; }
+    if (tid == 0) { c.n_matches[vl * 2 + cur] = m_total; c.results[lane_id].stereo_matches[oct] = m_total; }
+    // matches_lr_row_index (stage3_match_left_right.cpp:425-445): ri[y] = #pairings whose left keypoint has y <= y - 1
+    // (pairings are in ascending row order: binary search); ri[H] = M (documented deviation from S3:443, oracle too)
+    __threadfence_block();
+    __syncthreads();
+    {
+        int* ri = c.mrow_index + (long long)(vl * 2 + cur) * (c.max_h + 1);
+        const int H = c.oh[oct];
+        for (int y = tid; y <= H; y += blockDim.x) {
+            int v = m_total;
+            if (y < H) {
+                int lo = 0, hi = m_total;                      // first pairing with left y > y - 1
+                const float lim = (float)(y - 1);
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (kl[out[mid].queryIdx].y <= lim) lo = mid + 1; else hi = mid; }
+                v = y == 0 ? 0 : lo;
+            }
+            ri[y] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -143,28 +163,29 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
     unsigned* ltaken = (unsigned*)smem;                 // max_kps/32 words
     unsigned* rtaken = ltaken + c.max_kps / 32;
     __shared__ int chunk_tl[64], chunk_tr[64];
-    const int lane_id = blockIdx.x, lane = threadIdx.x;
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, lane = threadIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
     const LaneState& ls = c.lane[lane_id];
-    if (!ls.has_prev) { if (lane == 0) c.trk_nk[lane_id] = 0; return; }
+    if (!ls.has_prev) { if (lane == 0) c.trk_nk[vl] = 0; return; }
     const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
-    const int npm = c.n_matches[lane_id * 2 + prev], ncm = c.n_matches[lane_id * 2 + cur];
-    if (npm <= 0 || ncm <= 0) { if (lane == 0) c.trk_nk[lane_id] = 0; return; }
+    const int npm = c.n_matches[vl * 2 + prev], ncm = c.n_matches[vl * 2 + cur];
+    if (npm <= 0 || ncm <= 0) { if (lane == 0) c.trk_nk[vl] = 0; return; }
     for (int i = lane; i < c.max_kps / 32; i += 64) { ltaken[i] = 0; rtaken[i] = 0; }
     // the walk below is sequential: stage the packed matcher results in LDS first so that no step of it waits on HBM
     unsigned* pL = rtaken + c.max_kps / 32, *pR = pL + c.max_kps;
     int* kq_l = (int*)(pR + c.max_kps);      // kept list, LDS copy: a global store inside the walk would make every
                                              // workgroup-scope fence wait ~2 us for its write acknowledgement
     {
-        const unsigned* gL = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 1) * c.max_kps;
-        const unsigned* gR = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 2) * c.max_kps;
+        const unsigned* gL = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 1) * c.max_kps;
+        const unsigned* gR = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 2) * c.max_kps;
         for (int i = lane; i < npm; i += 64) { pL[i] = gL[i]; pR[i] = gR[i]; }
     }
     __syncthreads();
-    const svo_dmatch* pm = c.matches + match_base(c, lane_id, prev), *cm = c.matches + match_base(c, lane_id, cur);
-    const svo_keypoint* pkl = c.kps + feat_base(c, lane_id, prev, 0), *pkr = c.kps + feat_base(c, lane_id, prev, 1);
-    const svo_keypoint* ckl = c.kps + feat_base(c, lane_id, cur, 0), *ckr = c.kps + feat_base(c, lane_id, cur, 1);
-    int* kq = c.trk_kq + (long long)lane_id * c.max_kps;
-    float* ptsL = c.trk_pts + ((long long)lane_id * 2 + 0) * c.max_kps * 4, *ptsR = c.trk_pts + ((long long)lane_id * 2 + 1) * c.max_kps * 4;
+    const svo_dmatch* pm = c.matches + match_base(c, vl, prev), *cm = c.matches + match_base(c, vl, cur);
+    const svo_keypoint* pkl = c.kps + feat_base(c, vl, prev, 0), *pkr = c.kps + feat_base(c, vl, prev, 1);
+    const svo_keypoint* ckl = c.kps + feat_base(c, vl, cur, 0), *ckr = c.kps + feat_base(c, vl, cur, 1);
+    int* kq = c.trk_kq + (long long)vl * c.max_kps;
+    float* ptsL = c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4, *ptsR = c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4;
     int nk = 0;
     for (int base = 0; base < npm; base += 64) {
         const int k = base + lane;
@@ -217,7 +238,7 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
         const svo_keypoint e = pkr[mp.trainIdx], f = ckr[cm[tr].trainIdx];
         ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
     }
-    if (lane == 0) c.trk_nk[lane_id] = nk;
+    if (lane == 0) c.trk_nk[vl] = nk;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -239,10 +260,11 @@ __device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
 __global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c)
 {
     __shared__ double As[72][64];     // As[r*9+col][thread]: conflict-free (consecutive threads, consecutive banks)
-    const int h = blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, lane_id = blockIdx.z, tx = threadIdx.x;
-    const int n = c.trk_nk[lane_id];
+    const int h = blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z, tx = threadIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int n = c.trk_nk[vl];
     if (n < 8) return;
-    const float* pts = c.trk_pts + ((long long)lane_id * 2 + side) * c.max_kps * 4;
+    const float* pts = c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4;
     int s[8];
     {
         unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
@@ -305,7 +327,7 @@ __global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c)
         M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
         M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
     }
-    double* F = c.rs_F + (((long long)lane_id * 2 + side) * SVO_RANSAC_HYP + h) * 9;
+    double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_HYP + h) * 9;
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
         F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
@@ -331,11 +353,12 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
 {
     __shared__ double Fs[RC_HB][9];
     __shared__ int cnt_s[RC_HB];
-    const int side = blockIdx.y, lane_id = blockIdx.z, h0 = blockIdx.x * RC_HB, tid = threadIdx.x;
-    const int n = c.trk_nk[lane_id];
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = blockIdx.x * RC_HB, tid = threadIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int n = c.trk_nk[vl];
     if (n < 8) return;
-    const float4* pts = (const float4*)(c.trk_pts + ((long long)lane_id * 2 + side) * c.max_kps * 4);
-    const double* F = c.rs_F + (((long long)lane_id * 2 + side) * SVO_RANSAC_HYP + h0) * 9;
+    const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_HYP + h0) * 9;
     if (tid < RC_HB * 9) Fs[tid / 9][tid % 9] = F[tid];
     if (tid < RC_HB) cnt_s[tid] = 0;
     __syncthreads();
@@ -350,31 +373,28 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) { const int v = wave_reduce_sum_i32(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
     __syncthreads();
-    if (tid < RC_HB) c.rs_cnt[((long long)lane_id * 2 + side) * SVO_RANSAC_HYP + h0 + tid] = cnt_s[tid];
+    if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_HYP + h0 + tid] = cnt_s[tid];
 }
 
 // pick the model a sequential RANSAC with the 0.99-confidence stop would have returned, apply both masks
 // (S4:243-255), the consistency check (S4:282), and write tracked_pairs; then the bad-tracking gate (P:326-330)
 // and the first-frame rule (P:348-352).
-__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracking_th)
+__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* in_l = smem;                         // max_kps
     unsigned char* in_r = in_l + c.max_kps;             // max_kps
     int* scan = (int*)(in_r + c.max_kps);               // 32
     __shared__ int s_best[2], s_cnt[2];
-    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, oct = vl % c.oct_cap, tid = threadIdx.x;
+    if (oct >= c.n_oct) return;
     LaneState& ls = c.lane[lane_id];
-    svo_result& res = c.results[lane_id];
-    if (!ls.has_prev) {
-        if (tid == 0) { res.error_code = SVO_VOEC_FIRST_ITERATION; res.valid = 0; c.n_tracked[lane_id] = 0; }
-        return;
-    }
-    const int n = c.trk_nk[lane_id];
+    if (!ls.has_prev) { if (tid == 0) c.n_tracked[vl] = 0; return; }
+    const int n = c.trk_nk[vl];
     __shared__ int cnt_lds[2 * SVO_RANSAC_HYP];
     // the hypothesis scan below is serial and data dependent: stage the counts in LDS so that every step is an LDS
     // read instead of a dependent global load
-    for (int i = tid; i < 2 * SVO_RANSAC_HYP; i += blockDim.x) cnt_lds[i] = n >= 8 ? c.rs_cnt[(long long)lane_id * 2 * SVO_RANSAC_HYP + i] : 0;
+    for (int i = tid; i < 2 * SVO_RANSAC_HYP; i += blockDim.x) cnt_lds[i] = n >= 8 ? c.rs_cnt[(long long)vl * 2 * SVO_RANSAC_HYP + i] : 0;
     __syncthreads();
     if (tid == 0 || tid == 64) {
         const int side = tid >> 6;
@@ -404,13 +424,13 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracki
     const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
     const bool use_f = goodFL && goodFR;                             // S4:243
     if (use_f) {
-        const double* FL = c.rs_F + (((long long)lane_id * 2 + 0) * SVO_RANSAC_HYP + s_best[0]) * 9;
-        const double* FR = c.rs_F + (((long long)lane_id * 2 + 1) * SVO_RANSAC_HYP + s_best[1]) * 9;
+        const double* FL = c.rs_F + (((long long)vl * 2 + 0) * SVO_RANSAC_HYP + s_best[0]) * 9;
+        const double* FR = c.rs_F + (((long long)vl * 2 + 1) * SVO_RANSAC_HYP + s_best[1]) * 9;
         double fl[9], fr[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) { fl[i] = FL[i]; fr[i] = FR[i]; }
-        const float4* pl = (const float4*)(c.trk_pts + ((long long)lane_id * 2 + 0) * c.max_kps * 4);
-        const float4* pr = (const float4*)(c.trk_pts + ((long long)lane_id * 2 + 1) * c.max_kps * 4);
+        const float4* pl = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
+        const float4* pr = (const float4*)(c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4);
         for (int i = tid; i < n; i += blockDim.x) {
             const float4 a = pl[i], b = pr[i];
             in_l[i] = (unsigned char)fm_inlier(fl, a.x, a.y, a.z, a.w);
@@ -418,10 +438,10 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracki
         }
     }
     __syncthreads();
-    const unsigned* pL = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 1) * c.max_kps;
-    const unsigned* pR = (const unsigned*)c.bf_idx + ((long long)lane_id * 3 + 2) * c.max_kps;
-    const int* kq = c.trk_kq + (long long)lane_id * c.max_kps;
-    svo_index_pair* out = c.tracked + (long long)lane_id * c.max_kps;
+    const unsigned* pL = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 1) * c.max_kps;
+    const unsigned* pR = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 2) * c.max_kps;
+    const int* kq = c.trk_kq + (long long)vl * c.max_kps;
+    svo_index_pair* out = c.tracked + (long long)vl * c.max_kps;
     int t_total = 0;
     const int n_iter = (n + (int)blockDim.x - 1) / (int)blockDim.x;
     for (int it = 0; it < n_iter; it++) {
@@ -441,10 +461,21 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracki
         t_total += tot;
         __syncthreads();
     }
-    if (tid == 0) {
-        c.n_tracked[lane_id] = t_total;                                // m_num_tracked_pairs_from_last_frame (S4:743-752)
-        if (t_total < bad_tracking_th) { ls.m_error = SVO_VOEC_BAD_TRACKING; res.error_code = SVO_VOEC_BAD_TRACKING; }   // P:326-330
-    }
+    if (tid == 0) c.n_tracked[vl] = t_total;
+}
+
+// m_num_tracked_pairs_from_last_frame = sum over octaves (S4:743-752), then the bad-tracking gate (P:326-330) and the
+// first-frame rule (P:348-352).  One thread per lane.
+__global__ void k_track_gate(DevCtx c, int bad_tracking_th)
+{
+    const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane_id >= c.n_lanes) return;
+    LaneState& ls = c.lane[lane_id];
+    svo_result& res = c.results[lane_id];
+    if (!ls.has_prev) { res.error_code = SVO_VOEC_FIRST_ITERATION; res.valid = 0; return; }
+    int t = 0;
+    for (int o = 0; o < c.n_oct; o++) t += c.n_tracked[lane_id * c.oct_cap + o];
+    if (t < bad_tracking_th) { ls.m_error = SVO_VOEC_BAD_TRACKING; res.error_code = SVO_VOEC_BAD_TRACKING; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -452,30 +483,31 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int bad_tracki
 // ------------------------------------------------------------------------------------------------------------
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_hamming, dim3((c.max_kps + 255) / 256, c.n_lanes, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
+    hipLaunchKernelGGL(k_hamming, dim3((c.max_kps + 255) / 256, c.n_lanes * c.oct_cap, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)
 {
     const size_t sm = sizeof(unsigned) * c.max_kps + sizeof(int) * 32;
-    hipLaunchKernelGGL(k_match_lr_filter, dim3(c.n_lanes), dim3(1024), sm, st, c, one_to_one, max_y_diff);
+    hipLaunchKernelGGL(k_match_lr_filter, dim3(c.n_lanes * c.oct_cap), dim3(1024), sm, st, c, one_to_one, max_y_diff);
 }
 
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 3 * sizeof(unsigned), st, c);
+    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes * c.oct_cap), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 3 * sizeof(unsigned), st, c);
 }
 void launch_ransac_hyp(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ransac_hyp, dim3(SVO_RANSAC_HYP / 64, 2, c.n_lanes), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(k_ransac_hyp, dim3(SVO_RANSAC_HYP / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c);
 }
 void launch_ransac_count(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ransac_count, dim3(SVO_RANSAC_HYP / RC_HB, 2, c.n_lanes), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_ransac_count, dim3(SVO_RANSAC_HYP / RC_HB, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c, bad_tracking_th);
+    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c);
+    hipLaunchKernelGGL(k_track_gate, dim3((c.n_lanes + 63) / 64), dim3(64), 0, st, c, bad_tracking_th);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -27,7 +27,8 @@ struct svo_ctx {
     int fast_th, orb_th;
     hipStream_t stream; bool own_stream;
     DevCtx dc;
-    bool geom_ready; int geom_w, geom_h, geom_nfe, geom_nlevels;
+    bool geom_ready; int geom_w, geom_h, geom_nfe, geom_nlevels, geom_method, geom_noct;
+    int raw_cap_alloc;
     uint8_t* d_img0; int img0_pitch_internal;
     long long pyr_bytes_alloc; int cand_total_alloc, rtab_alloc;
     std::vector<void*> allocs;
@@ -42,7 +43,7 @@ static int align_up(int v, int a) { return (v + a - 1) / a * a; }
 extern "C" void svo_config_defaults(svo_config* c)
 {
     memset(c, 0, sizeof(*c));
-    c->device = 0; c->n_lanes = 1; c->max_w = 1280; c->max_h = 960; c->max_kps = 4096; c->max_cand = 1 << 17; c->kernel_times = 0; c->stream = nullptr;
+    c->device = 0; c->n_lanes = 1; c->max_w = 1280; c->max_h = 960; c->max_kps = 4096; c->max_cand = 1 << 17; c->kernel_times = 0; c->max_octaves = 1; c->stream = nullptr;
 }
 
 extern "C" void svo_params_defaults(svo_params* p)
@@ -138,7 +139,10 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     DevCtx& d = ctx->dc;
     memset(&d, 0, sizeof(d));
     const int L = cfg->n_lanes, NI = 2 * L, MK = cfg->max_kps;
-    d.n_lanes = L; d.n_img = NI; d.max_kps = MK; d.n_levels = SVO_MAX_LEVELS;
+    const int OC = cfg->max_octaves < 1 ? 1 : (cfg->max_octaves > SVO_MAX_OCTAVES ? SVO_MAX_OCTAVES : cfg->max_octaves);
+    const int NV = L * OC;                                  // lane-octaves
+    d.n_lanes = L; d.n_img = NI; d.max_kps = MK; d.n_levels = SVO_MAX_LEVELS; d.oct_cap = OC; d.n_oct = 1; d.max_h = cfg->max_h;
+    ctx->raw_cap_alloc = 2 * MK;
     ctx->pyr_bytes_alloc = pyramid_bytes(cfg->max_w, cfg->max_h, SVO_MAX_LEVELS);
     ctx->cand_total_alloc = (int)((long long)cfg->max_cand * 33 / 10) + 8 * 1024;
     ctx->rtab_alloc = 2 * (cfg->max_w + cfg->max_h) * SVO_MAX_LEVELS;
@@ -149,25 +153,27 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rtab, (size_t)ctx->rtab_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_keys, (size_t)NI * ctx->cand_total_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS * SVO_CNT_STRIDE));
-    HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * MK));
-    HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * MK));
+    HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * ctx->raw_cap_alloc));
+    HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.lvl_n, (size_t)NI * SVO_MAX_LEVELS));
-    HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * MK));
-    HIPCHECK(dev_alloc(ctx, &d.raw_desc, (size_t)NI * MK * 32));
+    HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * ctx->raw_cap_alloc));
+    HIPCHECK(dev_alloc(ctx, &d.raw_desc, (size_t)NI * ctx->raw_cap_alloc * 32));
     HIPCHECK(dev_alloc(ctx, &d.raw_n, (size_t)NI));
-    HIPCHECK(dev_alloc(ctx, &d.kps, (size_t)L * 4 * MK));
-    HIPCHECK(dev_alloc(ctx, &d.desc, (size_t)L * 4 * MK * 32));
-    HIPCHECK(dev_alloc(ctx, &d.n_kps, (size_t)L * 4));
-    HIPCHECK(dev_alloc(ctx, &d.matches, (size_t)L * 2 * MK));
-    HIPCHECK(dev_alloc(ctx, &d.n_matches, (size_t)L * 2));
-    HIPCHECK(dev_alloc(ctx, &d.bf_idx, (size_t)L * 3 * MK));
-    HIPCHECK(dev_alloc(ctx, &d.trk_kq, (size_t)L * MK));
-    HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)L));
-    HIPCHECK(dev_alloc(ctx, &d.trk_pts, (size_t)L * 2 * MK * 4));
-    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)L * 2 * SVO_RANSAC_HYP * 9));
-    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)L * 2 * SVO_RANSAC_HYP));
-    HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)L * MK));
-    HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.kps, (size_t)NV * 4 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.desc, (size_t)NV * 4 * MK * 32));
+    HIPCHECK(dev_alloc(ctx, &d.n_kps, (size_t)NV * 4));
+    HIPCHECK(dev_alloc(ctx, &d.matches, (size_t)NV * 2 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.n_matches, (size_t)NV * 2));
+    HIPCHECK(dev_alloc(ctx, &d.row_index, (size_t)NV * 4 * cfg->max_h));
+    HIPCHECK(dev_alloc(ctx, &d.mrow_index, (size_t)NV * 2 * (cfg->max_h + 1)));
+    HIPCHECK(dev_alloc(ctx, &d.bf_idx, (size_t)NV * 3 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.trk_kq, (size_t)NV * MK));
+    HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)NV));
+    HIPCHECK(dev_alloc(ctx, &d.trk_pts, (size_t)NV * 2 * MK * 4));
+    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)NV * 2 * SVO_RANSAC_HYP * 9));
+    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)NV * 2 * SVO_RANSAC_HYP));
+    HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)NV * MK));
+    HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.gn_lmk, (size_t)L * MK * 3));
     HIPCHECK(dev_alloc(ctx, &d.gn_obs, (size_t)L * MK * 8));
     HIPCHECK(dev_alloc(ctx, &d.residual, (size_t)L * MK));
@@ -239,9 +245,10 @@ extern "C" int svo_reset(svo_ctx* ctx, int lane)
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
         if (lane < 0 || lane == l) {
             HIPCHECK(hipMemset(ctx->dc.lane + l, 0, sizeof(LaneState)));
-            HIPCHECK(hipMemset(ctx->dc.n_kps + l * 4, 0, 4 * sizeof(int)));
-            HIPCHECK(hipMemset(ctx->dc.n_matches + l * 2, 0, 2 * sizeof(int)));
-            HIPCHECK(hipMemset(ctx->dc.n_tracked + l, 0, sizeof(int)));
+            const int OC = ctx->dc.oct_cap;
+            HIPCHECK(hipMemset(ctx->dc.n_kps + (size_t)l * OC * 4, 0, (size_t)OC * 4 * sizeof(int)));
+            HIPCHECK(hipMemset(ctx->dc.n_matches + (size_t)l * OC * 2, 0, (size_t)OC * 2 * sizeof(int)));
+            HIPCHECK(hipMemset(ctx->dc.n_tracked + (size_t)l * OC, 0, (size_t)OC * sizeof(int)));
             HIPCHECK(hipMemset(ctx->dc.results + l, 0, sizeof(svo_result)));
         }
     return SVO_OK;
@@ -273,16 +280,32 @@ static void resize_table(int src, int dst, int* idx, int* frac)
 static int ensure_geometry(svo_ctx* ctx, int w, int h)
 {
     const svo_params& p = ctx->params;
+    const bool fast_orb = p.detect_method == SVO_DM_FAST_ORB;
     const int nfe = p.non_maximal_suppression ? (int)(size_t)(1.5 * (double)(size_t)p.orb_nfeats) : p.orb_nfeats;   // stage2_detect.cpp:461-464
-    int nlev = p.orb_nlevels; if (nlev < 1) nlev = 1;
-    if (ctx->geom_ready && ctx->geom_w == w && ctx->geom_h == h && ctx->geom_nfe == nfe && ctx->geom_nlevels == nlev) return SVO_OK;
+    // stage1_rectify.cpp:80: one octave for dmORB (cv::ORB builds its own x1/1.2 pyramid), params_rectify.nOctaves otherwise
+    const int noct = fast_orb ? (p.nOctaves < 1 ? 1 : p.nOctaves) : 1;
+    int nlev = fast_orb ? noct : p.orb_nlevels; if (nlev < 1) nlev = 1;
+    if (ctx->geom_ready && ctx->geom_w == w && ctx->geom_h == h && ctx->geom_nfe == (fast_orb ? p.orb_nfeats : nfe) && ctx->geom_nlevels == nlev &&
+        ctx->geom_method == p.detect_method && ctx->geom_noct == noct) return SVO_OK;
     if (w > ctx->cfg.max_w || h > ctx->cfg.max_h || w < 64 || h < 64) return SVO_ERR_CAPACITY;
     if (nlev > SVO_MAX_LEVELS) return SVO_ERR_UNSUPPORTED;
+    if (noct > ctx->dc.oct_cap) return SVO_ERR_CAPACITY;       // svo_config.max_octaves
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     DevCtx& d = ctx->dc;
     int lw[SVO_MAX_LEVELS], lh[SVO_MAX_LEVELS], quota[SVO_MAX_LEVELS]; float sc[SVO_MAX_LEVELS];
-    level_sizes(w, h, nlev, lw, lh, sc);
-    level_quota(nfe, nlev, quota);
+    d.fast_orb = fast_orb ? 1 : 0; d.n_oct = noct;
+    // number of keypoints the reference's NMS may keep per octave (stage2_detect.cpp:404-407)
+    {
+        size_t k0 = (size_t)((double)(size_t)p.orb_nfeats * (double)(2 * noct) / (pow(2, noct) - 1));
+        for (int o = 0; o < SVO_MAX_OCTAVES; o++) d.kps_to_detect[o] = o == 0 ? (int)k0 : (o < noct ? (int)(size_t)round((double)k0 / pow(2, o)) : 0);
+    }
+    if (fast_orb) {
+        for (int l = 0; l < nlev; l++) { lw[l] = l ? lw[l - 1] / 2 : w; lh[l] = l ? lh[l - 1] / 2 : h; sc[l] = 1.0f; quota[l] = d.kps_to_detect[l]; }   // mrpt x1/2 octaves (S1:82-83)
+    } else {
+        level_sizes(w, h, nlev, lw, lh, sc);
+        level_quota(nfe, nlev, quota);
+    }
+    for (int o = 0; o < SVO_MAX_OCTAVES; o++) { d.ow[o] = fast_orb ? (o < noct ? lw[o] : 0) : (o == 0 ? w : 0); d.oh[o] = fast_orb ? (o < noct ? lh[o] : 0) : (o == 0 ? h : 0); }
     d.W = w; d.H = h; d.n_levels = nlev;
     long long off = 0; int tile_off = 0, slot_off = 0, cand_off = 0, rt_off = 0;
     std::vector<int> rtab;
@@ -299,7 +322,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
         if (cc < 1024) cc = 1024;
         g.cand_cap = (int)cc; g.cand_off = cand_off; cand_off += g.cand_cap;
         g.rtab_off = rt_off;
-        if (l >= 1) {
+        if (l >= 1 && !fast_orb) {
             std::vector<int> xi(g.w), xf(g.w), yi(g.h), yf(g.h);
             resize_table(lw[l - 1], g.w, xi.data(), xf.data());
             resize_table(lh[l - 1], g.h, yi.data(), yf.data());
@@ -307,15 +330,19 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
             rtab.insert(rtab.end(), yi.begin(), yi.end()); rtab.insert(rtab.end(), yf.begin(), yf.end());
             rt_off += 2 * (g.w + g.h);
         }
-        if (2 * g.quota > 2048) return SVO_ERR_UNSUPPORTED;           // k_select LDS budget (SEL_MAX)
+        if (!fast_orb && 2 * g.quota > 2048) return SVO_ERR_UNSUPPORTED;           // k_select LDS budget (SEL_MAX)
+        if (fast_orb && g.quota > d.max_kps) return SVO_ERR_CAPACITY;               // one octave's list must fit max_kps
     }
     for (int l = nlev; l < SVO_MAX_LEVELS; l++) { memset(&d.lv[l], 0, sizeof(LevelGeom)); d.lv[l].tile_off = tile_off; d.lv[l].slot_off = slot_off; }
     d.pyr_bytes = ctx->pyr_bytes_alloc;
-    if (off > ctx->pyr_bytes_alloc || cand_off > ctx->cand_total_alloc || (int)rtab.size() > ctx->rtab_alloc || slot_off > d.max_kps) return SVO_ERR_CAPACITY;
-    d.n_tiles = tile_off; d.n_slots = slot_off; d.raw_cap = d.max_kps; d.cand_total = ctx->cand_total_alloc;
+    d.raw_cap = ctx->raw_cap_alloc;
+    if (off > ctx->pyr_bytes_alloc || cand_off > ctx->cand_total_alloc || (int)rtab.size() > ctx->rtab_alloc || slot_off > d.raw_cap) return SVO_ERR_CAPACITY;
+    if (!fast_orb && slot_off > d.max_kps) return SVO_ERR_CAPACITY;                 // ORB mode: all levels feed one list
+    d.n_tiles = tile_off; d.n_slots = slot_off; d.cand_total = ctx->cand_total_alloc;
     if (!rtab.empty()) HIPCHECK(hipMemcpy(d.rtab, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHECK(configure_nms_rowsort(d));
-    ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = nfe; ctx->geom_nlevels = nlev;
+    ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = fast_orb ? p.orb_nfeats : nfe; ctx->geom_nlevels = nlev;
+    ctx->geom_method = p.detect_method; ctx->geom_noct = noct;
     return SVO_OK;
 }
 
@@ -374,7 +401,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     const svo_params& p = ctx->params;
     // P:54-76: invalid selectors are hard errors; the variants outside the hot path are refused explicitly
     if (p.detect_method < 0 || p.detect_method > 3 || p.match_method < 0 || p.match_method > 2 || p.ifm_method < 0 || p.ifm_method > 3) return SVO_ERR_ARG;
-    if ((flags & SVO_RUN_DETECT) && p.detect_method != SVO_DM_ORB) return SVO_ERR_UNSUPPORTED;
+    if ((flags & SVO_RUN_DETECT) && p.detect_method != SVO_DM_ORB && p.detect_method != SVO_DM_FAST_ORB) return SVO_ERR_UNSUPPORTED;   // KLT / FASTER: out of scope
     if ((flags & SVO_RUN_MATCH) && p.match_method != SVO_SM_DESC_BF) return SVO_ERR_UNSUPPORTED;
     if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF) return SVO_ERR_UNSUPPORTED;
     if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD) return SVO_ERR_UNSUPPORTED;
@@ -412,22 +439,28 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
     { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); }
     if (flags & SVO_RUN_DETECT) {
-        { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
-        { Span s(ctx, KT_FAST); launch_fast(d, st); }
-        { Span s(ctx, KT_SELECT); launch_select(d, st); }
-        { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
-        // kps_to_detect[0] for a single octave = 2 * orb_nfeats (stage2_detect.cpp:405)
-        const int num_out = (int)(size_t)((double)(size_t)p.orb_nfeats * 2.0 / (pow(2, 1) - 1));
-        { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression, p.min_distance, num_out, st); }
+        if (d.fast_orb) {       // stage2_detect.cpp:502-515 on the x1/2 octave pyramid
+            { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }
+            { Span s(ctx, KT_FAST); launch_fast(d, st); }
+            { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
+            { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
+            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, st); }
+        } else {                // stage2_detect.cpp:458-497
+            { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
+            { Span s(ctx, KT_FAST); launch_fast(d, st); }
+            { Span s(ctx, KT_SELECT); launch_select(d, st); }
+            { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
+            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression, p.min_distance, st); }
+        }
     }
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {
-        HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * 3 * d.max_kps * sizeof(int), st));
+        HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
         { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
         { Span s(ctx, KT_LR_FILTER); launch_match_lr_filter(d, p.enable_robust_1to1_match, p.max_y_diff, st); }
     }
     if (flags & SVO_RUN_TRACK) {
-        if (!(flags & SVO_RUN_MATCH)) HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * 3 * d.max_kps * sizeof(int), st));
+        if (!(flags & SVO_RUN_MATCH)) HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
         { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
         { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
         { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, st); }
@@ -477,44 +510,71 @@ extern "C" int svo_get_result(svo_ctx* ctx, int lane, svo_result* res)
     return SVO_OK;
 }
 
-extern "C" int svo_get_keypoints(svo_ctx* ctx, int lane, int which, int side, svo_keypoint* kps, uint8_t* desc, int cap)
+extern "C" int svo_get_keypoints_oct(svo_ctx* ctx, int lane, int which, int side, int octave, svo_keypoint* kps, uint8_t* desc, int cap)
 {
-    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1) return SVO_ERR_ARG;
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     if (which ? !s.has_prev : !s.has_cur) return 0;
-    const int slot = slot_of(s, which);
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave;
     int n = 0;
-    HIPCHECK(hipMemcpy(&n, ctx->dc.n_kps + (lane * 2 + slot) * 2 + side, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_kps + (vl * 2 + slot) * 2 + side, sizeof(int), hipMemcpyDeviceToHost));
     const int m = n < cap ? n : cap;
-    const long long base = (((long long)lane * 2 + slot) * 2 + side) * ctx->dc.max_kps;
+    const long long base = (((long long)vl * 2 + slot) * 2 + side) * ctx->dc.max_kps;
     if (kps && m > 0) HIPCHECK(hipMemcpy(kps, ctx->dc.kps + base, sizeof(svo_keypoint) * m, hipMemcpyDeviceToHost));
     if (desc && m > 0) HIPCHECK(hipMemcpy(desc, ctx->dc.desc + base * 32, (size_t)32 * m, hipMemcpyDeviceToHost));
     return n;
 }
-
-extern "C" int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* mm, int cap)
+extern "C" int svo_get_keypoints(svo_ctx* ctx, int lane, int which, int side, svo_keypoint* kps, uint8_t* desc, int cap)
 {
-    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1) return SVO_ERR_ARG;
+    return svo_get_keypoints_oct(ctx, lane, which, side, 0, kps, desc, cap);
+}
+
+extern "C" int svo_get_row_index(svo_ctx* ctx, int lane, int which, int side, int octave, int32_t* idx, int cap)
+{
+    if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave, H = ctx->dc.oh[octave];
+    const int m = H < cap ? H : cap;
+    if (idx && m > 0) HIPCHECK(hipMemcpy(idx, ctx->dc.row_index + (long long)((vl * 2 + slot) * 2 + side) * ctx->dc.max_h, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    return H;
+}
+
+extern "C" int svo_get_matches_oct(svo_ctx* ctx, int lane, int which, int octave, svo_dmatch* mm, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     if (which ? !s.has_prev : !s.has_cur) return 0;
-    const int slot = slot_of(s, which);
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave;
     int n = 0;
-    HIPCHECK(hipMemcpy(&n, ctx->dc.n_matches + lane * 2 + slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_matches + vl * 2 + slot, sizeof(int), hipMemcpyDeviceToHost));
     const int m = n < cap ? n : cap;
-    if (mm && m > 0) HIPCHECK(hipMemcpy(mm, ctx->dc.matches + ((long long)lane * 2 + slot) * ctx->dc.max_kps, sizeof(svo_dmatch) * m, hipMemcpyDeviceToHost));
+    if (mm && m > 0) HIPCHECK(hipMemcpy(mm, ctx->dc.matches + ((long long)vl * 2 + slot) * ctx->dc.max_kps, sizeof(svo_dmatch) * m, hipMemcpyDeviceToHost));
     return n;
+}
+extern "C" int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* mm, int cap) { return svo_get_matches_oct(ctx, lane, which, 0, mm, cap); }
+
+extern "C" int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int octave, int32_t* idx, int cap)
+{
+    if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave, H1 = ctx->dc.oh[octave] + 1;
+    const int m = H1 < cap ? H1 : cap;
+    if (idx && m > 0) HIPCHECK(hipMemcpy(idx, ctx->dc.mrow_index + (long long)(vl * 2 + slot) * (ctx->dc.max_h + 1), sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    return H1;
 }
 
-extern "C" int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int cap)
+extern "C" int svo_get_tracked_oct(svo_ctx* ctx, int lane, int octave, svo_index_pair* t, int cap)
 {
-    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
+    const int vl = lane * ctx->dc.oct_cap + octave;
     int n = 0;
-    HIPCHECK(hipMemcpy(&n, ctx->dc.n_tracked + lane, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_tracked + vl, sizeof(int), hipMemcpyDeviceToHost));
     const int m = n < cap ? n : cap;
-    if (t && m > 0) HIPCHECK(hipMemcpy(t, ctx->dc.tracked + (long long)lane * ctx->dc.max_kps, sizeof(svo_index_pair) * m, hipMemcpyDeviceToHost));
+    if (t && m > 0) HIPCHECK(hipMemcpy(t, ctx->dc.tracked + (long long)vl * ctx->dc.max_kps, sizeof(svo_index_pair) * m, hipMemcpyDeviceToHost));
     return n;
 }
+extern "C" int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int cap) { return svo_get_tracked_oct(ctx, lane, 0, t, cap); }
 
 extern "C" int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap)
 {
@@ -549,11 +609,11 @@ extern "C" int svo_put_features(svo_ctx* ctx, int lane, int which, int side, con
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     int rc = ensure_geometry(ctx, img_w, img_h); if (rc) return rc;
     LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
-    const int slot = slot_of(s, which);
-    const long long base = (((long long)lane * 2 + slot) * 2 + side) * ctx->dc.max_kps;
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap;       // octave 0
+    const long long base = (((long long)vl * 2 + slot) * 2 + side) * ctx->dc.max_kps;
     if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.kps + base, kps, sizeof(svo_keypoint) * n, hipMemcpyHostToDevice));
     if (n > 0 && desc) HIPCHECK(hipMemcpy(ctx->dc.desc + base * 32, desc, (size_t)32 * n, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->dc.n_kps + (lane * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_kps + (vl * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice));
     return mark_present(ctx, lane, which);
 }
 
@@ -562,9 +622,9 @@ extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmat
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !m)) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
-    const int slot = slot_of(s, which);
-    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.matches + ((long long)lane * 2 + slot) * ctx->dc.max_kps, m, sizeof(svo_dmatch) * n, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->dc.n_matches + lane * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap;       // octave 0
+    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.matches + ((long long)vl * 2 + slot) * ctx->dc.max_kps, m, sizeof(svo_dmatch) * n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_matches + vl * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
     return mark_present(ctx, lane, which);
 }
 
@@ -573,8 +633,10 @@ extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, 
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || n < 0 || (n > 0 && !t)) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     int rc = svo_wait(ctx); if (rc) return rc;
-    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.tracked + (long long)lane * ctx->dc.max_kps, t, sizeof(svo_index_pair) * n, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->dc.n_tracked + lane, &n, sizeof(int), hipMemcpyHostToDevice));
+    const int vl = lane * ctx->dc.oct_cap;                                   // octave 0; the other octaves of the lane are emptied
+    HIPCHECK(hipMemset(ctx->dc.n_tracked + vl, 0, sizeof(int) * ctx->dc.oct_cap));
+    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.tracked + (long long)vl * ctx->dc.max_kps, t, sizeof(svo_index_pair) * n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_tracked + vl, &n, sizeof(int), hipMemcpyHostToDevice));
     return SVO_OK;
 }
 
@@ -591,8 +653,9 @@ extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, i
     const svo_params& p = ctx->params;
     DevCtx& d = ctx->dc;
     int rc = svo_wait(ctx); if (rc) return rc;
-    if (!ctx->geom_ready) { d.W = cam->ncols; d.H = cam->nrows; }
+    if (!ctx->geom_ready) { d.W = cam->ncols; d.H = cam->nrows; d.ow[0] = cam->ncols; d.oh[0] = cam->nrows; }
     const int lane = 0;
+    const int saved_noct = d.n_oct; d.n_oct = 1;          // getChangeInPose packs everything into octave 0 (common.cpp:367)
     HIPCHECK(hipMemcpy(d.cams + lane, cam, sizeof(*cam), hipMemcpyHostToDevice));
     LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
     s.has_prev = 1; s.has_cur = 1;
@@ -600,9 +663,10 @@ extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, i
     auto put_k = [&](int which, int side, const svo_keypoint* k, int n) -> int {
         if (n > d.max_kps) return SVO_ERR_CAPACITY;
         const int slot = slot_of(s, which);
-        const long long base = (((long long)lane * 2 + slot) * 2 + side) * d.max_kps;
+        const int vl = lane * d.oct_cap;
+        const long long base = (((long long)vl * 2 + slot) * 2 + side) * d.max_kps;
         if (n > 0 && hipMemcpy(d.kps + base, k, sizeof(svo_keypoint) * n, hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
-        if (hipMemcpy(d.n_kps + (lane * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
+        if (hipMemcpy(d.n_kps + (vl * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
         return SVO_OK;
     };
     if ((rc = put_k(1, 0, pre_left, n_pl)) || (rc = put_k(1, 1, pre_right, n_pr)) || (rc = put_k(0, 0, cur_left, n_cl)) || (rc = put_k(0, 1, cur_right, n_cr))) return rc;
@@ -619,6 +683,7 @@ extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, i
     for (int k = 0; k < 6; k++) g.init[k] = init6 ? init6[k] : 0.0;
     // only lane 0 carries data; the other lanes see n_tracked == 0 and return invalid
     { Span sp(ctx, KT_GN); launch_gauss_newton(d, g, ctx->stream); }
+    d.n_oct = saved_noct;
     if ((rc = svo_get_result(ctx, lane, res))) return rc;
     if (residual && res->n_residual > 0) HIPCHECK(hipMemcpy(residual, d.residual, sizeof(double) * res->n_residual, hipMemcpyDeviceToHost));
     if (outliers && res->n_outliers > 0) HIPCHECK(hipMemcpy(outliers, d.outliers, sizeof(int32_t) * res->n_outliers, hipMemcpyDeviceToHost));

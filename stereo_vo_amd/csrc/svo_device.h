@@ -43,9 +43,17 @@ struct LaneState {
     int pad;
 };
 
+// Octaves: in the FAST+ORB mode (stage2_detect.cpp:502-515) the reference works on nOctaves x1/2 images per eye and
+// keeps one feature / pairing / track list per octave.  Every per-lane list below is therefore indexed by the
+// "lane-octave" vl = lane * oct_cap + octave (oct_cap = svo_config.max_octaves; ORB mode uses octave 0 only).
 struct DevCtx {
     int n_lanes, n_img, n_levels;
     int W, H;
+    int oct_cap, n_oct;       // allocated / active octaves
+    int ow[SVO_MAX_OCTAVES], oh[SVO_MAX_OCTAVES];      // octave image sizes
+    int kps_to_detect[SVO_MAX_OCTAVES];                // stage2_detect.cpp:404-407
+    int fast_orb;             // 1: detect_method == dmFAST_ORB (levels of lv[] are the octave images, keypoint size 7)
+    int max_h;                // row-index table pitch
     int img0_pitch;
     int max_kps, raw_cap, cand_total, n_tiles, n_slots;
     int fast_th, orb_th;
@@ -68,7 +76,9 @@ struct DevCtx {
     uint8_t* desc;
     int* n_kps;               // [n_lanes][2][2]
     svo_dmatch* matches;
-    int* n_matches;           // [n_lanes][2]
+    int* n_matches;           // [n_vl][2]
+    int* row_index;           // [n_vl][2 slots][2 sides][max_h]   m_update_indexes table (stage2_detect.cpp:103-129)
+    int* mrow_index;          // [n_vl][2 slots][max_h + 1]       matches_lr_row_index (stage3:425-445)
     // stage 3/4 scratch, per lane
     int* bf_idx;              // [n_lanes][3][max_kps]  best train index for: LR, prevL->curL, prevR->curR
     int* bf_dist;             // [n_lanes][3][max_kps]
@@ -97,9 +107,9 @@ __device__ __forceinline__ const uint8_t* level_ptr(const DevCtx& c, int img, in
     return c.pyr + (long long)img * c.pyr_bytes + c.lv[level].offset;
 }
 
-__device__ __forceinline__ long long feat_base(const DevCtx& c, int lane, int slot, int side)
+__device__ __forceinline__ long long feat_base(const DevCtx& c, int vl, int slot, int side)
 {
-    return (((long long)lane * 2 + slot) * 2 + side) * c.max_kps;
+    return (((long long)vl * 2 + slot) * 2 + side) * c.max_kps;
 }
 __device__ __forceinline__ int feat_cnt_idx(int lane, int slot, int side) { return (lane * 2 + slot) * 2 + side; }
 __device__ __forceinline__ long long match_base(const DevCtx& c, int lane, int slot) { return ((long long)lane * 2 + slot) * c.max_kps; }

@@ -23,6 +23,7 @@ EXPORTS = [
     "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
     "svo_get_orb_threshold", "svo_set_camera", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
+    "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_change_in_pose", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
@@ -31,7 +32,7 @@ EXPORTS = [
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("n_lanes", C.c_int32), ("max_w", C.c_int32), ("max_h", C.c_int32),
-                ("max_kps", C.c_int32), ("max_cand", C.c_int32), ("kernel_times", C.c_int32), ("_pad", C.c_int32),
+                ("max_kps", C.c_int32), ("max_cand", C.c_int32), ("kernel_times", C.c_int32), ("max_octaves", C.c_int32),
                 ("stream", C.c_void_p)]
 
 
@@ -77,12 +78,13 @@ def _vp(a):
 class Context:
     """n_lanes independent rso::CStereoOdometryEstimator streams driven through the HIP kernels together."""
 
-    def __init__(self, n_lanes=1, max_w=1280, max_h=960, max_kps=4096, max_cand=1 << 17, device=0, kernel_times=False, stream=None):
+    def __init__(self, n_lanes=1, max_w=1280, max_h=960, max_kps=4096, max_cand=1 << 17, device=0, kernel_times=False, stream=None, max_octaves=1):
         self.L = lib()
         cfg = Config()
         self.L.svo_config_defaults(C.byref(cfg))
         cfg.device, cfg.n_lanes, cfg.max_w, cfg.max_h, cfg.max_kps, cfg.max_cand = device, n_lanes, max_w, max_h, max_kps, max_cand
         cfg.kernel_times = int(kernel_times)
+        cfg.max_octaves = int(max_octaves)
         cfg.stream = stream
         self.n_lanes, self.max_kps = n_lanes, max_kps
         h = C.c_void_p()
@@ -188,13 +190,27 @@ class Context:
         self._ck(self.L.svo_copy_results_async(self.h, C.c_void_p(dst_ptr), C.c_size_t(nbytes)), "svo_copy_results_async")
 
     # -- lists -----------------------------------------------------------------------------------------
-    def keypoints(self, lane=0, which=0, side=0):
-        n = self._ck(self.L.svo_get_keypoints(self.h, lane, which, side, None, None, 0), "svo_get_keypoints")
+    def keypoints(self, lane=0, which=0, side=0, octave=0):
+        n = self._ck(self.L.svo_get_keypoints_oct(self.h, lane, which, side, octave, None, None, 0), "svo_get_keypoints_oct")
         k = np.zeros(n, keypoint_dtype)
         d = np.zeros((n, 32), np.uint8)
         if n:
-            self._ck(self.L.svo_get_keypoints(self.h, lane, which, side, _vp(k), _vp(d), n), "svo_get_keypoints")
+            self._ck(self.L.svo_get_keypoints_oct(self.h, lane, which, side, octave, _vp(k), _vp(d), n), "svo_get_keypoints_oct")
         return k, d
+
+    def row_index(self, lane=0, which=0, side=0, octave=0):
+        n = self._ck(self.L.svo_get_row_index(self.h, lane, which, side, octave, None, 0), "svo_get_row_index")
+        a = np.zeros(n, np.int32)
+        if n:
+            self._ck(self.L.svo_get_row_index(self.h, lane, which, side, octave, _vp(a), n), "svo_get_row_index")
+        return a
+
+    def matches_row_index(self, lane=0, which=0, octave=0):
+        n = self._ck(self.L.svo_get_matches_row_index(self.h, lane, which, octave, None, 0), "svo_get_matches_row_index")
+        a = np.zeros(n, np.int32)
+        if n:
+            self._ck(self.L.svo_get_matches_row_index(self.h, lane, which, octave, _vp(a), n), "svo_get_matches_row_index")
+        return a
 
     def raw_keypoints(self, lane=0, side=0):
         n = self._ck(self.L.svo_debug_get_raw_keypoints(self.h, lane, side, None, None, 0), "svo_debug_get_raw_keypoints")
@@ -216,18 +232,18 @@ class Context:
         self._ck(self.L.svo_debug_get_status_word(self.h, lane, C.byref(w)), "svo_debug_get_status_word")
         return w.value
 
-    def matches(self, lane=0, which=0):
-        n = self._ck(self.L.svo_get_matches(self.h, lane, which, None, 0), "svo_get_matches")
+    def matches(self, lane=0, which=0, octave=0):
+        n = self._ck(self.L.svo_get_matches_oct(self.h, lane, which, octave, None, 0), "svo_get_matches_oct")
         m = np.zeros(n, dmatch_dtype)
         if n:
-            self._ck(self.L.svo_get_matches(self.h, lane, which, _vp(m), n), "svo_get_matches")
+            self._ck(self.L.svo_get_matches_oct(self.h, lane, which, octave, _vp(m), n), "svo_get_matches_oct")
         return m
 
-    def tracked(self, lane=0):
-        n = self._ck(self.L.svo_get_tracked(self.h, lane, None, 0), "svo_get_tracked")
+    def tracked(self, lane=0, octave=0):
+        n = self._ck(self.L.svo_get_tracked_oct(self.h, lane, octave, None, 0), "svo_get_tracked_oct")
         t = np.zeros(n, index_pair_dtype)
         if n:
-            self._ck(self.L.svo_get_tracked(self.h, lane, _vp(t), n), "svo_get_tracked")
+            self._ck(self.L.svo_get_tracked_oct(self.h, lane, octave, _vp(t), n), "svo_get_tracked_oct")
         return t
 
     def residuals(self, lane=0):

@@ -286,3 +286,53 @@ def test_cpp_estimator_demo_matches_oracle_chain(tmp_path):
     assert got.shape == want.shape == (20, 6)
     assert np.abs(got - want).max() < 2e-3      # the file keeps 3 decimals (D:251)
     assert np.abs(got[-1, :3] - world.poses[19][:3, 3]).max() < 0.35   # and the chain follows the generator's ground truth
+
+
+def test_row_index_tables_match_oracle(golden_dir):
+    """a5 / a8: pyr_feats_index (stage2_detect.cpp:103-129) and matches_lr_row_index (stage3:425-445) on device."""
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(2):
+        ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+        orc.process(g["L%d" % t], g["R%d" % t], cam)
+        for side in (0, 1):
+            assert (ctx.row_index(0, 0, side) == orc.row_index(0, side)).all()
+        assert (ctx.matches_row_index(0, 0) == orc.matches_row_index(0)).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,nfe,noct", [(640, 480, 600, 3), (1280, 960, 3300, 3)])
+def test_fast_orb_multi_octave_matches_oracle(w, h, nfe, noct):
+    """a2 (stage2_detect.cpp:502-515) + nOctaves x1/2 pyramid: FAST + ORB describe per octave, per-octave pairing and
+    tracking, stage 5 on the merged octaves (S5:419-461) -- BASELINE.json configs[4]'s operator mix."""
+    from stereo_vo_amd.abi import DM_FAST_ORB
+    world = SyntheticStereoWorld(w, h, 400.0 * w / 640.0, 0.12, seed=21, n_frames=3)
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=nfe)
+    p.detect_method = DM_FAST_ORB; p.nOctaves = noct
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=4096, max_octaves=noct)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        L, R = [x.numpy() for x in world.render(t)]
+        ctx.process_host([(L, R)])
+        r, ro = ctx.result(0), orc.process(L, R, cam)
+        assert ctx.status_word(0) == 0
+        assert r.n_octaves == ro.n_octaves == noct
+        for o in range(noct):
+            for side in (0, 1):
+                k, d = ctx.keypoints(0, 0, side, o); ko, do = orc.keypoints(0, side, o)
+                assert len(k) == len(ko) and k.tobytes() == ko.tobytes() and (d == do).all(), (t, o, side, len(k), len(ko))
+                assert (ctx.row_index(0, 0, side, o) == orc.row_index(0, side, o)).all()
+            assert ctx.matches(0, 0, o).tobytes() == orc.matches(0, o).tobytes(), (t, o)
+            assert ctx.tracked(0, o).tobytes() == orc.tracked(o).tobytes(), (t, o)
+            assert (r.detected_left[o], r.detected_right[o], r.stereo_matches[o]) == (ro.detected_left[o], ro.detected_right[o], ro.stereo_matches[o])
+        assert (r.valid, r.error_code, r.n_residual, r.n_outliers) == (ro.valid, ro.error_code, ro.n_residual, ro.n_outliers)
+        if ro.valid:
+            dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
+            assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD
+            assert (ctx.outliers(0) == orc.outliers()).all()
+    assert ro.valid and ro.tracked_feats_from_last_frame > 20
+    ctx.close()
