@@ -151,6 +151,164 @@ __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_o
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// K8a': smDescRbR -- row-by-row left-right matching (stage3_match_left_right.cpp:185-419) with its quirks kept
+// (SURVEY.md appendix A #10): the left keypoints of row r are visited in iteration y = r - 1 and meet the right
+// keypoints of rows (y - d, y + d]; byte-wise popcount accumulated in a uint8_t (256 wraps to 0); the ratio test has
+// no effect; keypoints of the last occupied row never match (their row-table range is empty).
+// One 256-thread block per lane-octave.  The reference's sequential assignment (first claimant, or best claimant with
+// enable_robust_1to1_match) is order-independent once written as a minimum over the claimants of a right feature.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_match_lr_rbr(DevCtx c, int one_to_one, double max_y_diff, double minimum_response, int max_distance)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* right_best = (unsigned*)smem;              // max_kps: per right feature, min over its claimants
+    unsigned* left_pick = right_best + c.max_kps;        // max_kps: per left feature (min_idx << 8 | min_1) or ~0
+    int* scan = (int*)(left_pick + c.max_kps);           // 32
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, oct = vl % c.oct_cap, tid = threadIdx.x;
+    if (oct >= c.n_oct) return;
+    const LaneState& ls = c.lane[lane_id];
+    const int cur = 1 - ls.prev_slot;
+    const int nl = c.n_kps[feat_cnt_idx(vl, cur, 0)], nr = c.n_kps[feat_cnt_idx(vl, cur, 1)];
+    const svo_keypoint* kl = c.kps + feat_base(c, vl, cur, 0), *kr = c.kps + feat_base(c, vl, cur, 1);
+    const uint8_t* dl = c.desc + feat_base(c, vl, cur, 0) * 32, *dr = c.desc + feat_base(c, vl, cur, 1) * 32;
+    const int* idxL = c.row_index + (long long)feat_cnt_idx(vl, cur, 0) * c.max_h, *idxR = c.row_index + (long long)feat_cnt_idx(vl, cur, 1) * c.max_h;
+    svo_dmatch* out = c.matches + match_base(c, vl, cur);
+    const int W = c.ow[oct], H = c.oh[oct];
+    const int max_disparity = (int)((double)W * 0.7);                          // S3:247
+    const int d_round = (int)round(max_y_diff);                                 // S3:254-255
+    for (int j = tid; j < nr; j += blockDim.x) right_best[j] = 0xFFFFFFFFu;
+    for (int i = tid; i < nl; i += blockDim.x) left_pick[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int iL = tid; iL < nl; iL += blockDim.x) {
+        const svo_keypoint fL = kl[iL];
+        const int y = (int)fL.y - 1;                                            // the iteration that visits this keypoint
+        if (y < 0 || y + 1 > H - 1) continue;
+        if (!(idxL[y] <= iL && iL < idxL[y + 1])) continue;                     // S3:253, 265 (empty / wrapped ranges)
+        const int mrr = y - d_round, xrr = y + d_round;
+        const int R0 = idxR[mrr > 0 ? mrr : 0], R1 = idxR[xrr < H - 1 ? xrr : H - 1];   // S3:254-256
+        const ulonglong2 qa = ((const ulonglong2*)(dl + (long long)iL * 32))[0], qb = ((const ulonglong2*)(dl + (long long)iL * 32))[1];
+        unsigned min_1 = 0xFFFFFFFFu; int min_idx = -1;
+        for (int iR = R0; iR < R1; iR++) {                                      // S3:274 (R1 <= R0: no candidates)
+            const svo_keypoint fR = kr[iR];
+            if ((double)fL.response < minimum_response || (double)fR.response < minimum_response) continue;   // S3:279
+            const int disparity = (int)(fL.x - fR.x);                           // S3:283
+            if (disparity < 1 || disparity > max_disparity) continue;
+            const ulonglong2 ta = ((const ulonglong2*)(dr + (long long)iR * 32))[0], tb = ((const ulonglong2*)(dr + (long long)iR * 32))[1];
+            const unsigned dist = (unsigned)(__popcll(qa.x ^ ta.x) + __popcll(qa.y ^ ta.y) + __popcll(qb.x ^ tb.x) + __popcll(qb.y ^ tb.y)) & 0xFFu;   // uint8_t accumulator (S3:321-331)
+            if ((int)dist > max_distance) continue;                             // S3:334
+            if (dist < min_1) { min_1 = dist; min_idx = iR; }                   // S3:338-343 (first minimum)
+        }
+        if (min_idx >= 0) {
+            left_pick[iL] = ((unsigned)min_idx << 8) | min_1;
+            // S3:359-387: best claimant (robust) or first claimant wins the right feature
+            atomicMin(&right_best[min_idx], one_to_one ? ((min_1 << 16) | (unsigned)iL) : (unsigned)iL);
+        }
+    }
+    __syncthreads();
+    int m_total = 0;
+    const int n_iter = (nl + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (int it = 0; it < n_iter; it++) {
+        const int i = it * blockDim.x + tid;
+        int keep = 0; unsigned pk = 0xFFFFFFFFu;
+        if (i < nl && (pk = left_pick[i]) != 0xFFFFFFFFu) keep = (int)(right_best[pk >> 8] & 0xFFFFu) == i;
+        int tot;
+        const int off = block_exclusive_scan(keep, scan, &tot);
+        if (keep) { svo_dmatch d; d.queryIdx = i; d.trainIdx = (int)(pk >> 8); d.imgIdx = -1; d.distance = (float)(pk & 0xFFu); out[m_total + off] = d; }   // DMatch(i, fr, d): S3:404
+        m_total += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { c.n_matches[vl * 2 + cur] = m_total; c.results[lane_id].stereo_matches[oct] = m_total; }
+    __threadfence_block();
+    __syncthreads();
+    {
+        int* ri = c.mrow_index + (long long)(vl * 2 + cur) * (c.max_h + 1);
+        for (int y = tid; y <= H; y += blockDim.x) {
+            int v = m_total;
+            if (y < H) {
+                int lo = 0, hi = m_total;
+                const float lim = (float)(y - 1);
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (kl[out[mid].queryIdx].y <= lim) lo = mid + 1; else hi = mid; }
+                v = y == 0 ? 0 : lo;
+            }
+            ri[y] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8c: ifmDescWin -- window tracker (stage4_match_consecutive.cpp:435-738) with its quirks kept (appendix A #12):
+// ifm_win_w is the VERTICAL half-size and ifm_win_h the horizontal one; left descriptors only, uint8_t accumulator,
+// no distance threshold, best = strict "<" from 255.  A previous pairing of row iteration y meets the current pairings
+// of rows [y - WIN_W, y + WIN_W]; a current pairing keeps its best claimant (first on ties).  Survivors are listed in
+// ascending current index and handed to the same RANSAC kernels as the brute-force tracker.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_H)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* cur_best = (unsigned*)smem;                // max_kps: (dist << 16 | pi) min over claimants
+    int* scan = (int*)(cur_best + c.max_kps);
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, oct = vl % c.oct_cap, tid = threadIdx.x;
+    if (oct >= c.n_oct) return;
+    const LaneState& ls = c.lane[lane_id];
+    if (!ls.has_prev) { if (tid == 0) c.trk_nk[vl] = 0; return; }
+    const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
+    const int npm = c.n_matches[vl * 2 + prev], ncm = c.n_matches[vl * 2 + cur];
+    const svo_dmatch* pm = c.matches + match_base(c, vl, prev), *cm = c.matches + match_base(c, vl, cur);
+    const svo_keypoint* pkl = c.kps + feat_base(c, vl, prev, 0), *pkr = c.kps + feat_base(c, vl, prev, 1);
+    const svo_keypoint* ckl = c.kps + feat_base(c, vl, cur, 0), *ckr = c.kps + feat_base(c, vl, cur, 1);
+    const uint8_t* pdl = c.desc + feat_base(c, vl, prev, 0) * 32, *cdl = c.desc + feat_base(c, vl, cur, 0) * 32;
+    const int* ri_p = c.mrow_index + (long long)(vl * 2 + prev) * (c.max_h + 1), *ri_c = c.mrow_index + (long long)(vl * 2 + cur) * (c.max_h + 1);
+    const int W = c.ow[oct], H = c.oh[oct];
+    const int awx = W - 1, awy = H - 1;                                          // S4:489-490 (descriptor variant)
+    for (int i = tid; i < ncm; i += blockDim.x) cur_best[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int pi = tid; pi < npm; pi += blockDim.x) {
+        const svo_keypoint pl = pkl[pm[pi].queryIdx], pr = pkr[pm[pi].trainIdx];
+        const int y = (int)ceilf(pl.y);                                          // the row iteration whose range [ri[y], ri[y+1]) holds pi
+        if (y < 0 || y >= H - 1) continue;                                       // S4:514
+        if (!(ri_p[y] <= pi && pi < ri_p[y + 1])) continue;
+        const int wy_min = (y - WIN_W) > 0 ? (y - WIN_W) : 0, wy_max = awy < (y + WIN_W) ? awy : (y + WIN_W);   // S4:525-526
+        const int c0 = ri_c[wy_min], c1 = ri_c[wy_max + 1];                      // S4:529-530
+        const int a = (int)(pl.x - (float)WIN_H), b = (int)(pl.x + (float)WIN_H), cc = (int)(pr.x - (float)WIN_H), d = (int)(pr.x + (float)WIN_H);
+        const int wxl0 = a > 0 ? a : 0, wxl1 = awx < b ? awx : b, wxr0 = cc > 0 ? cc : 0, wxr1 = awx < d ? awx : d;   // S4:552-555
+        const ulonglong2 qa = ((const ulonglong2*)(pdl + (long long)pm[pi].queryIdx * 32))[0], qb = ((const ulonglong2*)(pdl + (long long)pm[pi].queryIdx * 32))[1];
+        int best_c = -1; unsigned best_orb = 255;                                // S4:543-545
+        for (int ci = c0; ci < c1; ci++) {
+            const svo_dmatch mc = cm[ci];
+            const svo_keypoint fl = ckl[mc.queryIdx], fr = ckr[mc.trainIdx];
+            if (fl.x < (float)wxl0 || fl.x > (float)wxl1 || fr.x < (float)wxr0 || fr.x > (float)wxr1) continue;   // S4:567
+            const ulonglong2 ta = ((const ulonglong2*)(cdl + (long long)mc.queryIdx * 32))[0], tb = ((const ulonglong2*)(cdl + (long long)mc.queryIdx * 32))[1];
+            const unsigned orb_l = (unsigned)(__popcll(qa.x ^ ta.x) + __popcll(qa.y ^ ta.y) + __popcll(qb.x ^ tb.x) + __popcll(qb.y ^ tb.y)) & 0xFFu;   // S4:596-609
+            if (orb_l < best_orb) { best_orb = orb_l; best_c = ci; }             // S4:614-618
+        }
+        if (best_c >= 0) atomicMin(&cur_best[best_c], (best_orb << 16) | (unsigned)pi);   // S4:622-636
+    }
+    __syncthreads();
+    int* kq = c.trk_kq + (long long)vl * c.max_kps;                              // previous pairing index of survivor i
+    int* cq = c.bf_idx + ((long long)vl * 3 + 1) * c.max_kps;                    // current pairing index of survivor i
+    float* ptsL = c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4, *ptsR = c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4;
+    int np_total = 0;
+    const int n_iter = (ncm + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (int it = 0; it < n_iter; it++) {                                        // S4:640-679: ascending current index
+        const int i = it * blockDim.x + tid;
+        unsigned v = 0xFFFFFFFFu;
+        const int keep = (i < ncm && (v = cur_best[i]) != 0xFFFFFFFFu) ? 1 : 0;
+        int tot;
+        const int off = block_exclusive_scan(keep, scan, &tot);
+        if (keep) {
+            const int pi = (int)(v & 0xFFFFu), o = np_total + off;
+            kq[o] = pi; cq[o] = i;
+            const svo_keypoint a = pkl[pm[pi].queryIdx], b = ckl[cm[i].queryIdx], e = pkr[pm[pi].trainIdx], f = ckr[cm[i].trainIdx];
+            ptsL[o * 4] = a.x; ptsL[o * 4 + 1] = a.y; ptsL[o * 4 + 2] = b.x; ptsL[o * 4 + 3] = b.y;
+            ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
+        }
+        np_total += tot;
+        __syncthreads();
+    }
+    if (tid == 0) c.trk_nk[vl] = np_total;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // K8b: the tracker's joint sequential filter (S4:145-160), exact, one wave per lane.
 // k is kept iff dL <= th and dR <= th and neither its left nor its right train index was taken by an EARLIER
 // KEPT k.  Earlier chunks of 64 are remembered in two LDS bitmaps; inside a chunk the chain is resolved in rank
@@ -379,7 +537,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
 // pick the model a sequential RANSAC with the 0.99-confidence stop would have returned, apply both masks
 // (S4:243-255), the consistency check (S4:282), and write tracked_pairs; then the bad-tracking gate (P:326-330)
 // and the first-frame rule (P:348-352).
-__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c)
+__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* in_l = smem;                         // max_kps
@@ -449,11 +607,14 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c)
         int keep = 0, k = 0, tl = 0;
         if (i < n) {
             k = kq[i];
-            tl = (int)(pL[k] & 0xFFFFu);
-            const int tr = (int)(pR[k] & 0xFFFFu);
             keep = 1;
             if (use_f && (in_l[i] == 0 || in_r[i] == 0)) keep = 0;
-            if (tl != tr) keep = 0;                                   // S4:282
+            if (win_mode) tl = (int)pL[i];                            // survivor list of k_track_win: (previous, current) pairing (S4:708-714)
+            else {
+                tl = (int)(pL[k] & 0xFFFFu);
+                const int tr = (int)(pR[k] & 0xFFFFu);
+                if (tl != tr) keep = 0;                               // S4:282
+            }
         }
         int tot;
         const int off = block_exclusive_scan(keep, scan, &tot);
@@ -492,6 +653,15 @@ void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, 
     hipLaunchKernelGGL(k_match_lr_filter, dim3(c.n_lanes * c.oct_cap), dim3(1024), sm, st, c, one_to_one, max_y_diff);
 }
 
+void launch_match_lr_rbr(const DevCtx& c, int one_to_one, double max_y_diff, double minimum_response, int max_distance, hipStream_t st)
+{
+    const size_t sm = sizeof(unsigned) * 2 * c.max_kps + sizeof(int) * 32;
+    hipLaunchKernelGGL(k_match_lr_rbr, dim3(c.n_lanes * c.oct_cap), dim3(256), sm, st, c, one_to_one, max_y_diff, minimum_response, max_distance);
+}
+void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_track_win, dim3(c.n_lanes * c.oct_cap), dim3(256), sizeof(unsigned) * c.max_kps + sizeof(int) * 32, st, c, win_w, win_h);
+}
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
     hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes * c.oct_cap), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 3 * sizeof(unsigned), st, c);
@@ -504,9 +674,9 @@ void launch_ransac_count(const DevCtx& c, hipStream_t st)
 {
     hipLaunchKernelGGL(k_ransac_count, dim3(SVO_RANSAC_HYP / RC_HB, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c);
 }
-void launch_track_finalize(const DevCtx& c, int bad_tracking_th, hipStream_t st)
+void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c);
+    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c, win_mode);
     hipLaunchKernelGGL(k_track_gate, dim3((c.n_lanes + 63) / 64), dim3(64), 0, st, c, bad_tracking_th);
 }
 

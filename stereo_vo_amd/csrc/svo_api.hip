@@ -402,8 +402,8 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     // P:54-76: invalid selectors are hard errors; the variants outside the hot path are refused explicitly
     if (p.detect_method < 0 || p.detect_method > 3 || p.match_method < 0 || p.match_method > 2 || p.ifm_method < 0 || p.ifm_method > 3) return SVO_ERR_ARG;
     if ((flags & SVO_RUN_DETECT) && p.detect_method != SVO_DM_ORB && p.detect_method != SVO_DM_FAST_ORB) return SVO_ERR_UNSUPPORTED;   // KLT / FASTER: out of scope
-    if ((flags & SVO_RUN_MATCH) && p.match_method != SVO_SM_DESC_BF) return SVO_ERR_UNSUPPORTED;
-    if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF) return SVO_ERR_UNSUPPORTED;
+    if ((flags & SVO_RUN_MATCH) && p.match_method != SVO_SM_DESC_BF && p.match_method != SVO_SM_DESC_RBR) return SVO_ERR_UNSUPPORTED;   // smSAD: out of scope
+    if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF && p.ifm_method != SVO_IFM_DESC_WIN) return SVO_ERR_UNSUPPORTED;      // ifmSAD / optical flow: out of scope
     if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD) return SVO_ERR_UNSUPPORTED;
     if (p.min_distance < 2) return SVO_ERR_ARG;            // cell size 0 divides by zero in the reference (S2:331-332)
     DevCtx& d = ctx->dc;
@@ -456,16 +456,27 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {
         HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
-        { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
-        { Span s(ctx, KT_LR_FILTER); launch_match_lr_filter(d, p.enable_robust_1to1_match, p.max_y_diff, st); }
+        if (p.match_method == SVO_SM_DESC_BF) {
+            { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
+            { Span s(ctx, KT_LR_FILTER); launch_match_lr_filter(d, p.enable_robust_1to1_match, p.max_y_diff, st); }
+        } else {                                                // smDescRbR (stage3_match_left_right.cpp:185-419)
+            const double minresp = p.detect_method == SVO_DM_ORB ? p.minimum_ORB_response : 0.0;   // S3:189-193
+            Span s(ctx, KT_LR_FILTER);
+            launch_match_lr_rbr(d, p.enable_robust_1to1_match, p.max_y_diff, minresp, (int)(size_t)p.orb_max_distance, st);
+        }
     }
     if (flags & SVO_RUN_TRACK) {
-        if (!(flags & SVO_RUN_MATCH)) HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
-        { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
-        { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
+        const int win = p.ifm_method == SVO_IFM_DESC_WIN;
+        if (!win) {
+            if (!(flags & SVO_RUN_MATCH) || p.match_method != SVO_SM_DESC_BF) HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
+            { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
+            { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
+        } else {                                                // ifmDescWin (stage4_match_consecutive.cpp:435-738)
+            Span s(ctx, KT_TRK_FILTER); launch_track_win(d, p.ifm_win_w, p.ifm_win_h, st);
+        }
         { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, st); }
         { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, st); }
-        { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, st); }
+        { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, win, st); }
     }
     if (flags & SVO_RUN_OPTIMIZE) {
         GNParams g; memset(&g, 0, sizeof(g));

@@ -336,3 +336,29 @@ def test_fast_orb_multi_octave_matches_oracle(w, h, nfe, noct):
             assert (ctx.outliers(0) == orc.outliers()).all()
     assert ro.valid and ro.tracked_feats_from_last_frame > 20
     ctx.close()
+
+
+@pytest.mark.parametrize("match_method,ifm_method,one2one,ydiff", [(1, 0, 1, 1.0), (0, 1, 1, 1.0), (1, 1, 0, 2.0), (1, 1, 1, 0.0)])
+def test_row_by_row_and_window_variants_match_oracle(match_method, ifm_method, one2one, ydiff):
+    """a7 smDescRbR (stage3:185-419) and a10 ifmDescWin (stage4:435-738), with the reference's quirks, vs the oracle."""
+    w, h = 640, 480
+    world = SyntheticStereoWorld(w, h, 400.0, 0.12, seed=31, n_frames=3)
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=700)
+    p.match_method = match_method; p.ifm_method = ifm_method; p.enable_robust_1to1_match = one2one; p.max_y_diff = ydiff
+    p.ifm_win_w = 20; p.ifm_win_h = 30; p.minimum_ORB_response = 1e-5
+    ctx = hip.Context(n_lanes=2, max_w=w, max_h=h, max_kps=2048)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        L, R = [x.numpy() for x in world.render(t)]
+        ctx.process_host([(L, R), (L, R)])
+        ro = orc.process(L, R, cam)
+        for lane in (0, 1):
+            assert_same_frame(ctx, lane, orc, ctx.result(lane), ro, "mm=%d ifm=%d t=%d lane=%d" % (match_method, ifm_method, t, lane))
+            assert (ctx.matches_row_index(lane, 0) == orc.matches_row_index(0)).all()
+    if ydiff > 0:
+        assert ro.stereo_matches[0] > 50 and ro.tracked_feats_from_last_frame > 10
+    else:
+        assert ro.stereo_matches[0] == 0        # max_y_diff = 0 -> empty right window (appendix A #10)
+    ctx.close()
