@@ -113,6 +113,11 @@ int svo_get_matches_oct(svo_ctx* ctx, int lane, int which, int octave, svo_dmatc
 int svo_get_tracked_oct(svo_ctx* ctx, int lane, int octave, svo_index_pair* t, int cap);
 int svo_get_row_index(svo_ctx* ctx, int lane, int which, int side, int octave, int32_t* idx, int cap);
 int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int octave, int32_t* idx, int cap);
+/* match-ID bookkeeping of params_general.vo_use_matches_ids: matches_IDs (H:794, getRefCurrentIDs H:701),
+ * resetIds (H:684) and setThisFrameAsKF (H:675-683); result.tracked_feats_from_last_KF counts against the key frame */
+int svo_get_match_ids(svo_ctx* ctx, int lane, int which, int octave, int32_t* ids, int cap);
+int svo_reset_ids(svo_ctx* ctx, int lane);
+int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane);
 
 /* the precomputed-data bypass (request_data.use_precomputed_data, H:214-218, P:131-162, P:219-251):
  * load caller-supplied features / pairings into a lane's current (which=0) or previous (which=1) frame. */

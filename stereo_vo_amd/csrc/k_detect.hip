@@ -62,7 +62,7 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
             for (int o = 0; o < c.oct_cap; o++) {
                 const int vl = t * c.oct_cap + o;
                 c.n_kps[feat_cnt_idx(vl, cur, 0)] = 0; c.n_kps[feat_cnt_idx(vl, cur, 1)] = 0;
-                c.n_matches[vl * 2 + cur] = 0;
+                c.n_matches[vl * 2 + cur] = 0; c.n_ids[vl * 2 + cur] = 0;
             }
             if (!repeat) s.it_counter++;                                               // P:380-381
         }

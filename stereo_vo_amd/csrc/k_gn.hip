@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
         for (int k = 0; k < 6; k++) { res.outPose[k] = pose[k]; res.delta[k] = delta[k]; }
         if (!P.use_custom_initial_pose && P.use_previous_pose_as_initial) for (int k = 0; k < 6; k++) ls.last_pose[k] = delta[k];   // S5:720-721
         res.tracked_feats_from_last_frame = T;                                                                       // S5:724
-        res.tracked_feats_from_last_KF = 0;
+        res.tracked_feats_from_last_KF = ls.num_tracked_last_kf;                                                     // S5:725
         res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code;
         res.n_residual = n_res > T ? n_res : T; res.n_outliers = n_out;
         res.valid = !abort_;                                                                                         // S5:727

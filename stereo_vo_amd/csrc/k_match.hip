@@ -640,6 +640,77 @@ __global__ void k_track_gate(DevCtx c, int bad_tracking_th)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Match-ID bookkeeping (params_general.vo_use_matches_ids; H:735-742): IDs follow a pairing through time.
+//   reset (P:254-267): previous IDs renumbered 0..N-1, the frame becomes the key frame;
+//   first frame (S3:67, 172-173): every pairing receives a fresh ID, octave by octave;
+//   later frames (S4:268-305 / 716-733): tracked pairings inherit the previous ID, the others receive fresh ones in
+//   index order; the key-frame counter is the number of current IDs <= m_last_kf_max_id (S4:747-751).
+// One 256-thread block per lane; the fresh IDs are numbered with block scans so that the order is the reference's.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
+{
+    __shared__ int scan[32];
+    __shared__ int s_next, s_kf;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tracked_flag = smem;                  // max_kps
+    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    LaneState& ls = c.lane[lane_id];
+    const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
+    int next_id = ls.last_match_id, kf_max = ls.last_kf_max_id;
+    if (ls.reset_ids) {                                                          // P:254-267
+        next_id = 0;
+        if (ls.has_prev)
+            for (int o = 0; o < c.n_oct; o++) {
+                const int vl = lane_id * c.oct_cap + o, n = c.n_ids[vl * 2 + prev];
+                int* pid = c.ids + ((long long)vl * 2 + prev) * c.max_kps;
+                for (int m = tid; m < n; m += blockDim.x) pid[m] = next_id + m;
+                next_id += n;
+            }
+        kf_max = next_id - 1;
+    }
+    __syncthreads();
+    int kf_count = 0;
+    if (!ls.has_prev && (flags & SVO_RUN_MATCH)) {                               // first frame: S3:172-173
+        for (int o = 0; o < c.n_oct; o++) {
+            const int vl = lane_id * c.oct_cap + o, n = c.n_matches[vl * 2 + cur];
+            int* cid = c.ids + ((long long)vl * 2 + cur) * c.max_kps;
+            for (int m = tid; m < n; m += blockDim.x) cid[m] = next_id + m;
+            if (tid == 0) c.n_ids[vl * 2 + cur] = n;
+            next_id += n;
+        }
+    } else if (ls.has_prev && (flags & SVO_RUN_TRACK)) {
+        for (int o = 0; o < c.n_oct; o++) {
+            const int vl = lane_id * c.oct_cap + o, ncm = c.n_matches[vl * 2 + cur], T = c.n_tracked[vl], npid = c.n_ids[vl * 2 + prev];
+            const svo_index_pair* trk = c.tracked + (long long)vl * c.max_kps;
+            const int* pid = c.ids + ((long long)vl * 2 + prev) * c.max_kps;
+            int* cid = c.ids + ((long long)vl * 2 + cur) * c.max_kps;
+            for (int k = tid; k < ncm; k += blockDim.x) tracked_flag[k] = 0;
+            __syncthreads();
+            for (int k = tid; k < T; k += blockDim.x) { const svo_index_pair p = trk[k]; cid[p.second] = p.first < npid ? pid[p.first] : 0; tracked_flag[p.second] = 1; }   // S4:290-291
+            __syncthreads();
+            for (int base = 0; base < ncm; base += blockDim.x) {                 // S4:302-304: fresh IDs in index order
+                const int k = base + tid;
+                const int fresh = (k < ncm && !tracked_flag[k]) ? 1 : 0;
+                int tot;
+                const int off = block_exclusive_scan(fresh, scan, &tot);
+                if (fresh) cid[k] = next_id + off;
+                next_id += tot;
+                __syncthreads();
+            }
+            if (tid == 0) c.n_ids[vl * 2 + cur] = ncm;
+            __threadfence_block();
+            __syncthreads();
+            for (int k = tid; k < ncm; k += blockDim.x) kf_count += cid[k] <= kf_max ? 1 : 0;   // S4:747-751
+        }
+        int tot;
+        block_exclusive_scan(kf_count, scan, &tot);
+        kf_count = tot;
+    }
+    (void)s_next; (void)s_kf;
+    if (tid == 0) { ls.reset_ids = 0; ls.last_match_id = next_id; ls.last_kf_max_id = kf_max; ls.num_tracked_last_kf = kf_count; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
@@ -661,6 +732,10 @@ void launch_match_lr_rbr(const DevCtx& c, int one_to_one, double max_y_diff, dou
 void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st)
 {
     hipLaunchKernelGGL(k_track_win, dim3(c.n_lanes * c.oct_cap), dim3(256), sizeof(unsigned) * c.max_kps + sizeof(int) * 32, st, c, win_w, win_h);
+}
+void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_match_ids, dim3(c.n_lanes), dim3(256), (size_t)c.max_kps, st, c, flags);
 }
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {

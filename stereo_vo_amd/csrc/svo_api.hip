@@ -166,6 +166,8 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.n_matches, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.row_index, (size_t)NV * 4 * cfg->max_h));
     HIPCHECK(dev_alloc(ctx, &d.mrow_index, (size_t)NV * 2 * (cfg->max_h + 1)));
+    HIPCHECK(dev_alloc(ctx, &d.ids, (size_t)NV * 2 * MK));
+    HIPCHECK(dev_alloc(ctx, &d.n_ids, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.bf_idx, (size_t)NV * 3 * MK));
     HIPCHECK(dev_alloc(ctx, &d.trk_kq, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)NV));
@@ -249,6 +251,7 @@ extern "C" int svo_reset(svo_ctx* ctx, int lane)
             HIPCHECK(hipMemset(ctx->dc.n_kps + (size_t)l * OC * 4, 0, (size_t)OC * 4 * sizeof(int)));
             HIPCHECK(hipMemset(ctx->dc.n_matches + (size_t)l * OC * 2, 0, (size_t)OC * 2 * sizeof(int)));
             HIPCHECK(hipMemset(ctx->dc.n_tracked + (size_t)l * OC, 0, (size_t)OC * sizeof(int)));
+            HIPCHECK(hipMemset(ctx->dc.n_ids + (size_t)l * OC * 2, 0, (size_t)OC * 2 * sizeof(int)));
             HIPCHECK(hipMemset(ctx->dc.results + l, 0, sizeof(svo_result)));
         }
     return SVO_OK;
@@ -478,6 +481,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, st); }
         { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, win, st); }
     }
+    if (p.vo_use_matches_ids && (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK))) { Span s(ctx, KT_TRK_FINAL); launch_match_ids(d, flags, st); }
     if (flags & SVO_RUN_OPTIMIZE) {
         GNParams g; memset(&g, 0, sizeof(g));
         g.use_robust_kernel = p.use_robust_kernel; g.max_iters = p.max_iters; g.initial_max_iters = p.initial_max_iters; g.max_incr_cost = p.max_incr_cost;
@@ -586,6 +590,46 @@ extern "C" int svo_get_tracked_oct(svo_ctx* ctx, int lane, int octave, svo_index
     return n;
 }
 extern "C" int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int cap) { return svo_get_tracked_oct(ctx, lane, 0, t, cap); }
+
+extern "C" int svo_get_match_ids(svo_ctx* ctx, int lane, int which, int octave, int32_t* ids, int cap)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    if (which ? !s.has_prev : !s.has_cur) return 0;
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave;
+    int n = 0;
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_ids + vl * 2 + slot, sizeof(int), hipMemcpyDeviceToHost));
+    const int m = n < cap ? n : cap;
+    if (ids && m > 0) HIPCHECK(hipMemcpy(ids, ctx->dc.ids + ((long long)vl * 2 + slot) * ctx->dc.max_kps, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+// resetIds (H:684): the next frame renumbers the previous IDs and becomes the key frame (P:254-267)
+extern "C" int svo_reset_ids(svo_ctx* ctx, int lane)
+{
+    if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    for (int l = 0; l < ctx->cfg.n_lanes; l++)
+        if (lane < 0 || lane == l) { LaneState s; int rc = lane_state(ctx, l, &s); if (rc) return rc; s.reset_ids = 1; HIPCHECK(hipMemcpy(ctx->dc.lane + l, &s, sizeof(s), hipMemcpyHostToDevice)); }
+    return SVO_OK;
+}
+
+// setThisFrameAsKF (H:675-683): m_last_kf_max_id = max ID of the current frame's octave-0 pairings
+extern "C" int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    if (!s.has_cur) return SVO_ERR_STATE;                 // ASSERTMSG_ "Current frame does not exist" (H:677)
+    const int vl = lane * ctx->dc.oct_cap, slot = slot_of(s, 0);
+    int n = 0;
+    HIPCHECK(hipMemcpy(&n, ctx->dc.n_ids + vl * 2 + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n <= 0) return SVO_ERR_STATE;
+    std::vector<int32_t> ids((size_t)n);
+    HIPCHECK(hipMemcpy(ids.data(), ctx->dc.ids + ((long long)vl * 2 + slot) * ctx->dc.max_kps, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    int mx = ids[0]; for (int i = 1; i < n; i++) if (ids[i] > mx) mx = ids[i];
+    s.last_kf_max_id = mx;
+    HIPCHECK(hipMemcpy(ctx->dc.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
 
 extern "C" int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap)
 {

@@ -40,6 +40,10 @@ struct LaneState {
     int m_error;          // CStereoOdometryEstimator::m_error (C:38)
     double last_pose[6];  // m_last_computed_pose (C:49)
     unsigned it_counter;
+    int reset_ids;        // m_reset (H:684, P:254-267)
+    int last_match_id;    // m_last_match_ID (H:741)
+    int last_kf_max_id;   // m_last_kf_max_id (H:738; uninitialised in the reference, 0 here)
+    int num_tracked_last_kf;   // m_num_tracked_pairs_from_last_kf (S4:743-751)
     int pad;
 };
 
@@ -79,6 +83,8 @@ struct DevCtx {
     int* n_matches;           // [n_vl][2]
     int* row_index;           // [n_vl][2 slots][2 sides][max_h]   m_update_indexes table (stage2_detect.cpp:103-129)
     int* mrow_index;          // [n_vl][2 slots][max_h + 1]       matches_lr_row_index (stage3:425-445)
+    int* ids;                 // [n_vl][2 slots][max_kps]         matches_IDs (H:794), only with vo_use_matches_ids
+    int* n_ids;               // [n_vl][2]
     // stage 3/4 scratch, per lane
     int* bf_idx;              // [n_lanes][3][max_kps]  best train index for: LR, prevL->curL, prevR->curR
     int* bf_dist;             // [n_lanes][3][max_kps]

@@ -31,6 +31,7 @@ void launch_ransac_count(const DevCtx& c, hipStream_t st);
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st);
 void launch_match_lr_rbr(const DevCtx& c, int one_to_one, double max_y_diff, double minimum_response, int max_distance, hipStream_t st);
 void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st);
+void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st);
 void launch_hamming_plain(const uint8_t* q, int nq, const uint8_t* t, int nt, unsigned* out, int nsplit, hipStream_t st);
 hipError_t configure_gauss_newton(int pmax);
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st);

@@ -23,7 +23,7 @@ EXPORTS = [
     "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
     "svo_get_orb_threshold", "svo_set_camera", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
-    "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index",
+    "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_change_in_pose", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
@@ -238,6 +238,19 @@ class Context:
         if n:
             self._ck(self.L.svo_get_matches_oct(self.h, lane, which, octave, _vp(m), n), "svo_get_matches_oct")
         return m
+
+    def match_ids(self, lane=0, which=0, octave=0):
+        n = self._ck(self.L.svo_get_match_ids(self.h, lane, which, octave, None, 0), "svo_get_match_ids")
+        a = np.zeros(n, np.int32)
+        if n:
+            self._ck(self.L.svo_get_match_ids(self.h, lane, which, octave, _vp(a), n), "svo_get_match_ids")
+        return a
+
+    def reset_ids(self, lane=-1):
+        self._ck(self.L.svo_reset_ids(self.h, lane), "svo_reset_ids")
+
+    def set_this_frame_as_kf(self, lane=0):
+        self._ck(self.L.svo_set_this_frame_as_kf(self.h, lane), "svo_set_this_frame_as_kf")
 
     def tracked(self, lane=0, octave=0):
         n = self._ck(self.L.svo_get_tracked_oct(self.h, lane, octave, None, 0), "svo_get_tracked_oct")

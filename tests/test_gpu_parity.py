@@ -362,3 +362,25 @@ def test_row_by_row_and_window_variants_match_oracle(match_method, ifm_method, o
     else:
         assert ro.stereo_matches[0] == 0        # max_y_diff = 0 -> empty right window (appendix A #10)
     ctx.close()
+
+
+def test_match_ids_and_keyframe_counter(golden_dir):
+    """a11: vo_use_matches_ids bookkeeping (S3:172-173, S4:268-305, 743-751, P:254-267) against the oracle."""
+    g, cam, p = load_small(golden_dir)
+    p = p.copy(); p.vo_use_matches_ids = 1
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(4):
+        if t == 3:
+            ctx.reset_ids(0); orc.L.svo_oracle_reset_ids(orc.h)
+        ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+        r, ro = ctx.result(0), orc.process(g["L%d" % t], g["R%d" % t], cam)
+        assert (ctx.match_ids(0, 0) == orc.match_ids(0)).all() and len(ctx.match_ids(0, 0)) == ro.stereo_matches[0], t
+        if t > 0:
+            assert (ctx.match_ids(0, 1) == orc.match_ids(1)).all(), t
+        assert r.tracked_feats_from_last_KF == ro.tracked_feats_from_last_KF, (t, r.tracked_feats_from_last_KF, ro.tracked_feats_from_last_KF)
+        if t == 1:
+            ctx.set_this_frame_as_kf(0); orc.L.svo_oracle_set_this_frame_as_kf(orc.h)
+    assert ro.tracked_feats_from_last_KF > 0
+    ctx.close()
