@@ -384,3 +384,37 @@ def test_match_ids_and_keyframe_counter(golden_dir):
             ctx.set_this_frame_as_kf(0); orc.L.svo_oracle_set_this_frame_as_kf(orc.h)
     assert ro.tracked_feats_from_last_KF > 0
     ctx.close()
+
+
+def test_config5_high_res_three_octaves():
+    """BASELINE.json configs[4]: 2048x1536, FAST+ORB on a 3-octave x1/2 pyramid, ~5000 keypoints per image in total
+    (orb_nfeats = 3300 -> 2828 + 1414 + 707), pseudo-Huber kernel (kernel_param 3): parity with the oracle."""
+    from stereo_vo_amd.abi import DM_FAST_ORB
+    w, h = 2048, 1536
+    world = SyntheticStereoWorld(w, h, 1280.0, 0.12, seed=41, n_frames=2)
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=3300)
+    p.detect_method = DM_FAST_ORB; p.nOctaves = 3; p.use_robust_kernel = 1; p.kernel_param = 3.0
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=4096, max_octaves=3, max_cand=1 << 18)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(2):
+        L, R = [x.numpy() for x in world.render(t)]
+        ctx.process_host([(L, R)])
+        r, ro = ctx.result(0), orc.process(L, R, cam)
+        assert ctx.status_word(0) == 0
+        tot = 0
+        for o in range(3):
+            for side in (0, 1):
+                k, d = ctx.keypoints(0, 0, side, o); ko, do = orc.keypoints(0, side, o)
+                assert k.tobytes() == ko.tobytes() and (d == do).all(), (t, o, side, len(k), len(ko))
+            assert ctx.matches(0, 0, o).tobytes() == orc.matches(0, o).tobytes()
+            assert ctx.tracked(0, o).tobytes() == orc.tracked(o).tobytes()
+            tot += r.detected_left[o]
+        assert tot > 4000
+        assert (r.valid, r.error_code) == (ro.valid, ro.error_code)
+        if ro.valid:
+            dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
+            assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD
+    assert ro.valid
+    ctx.close()
