@@ -103,7 +103,15 @@ def main():
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--orb-nfeats", type=int, default=2000)
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of one stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
+                    help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
+    detect_fast_orb, n_octaves, kitti = False, 1, False
+    if args.workload == "config3":
+        args.width, args.height, args.orb_nfeats, kitti = 1241, 376, 900, True
+    elif args.workload == "config5":
+        args.width, args.height, args.orb_nfeats, detect_fast_orb, n_octaves = 2048, 1536, 3300, True, 3
+        args.lanes = min(args.lanes, 32)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,17 +127,23 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     W, H, B, F = args.width, args.height, args.lanes, args.frames
-    focal = 800.0 * W / 1280.0
+    focal = 718.856 if kitti else 800.0 * W / 1280.0
+    baseline = 0.537 if kitti else 0.12
+    cxy = dict(cx=607.19, cy=185.22) if kitti else {}
     seeds = lane_seeds(rank, world, B)
     # four scenes shared by the streams (textures are the slow part to mint), one trajectory per stream
-    worlds = [SyntheticStereoWorld(W, H, focal, 0.12, seed=s, n_frames=F, device=dev, scene_seed=s % 4) for s in seeds]
+    worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=s, n_frames=F, device=dev, scene_seed=s % 4, **cxy) for s in seeds]
     frames = [[w.render(t) for t in range(F)] for w in worlds]          # [lane][t] -> (L, R) uint8 on device
     cam = worlds[0].camera()
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream(dev)
     p = north_star_params(hip.default_params(), orb_nfeats=args.orb_nfeats)
-    ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=4096, device=local_rank, kernel_times=True, stream=stream.cuda_stream)
+    if detect_fast_orb:
+        from stereo_vo_amd.abi import DM_FAST_ORB
+        p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
+    ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=4096, device=local_rank, kernel_times=True, stream=stream.cuda_stream,
+                      max_octaves=n_octaves, max_cand=(1 << 18) if W * H > 2000000 else (1 << 17))
     ctx.set_params(p)
     ctx.set_camera(cam)
     rec = torch.zeros((B, C.sizeof(Result)), dtype=torch.uint8, device=dev)
@@ -210,11 +224,11 @@ def main():
                             "sample": "%d frames of stream 0 (%dx%d, orb_nfeats=%d) on the single-threaded C oracle, host has %d cores"
                                       % (args.cpu_frames, W, H, args.orb_nfeats, os.cpu_count() or 0)}
         line = {
-            "metric": "stereo pairs/sec @1280x960", "value": round(value, 2), "unit": "stereo pairs/s",
+            "metric": "stereo pairs/sec @%dx%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic stereo streams, ORB %d feats x 8 levels (~%d kps/image after NMS), BF match, BF track, robust GN; %d independent streams per GPU, one frame per stream per step"
-                                   % (W, H, args.orb_nfeats, int(mean_kps), B),
+            "config": {"workload": "%s: %dx%d synthetic stereo streams, %s, orb_nfeats %d (~%d kps/image in octave 0 after NMS), BF match, BF track, robust GN; %d independent streams per GPU, one frame per stream per step"
+                                   % (args.workload, W, H, "FAST+ORB on %d x1/2 octaves" % n_octaves if detect_fast_orb else "ORB x 8 levels", args.orb_nfeats, int(mean_kps), B),
                        "lanes_per_gpu": B, "frames_per_stream": F, "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -89,10 +89,10 @@ public:
     // the seven parameter groups (H:266-508) collapse into the flat record whose fields carry the reference's names
     svo_params params;
 
-    explicit CStereoOdometryEstimator(int max_w = 1280, int max_h = 960, int device = 0) : m_ctx(NULL), m_verbose_level(1) {
+    explicit CStereoOdometryEstimator(int max_w = 1280, int max_h = 960, int device = 0, int max_octaves = 4) : m_ctx(NULL), m_verbose_level(1) {
         svo_params_defaults(&params);
         svo_config cfg; svo_config_defaults(&cfg);
-        cfg.device = device; cfg.n_lanes = 1; cfg.max_w = max_w; cfg.max_h = max_h;
+        cfg.device = device; cfg.n_lanes = 1; cfg.max_w = max_w; cfg.max_h = max_h; cfg.max_octaves = max_octaves;
         const int rc = svo_create(&cfg, &m_ctx);
         if (rc != SVO_OK) { std::string msg = std::string("svo_create: ") + svo_strerror(rc) + " " + (m_ctx ? svo_last_error(m_ctx) : ""); if (m_ctx) svo_destroy(m_ctx); m_ctx = NULL; throw std::runtime_error(msg); }
     }
@@ -157,13 +157,20 @@ public:
         return result.valid;
     }
 
-    /** getValues (H:704-724): copies of the current frame's lists */
-    void getValues(TKeyPointList& leftKP, TKeyPointList& rightKP, std::vector<uint8_t>& leftDesc, std::vector<uint8_t>& rightDesc, TDMatchList& matches) {
+    /** getValues (H:704-724): copies of the current frame's octave-0 lists */
+    void getValues(TKeyPointList& leftKP, TKeyPointList& rightKP, std::vector<uint8_t>& leftDesc, std::vector<uint8_t>& rightDesc, TDMatchList& matches,
+                   std::vector<size_t>& matches_id) {
         fetch_kps(0, leftKP, leftDesc); fetch_kps(1, rightKP, rightDesc);
         const int n = check(svo_get_matches(m_ctx, 0, 0, NULL, 0), "svo_get_matches");
         matches.resize(n);
         if (n) check(svo_get_matches(m_ctx, 0, 0, matches.data(), n), "svo_get_matches");
+        const int ni = check(svo_get_match_ids(m_ctx, 0, 0, 0, NULL, 0), "svo_get_match_ids");
+        std::vector<int32_t> ids((size_t)ni);
+        if (ni) check(svo_get_match_ids(m_ctx, 0, 0, 0, ids.data(), ni), "svo_get_match_ids");
+        matches_id.assign(ids.begin(), ids.end());
     }
+    void resetIds() { check(svo_reset_ids(m_ctx, 0), "svo_reset_ids"); }                         // H:684
+    void setThisFrameAsKF() { check(svo_set_this_frame_as_kf(m_ctx, 0), "svo_set_this_frame_as_kf"); }   // H:675-683
 
     svo_ctx* handle() { return m_ctx; }
 
