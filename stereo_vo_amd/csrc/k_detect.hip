@@ -151,93 +151,92 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 // ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
 // Integer VALU issue is what bounds this kernel (measured ~90 % VALU-busy), so the design minimises instructions:
-// Tile = 64x32 interior pixels.  The 80x40 source window (3 px circle radius + 1 px NMS halo, start aligned to
-// 8 bytes) is staged in LDS with coalesced dword loads.  A three-step cascade keeps the expensive work dense:
-//   (1) every position of the score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
+// Tile = 64x28 interior pixels.  The 80x36 source window (3 px circle radius + 1 px NMS halo, start aligned to
+// 8 bytes) is staged in LDS with two 8-byte loads per thread.  A three-step cascade keeps the expensive work dense:
+//   (1) every position of the 68x30 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
 //       contains two ADJACENT compass points, so a corner needs two adjacent compass pixels both brighter than
 //       c+t or both darker than c-t.  It runs on FOUR positions per lane-op: the centre row / N / S come in as
 //       aligned LDS dwords, E / W by v_alignbyte, and the comparisons are saturating packed-16-bit subtractions
-//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  Survivors are compacted into an LDS list by one scan;
-//   (2) only the listed positions run the 16-pixel bit-mask test and, if they pass, the arc-min score (one sign-
-//       folded pass of the log-step min network unless both polarities hit);
+//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  30 rows x 17 groups = 2 x 255 tasks: two per thread,
+//       15 rows apart, so the index arithmetic is done once.  Survivors are compacted into an LDS list by one scan;
+//   (2) only the listed positions compute the arc-min score (both polarities through one packed min network);
 //   (3) the 3x3 NMS also walks the list; survivors are appended to the level's candidate list with one global
 //       atomic per tile, issued by a single wave.
 // The score window is 68 columns wide (x0-3 .. x0+64) so that groups of four positions sit on dword boundaries.
+// No position is bounds-checked before step (3): the staged window only ever holds readable memory, and a position
+// outside [EDGE-1, dim-EDGE] is never a neighbour of an interior position, so whatever score it gets is never read.
 // ------------------------------------------------------------------------------------------------------------
-#define FT_W 64
-#define FT_H 32
+#define FT_W SVO_FT_W
+#define FT_H SVO_FT_H
 #define FT_LW 80              // LDS window pitch; window x origin = x0 - 7 (x0 = 31 + 64*bx, so x0 - 7 is a multiple of 8)
 #define FT_LH (FT_H + 8)      // window y origin = y0 - 4
 #define FT_SW 68              // score window: x = x0 - 3 + q, q in [0, 68); interior q in [3, 67)
-#define FT_SH (FT_H + 2)      // y = y0 - 1 + r, r in [0, 34); interior r in [1, 33)
+#define FT_SH (FT_H + 2)      // y = y0 - 1 + r, r in [0, 30); interior r in [1, 29)
 #define FT_SP 72              // score map pitch
 #define FT_NG (FT_SW / 4)     // 17 groups of four positions per row
+static_assert(FT_SH == 30 && FT_NG == 17 && FT_LH == 36, "k_fast's thread mapping is written for the 64x28 tile");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-// cardinal-pair test of the two positions packed in one register half (bytes 0,2 or 1,3 of the centre dword)
+// cardinal-pair test of two positions held in the 16-bit halves of each operand (either as v or as v << 8: the
+// caller scales the threshold the same way).  A half of the result is nonzero when its position passes.
 __device__ __forceinline__ uint32_t quick_half(uint32_t c, uint32_t n, uint32_t e, uint32_t s, uint32_t w, u16x2 t2)
 {
-    const u16x2 cc = as_u16x2(c), hi = cc + t2, lo = __builtin_elementwise_sub_sat(cc, t2);
+    const u16x2 cc = as_u16x2(c), hi = __builtin_elementwise_add_sat(cc, t2), lo = __builtin_elementwise_sub_sat(cc, t2);
     const u16x2 N = as_u16x2(n), E = as_u16x2(e), S = as_u16x2(s), W = as_u16x2(w);
     // "two adjacent compass points bright" == (N or S bright) and (E or W bright): any N/S point is adjacent to any E/W point
     const u16x2 bns = __builtin_elementwise_sub_sat(__builtin_elementwise_max(N, S), hi), bew = __builtin_elementwise_sub_sat(__builtin_elementwise_max(E, W), hi);
     const u16x2 dns = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(N, S)), dew = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(E, W));
-    const u16x2 r = __builtin_elementwise_min(bns, bew) | __builtin_elementwise_min(dns, dew);
-    return as_u32(r);
+    return as_u32(__builtin_elementwise_min(bns, bew) | __builtin_elementwise_min(dns, dew));
 }
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // FAST-9 score of the pixel at byte offset `off` of the LDS window: the largest t for which it is still a corner
 // = max over the 16 arcs of 9 contiguous circle pixels of the min one-sided difference, minus 1; 0 when that is
-// below th.  Both polarities run through one log-step min network on packed signed 16-bit pairs: the 16 differences
-// live in 8 registers as (d[2k], d[2k+1]), so rotations by 2, 4 and 8 circle positions are register renames and
-// only the rotation by one position costs a v_alignbit.
+// not above th.  Both polarities ride in the two halves of one register, v[i] = (p_i - c, c - p_i), so one min
+// network serves both.  The 16 circular 9-windows come from block prefix/suffix minima (van Herk): with the circle
+// cut into [0,8) and [8,16), window [i, i+8] = suffix_i of one block + prefix_i of the other: 28 + 16 + 15 packed ops.
 __device__ __forceinline__ int fast_score_lds(const uint8_t* win, int off, int th)
 {
-    // every byte read goes through its own laundered index: left alone the compiler fuses neighbouring bytes into
-    // ds_read_u16 at odd addresses, which the LDS replays lane by lane
-    auto rd = [&](int o) -> int { int a = off + o; asm volatile("" : "+v"(a)); return (int)win[a]; };
-    const int c = rd(0);
-    const int o16[16] = { -3 * FT_LW, -3 * FT_LW + 1, -2 * FT_LW + 2, -FT_LW + 3, 3, FT_LW + 3, 2 * FT_LW + 2, 3 * FT_LW + 1,
-                          3 * FT_LW, 3 * FT_LW - 1, 2 * FT_LW - 2, FT_LW - 3, -3, -FT_LW - 3, -2 * FT_LW - 2, -3 * FT_LW - 1 };
-    i16x2 v[8];
+    // immediate offsets from one base; the middle byte of the two 3-byte runs (rows -3 and +3) goes through a second,
+    // opaque copy of the base: left alone the compiler fuses neighbouring bytes into ds_read_u16 at odd addresses,
+    // which the LDS replays lane by lane
+    const int base = off - 3 * FT_LW - 3;
+    int basem = base; asm volatile("" : "+v"(basem));
+#define FO(dx, dy) (((dy) + 3) * FT_LW + (dx) + 3)
+    const int c = win[base + FO(0, 0)];
+    int p[16];
+    p[0] = win[basem + FO(0, -3)]; p[1] = win[base + FO(1, -3)]; p[2] = win[base + FO(2, -2)]; p[3] = win[base + FO(3, -1)];
+    p[4] = win[base + FO(3, 0)];   p[5] = win[base + FO(3, 1)];  p[6] = win[base + FO(2, 2)];  p[7] = win[base + FO(1, 3)];
+    p[8] = win[basem + FO(0, 3)];  p[9] = win[base + FO(-1, 3)]; p[10] = win[base + FO(-2, 2)]; p[11] = win[base + FO(-3, 1)];
+    p[12] = win[base + FO(-3, 0)]; p[13] = win[base + FO(-3, -1)]; p[14] = win[base + FO(-2, -2)]; p[15] = win[base + FO(-1, -3)];
+#undef FO
+    const i16x2 K = { (short)(-c), (short)c };
+    i16x2 v[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { v[k].x = (short)(rd(o16[2 * k]) - c); v[k].y = (short)(rd(o16[2 * k + 1]) - c); }
-    int best = 0;
+    for (int i = 0; i < 16; i++) v[i] = __builtin_bit_cast(i16x2, __mul24(p[i], -65535)) + K;      // (p, -p) + (-c, c)
+    i16x2 s0[8], s1[8], p0[8], p1[8];       // suffix / prefix minima of the blocks [0,8) and [8,16)
+    s0[7] = v[7]; s1[7] = v[15]; p0[0] = v[0]; p1[0] = v[8];
 #pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        i16x2 a[8], b[8];
-        if (pass) {
+    for (int j = 6; j >= 0; j--) { s0[j] = __builtin_elementwise_min(s0[j + 1], v[j]); s1[j] = __builtin_elementwise_min(s1[j + 1], v[8 + j]); }
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = -v[k];
-        }
-        // a[k] = min over 2: (min(d2k, d2k+1), min(d2k+1, d2k+2)); the one-position rotation pairs v[k].y with v[k+1].x
+    for (int j = 1; j < 8; j++) { p0[j] = __builtin_elementwise_min(p0[j - 1], v[j]); p1[j] = __builtin_elementwise_min(p1[j - 1], v[8 + j]); }
+    i16x2 m = __builtin_elementwise_min(s0[0], p1[0]);                                  // window [0, 8]
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t lo = __builtin_bit_cast(uint32_t, v[k]), hi = __builtin_bit_cast(uint32_t, v[(k + 1) & 7]);
-            const i16x2 r1 = __builtin_bit_cast(i16x2, __builtin_amdgcn_alignbit(hi, lo, 16));      // (d2k+1, d2k+2)
-            a[k] = __builtin_elementwise_min(v[k], r1);
-        }
+    for (int i = 1; i < 8; i++) m = __builtin_elementwise_max(m, __builtin_elementwise_min(s0[i], p1[i]));      // [i, i+8]
 #pragma unroll
-        for (int k = 0; k < 8; k++) b[k] = __builtin_elementwise_min(a[k], a[(k + 1) & 7]);          // min over 4
-#pragma unroll
-        for (int k = 0; k < 8; k++) a[k] = __builtin_elementwise_min(b[k], b[(k + 2) & 7]);          // min over 8
-        i16x2 m = __builtin_elementwise_min(a[0], v[4]);                                             // the 9th pixel: d[i+8]
-#pragma unroll
-        for (int k = 1; k < 8; k++) m = __builtin_elementwise_max(m, __builtin_elementwise_min(a[k], v[(k + 4) & 7]));
-        best = max(best, max((int)m.x, (int)m.y));
-    }
+    for (int i = 0; i < 8; i++) m = __builtin_elementwise_max(m, __builtin_elementwise_min(s1[i], p0[i]));      // [8+i, 16+i]
+    const int best = max((int)m.x, (int)m.y);
     return best > th ? best - 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_fast(DevCtx c)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
-    __shared__ __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP];
+    __shared__ __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 16];
     __shared__ unsigned short list[FT_SH * FT_SW];
     __shared__ unsigned s_count;
     __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
@@ -248,68 +247,78 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && (int)blockIdx.x >= c.lv[l].tile_off) level = l;
     const LevelGeom& g = c.lv[level];
     const int t = blockIdx.x - g.tile_off;
-    const int bx = t % g.tiles_x, by = t / g.tiles_x;
+    const int by = t / g.tiles_x, bx = t - by * g.tiles_x;
     const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
     int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
     if (tid == 0) { s_nout = 0; s_count = 0; }
-    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+36), clear the score map ----
-    if ((((uintptr_t)src | (uintptr_t)pitch) & 3) == 0) {
-        for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
-            const int r = i / (FT_LW / 4), q = i - r * (FT_LW / 4);
-            const int yy = min(y0 - 4 + r, g.h - 1);
-            const int xx = min(x0 - 7 + q * 4, pitch - 4);           // rows are readable up to the pitch
-            *(uint32_t*)&tile[r * FT_LW + q * 4] = *(const uint32_t*)(src + (long long)yy * pitch + xx);
+    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+32): 36 rows x 10 chunks of 8 bytes, rows r and r+18 per thread ----
+    if (tid < 180) {
+        const int r = tid / 10, q = tid - r * 10;
+        const int ya = min(y0 - 4 + r, g.h - 1), yb = min(y0 - 4 + r + 18, g.h - 1);
+        uint2 va, vb;
+        if ((((uintptr_t)src | (uintptr_t)pitch) & 7) == 0) {
+            const int xx = min(x0 - 7 + q * 8, pitch - 8);              // rows are readable up to the pitch
+            va = *(const uint2*)(src + (long long)ya * pitch + xx);
+            vb = *(const uint2*)(src + (long long)yb * pitch + xx);
+        } else {
+            // any pointer / stride: aligned-down dwords funnel-shifted into place.  Every dword read contains at least
+            // one byte of the image (addresses are clamped to the dword of the last byte), so it cannot fault.
+            const uintptr_t last = ((uintptr_t)src + (uintptr_t)((long long)g.h * pitch) - 1) & ~(uintptr_t)3;
+            const uintptr_t aa = (uintptr_t)src + (uintptr_t)((long long)ya * pitch + x0 - 7 + q * 8);
+            const uintptr_t ab = (uintptr_t)src + (uintptr_t)((long long)yb * pitch + x0 - 7 + q * 8);
+            const uintptr_t a0 = aa & ~(uintptr_t)3, b0 = ab & ~(uintptr_t)3;
+            const uint32_t a_0 = *(const uint32_t*)min(a0, last), a_1 = *(const uint32_t*)min(a0 + 4, last), a_2 = *(const uint32_t*)min(a0 + 8, last);
+            const uint32_t b_0 = *(const uint32_t*)min(b0, last), b_1 = *(const uint32_t*)min(b0 + 4, last), b_2 = *(const uint32_t*)min(b0 + 8, last);
+            const uint32_t sa = (uint32_t)(aa & 3) * 8u, sb = (uint32_t)(ab & 3) * 8u;
+            va.x = __builtin_amdgcn_alignbit(a_1, a_0, sa); va.y = __builtin_amdgcn_alignbit(a_2, a_1, sa);
+            vb.x = __builtin_amdgcn_alignbit(b_1, b_0, sb); vb.y = __builtin_amdgcn_alignbit(b_2, b_1, sb);
         }
-    } else {                                                          // unaligned caller image: byte loads
-        for (int i = tid; i < FT_LH * FT_LW; i += 256) {
-            const int r = i / FT_LW, q = i - r * FT_LW;
-            tile[i] = src[(long long)min(y0 - 4 + r, g.h - 1) * pitch + min(x0 - 7 + q, g.w - 1)];
-        }
+        *(uint2*)&tile[r * FT_LW + q * 8] = va;
+        *(uint2*)&tile[(r + 18) * FT_LW + q * 8] = vb;
     }
-    for (int i = tid; i < FT_SH * FT_SP / 4; i += 256) ((uint32_t*)score)[i] = 0;
+    if (tid < (FT_SH * FT_SP + 15) / 16) ((uint4*)score)[tid] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (c.debug_mode == 1) return;
-    // ---- (1) packed cardinal test: 34 rows x 17 groups of four positions ----
-    const int xlim = g.w - SVO_EDGE + 1, ylim = g.h - SVO_EDGE + 1;     // scores exist on [EDGE-1, dim-EDGE+1)
+    // ---- (1) packed cardinal test: 30 rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + 15, gq) ----
     const uint32_t* T32 = (const uint32_t*)tile;
-    const u16x2 t2 = { (unsigned short)c.fast_th, (unsigned short)c.fast_th };
-    unsigned passmask = 0;                                              // 4 bits per task, up to 3 tasks per thread
+    const uint32_t th = (uint32_t)c.fast_th;
+    const u16x2 t2 = { (unsigned short)th, (unsigned short)th }, t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
+    const int r0 = tid / FT_NG, gq = tid - r0 * FT_NG;
+    uint32_t pe[2] = { 0, 0 }, po[2] = { 0, 0 };                        // nonzero halves = passing positions
+    if (tid < 15 * FT_NG) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int task = tid + 256 * k;
-        if (task < FT_SH * FT_NG) {
-            const int r = task / FT_NG, gq = task - r * FT_NG;
-            const uint32_t* row = T32 + (r + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
+        for (int k = 0; k < 2; k++) {
+            const uint32_t* row = T32 + (r0 + 15 * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
             const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
             const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3), W = __builtin_amdgcn_alignbyte(C, Cp, 1);
-            const uint32_t m8 = 0x00FF00FFu;
-            const uint32_t pe = quick_half(C & m8, N & m8, E & m8, S & m8, W & m8, t2);                                     // positions 0, 2
-            const uint32_t po = quick_half((C >> 8) & m8, (N >> 8) & m8, (E >> 8) & m8, (S >> 8) & m8, (W >> 8) & m8, t2);   // positions 1, 3
-            const int xb = x0 - 3 + 4 * gq;
-            unsigned m = 0;
-            if (y0 - 1 + r < ylim) {
-                if ((pe & 0xFFFFu) && xb < xlim) m |= 1u;
-                if ((po & 0xFFFFu) && xb + 1 < xlim) m |= 2u;
-                if ((pe >> 16) && xb + 2 < xlim) m |= 4u;
-                if ((po >> 16) && xb + 3 < xlim) m |= 8u;
-            }
-            passmask |= m << (4 * k);
+            const uint32_t m8 = 0x00FF00FFu, m8h = 0xFF00FF00u;
+            pe[k] = quick_half(C & m8, N & m8, E & m8, S & m8, W & m8, t2);               // positions 0 (low half), 2 (high half)
+            po[k] = quick_half(C & m8h, N & m8h, E & m8h, S & m8h, W & m8h, t2h);         // positions 1, 3, values << 8
         }
     }
-    {   // compaction: wave-inclusive scan of the pass counts, one LDS atomic per wave (list order is irrelevant)
-        const int cnt = __popc(passmask), lane = tid & 63;
-        int inc = cnt;
+    {   // compaction by ballots: eight 64-lane masks (two tasks x four positions), counts and prefixes on the scalar
+        // unit, one LDS atomic per wave (list order is irrelevant)
+        bool f[8];
+        unsigned long long bm[8];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+        for (int k = 0; k < 2; k++) {
+            f[4 * k + 0] = (pe[k] & 0xFFFFu) != 0; f[4 * k + 1] = (po[k] & 0xFFFFu) != 0;
+            f[4 * k + 2] = (pe[k] >> 16) != 0;     f[4 * k + 3] = (po[k] >> 16) != 0;
+        }
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { bm[j] = __ballot(f[j]); total += __popcll(bm[j]); }
         unsigned wbase = 0;
-        if (lane == 63 && inc) wbase = atomicAdd(&s_count, (unsigned)inc);
-        wbase = __shfl(wbase, 63, 64);
-        int off = (int)wbase + inc - cnt;
+        if (total) {
+            if ((tid & 63) == 0) wbase = atomicAdd(&s_count, (unsigned)total);
+            wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+            const int p0 = r0 * FT_SP + 4 * gq;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int task = tid + 256 * k, r = task / FT_NG, gq = task - r * FT_NG;
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (passmask & (1u << (4 * k + j))) list[off++] = (unsigned short)(r * FT_SP + 4 * gq + j);
+            for (int j = 0; j < 8; j++) {
+                const unsigned idx = __builtin_amdgcn_mbcnt_hi((unsigned)(bm[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[j], wbase));
+                if (f[j]) list[idx] = (unsigned short)(p0 + (j >> 2) * 15 * FT_SP + (j & 3));
+                wbase += (unsigned)__popcll(bm[j]);
+            }
         }
     }
     __syncthreads();
@@ -328,11 +337,15 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
         bool keep = false; uint32_t key = 0;
         if (i < ns) {
             const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
-            const uint8_t* sp = &score[pos];
-            const int v = sp[0];
+            // nine byte reads at immediate offsets, issued together; the middle column goes through an opaque copy of
+            // the base so that no two fuse into a misaligned ds_read_u16.  (r = 0 reads below the map: rejected below.)
+            const int nb = pos - FT_SP - 1; int nbm = nb; asm volatile("" : "+v"(nbm));
+            const int v = score[nbm + FT_SP + 1];
+            const int n0 = score[nb], n1 = score[nbm + 1], n2 = score[nb + 2], n3 = score[nb + FT_SP], n4 = score[nb + FT_SP + 2];
+            const int n5 = score[nb + 2 * FT_SP], n6 = score[nbm + 2 * FT_SP + 1], n7 = score[nb + 2 * FT_SP + 2];
+            const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
             const int x = x0 - 3 + q, y = y0 - 1 + r;
-            if (v && r >= 1 && r <= FT_H && q >= 3 && q < 3 + FT_W && x < g.w - SVO_EDGE && y < g.h - SVO_EDGE)
-                keep = v > sp[-1] && v > sp[1] && v > sp[-FT_SP - 1] && v > sp[-FT_SP] && v > sp[-FT_SP + 1] && v > sp[FT_SP - 1] && v > sp[FT_SP] && v > sp[FT_SP + 1];
+            keep = (v > mx) & (r >= 1) & (r <= FT_H) & (q >= 3) & (q < 3 + FT_W) & (x < g.w - SVO_EDGE) & (y < g.h - SVO_EDGE);
             key = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
         }
         const unsigned long long m = __ballot(keep);

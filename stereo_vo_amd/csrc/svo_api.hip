@@ -318,7 +318,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
         g.offset = off; if (l >= 1) off += (long long)g.pitch * g.h;
         const int iw = g.w - 2 * SVO_EDGE, ih = g.h - 2 * SVO_EDGE;
         const bool live = iw > 0 && ih > 0 && quota[l] > 0;
-        g.tiles_x = live ? (iw + 63) / 64 : 0; g.tiles_y = live ? (ih + 31) / 32 : 0;     // k_fast tile = 64 x 32
+        g.tiles_x = live ? (iw + SVO_FT_W - 1) / SVO_FT_W : 0; g.tiles_y = live ? (ih + SVO_FT_H - 1) / SVO_FT_H : 0;
         g.tile_off = tile_off; tile_off += g.tiles_x * g.tiles_y;
         g.quota = live ? quota[l] : 0; g.slot_off = slot_off; slot_off += g.quota;
         long long cc = (long long)ctx->cfg.max_cand * ((long long)g.w * g.h) / ((long long)lw[0] * lh[0]);

@@ -16,6 +16,8 @@
 
 #define SVO_EDGE 31
 #define SVO_RANSAC_HYP 256
+#define SVO_FT_W 64          // k_fast tile (interior pixels)
+#define SVO_FT_H 28
 #define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each
 #define SVO_RANSAC_SEED 0x5EEDF00DCAFE1234ULL
 
