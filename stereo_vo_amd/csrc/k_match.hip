@@ -11,75 +11,94 @@
 
 // ------------------------------------------------------------------------------------------------------------
 // K7: Hamming brute force, first minimum.  mode 0: current left -> current right (stage 3).  mode 1: previous
-// pairings -> current pairings, blockIdx.z & 1 = side (left-left / right-right), rows addressed through the
-// DMatch lists (the descriptor gather of S4:105-131 is folded into the loads).
-// Each thread owns one query descriptor in registers (4 x u64); train descriptors stream through LDS in tiles of
-// 256 x 32 B and are read as wave-wide broadcasts; distance and train index are packed (dist << 16 | idx) so that
-// min() is the first-minimum rule of cv::BFMatcher, and partial results of the train splits merge by atomicMin.
+// pairings -> current pairings, blockIdx.z / nsplit = side (left-left / right-right) on the descriptor rows that
+// k_gather_mdesc laid out contiguously in pairing order (the gather of S4:105-131).
+// Each thread owns one query descriptor in registers (8 dwords).  The train row is the same for every lane of a
+// wave, so it never touches a vector register or LDS: the loop reads it with SCALAR loads (s_load_dwordx8 through
+// the constant cache) and xors it in as an SGPR operand.  That leaves 8 v_xor + 8 v_bcnt + 2 per pair -- the VALU
+// floor of a 256-bit popcount distance -- where the LDS-broadcast version spent as many LDS cycles again.
+// Distance and train index are packed (dist << 16 | idx) so that min() is the first-minimum rule of
+// cv::BFMatcher; partial results of the train splits merge by atomicMin.
 // ------------------------------------------------------------------------------------------------------------
 #define HM_TILE 256
 
+__global__ void __launch_bounds__(256) k_gather_mdesc(DevCtx c)
+{
+    // blockIdx.z: bit 0 = side, bit 1 = 0 previous / 1 current slot; 8 threads per descriptor (one dword each)
+    const int vl = blockIdx.y, lane_id = vl / c.oct_cap;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const LaneState& ls = c.lane[lane_id];
+    if (!ls.has_prev) return;
+    const int side = blockIdx.z & 1, slot = (blockIdx.z & 2) ? 1 - ls.prev_slot : ls.prev_slot;
+    const int n = c.n_matches[vl * 2 + slot];
+    const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, w = threadIdx.x & 7;
+    if (m >= n) return;
+    const svo_dmatch* mm = c.matches + match_base(c, vl, slot);
+    const int row = side ? mm[m].trainIdx : mm[m].queryIdx;
+    const uint32_t* src = (const uint32_t*)(c.desc + (feat_base(c, vl, slot, side) + row) * 32);
+    uint32_t* dst = (uint32_t*)(c.mdesc + (feat_base(c, vl, slot, side) + m) * 32);
+    dst[w] = src[w];
+}
+
+#define HM_QPT 1          // queries per thread (2 or 4 amortise the scalar loads further; measured no faster)
+
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
 {
-    __shared__ __attribute__((aligned(16))) unsigned long long tile[HM_TILE * 4];
-    const int vl = blockIdx.y, lane_id = vl / c.oct_cap;
+    // grid = (lane-octave, query block, side x split): the query blocks past nq exit at once, and with the lane index
+    // fastest they sit at the END of the dispatch order.  (With the query block fastest, live and dead workgroups
+    // alternate, the dispatcher hands them to the two halves of each XCD in turn, and half the CUs idle: measured 2x.)
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int side = mode ? (blockIdx.z / nsplit) : 0, split = blockIdx.z % nsplit;
     const LaneState& ls = c.lane[lane_id];
     const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
-    int nq, nt; const uint8_t* qd, *td; const svo_dmatch* qm = nullptr, *tm = nullptr;
+    int nq, nt; const uint8_t* qd, *td;
     if (mode == 0) {
         nq = c.n_kps[feat_cnt_idx(vl, cur, 0)]; nt = c.n_kps[feat_cnt_idx(vl, cur, 1)];
         qd = c.desc + feat_base(c, vl, cur, 0) * 32; td = c.desc + feat_base(c, vl, cur, 1) * 32;
     } else {
         if (!ls.has_prev) return;
         nq = c.n_matches[vl * 2 + prev]; nt = c.n_matches[vl * 2 + cur];
-        qd = c.desc + feat_base(c, vl, prev, side) * 32; td = c.desc + feat_base(c, vl, cur, side) * 32;
-        qm = c.matches + match_base(c, vl, prev); tm = c.matches + match_base(c, vl, cur);
+        qd = c.mdesc + feat_base(c, vl, prev, side) * 32; td = c.mdesc + feat_base(c, vl, cur, side) * 32;
     }
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if ((int)(blockIdx.x * blockDim.x) >= nq || nt <= 0) return;            // block-uniform
-    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    if (q < nq) {
-        const int row = mode ? (side ? qm[q].trainIdx : qm[q].queryIdx) : q;
-        const ulonglong2* p = (const ulonglong2*)(qd + (long long)row * 32);
-        const ulonglong2 a = p[0], b = p[1];
-        q0 = a.x; q1 = a.y; q2 = b.x; q3 = b.y;
+    const int qbase = blockIdx.y * (256 * HM_QPT) + threadIdx.x;              // queries qbase + 256 * i
+    if ((int)(blockIdx.y * 256 * HM_QPT) >= nq || nt <= 0) return;            // block-uniform
+    uint32_t qw[HM_QPT][8];
+#pragma unroll
+    for (int i = 0; i < HM_QPT; i++) {
+        const int q = min(qbase + 256 * i, nq - 1);                           // out-of-range slots redo the last query, never stored
+        const uint4* p = (const uint4*)(qd + (long long)q * 32);
+        const uint4 a = p[0], b = p[1];
+        qw[i][0] = a.x; qw[i][1] = a.y; qw[i][2] = a.z; qw[i][3] = a.w; qw[i][4] = b.x; qw[i][5] = b.y; qw[i][6] = b.z; qw[i][7] = b.w;
     }
-    // this block's share of the train rows, in whole tiles
-    const int tiles = (nt + HM_TILE - 1) / HM_TILE;
-    const int t_per = (tiles + nsplit - 1) / nsplit;
-    const int t_begin = split * t_per, t_end = min(tiles, t_begin + t_per);
-    unsigned best = 0xFFFFFFFFu;
-    // software pipeline: the next train tile is fetched into registers while the current one is compared, so the
-    // global-load latency of a tile hides behind ~10k cycles of popcount work
-    ulonglong2 pa = make_ulonglong2(0, 0), pb = make_ulonglong2(0, 0);
-    auto fetch = [&](int t) {
-        const int j = t * HM_TILE + (int)threadIdx.x;
-        if (t < t_end && j < nt) {
-            const int row = mode ? (side ? tm[j].trainIdx : tm[j].queryIdx) : j;
-            const ulonglong2* p = (const ulonglong2*)(td + (long long)row * 32);
-            pa = p[0]; pb = p[1];
-        }
-    };
-    fetch(t_begin);
-    for (int t = t_begin; t < t_end; t++) {
-        const int j0 = t * HM_TILE, jn = min(HM_TILE, nt - j0);
-        __syncthreads();
-        ((ulonglong2*)tile)[threadIdx.x * 2] = pa;
-        ((ulonglong2*)tile)[threadIdx.x * 2 + 1] = pb;
-        __syncthreads();
-        fetch(t + 1);
+    // this block's share of the train rows
+    const int per = (nt + nsplit - 1) / nsplit;
+    const int j_begin = split * per, j_end = min(nt, j_begin + per);
+    unsigned best[HM_QPT];
+#pragma unroll
+    for (int i = 0; i < HM_QPT; i++) best[i] = 0xFFFFFFFFu;
+    const uint32_t* __restrict__ tw = (const uint32_t*)td;
 #pragma unroll 4
-        for (int j = 0; j < jn; j++) {
-            const ulonglong2 a = ((const ulonglong2*)tile)[j * 2], b = ((const ulonglong2*)tile)[j * 2 + 1];
-            const unsigned d = __popcll(q0 ^ a.x) + __popcll(q1 ^ a.y) + __popcll(q2 ^ b.x) + __popcll(q3 ^ b.y);
-            best = min(best, (d << 16) | (unsigned)(j0 + j));
+    for (int j = j_begin; j < j_end; j++) {
+        const uint32_t* __restrict__ t = tw + (long long)j * 8;             // wave-uniform address: scalar loads
+        uint32_t tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) tv[k] = t[k];
+#pragma unroll
+        for (int i = 0; i < HM_QPT; i++) {
+            unsigned d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) d += __popc(qw[i][k] ^ tv[k]);
+            best[i] = min(best[i], (d << 16) | (unsigned)j);
         }
     }
-    if (q < nq && best != 0xFFFFFFFFu) {
-        unsigned* out = (unsigned*)c.bf_idx + ((long long)vl * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
-        if (nsplit > 1) atomicMin(out, best); else *out = best;
+#pragma unroll
+    for (int i = 0; i < HM_QPT; i++) {
+        const int q = qbase + 256 * i;
+        if (q < nq && best[i] != 0xFFFFFFFFu) {
+            unsigned* out = (unsigned*)c.bf_idx + ((long long)vl * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
+            if (nsplit > 1) atomicMin(out, best[i]); else *out = best[i];
+        }
     }
 }
 
@@ -715,7 +734,8 @@ __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 // ------------------------------------------------------------------------------------------------------------
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_hamming, dim3((c.max_kps + 255) / 256, c.n_lanes * c.oct_cap, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
+    if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_hamming, dim3(c.n_lanes * c.oct_cap, (c.max_kps + 256 * HM_QPT - 1) / (256 * HM_QPT), (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)

@@ -161,6 +161,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.raw_n, (size_t)NI));
     HIPCHECK(dev_alloc(ctx, &d.kps, (size_t)NV * 4 * MK));
     HIPCHECK(dev_alloc(ctx, &d.desc, (size_t)NV * 4 * MK * 32));
+    HIPCHECK(dev_alloc(ctx, &d.mdesc, (size_t)NV * 4 * MK * 32));
     HIPCHECK(dev_alloc(ctx, &d.n_kps, (size_t)NV * 4));
     HIPCHECK(dev_alloc(ctx, &d.matches, (size_t)NV * 2 * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_matches, (size_t)NV * 2));
@@ -395,7 +396,13 @@ extern "C" int svo_kernel_times_reset(svo_ctx* ctx)
 
 // train-side splits of the brute-force matcher: enough workgroups for ~8 waves per SIMD (a ~2000 x 2000 problem is
 // 8 query blocks x 8 train tiles; with one split per lane a 16-lane launch keeps ONE wave per SIMD busy)
-static int hamming_splits(const svo_ctx* ctx) { int s = 2048 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 8 ? 8 : s); }
+static int hamming_splits(const svo_ctx* ctx)
+{
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("SVO_HAM_SPLITS"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return forced;
+    int s = 4096 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
 
 // ---- processNewImagePair ---------------------------------------------------------------------------------
 extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags)
