@@ -13,9 +13,11 @@
 __constant__ int c_umax[16];
 __constant__ int c_gauss7[7];
 __device__ __attribute__((aligned(16))) int8_t g_brief_rot[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS * 4];
-// the 749 pixels of the radius-15 disc as (LDS byte offset in the 37x40 window) | u << 16 | v << 24, padded to 768
-#define SVO_DISC_N 768
-__device__ uint32_t g_disc[SVO_DISC_N];
+// the radius-15 disc by rows of the describe window, for v_dot4_u32_u8: entry e = (v + 15) * 8 + d covers the window
+// bytes 4 + 4d .. 7 + 4d of row v + 18 (columns u = 4d - 15 .. 4d - 12); g_disc_m holds 1 per disc pixel,
+// g_disc_x holds u + 15 per disc pixel (0 outside), one byte each
+#define SVO_DISC_E 256
+__device__ uint32_t g_disc_m[SVO_DISC_E], g_disc_x[SVO_DISC_E];
 
 hipError_t svo_upload_tables()
 {
@@ -25,14 +27,18 @@ hipError_t svo_upload_tables()
     if (e != hipSuccess) return e;
     e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_rot), svo_brief_rot, sizeof(svo_brief_rot));
     if (e != hipSuccess) return e;
-    uint32_t disc[SVO_DISC_N];
-    int n = 0;
+    uint32_t dm[SVO_DISC_E], dx[SVO_DISC_E];
+    for (int i = 0; i < SVO_DISC_E; i++) { dm[i] = 0; dx[i] = 0; }
     for (int v = -15; v <= 15; v++) {
         const int um = svo_umax[v < 0 ? -v : v];
-        for (int u = -um; u <= um; u++) disc[n++] = (uint32_t)((v + 18) * 40 + (u + 18)) | ((uint32_t)(uint8_t)(int8_t)u << 16) | ((uint32_t)(uint8_t)(int8_t)v << 24);
+        for (int u = -um; u <= um; u++) {
+            const int en = (v + 15) * 8 + (u + 15) / 4, by = (u + 15) & 3;
+            dm[en] |= 1u << (8 * by); dx[en] |= (uint32_t)(u + 15) << (8 * by);
+        }
     }
-    while (n < SVO_DISC_N) disc[n++] = (uint32_t)(18 * 40 + 18);      // u = v = 0: contributes nothing
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_disc), disc, sizeof(disc));
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_disc_m), dm, sizeof(dm));
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_disc_x), dx, sizeof(dx));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -502,18 +508,24 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     const int nout = min((int)K, g.quota);
     for (int i = tid; i < nout; i += blockDim.x) {
         const unsigned long long k = keys[i];
-        c.lvl_pos[(long long)img * c.raw_cap + g.slot_off + i] = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+        const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+        c.lvl_pos[(long long)img * c.raw_cap + g.slot_off + i] = (pos % (uint32_t)g.w) | ((pos / (uint32_t)g.w) << 16);   // x | y << 16
         c.lvl_resp[(long long)img * c.raw_cap + g.slot_off + i] = inv_ord32((uint32_t)(k >> 32));
     }
     if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = nout;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x37 window.
+// K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x40 window.
 // One wave per keypoint slot, 4 independent waves per block (no block barriers: every wave owns its LDS region).
-//   A  the 37x40 window is fetched as aligned dwords and byte-aligned with v_alignbyte on the way into LDS;
-//   B  moments from a precomputed list of the 749 disc pixels (12 per lane);
-//   C  horizontal 7-tap pass: one lane = one row x 4 columns from three LDS dwords, 4 x u16 out as one b64;
+// VALU issue bounds this kernel (PMC: ~85 % busy), so every phase is written for instruction count:
+//   A  window rows y-18..y+18, columns x-19..x+20 fetched as aligned dwords, byte-aligned with v_alignbyte on the
+//      way into LDS; lane = (row mod 6, dword), seven steps of 6 rows with one 64-bit add each;
+//   B  moments by v_dot4_u32_u8: the disc starts on a dword boundary (column x-15 = byte 4), one lane = one
+//      (row, dword) with a 0/1 weight dword (row sums -> m01) and a (u+15) weight dword (-> m10 + 15 * sum);
+//      248 lane-tasks, 4 per lane; wave sums by DPP + readlane;
+//   C  horizontal 7-tap pass by two v_dot4_u32_u8 per output (taps 18,33,49,56 | 49,33,18,0 on bytes funnel-shifted
+//      into place), 4 outputs per lane-task, 4 x u16 out as one b64;
 //   D  the vertical 7-tap pass is evaluated ONLY at the 512 sample points the 256 tests need (8 per lane);
 //   E  256 tests packed with four wave ballots.
 // ------------------------------------------------------------------------------------------------------------
@@ -546,9 +558,26 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// sum over the 64 lanes (all active), returned wave-uniform: four DPP steps inside each row of 16, then one
+// v_readlane per row -- no LDS traffic, unlike the ds_bpermute butterflies of __shfl_xor
+__device__ __forceinline__ int wave_sum_uniform(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
+{
+    // the builtin, not inline asm: the hazard recogniser must see a DOT op to pad its result's wait states
+    return __builtin_amdgcn_udot4(a, b, acc, false);
+}
+
 __global__ void __launch_bounds__(256) k_describe(DevCtx c)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10];
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10 + 6];
     __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * 32];    // horizontal pass, 32 columns (31 used)
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int img = blockIdx.y;
@@ -561,55 +590,69 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
     const int rank = slot - g.slot_off;
     if (rank >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
     const uint32_t pos = c.lvl_pos[(long long)img * c.raw_cap + slot];
-    const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
+    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     uint32_t* R32 = raw32[wid];
-    const uint8_t* R = (const uint8_t*)R32;
-    // ---- A: window rows y-18..y+18, columns x-18..x+21 ----
+    // ---- A: window rows y-18..y+18, columns x-19..x+20 ----
     if ((((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0) {
-        const int xa = (x - 18) & ~3, sh = (x - 18) & 3;
-        for (int t = lane; t < 370; t += 64) {
-            const int r = t / 10, k = t - r * 10;
-            const uint32_t* p = (const uint32_t*)(lim + (long long)(y - 18 + r) * pitch + xa) + k;
-            R32[t] = __builtin_amdgcn_alignbyte(p[1], p[0], sh);
+        const int xa = (x - 19) & ~3, sh = (x - 19) & 3;
+        if (lane < 60) {
+            const int r0 = lane / 10, k = lane - r0 * 10;
+            const uint32_t* p = (const uint32_t*)(lim + (long long)(y - 18 + r0) * pitch + xa) + k;
+            const long long step = (long long)6 * pitch;
+            uint32_t* dst = R32 + lane;                                         // (r0 + 6 i) * 10 + k = lane + 60 i
+            uint32_t lo[7], hi[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                if (i < 6 || r0 == 0) { lo[i] = p[0]; hi[i] = p[1]; }          // rows 36 + r0 exist for r0 = 0 only
+                p = (const uint32_t*)((const uint8_t*)p + step);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) if (i < 6 || r0 == 0) dst[60 * i] = __builtin_amdgcn_alignbyte(hi[i], lo[i], sh);
         }
     } else {
+        const uint8_t* Rb = (const uint8_t*)R32; (void)Rb;
         for (int t = lane; t < 370; t += 64) {
             const int r = t / 10, k = t - r * 10;
-            const uint8_t* p = lim + (long long)(y - 18 + r) * pitch + (x - 18 + 4 * k);
+            const uint8_t* p = lim + (long long)(y - 18 + r) * pitch + (x - 19 + 4 * k);
             R32[t] = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
         }
     }
     wave_lds_sync();
-    // ---- B: moments ----
-    int m10 = 0, m01 = 0;
+    // ---- B: moments over the disc: 31 rows x 8 dwords = 248 lane-tasks ----
+    uint32_t m10u = 0; int m01 = 0, msum = 0;
 #pragma unroll
-    for (int i = 0; i < SVO_DISC_N / 64; i++) {
-        const uint32_t e = g_disc[i * 64 + lane];
-        const int I = R[e & 0xFFFFu];
-        m10 += __mul24((int)(int8_t)(e >> 16), I); m01 += __mul24((int)(int8_t)(e >> 24), I);
+    for (int i = 0; i < 4; i++) {
+        const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read rows that exist
+        const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 3 (vr = 31: row 34)
+        const uint32_t px = R32[(vr + 3) * 10 + 1 + d];
+        const uint32_t s = udot4(px, g_disc_m[en], 0u);
+        m10u = udot4(px, g_disc_x[en], m10u);
+        msum += (int)s;
+        m01 += __mul24(vr - 15, (int)s);
     }
-    m10 = wave_reduce_sum_i32(m10); m01 = wave_reduce_sum_i32(m01);
+    const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
+    m01 = wave_sum_uniform(m01);
     const float angle = atan2_deg((float)m01, (float)m10);
     int bin = (int)(angle * (1.0f / 12.0f) + 0.5f);
     if (bin >= SVO_BRIEF_NBINS) bin -= SVO_BRIEF_NBINS;
-    // ---- C: horizontal pass; Hb[r][q] = sum_k g[k] * raw[r][q + k], q = 0..31 ----
-    const int G0 = c_gauss7[0], G1 = c_gauss7[1], G2 = c_gauss7[2], G3 = c_gauss7[3];
+    // ---- C: horizontal pass; Hb[r][q] = sum_k g[k] * raw[r][q + 1 + k], q = 0..31 (column x - 15 + q) ----
+    const uint32_t GA = (uint32_t)c_gauss7[0] | ((uint32_t)c_gauss7[1] << 8) | ((uint32_t)c_gauss7[2] << 16) | ((uint32_t)c_gauss7[3] << 24);
+    const uint32_t GB = (uint32_t)c_gauss7[4] | ((uint32_t)c_gauss7[5] << 8) | ((uint32_t)c_gauss7[6] << 16);
     unsigned short* Hb = hb[wid];
     for (int t = lane; t < 37 * 8; t += 64) {
         const int r = t >> 3, gq = t & 7;
         const uint32_t w0 = R32[r * 10 + gq], w1 = R32[r * 10 + gq + 1], w2 = R32[r * 10 + gq + 2];
-        int pb[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { pb[k] = (w0 >> (8 * k)) & 0xFF; pb[4 + k] = (w1 >> (8 * k)) & 0xFF; pb[8 + k] = (w2 >> (8 * k)) & 0xFF; }
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) o[j] = (uint32_t)(__mul24(G0, pb[j] + pb[j + 6]) + __mul24(G1, pb[j + 1] + pb[j + 5]) + __mul24(G2, pb[j + 2] + pb[j + 4]) + __mul24(G3, pb[j + 3]));
-        uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
+        const uint32_t o0 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), GA, 0u));
+        const uint32_t o1 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), GA, 0u));
+        const uint32_t o2 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), GA, 0u));
+        const uint32_t o3 = udot4(w2, GB, udot4(w1, GA, 0u));
+        uint2 pk; pk.x = o0 | (o1 << 16); pk.y = o2 | (o3 << 16);
         *(uint2*)&Hb[r * 32 + gq * 4] = pk;
     }
     wave_lds_sync();
     // ---- D + E: vertical pass at the sample points only, then the tests ----
+    const int G0 = c_gauss7[0], G1 = c_gauss7[1], G2 = c_gauss7[2], G3 = c_gauss7[3];
     const int8_t* pat = g_brief_rot + bin * (SVO_BRIEF_NPAIRS * 4);
     unsigned long long bits[4];
 #pragma unroll
@@ -919,7 +962,8 @@ __global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance
             if (keep && o_idx < cap) {
                 const uint32_t k = (uint32_t)keys[i];
                 const long long o = (long long)img * c.raw_cap + g.slot_off + o_idx;
-                c.lvl_pos[o] = 0xFFFFFFu - (k & 0xFFFFFFu);
+                const uint32_t pos = 0xFFFFFFu - (k & 0xFFFFFFu);
+                c.lvl_pos[o] = (pos % (uint32_t)g.w) | ((pos / (uint32_t)g.w) << 16);                      // x | y << 16
                 c.lvl_resp[o] = (float)(k >> 24);                          // cv::FAST response = score
                 if (do_nms) { const uint32_t cxy = cellxy[i]; acc_cells[o_idx] = (cxy >> 16) * gly + (cxy & 0xFFFFu); }
             }

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_gather_mdesc(DevCtx c)
     dst[w] = src[w];
 }
 
-#define HM_QPT 1          // queries per thread (2 or 4 amortise the scalar loads further; measured no faster)
+#define HM_QPT 2          // queries per thread: each scalar train load feeds two distances (tools/ubench/ham_real: ~8 % over 1)
 
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
 {

@@ -401,7 +401,7 @@ static int hamming_splits(const svo_ctx* ctx)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("SVO_HAM_SPLITS"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return forced;
-    int s = 4096 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 16 ? 16 : s);
+    int s = 8192 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 
 // ---- processNewImagePair ---------------------------------------------------------------------------------

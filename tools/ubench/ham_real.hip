@@ -104,16 +104,14 @@ int main()
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = s; }
     hipMemcpy(dt, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     std::vector<int> c(lanes * 2, n); hipMemcpy(cnt, c.data(), lanes * 8, hipMemcpyHostToDevice);
-    for (int nsplit : { 1, 2, 4, 8, 16 }) {
-        run<1, 4, true, false>("smem qpt1 unroll4 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<1, 4, true, false>("smem qpt1 unroll4 atomic compact-grid", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
-        run<1, 4, false, false>("smem qpt1 unroll4 no-atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<2, 2, true, false>("smem qpt2 unroll2 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<2, 4, true, false>("smem qpt2 unroll4 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<4, 2, true, false>("smem qpt4 unroll2 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<1, 4, true, true>("lds  qpt1 unroll4 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<2, 4, true, true>("lds  qpt2 unroll4 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
-        run<4, 2, true, true>("lds  qpt4 unroll2 atomic", dq, dt, cnt, out, lanes, max_kps, nsplit, n, false);
+    for (int nsplit : { 4, 8, 16 }) {
+        run<1, 4, true, false>("smem qpt1 unroll4 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
+        run<1, 8, true, false>("smem qpt1 unroll8 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
+        run<2, 4, true, false>("smem qpt2 unroll4 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
+        run<1, 4, true, true>("lds  qpt1 unroll4 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
+        run<2, 4, true, true>("lds  qpt2 unroll4 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
+        run<4, 2, true, true>("lds  qpt4 unroll2 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
+        run<4, 4, true, true>("lds  qpt4 unroll4 compact", dq, dt, cnt, out, lanes, max_kps, nsplit, n, true);
     }
     return 0;
 }

@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(256) name(uint32_t* out, int iters, uint32_t s
     uint32_t b = seed * 0x9E3779B9u + threadIdx.x, c = b ^ 0x55AA55AAu;                              \
     for (int i = 0; i < iters; i++) {                                                               \
         REP16(asm volatile(ASM(0) "\n" ASM(1) "\n" ASM(2) "\n" ASM(3)                                 \
-              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)                           \
+              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc", "s20", "s21", "s22");)                           \
     }                                                                                               \
     if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345678u) out[0] = a0;                                             \
 }
@@ -58,6 +58,37 @@ __global__ void __launch_bounds__(256) name(uint32_t* out, int iters, uint32_t s
 #define A_MADU16(n)  "v_mad_u16 %" #n ", %4, %5, %" #n
 #define A_ADDSDWA(n) "v_add_u32_sdwa %" #n ", %4, %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
 #define A_XORS(n)    "v_xor_b32 %" #n ", s4, %" #n
+#define A_ANDLIT(n)  "v_and_b32 %" #n ", 0xff00ff, %" #n
+#define A_ANDINL(n)  "v_and_b32 %" #n ", 63, %" #n
+#define A_ANDV(n)    "v_and_b32 %" #n ", %4, %" #n
+#define A_ORV(n)     "v_or_b32 %" #n ", %4, %" #n
+#define A_SUBV(n)    "v_sub_u32 %" #n ", %4, %" #n
+#define A_MAXU(n)    "v_max_u32 %" #n ", %4, %" #n
+#define A_MAXU16(n)  "v_max_u16 %" #n ", %4, %" #n
+#define A_ADDU16(n)  "v_add_u16 %" #n ", %4, %" #n
+#define A_MULU16(n)  "v_mul_lo_u16 %" #n ", %4, %" #n
+#define A_LSHLV(n)   "v_lshlrev_b32 %" #n ", %4, %" #n
+#define A_ASHR(n)    "v_ashrrev_i32 %" #n ", 3, %" #n
+#define A_MOV(n)     "v_mov_b32 %" #n ", %4"
+#define A_CMPVCC(n)  "v_cmp_gt_u32 vcc, %4, %" #n
+#define A_CMPS(n)    "v_cmp_gt_u32 s[20:21], %4, %" #n
+#define A_CNDS(n)    "v_cndmask_b32 %" #n ", %4, %" #n ", s[20:21]"
+#define A_CNDVCC2(n) "v_cndmask_b32 %" #n ", %4, %5, vcc"
+#define A_ADDCO(n)   "v_add_co_u32 %" #n ", vcc, %4, %" #n
+#define A_SUBREV(n)  "v_subrev_u32 %" #n ", %4, %" #n
+#define A_CVT(n)     "v_cvt_f32_u32 %" #n ", %" #n
+#define A_MULF(n)    "v_mul_f32 %" #n ", %4, %" #n
+#define A_ADDF(n)    "v_add_f32 %" #n ", %4, %" #n
+#define A_PKFMA32(n) "v_pk_fma_f32 %" #n ", %4, %5, %" #n   /* placeholder */
+#define A_RCP(n)     "v_rcp_f32 %" #n ", %" #n
+#define A_MOVDPP(n)  "v_mov_b32_dpp %" #n ", %4 row_shr:1 row_mask:0xf bank_mask:0xf"
+#define A_ADDDPP(n)  "v_add_u32_dpp %" #n ", %4, %" #n " row_shr:1 row_mask:0xf bank_mask:0xf"
+#define A_READLN(n)  "v_readlane_b32 s22, %" #n ", 3"
+#define A_FMA64(n)   "v_add_f32 %" #n ", %4, %" #n
+#define A_CND64VCC(n) "v_cndmask_b32_e64 %" #n ", %4, %" #n ", vcc"
+#define A_CNDINIT(n)  "s_mov_b64 vcc, 0x5555\n v_cndmask_b32 %" #n ", %4, %" #n ", vcc"
+#define A_CNDCONST(n) "v_cndmask_b32_e64 %" #n ", 0, 1, vcc"
+#define A_CMPCND(n)   "v_cmp_gt_u32 vcc, %4, %" #n "\n v_cndmask_b32 %" #n ", %5, %" #n ", vcc"
 #define A_LSHL64(n)  "v_lshlrev_b64 %" #n ", 3, %" #n   /* placeholder, not used */
 
 DEFK(k_xor, A_XOR) DEFK(k_bcnt, A_BCNT) DEFK(k_add, A_ADD) DEFK(k_mul24, A_MUL24) DEFK(k_mad24, A_MAD24) DEFK(k_mullo, A_MULLO)
@@ -68,6 +99,10 @@ DEFK(k_sad, A_SAD) DEFK(k_sad16, A_SAD16) DEFK(k_msad, A_MSAD) DEFK(k_dot4, A_DO
 DEFK(k_bfi, A_BFI) DEFK(k_xad, A_XAD) DEFK(k_add3, A_ADD3) DEFK(k_or3, A_OR3) DEFK(k_mbcnt, A_MBCNT) DEFK(k_lshr, A_LSHR)
 DEFK(k_cndmask, A_CNDMASK) DEFK(k_fma, A_FMA) DEFK(k_pkfma16, A_PKFMA) DEFK(k_ffbh, A_FFBH) DEFK(k_madu16, A_MADU16) DEFK(k_addsdwa, A_ADDSDWA)
 DEFK(k_xor_sgpr, A_XORS)
+DEFK(k_andlit, A_ANDLIT) DEFK(k_andinl, A_ANDINL) DEFK(k_andv, A_ANDV) DEFK(k_orv, A_ORV) DEFK(k_subv, A_SUBV) DEFK(k_maxu, A_MAXU) DEFK(k_maxu16, A_MAXU16)
+DEFK(k_addu16, A_ADDU16) DEFK(k_mulu16, A_MULU16) DEFK(k_lshlv, A_LSHLV) DEFK(k_ashr, A_ASHR) DEFK(k_mov, A_MOV) DEFK(k_cmpvcc, A_CMPVCC) DEFK(k_cmps, A_CMPS)
+DEFK(k_cnds, A_CNDS) DEFK(k_cndvcc2, A_CNDVCC2) DEFK(k_addco, A_ADDCO) DEFK(k_subrev, A_SUBREV) DEFK(k_cvt, A_CVT) DEFK(k_mulf, A_MULF) DEFK(k_addf, A_ADDF) DEFK(k_rcp, A_RCP)
+DEFK(k_cnd64vcc, A_CND64VCC) DEFK(k_cndinit, A_CNDINIT) DEFK(k_cndconst, A_CNDCONST) DEFK(k_cmpcnd, A_CMPCND) DEFK(k_movdpp, A_MOVDPP) DEFK(k_adddpp, A_ADDDPP) DEFK(k_readlane, A_READLN)
 
 typedef void (*kern_t)(uint32_t*, int, uint32_t);
 struct Entry { const char* name; kern_t k; };
@@ -86,6 +121,10 @@ int main()
         {"v_lshl_or_b32", k_lshlor}, {"v_lshl_add_u32", k_lshladd}, {"v_and_or_b32", k_andor}, {"v_or3_b32", k_or3}, {"v_add3_u32", k_add3}, {"v_xad_u32", k_xad},
         {"v_min_u32", k_min}, {"v_min3_u32", k_min3}, {"v_max3_i32", k_max3}, {"v_lshrrev_b32", k_lshr}, {"v_cndmask_b32", k_cndmask},
         {"v_sad_u8", k_sad}, {"v_sad_u16", k_sad16}, {"v_msad_u8", k_msad}, {"v_dot4_u32_u8", k_dot4}, {"v_dot4_i32_i8", k_dot4i}, {"v_dot8_u32_u4", k_dot8}, {"v_dot2_u32_u16", k_dot2},
+        {"v_and_b32 literal", k_andlit}, {"v_and_b32 inline const", k_andinl}, {"v_and_b32 vgpr", k_andv}, {"v_or_b32", k_orv}, {"v_sub_u32", k_subv}, {"v_subrev_u32", k_subrev},
+        {"v_max_u32", k_maxu}, {"v_max_u16", k_maxu16}, {"v_add_u16", k_addu16}, {"v_mul_lo_u16", k_mulu16}, {"v_lshlrev_b32 vgpr shift", k_lshlv}, {"v_ashrrev_i32", k_ashr}, {"v_mov_b32", k_mov},
+        {"v_cmp_gt_u32 -> vcc", k_cmpvcc}, {"v_cmp_gt_u32 -> sgpr", k_cmps}, {"v_cndmask sgpr mask (VOP3)", k_cnds}, {"v_cndmask vcc 2 src", k_cndvcc2}, {"v_add_co_u32", k_addco}, {"v_cndmask e64 vcc", k_cnd64vcc}, {"s_mov vcc + v_cndmask e32", k_cndinit}, {"v_cndmask e64 0,1,vcc", k_cndconst}, {"v_cmp + v_cndmask (pair)", k_cmpcnd},
+        {"v_cvt_f32_u32", k_cvt}, {"v_mul_f32", k_mulf}, {"v_add_f32", k_addf}, {"v_rcp_f32", k_rcp}, {"v_mov_b32 dpp row_shr", k_movdpp}, {"v_add_u32 dpp", k_adddpp}, {"v_readlane_b32", k_readlane},
         {"v_add_u32_sdwa", k_addsdwa}, {"v_fma_f32", k_fma}, {"v_pk_fma_f16", k_pkfma16},
     };
     const int iters = 2000, blocks = n_cu * 8;          // 8 x 4 waves per CU = 8 waves per SIMD
