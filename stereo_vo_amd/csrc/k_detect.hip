@@ -12,7 +12,8 @@
 // device copies of the frozen tables
 __constant__ int c_umax[16];
 __constant__ int c_gauss7[7];
-__device__ __attribute__((aligned(16))) int8_t g_brief_rot[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS * 4];
+// steered BRIEF pairs as byte offsets into the 37x32 u16 horizontal-pass map: offA | offB << 16, off = ((y + 15) * 32 + x + 15) * 2
+__device__ __attribute__((aligned(16))) uint32_t g_brief_off[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS];
 // the radius-15 disc by rows of the describe window, for v_dot4_u32_u8: entry e = (v + 15) * 8 + d covers the window
 // bytes 4 + 4d .. 7 + 4d of row v + 18 (columns u = 4d - 15 .. 4d - 12); g_disc_m holds 1 per disc pixel,
 // g_disc_x holds u + 15 per disc pixel (0 outside), one byte each
@@ -25,8 +26,17 @@ hipError_t svo_upload_tables()
     if (e != hipSuccess) return e;
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_gauss7), svo_gauss7, sizeof(svo_gauss7));
     if (e != hipSuccess) return e;
-    e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_rot), svo_brief_rot, sizeof(svo_brief_rot));
-    if (e != hipSuccess) return e;
+    {
+        static uint32_t off[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS];
+        for (int b = 0; b < SVO_BRIEF_NBINS; b++)
+            for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) {
+                const int8_t* pr = svo_brief_rot[b][i];
+                const uint32_t oa = (uint32_t)(((pr[1] + 15) * 32 + pr[0] + 15) * 2), ob = (uint32_t)(((pr[3] + 15) * 32 + pr[2] + 15) * 2);
+                off[b * SVO_BRIEF_NPAIRS + i] = oa | (ob << 16);
+            }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_off), off, sizeof(off));
+        if (e != hipSuccess) return e;
+    }
     uint32_t dm[SVO_DISC_E], dx[SVO_DISC_E];
     for (int i = 0; i < SVO_DISC_E; i++) { dm[i] = 0; dx[i] = 0; }
     for (int v = -15; v <= 15; v++) {
@@ -533,18 +543,14 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
 
 __device__ __forceinline__ float atan2_deg(float y, float x)
 {
+    // the oracle's octant formula, with its two branch divisions folded into one (same operands, same IEEE result)
     const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, cq, c2;
-    if (ax >= ay) {
-        cq = ay / (ax + 2.220446e-16f);
-        c2 = cq * cq;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cq;
-    } else {
-        cq = ax / (ay + 2.220446e-16f);
-        c2 = cq * cq;
-        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cq;
-    }
+    const bool steep = !(ax >= ay);
+    const float cq = (steep ? ax : ay) / ((steep ? ay : ax) + 2.220446e-16f);
+    const float c2 = cq * cq;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cq;
+    if (steep) a = 90.0f - a;
     if (x < 0.0f) a = 180.0f - a;
     if (y < 0.0f) a = 360.0f - a;
     return a;
@@ -579,7 +585,9 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
 {
     __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10 + 6];
     __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * 32];    // horizontal pass, 32 columns (31 used)
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
+    // the scalar unit
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int img = blockIdx.y;
     const int slot = blockIdx.x * 4 + wid;       // position in the level-segmented arrays
     if (slot >= c.n_slots) return;
@@ -589,7 +597,7 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
     const LevelGeom& g = c.lv[level];
     const int rank = slot - g.slot_off;
     if (rank >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
-    const uint32_t pos = c.lvl_pos[(long long)img * c.raw_cap + slot];
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     uint32_t* R32 = raw32[wid];
@@ -653,14 +661,12 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c)
     wave_lds_sync();
     // ---- D + E: vertical pass at the sample points only, then the tests ----
     const int G0 = c_gauss7[0], G1 = c_gauss7[1], G2 = c_gauss7[2], G3 = c_gauss7[3];
-    const int8_t* pat = g_brief_rot + bin * (SVO_BRIEF_NPAIRS * 4);
+    const uint32_t* pat = g_brief_off + bin * SVO_BRIEF_NPAIRS;
     unsigned long long bits[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int i = k * 64 + lane;
-        const int pr = *(const int*)(pat + i * 4);
-        const int ax = (int8_t)(pr & 0xFF), ay = (int8_t)((pr >> 8) & 0xFF), bx = (int8_t)((pr >> 16) & 0xFF), by = (int8_t)((pr >> 24) & 0xFF);
-        const unsigned short* pa = &Hb[(ay + 15) * 32 + (ax + 15)], *pb2 = &Hb[(by + 15) * 32 + (bx + 15)];
+        const uint32_t pr = pat[k * 64 + lane];
+        const unsigned short* pa = (const unsigned short*)((const uint8_t*)Hb + (pr & 0xFFFFu)), *pb2 = (const unsigned short*)((const uint8_t*)Hb + (pr >> 16));
         const int sa = __mul24(G0, pa[0] + pa[6 * 32]) + __mul24(G1, pa[32] + pa[5 * 32]) + __mul24(G2, pa[2 * 32] + pa[4 * 32]) + __mul24(G3, pa[3 * 32]);
         const int sb = __mul24(G0, pb2[0] + pb2[6 * 32]) + __mul24(G1, pb2[32] + pb2[5 * 32]) + __mul24(G2, pb2[2 * 32] + pb2[4 * 32]) + __mul24(G3, pb2[3 * 32]);
         const int a = (sa + 32768) >> 16, b = (sb + 32768) >> 16;
