@@ -94,20 +94,26 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
 
 // ------------------------------------------------------------------------------------------------------------
 // K1: one pyramid level from the previous one, bilinear with the frozen 11-bit integer tables.
-// HBM-bound by design: ~1.44 source bytes read and 1 byte written per output pixel.  A 256-thread block produces
-// a 128x32 destination tile (big enough that ~6 dword loads per thread are in flight, the kernel is latency-bound
-// otherwise): the <= 160x41 source window is staged in LDS with aligned dword loads, the tile's slice of the x/y
-// tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
+// HBM-bound on paper (~1.44 source bytes read + 1 written per output pixel), VALU-issue-bound in practice, so the
+// blend is written for instruction count.  A 256-thread block produces a 128x32 destination tile: the <= 160x41
+// source window is staged in LDS by aligned dwords (240 threads x 7 passes of 6 rows), the tile's slice of the
+// x / y tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
+// Per pixel: the two taps of each source row come out of two aligned LDS dwords as a u16 pair by one v_perm (the
+// selector is a per-column constant), v_dot2_u32_u16 applies (2048 - ax, ax), two 24-bit multiply-adds apply the
+// row weights pre-scaled by 4 so that the rounded result lands in byte 3, and three v_perm pack four results.
+// Exact: p00*wx0*wy0 + p01*wx1*wy0 + p10*wx0*wy1 + p11*wx1*wy1 regrouped, every intermediate < 2^32.
 // ------------------------------------------------------------------------------------------------------------
 #define RZ_W 128
 #define RZ_H 32
 #define RZ_SP 160     // LDS window pitch in bytes (40 dwords >= 128 * 1.2 + 2 + 3)
 #define RZ_SH 41      // >= 32 * 1.2 + 2
 
+typedef unsigned short rz_u16x2 __attribute__((ext_vector_type(2)));
+
 __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t win[RZ_SH * RZ_SP];
-    __shared__ uint32_t xtab[RZ_W], ytab[RZ_H];
+    __shared__ __attribute__((aligned(16))) uint32_t win[(RZ_SH + 1) * (RZ_SP / 4)];
+    __shared__ uint32_t xw[RZ_W], xr[RZ_W], yw[RZ_H], yr[RZ_H];
     const int img = blockIdx.z, tid = threadIdx.x;
     const LevelGeom& d = c.lv[level];
     const LevelGeom& s = c.lv[level - 1];
@@ -116,49 +122,64 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
     uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
     const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
     const int sx0 = xi[dx0] & ~3, sy0 = yi[dy0];                       // window origin (block-uniform)
-    if (tid < RZ_W) { const int x = min(dx0 + tid, d.w - 1); xtab[tid] = ((uint32_t)(xi[x] - sx0) << 16) | (uint32_t)xf[x]; }
-    else if (tid < RZ_W + RZ_H) { const int y = min(dy0 + tid - RZ_W, d.h - 1); ytab[tid - RZ_W] = ((uint32_t)(yi[y] - sy0) << 16) | (uint32_t)yf[y]; }
+    if (tid < RZ_W) {
+        const int x = min(dx0 + tid, d.w - 1), rx = xi[x] - sx0, ax = xf[x];
+        xw[tid] = (uint32_t)(2048 - ax) | ((uint32_t)ax << 16);                                    // dot2 weights
+        xr[tid] = (uint32_t)rx;
+    } else if (tid < RZ_W + RZ_H) {
+        const int y = min(dy0 + tid - RZ_W, d.h - 1), ay = yf[y];
+        yw[tid - RZ_W] = (uint32_t)(4 * (2048 - ay)) | ((uint32_t)(4 * ay) << 16);
+        yr[tid - RZ_W] = (uint32_t)(yi[y] - sy0);
+    }
     if (c.debug_mode == 5) { /* ablation: no staging */ }
     else if ((((uintptr_t)src | (uintptr_t)spitch) & 3) == 0) {
-        for (int i = tid; i < RZ_SH * (RZ_SP / 4); i += 256) {
-            const int r = i / (RZ_SP / 4), q = i - r * (RZ_SP / 4);
-            const int yy = min(sy0 + r, s.h - 1), xx = min(sx0 + 4 * q, spitch - 4);
-            *(uint32_t*)&win[r * RZ_SP + 4 * q] = *(const uint32_t*)(src + (long long)yy * spitch + xx);
+        if (tid < 240) {
+            const int r = tid / 40, q = tid - r * 40;
+            const uint32_t xx = (uint32_t)min(sx0 + 4 * q, spitch - 4);
+            uint32_t v[7];
+#pragma unroll
+            for (int p = 0; p < 7; p++) {
+                const uint32_t yy = (uint32_t)min(sy0 + r + 6 * p, s.h - 1);
+                v[p] = *(const uint32_t*)(src + (__umul24(yy, (uint32_t)spitch) + xx));          // 32-bit offset from a uniform base
+            }
+#pragma unroll
+            for (int p = 0; p < 7; p++) win[tid + 240 * p] = v[p];                                 // rows 0..41 (pitch 40 dwords)
         }
     } else {
+        uint8_t* wb = (uint8_t*)win;
         for (int i = tid; i < RZ_SH * RZ_SP; i += 256) {
             const int r = i / RZ_SP, q = i - r * RZ_SP;
-            win[i] = src[(long long)min(sy0 + r, s.h - 1) * spitch + min(sx0 + q, s.w - 1)];
+            wb[i] = src[(long long)min(sy0 + r, s.h - 1) * spitch + min(sx0 + q, s.w - 1)];
         }
     }
     __syncthreads();
     const int gx = (tid & 31) * 4, x4 = dx0 + gx;                       // 4 adjacent pixels per row, 4 rows per thread
     if (x4 >= d.w || c.debug_mode == 6) return;
-    uint32_t tx[4];
+    uint32_t wx[4], sel[4]; int wi[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) tx[k] = xtab[gx + k];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t rx = xr[gx + k];
+        wx[k] = xw[gx + k]; wi[k] = (int)(rx >> 2);
+        sel[k] = 0x0c010c00u + (rx & 3u) * 0x00010001u;                 // bytes (rx & 3, rx & 3 + 1) of {hi, lo} -> u16 pair
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int gy = (tid >> 5) + 8 * j, y = dy0 + gy;
         if (y >= d.h) continue;
-        const uint32_t ty = ytab[gy];
-        const int ry = (int)(ty >> 16), ay = (int)(ty & 0xFFFFu);
-        const uint32_t* r0 = (const uint32_t*)&win[ry * RZ_SP], *r1 = r0 + RZ_SP / 4;
-        uint32_t out = 0;
+        const uint32_t wy = yw[gy];
+        const uint32_t wy0 = wy & 0xFFFFu, wy1 = wy >> 16;
+        const uint32_t* r0 = win + yr[gy] * (RZ_SP / 4), *r1 = r0 + RZ_SP / 4;
+        uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int rx = (int)(tx[k] >> 16), ax = (int)(tx[k] & 0xFFFFu);
-            // the two taps of a row are fetched as ALIGNED dwords and byte-aligned in registers: left to itself the
-            // compiler fuses the byte pair into one ds_read_u16 at an odd address, which the LDS replays lane by lane
-            const uint32_t t0 = __builtin_amdgcn_alignbyte(r0[(rx >> 2) + 1], r0[rx >> 2], rx & 3);
-            const uint32_t t1 = __builtin_amdgcn_alignbyte(r1[(rx >> 2) + 1], r1[rx >> 2], rx & 3);
-            // exact integer regrouping of p00*wx0*wy0 + p01*wx1*wy0 + p10*wx0*wy1 + p11*wx1*wy1 with 24-bit multiplies
-            // (v_mul_u32_u24 / v_mad_u32_u24 are full rate, the 32-bit v_mul_lo_u32 is not): operands < 2^24
-            const unsigned top = __umul24(t0 & 0xFFu, 2048 - ax) + __umul24((t0 >> 8) & 0xFFu, ax);
-            const unsigned bot = __umul24(t1 & 0xFFu, 2048 - ax) + __umul24((t1 >> 8) & 0xFFu, ax);
-            const unsigned v = __umul24(top, 2048 - ay) + __umul24(bot, ay);
-            out |= ((v + (1u << 21)) >> 22) << (8 * k);
+            const uint32_t t0 = __builtin_amdgcn_perm(r0[wi[k] + 1], r0[wi[k]], sel[k]);
+            const uint32_t t1 = __builtin_amdgcn_perm(r1[wi[k] + 1], r1[wi[k]], sel[k]);
+            const uint32_t top = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t0), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
+            const uint32_t bot = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t1), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
+            v[k] = __umul24(bot, wy1) + (__umul24(top, wy0) + (1u << 23));                       // result in byte 3
         }
+        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x07030c0cu);
+        const uint32_t out = lo | hi;
         if (c.debug_mode == 7 && out != 0x12345678u) continue;
         *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64: the tail of the last dword is padding
     }
