@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
 // and keep the best quota.  One 512-thread block per (image, level).
 // ------------------------------------------------------------------------------------------------------------
 #define SEL_MAX 2048     // >= 2 * quota[0]
+#define SEL_TIE_MAX (2 * SEL_MAX)      // LDS tie list: u32 entries aliasing the u64 key array
 
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x, int y)
 {
@@ -480,8 +481,10 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     __shared__ uint32_t sel[SEL_MAX];
     __shared__ unsigned hist[256];
     __shared__ int scan_s[32];
-    __shared__ unsigned s_prefix, s_need, s_sel;
-    const int level = blockIdx.x, img = blockIdx.y;
+    __shared__ unsigned s_prefix, s_need, s_sel, s_tie, s_ntie;
+    // image index fastest: consecutive workgroups go to consecutive XCDs, so with the level fastest every level-0 block
+    // (the heavy ones) landed on the same XCD
+    const int level = blockIdx.y, img = blockIdx.x;
     const LevelGeom& g = c.lv[level];
     const int tid = threadIdx.x;
     unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
@@ -489,41 +492,82 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     const unsigned K = min(nc, (unsigned)(2 * g.quota));
     if (K == 0 || g.quota <= 0) { if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; return; }
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
-    // ---- radix select: the K-th largest of the unique 32-bit keys, 8 bits per pass ----
+    // ---- the K largest of the unique 32-bit keys (score << 24 | inverted position) ----
+    // Two sweeps over the candidate list, eight independent loads in flight per thread (a one-load-per-iteration loop
+    // pays the ~1 us global latency 64 times per sweep on level 0): (1) histogram of the score byte -> the score bin
+    // b that holds the K-th key; (2) keys above b go straight to sel[], keys in bin b to an LDS tie list, which three
+    // LDS-resident radix passes then cut at exactly K.  A tie list that does not fit falls back to global passes.
+    uint32_t* tie = (uint32_t*)keys;                                   // SEL_TIE_MAX u32 alias the u64 key array (free until Harris)
+    for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+    if (tid == 0) { s_sel = 0; s_tie = 0; }
+    __syncthreads();
+    for (unsigned base = tid; base < nc; base += 8 * 512) {
+        uint32_t k[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const unsigned i = base + u * 512; k[u] = i < nc ? ck[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (base + u * 512 < nc) atomicAdd(&hist[k[u] >> 24], 1u);
+    }
+    __syncthreads();
     unsigned prefix = 0, mask = 0, need = K;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u); }
-        __syncthreads();
-        // bins in DESCENDING order: thread t owns bin 255 - t; the bin where the running count first reaches `need`
-        const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+    {
+        const int mine = tid < 256 ? (int)hist[255 - tid] : 0;         // bins in DESCENDING order: thread t owns bin 255 - t
         int tot;
         const int before = block_exclusive_scan(mine, scan_s, &tot);
-        if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { s_prefix = prefix | ((unsigned)(255 - tid) << shift); s_need = need - (unsigned)before; }
+        if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { s_prefix = (unsigned)(255 - tid) << 24; s_need = need - (unsigned)before; s_ntie = (unsigned)mine; }
         __syncthreads();
-        prefix = s_prefix; need = s_need; mask |= 255u << shift;
-        __syncthreads();
+        prefix = s_prefix; need = s_need; mask = 0xFF000000u;
     }
-    const uint32_t cutoff = prefix;     // exactly K keys are >= cutoff (keys are unique)
-    // ---- compact the K winners, then compute their Harris responses densely ----
-    if (tid == 0) s_sel = 0;
-    for (int i = tid; i < SEL_MAX; i += blockDim.x) keys[i] = 0;
-    __syncthreads();
-    for (unsigned base = 0; base < nc; base += blockDim.x) {
-        const unsigned i = base + tid;
-        uint32_t k = 0;
-        const bool take = i < nc && (k = ck[i]) >= cutoff;
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            unsigned b0 = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if ((tid & 63) == leader) b0 = atomicAdd(&s_sel, (unsigned)__popcll(m));
-            b0 = __shfl(b0, leader, 64);
-            const unsigned slot = b0 + __popcll(m & ((1ull << (tid & 63)) - 1ull));
-            if (take && slot < SEL_MAX) sel[slot] = k;
+    const unsigned n_tie = s_ntie;
+    uint32_t cutoff;
+    if (n_tie <= SEL_TIE_MAX) {
+        for (unsigned base = tid; base < nc; base += 8 * 512) {
+            uint32_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const unsigned i = base + u * 512; k[u] = i < nc ? ck[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (base + u * 512 >= nc) continue;
+                if ((k[u] & 0xFF000000u) > prefix) sel[atomicAdd(&s_sel, 1u)] = k[u];          // < K of these, K <= SEL_MAX
+                else if ((k[u] & 0xFF000000u) == prefix) tie[atomicAdd(&s_tie, 1u)] = k[u];
+            }
         }
+        __syncthreads();
+        for (int shift = 16; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (unsigned i = tid; i < n_tie; i += blockDim.x) { const uint32_t k = tie[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u); }
+            __syncthreads();
+            const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+            int tot;
+            const int before = block_exclusive_scan(mine, scan_s, &tot);
+            if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { s_prefix = prefix | ((unsigned)(255 - tid) << shift); s_need = need - (unsigned)before; }
+            __syncthreads();
+            prefix = s_prefix; need = s_need; mask |= 255u << shift;
+            __syncthreads();
+        }
+        cutoff = prefix;     // exactly K keys are >= cutoff (keys are unique)
+        for (unsigned i = tid; i < n_tie; i += blockDim.x) { const uint32_t k = tie[i]; if (k >= cutoff) sel[atomicAdd(&s_sel, 1u)] = k; }
+        __syncthreads();
+    } else {
+        for (int shift = 16; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u); }
+            __syncthreads();
+            const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+            int tot;
+            const int before = block_exclusive_scan(mine, scan_s, &tot);
+            if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { s_prefix = prefix | ((unsigned)(255 - tid) << shift); s_need = need - (unsigned)before; }
+            __syncthreads();
+            prefix = s_prefix; need = s_need; mask |= 255u << shift;
+            __syncthreads();
+        }
+        cutoff = prefix;
+        for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if (k >= cutoff) { const unsigned sl = atomicAdd(&s_sel, 1u); if (sl < SEL_MAX) sel[sl] = k; } }
+        __syncthreads();
     }
+    for (int i = tid; i < SEL_MAX; i += blockDim.x) keys[i] = 0;
     __syncthreads();
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     const bool aligned = (((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0;
@@ -1030,7 +1074,7 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 
 void launch_select(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_select, dim3(c.n_levels, c.n_img), dim3(512), 0, st, c);
+    hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
 }
 
 void launch_describe(const DevCtx& c, hipStream_t st)
