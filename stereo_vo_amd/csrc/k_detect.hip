@@ -107,17 +107,27 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
 #define RZ_H 32
 #define RZ_SP 160     // LDS window pitch in bytes (40 dwords >= 128 * 1.2 + 2 + 3)
 #define RZ_SH 41      // >= 32 * 1.2 + 2
+#define RZ_CHUNK 16   // consecutive tiles per XCD turn
 
 typedef unsigned short rz_u16x2 __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
+__global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div_img, FastDiv div_ntx)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[(RZ_SH + 1) * (RZ_SP / 4)];
     __shared__ uint32_t xw[RZ_W], xr[RZ_W], yw[RZ_H], yr[RZ_H];
-    const int img = blockIdx.z, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const LevelGeom& d = c.lv[level];
     const LevelGeom& s = c.lv[level - 1];
-    const int dx0 = blockIdx.x * RZ_W, dy0 = blockIdx.y * RZ_H;
+    // XCD-aware tile order (see k_fast): chunks of RZ_CHUNK consecutive tiles of the image-major tile list per XCD turn.
+    // A 160-byte source row touches two or three 128-byte L2 lines, shared with the tiles left and right: through
+    // one L2 they are fetched once, through eight they were fetched twice (measured 940 MB -> for 475 MB of source).
+    const int ntx = (d.w + RZ_W - 1) / RZ_W, nty = (d.h + RZ_H - 1) / RZ_H, per_img = ntx * nty;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t work = c.debug_mode == 8 ? blockIdx.x : (((slot / RZ_CHUNK) * 8 + (blockIdx.x & 7)) * RZ_CHUNK + slot % RZ_CHUNK);
+    const int img = (int)fastdiv(work, div_img);
+    if (img >= c.n_img) return;
+    const int tt = (int)work - img * per_img, tby = (int)fastdiv((uint32_t)tt, div_ntx), tbx = tt - tby * ntx;
+    const int dx0 = tbx * RZ_W, dy0 = tby * RZ_H;
     int spitch; const uint8_t* src = level_ptr(c, img, level - 1, spitch);
     uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
     const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
@@ -211,6 +221,7 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level)
 #define FT_SH (FT_H + 2)      // y = y0 - 1 + r, r in [0, 30); interior r in [1, 29)
 #define FT_SP 72              // score map pitch
 #define FT_NG (FT_SW / 4)     // 17 groups of four positions per row
+#define FT_CHUNK 32            // consecutive tiles per XCD turn
 static_assert(FT_SH == 30 && FT_NG == 17 && FT_LH == 36, "k_fast's thread mapping is written for the 64x28 tile");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -278,12 +289,21 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     __shared__ unsigned s_count;
     __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
     __shared__ unsigned s_nout;
-    const int img = blockIdx.y, tid = threadIdx.x;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The global work list
+    // (image-major, then the image's tiles of all levels) is cut into chunks of FT_CHUNK consecutive tiles and chunk k
+    // goes to XCD k % 8, so the halo columns / rows that neighbouring tiles share are re-read from that XCD's L2 rather
+    // than through another one.  (One contiguous eighth of every image per XCD shares more, but gives each XCD a
+    // fixed set of pyramid levels -- their corner densities differ and the launch waits for the slowest XCD: measured.)
+    const int tid = threadIdx.x;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t work = c.debug_mode == 8 ? blockIdx.x : (((slot / FT_CHUNK) * 8 + (blockIdx.x & 7)) * FT_CHUNK + slot % FT_CHUNK);
+    const int img = (int)fastdiv(work, c.div_tiles), tile_id = (int)work - img * c.n_tiles;
+    if (img >= c.n_img) return;
     int level = 0;
 #pragma unroll
-    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && (int)blockIdx.x >= c.lv[l].tile_off) level = l;
+    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && tile_id >= c.lv[l].tile_off) level = l;
     const LevelGeom& g = c.lv[level];
-    const int t = blockIdx.x - g.tile_off;
+    const int t = tile_id - g.tile_off;
     const int by = t / g.tiles_x, bx = t - by * g.tiles_x;
     const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
     int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
@@ -1063,13 +1083,16 @@ void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned fl
 void launch_resize(const DevCtx& c, int level, hipStream_t st)
 {
     const LevelGeom& d = c.lv[level];
-    hipLaunchKernelGGL(k_resize, dim3((d.w + RZ_W - 1) / RZ_W, (d.h + RZ_H - 1) / RZ_H, c.n_img), dim3(256), 0, st, c, level);
+    const int ntx = (d.w + RZ_W - 1) / RZ_W, per_img = ntx * ((d.h + RZ_H - 1) / RZ_H);
+    const long long total = (long long)per_img * c.n_img, unit = 8 * RZ_CHUNK;
+    hipLaunchKernelGGL(k_resize, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(256), 0, st, c, level, make_fastdiv((uint32_t)per_img), make_fastdiv((uint32_t)ntx));
 }
 
 void launch_fast(const DevCtx& c, hipStream_t st)
 {
     if (c.n_tiles <= 0) return;
-    hipLaunchKernelGGL(k_fast, dim3(c.n_tiles, c.n_img), dim3(256), 0, st, c);
+    const long long total = (long long)c.n_tiles * c.n_img, unit = 8 * FT_CHUNK;
+    hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(256), 0, st, c);
 }
 
 void launch_select(const DevCtx& c, hipStream_t st)

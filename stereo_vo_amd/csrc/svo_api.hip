@@ -343,6 +343,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     if (off > ctx->pyr_bytes_alloc || cand_off > ctx->cand_total_alloc || (int)rtab.size() > ctx->rtab_alloc || slot_off > d.raw_cap) return SVO_ERR_CAPACITY;
     if (!fast_orb && slot_off > d.max_kps) return SVO_ERR_CAPACITY;                 // ORB mode: all levels feed one list
     d.n_tiles = tile_off; d.n_slots = slot_off; d.cand_total = ctx->cand_total_alloc;
+    d.div_tiles = make_fastdiv((uint32_t)(tile_off > 0 ? tile_off : 1));
     if (!rtab.empty()) HIPCHECK(hipMemcpy(d.rtab, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHECK(configure_nms_rowsort(d));
     ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = fast_orb ? p.orb_nfeats : nfe; ctx->geom_nlevels = nlev;

@@ -25,6 +25,26 @@
 #define SVO_ST_CAND_OVERFLOW 1u
 #define SVO_ST_KPS_OVERFLOW 2u
 
+// division of a 32-bit unsigned by a launch-time constant (Granlund-Montgomery round-up): exact for every x, and on a
+// wave-uniform x it compiles to s_mul_hi_u32 + three scalar ops -- the hardware has no integer divide, and the
+// compiler's expansion costs ~25 VALU instructions per use
+struct FastDiv { uint32_t m, s1, s2, d; };
+static inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f; f.d = d;
+    uint32_t l = 0; while ((1ull << l) < d) l++;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.s1 = l < 1 ? l : 1; f.s2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, const FastDiv& f)
+{
+    const uint32_t t = __umulhi(f.m, x);
+    return (t + ((x - t) >> f.s1)) >> f.s2;
+}
+#endif
+
 struct LevelGeom {
     int w, h, pitch;
     int tiles_x, tiles_y, tile_off;   // FAST tiling of the [EDGE, w-EDGE) x [EDGE, h-EDGE) interior
@@ -62,6 +82,7 @@ struct DevCtx {
     int max_h;                // row-index table pitch
     int img0_pitch;
     int max_kps, raw_cap, cand_total, n_tiles, n_slots;
+    FastDiv div_tiles;        // / n_tiles
     int fast_th, orb_th;
     int debug_mode;           // SVO_DEBUG_MODE env (kernel ablations while tuning; 0 in production)
     long long pyr_bytes;
