@@ -512,14 +512,24 @@ __global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c)
     }
 }
 
+// Symmetric epipolar test e = max(dA^2 / |lA|^2, dB^2 / |lB|^2) <= 1 with the oracle's arithmetic, minus its two f64
+// divisions in all but borderline cases: the oracle's e_X = fl(fl(d*d) * fl(1 / den)) is within 2 ulp of dd / den, so
+// dd <= den * (1 - 2^-40) decides "inlier" and dd >= den * (1 + 2^-40) decides "outlier" with certainty; only a point
+// inside that band (or a degenerate line, den <= 0 / NaN) replays the exact expression.  Same decisions, bit for bit.
 __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, float fx2, float fy2)
 {
     const double x1 = (double)fx1, y1 = (double)fy1, x2 = (double)fx2, y2 = (double)fy2;
     double a = (F[0] * x1 + F[1] * y1) + F[2], b = (F[3] * x1 + F[4] * y1) + F[5], cc = (F[6] * x1 + F[7] * y1) + F[8];
-    const double sB = 1.0 / (a * a + b * b), dB = (x2 * a + y2 * b) + cc;
+    const double denB = a * a + b * b, dB = (x2 * a + y2 * b) + cc;
     a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; cc = (F[2] * x2 + F[5] * y2) + F[8];
-    const double sA = 1.0 / (a * a + b * b), dA = (x1 * a + y1 * b) + cc;
-    const double eA = (dA * dA) * sA, eB = (dB * dB) * sB;
+    const double denA = a * a + b * b, dA = (x1 * a + y1 * b) + cc;
+    const double ddA = dA * dA, ddB = dB * dB;
+    const double lo = 1.0 - 9.094947017729282e-13, hi = 1.0 + 9.094947017729282e-13;            // 1 -+ 2^-40
+    const bool inA = ddA <= denA * lo, inB = ddB <= denB * lo, outA = ddA >= denA * hi, outB = ddB >= denB * hi;
+    const bool sure = (denA > 0.0) & (denB > 0.0) & (inA | outA) & (inB | outB);
+    if (__builtin_expect(sure, 1)) return inA & inB;
+    const double sB = 1.0 / denB, sA = 1.0 / denA;
+    const double eA = ddA * sA, eB = ddB * sB;
     const double e = eA > eB ? eA : eB;
     return e <= 1.0;
 }
@@ -548,7 +558,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
         for (int h = 0; h < RC_HB; h++) cnt[h] += fm_inlier(Fs[h], p.x, p.y, p.z, p.w);
     }
 #pragma unroll
-    for (int h = 0; h < RC_HB; h++) { const int v = wave_reduce_sum_i32(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
+    for (int h = 0; h < RC_HB; h++) { const int v = wave_sum_uniform(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
     __syncthreads();
     if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_HYP + h0 + tid] = cnt_s[tid];
 }

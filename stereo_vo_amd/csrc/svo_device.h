@@ -180,6 +180,17 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int P
     __syncthreads();
 }
 
+// sum over the 64 lanes (all active), returned wave-uniform: four DPP steps inside each row of 16, then one
+// v_readlane per row -- no LDS traffic, unlike the ds_bpermute butterflies of __shfl_xor
+__device__ __forceinline__ int wave_sum_uniform(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);     // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 __device__ __forceinline__ int wave_reduce_sum_i32(int v)
 {
 #pragma unroll
