@@ -204,21 +204,34 @@ __device__ __forceinline__ double wave_reduce_sum_f64(double v)
     return v;
 }
 
-// exclusive prefix sum of one int per thread over the block (blockDim.x <= 1024); `scratch` has >= 17 ints.
-// returns the exclusive prefix; *total receives the block sum.
+// inclusive prefix sum over the 64 lanes (all active) on the DPP network: row_shr 1/2/4/8 scan each row of 16,
+// row_bcast15 / row_bcast31 carry the row totals forward.  Six VALU instructions, no LDS (the __shfl_up version is
+// six ds_bpermute round trips plus selects).
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// exclusive prefix sum of one int per thread over the block (blockDim.x <= 1024, a multiple of 64, called by ALL
+// threads); `scratch` has >= 17 ints.  Returns the exclusive prefix; *total receives the block sum.
+// Two barriers: one so that the previous call's readers are done with `scratch`, one after the wave totals land;
+// every wave then sums the totals below it itself (16 lanes, DPP) instead of waiting for a serial pass of thread 0.
 __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total)
 {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (blockDim.x + 63) >> 6;
+    const int inc = wave_inclusive_scan(v);
     __syncthreads();
     if (lane == 63) scratch[wid] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < nw; w++) { int t = scratch[w]; scratch[w] = s; s += t; } scratch[16] = s; }
-    __syncthreads();
-    const int base = scratch[wid];
-    *total = scratch[16];
+    const int t = lane < nw ? scratch[lane] : 0;
+    *total = wave_sum_uniform(t);
+    const int base = wave_sum_uniform(lane < wid ? t : 0);
     return base + inc - v;
 }
 
