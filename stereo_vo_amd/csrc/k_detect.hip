@@ -641,14 +641,6 @@ __device__ __forceinline__ float atan2_deg(float y, float x)
     return a;
 }
 
-// make this wave's LDS writes visible to its own later reads (no s_barrier: waves do not share data here)
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
 {
     // the builtin, not inline asm: the hazard recogniser must see a DOT op to pad its result's wait states

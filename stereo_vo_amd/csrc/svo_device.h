@@ -159,21 +159,32 @@ __device__ __forceinline__ float inv_ord32(uint32_t k)
 // ---- block-wide bitonic sort of P (power of two) 64-bit keys held in LDS ---------------------------------
 // DESC = true sorts descending.  All threads of the block must call it; keys beyond the live count must be
 // padded by the caller (0 for descending, ~0 for ascending).
+// make this wave's LDS writes visible to its own later reads (no s_barrier: waves do not share data here)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <bool DESC>
 __device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int P)
 {
-    const int tid = threadIdx.x, nt = blockDim.x;
+    // One compare-exchange per work item t in [0, P/2): i = t with a zero bit inserted at log2(j), partner i | j -- every
+    // thread is busy in every stage.  A wave's 64 consecutive work items stay inside one aligned 128-key segment while
+    // j <= 64, so those stages need no block barrier, only the wave's own LDS ordering; for P = 2048 that leaves 14
+    // block barriers out of 66 stages.
+    const int tid = threadIdx.x, nt = blockDim.x, half = P >> 1;
+    __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            for (int i = tid; i < P; i += nt) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
-                    const bool up = ((i & k) == 0);
-                    const bool sw = DESC ? (up ? a < b : a > b) : (up ? a > b : a < b);
-                    if (sw) { keys[i] = b; keys[ixj] = a; }
-                }
+            if (j >= 128 || (j == 64 && k >= 256)) __syncthreads(); else wave_lds_sync();
+            for (int t = tid; t < half; t += nt) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+                const unsigned long long a = keys[i], b = keys[ixj];
+                const bool up = ((i & k) == 0);
+                const bool sw = DESC ? (up ? a < b : a > b) : (up ? a > b : a < b);
+                if (sw) { keys[i] = b; keys[ixj] = a; }
             }
         }
     }
