@@ -193,14 +193,15 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
         abytes = algorithmic_bytes(dom, 2 * B, lv, mean_kps, mean_match, mean_track)
         achieved = abytes / (per_kernel[dom]["ms_per_launch"] * 1e-3) / 1e9
-        # HBM traffic of that kernel from the committed PMC pass (separate rocprofv3 --pmc runs: FETCH_SIZE, WRITE_SIZE),
-        # scaled from the profiled lane count to this run's; None when no profile matches the kernel
+        # HBM traffic of that kernel from the committed PMC passes (tools/pmc_traffic.py: L2 memory-side read / write
+        # requests counted by size in separate rocprofv3 --pmc runs of this same command), scaled from the profiled
+        # lane count to this run's; None when the profile does not cover this workload
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
-            if (W, H) == (1280, 960) and kk in pm["fetch_kb"]:
-                traffic = int((pm["fetch_kb"][kk] + pm["write_kb"][kk]) * 1024 * B / pm["lanes"])
+            if pm.get("workload") == args.workload and kk in pm["read_bytes"]:
+                traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * B / pm["lanes"])
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
