@@ -40,7 +40,9 @@ enum {
     SVO_FLAG_REPEAT = 16,   /* request_data.repeat (H:221, P:86-92)                    */
     SVO_FLAG_NO_SHIFT = 32, /* do not run the prev/cur shift of P:86-100 (staged tests and the
                                precomputed-data bypass of P:131-162 / P:219-251 after svo_put_*) */
-    SVO_FLAG_DEVICE_IMAGES = 64  /* svo_image.data are device pointers (already resident in HBM) */
+    SVO_FLAG_DEVICE_IMAGES = 64, /* svo_image.data are device pointers (already resident in HBM) */
+    SVO_FLAG_BGR_IMAGES = 128    /* svo_image.data are 8-bit 3-channel BGR (stride in bytes): stage 1's grey conversion runs
+                                    on the device (stage1_rectify.cpp:50-51) */
 };
 
 typedef struct svo_ctx svo_ctx;
@@ -84,6 +86,13 @@ int svo_get_fast_threshold(const svo_ctx* ctx);
 int svo_get_orb_threshold(const svo_ctx* ctx);
 /* request_data.stereo_cam (H:211), per lane; lane = -1 sets every lane */
 int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam);
+/* Stage 1 on the device (stage1_rectify.cpp:47-85).  Rectification maps of one camera of one lane (lane = -1: every
+ * lane): HOST float arrays [h][w] of source coordinates per output pixel, as cv::initUndistortRectifyMap(CV_32FC1)
+ * -- what mrpt::vision::CStereoRectifyMap::setFromCamParams (S1:66-68) precomputes -- yields.  They are converted
+ * once to the 1/32-pixel fixed point of cv::remap and kept on the device; from then on svo_process rectifies that
+ * camera's images (bilinear, constant-0 border, S1:70-72) before detection.  map_x = map_y = NULL clears the map
+ * (areImagesRectified(), S1:61-65). */
+int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float* map_x, const float* map_y, int w, int h);
 /* forget both frames and the warm start of one lane (a freshly constructed estimator, C:28-50); -1 = all */
 int svo_reset(svo_ctx* ctx, int lane);
 

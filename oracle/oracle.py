@@ -314,6 +314,25 @@ def delta_to_pose(delta):
     return out
 
 
+def prepare(src, map_x=None, map_y=None):
+    """Stage 1 (grey conversion + rectification): src is HxW (grey) or HxWx3 (BGR) uint8; maps are HxW float32 or None."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    assert ch in (1, 3)
+    dst = np.zeros((h, w), dtype=np.uint8)
+    mx = my = None
+    if map_x is not None:
+        mx = np.ascontiguousarray(map_x, dtype=np.float32); my = np.ascontiguousarray(map_y, dtype=np.float32)
+        assert mx.shape == (h, w) and my.shape == (h, w)
+    f = lib().svo_oracle_prepare
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    f(src.ctypes.data, w, h, src.strides[0], ch, mx.ctypes.data if mx is not None else None, my.ctypes.data if my is not None else None,
+      dst.ctypes.data, dst.strides[0])
+    return dst
+
+
 def sad8(l, r, lx, ly, rx, ry):
     l, r = _img(l), _img(r)
     return int(lib().svo_oracle_sad8(_ptr(l, u8p), _ptr(r, u8p), C.c_size_t(l.shape[1]), lx, ly, rx, ry))

@@ -75,6 +75,58 @@ void svo_oracle_params_defaults(svo_params* p)
 /* ------------------------------------------------------------------------------------------------ */
 /* compute_SAD8_default  (SAD:71-98) -- known-answer only                                           */
 /* ------------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------------------------
+ * Stage 1: grey conversion + rectification (stage1_rectify.cpp:47-85).
+ *   S1:50-51  CImage(obs->imageLeft, FAST_REF_OR_CONVERT_TO_GRAY)  -> cvCvtColor(BGR2GRAY)
+ *   S1:66-72  m_stereo_rectifier.rectify(...)  -> mrpt::vision::CStereoRectifyMap -> cv::remap(INTER_LINEAR,
+ *             BORDER_CONSTANT 0) with the maps of cv::initUndistortRectifyMap
+ * Neither MRPT nor OpenCV is available (parity unpinned, see the header of this file); the published fixed-point
+ * rules are frozen here:
+ *   grey  = (4899 R + 9617 G + 1868 B + 8192) >> 14                      (8-bit cvtColor, 14-bit coefficients)
+ *   remap : coordinates rounded to 1/32 pixel (cvRound = round-half-even of 32 x), sx = ix >> 5, fx = ix & 31;
+ *           weights (32-fx)(32-fy)*32 ... fx*fy*32 (their sum is exactly 32768, which is what cv::remap's
+ *           INTER_REMAP_COEF_SCALE table holds); out = (sum p*w + 16384) >> 15; taps outside the image read 0.
+ * Deviation: the reference hands the UNCONVERTED images to the rectifier (S1:70-72 passes obs->imageLeft, not the
+ * grey copy); for grey input that is the same thing, for colour input this restatement converts first.
+ * ------------------------------------------------------------------------------------------------------------ */
+static inline int grey_of(const uint8_t* p, int channels)
+{
+    if (channels == 1) return p[0];
+    return (4899 * (int)p[2] + 9617 * (int)p[1] + 1868 * (int)p[0] + 8192) >> 14;
+}
+
+int svo_oracle_map_fixed(float mx, float my, int w, int h, int* sx, int* sy, int* fx, int* fy)
+{
+    *sx = *sy = -2; *fx = *fy = 0;
+    if (!(mx > -4.0f && mx < (float)(w + 4) && my > -4.0f && my < (float)(h + 4))) return 0;      /* also NaN */
+    const long ix = lrintf(mx * 32.0f), iy = lrintf(my * 32.0f);         /* cvRound: round half to even */
+    const int x = (int)(ix >> 5), y = (int)(iy >> 5);
+    if (x < -1 || x >= w || y < -1 || y >= h) return 0;
+    *sx = x; *sy = y; *fx = (int)(ix & 31); *fy = (int)(iy & 31);
+    return 1;
+}
+
+void svo_oracle_prepare(const uint8_t* src, int w, int h, long stride, int channels,
+                        const float* map_x, const float* map_y, uint8_t* dst, long dst_stride)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            if (!map_x || !map_y) { dst[(long)y * dst_stride + x] = (uint8_t)grey_of(src + (long)y * stride + (long)x * channels, channels); continue; }
+            int sx, sy, fx, fy, v = 0;
+            if (svo_oracle_map_fixed(map_x[(long)y * w + x], map_y[(long)y * w + x], w, h, &sx, &sy, &fx, &fy)) {
+                int p[2][2];
+                for (int dy = 0; dy < 2; dy++)
+                    for (int dx = 0; dx < 2; dx++) {
+                        const int xx = sx + dx, yy = sy + dy;
+                        p[dy][dx] = (xx >= 0 && xx < w && yy >= 0 && yy < h) ? grey_of(src + (long)yy * stride + (long)xx * channels, channels) : 0;
+                    }
+                const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+                v = (p[0][0] * w00 + p[0][1] * w01 + p[1][0] * w10 + p[1][1] * w11 + 16384) >> 15;
+            }
+            dst[(long)y * dst_stride + x] = (uint8_t)v;
+        }
+}
+
 uint32_t svo_oracle_sad8(const uint8_t* l, const uint8_t* r, size_t stride, int lx, int ly, int rx, int ry)
 {
     const uint8_t* pl = l + stride * (size_t)(ly - 3) + (lx - 3);   /* window [x-3,x+4] x [y-3,y+4] */

@@ -104,6 +104,14 @@ void svo_oracle_project(const double* lmks3, int n, const svo_stereo_camera* cam
 /* CPose3D( CPose3DRotVec(delta).getInverse() ) -> x y z yaw pitch roll (S5:717-718) */
 void svo_oracle_delta_to_pose(const double* delta6, double* pose6);
 /* compute_SAD8 (compute_SAD8.cpp:71-98) -- toolchain known-answer only */
+/* ---- stage 1 (stage1_rectify.cpp:47-85): grey conversion and rectification, the step before the hot path ---- */
+/* channels 1 or 3 (BGR, the colour order of cv::Mat / mrpt::utils::CImage); map_x / map_y: float source coordinates
+ * per output pixel as cv::initUndistortRectifyMap(CV_32FC1) yields (both NULL: no rectification). */
+void svo_oracle_prepare(const uint8_t* src, int w, int h, long stride, int channels,
+                        const float* map_x, const float* map_y, uint8_t* dst, long dst_stride);
+/* the fixed-point form of one map entry: returns 0 when the sample lies wholly outside the image */
+int svo_oracle_map_fixed(float mx, float my, int w, int h, int* sx, int* sy, int* fx, int* fy);
+
 uint32_t svo_oracle_sad8(const uint8_t* l, const uint8_t* r, size_t stride, int lx, int ly, int rx, int ry);
 
 #ifdef __cplusplus

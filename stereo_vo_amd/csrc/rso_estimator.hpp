@@ -169,6 +169,12 @@ public:
         if (ni) check(svo_get_match_ids(m_ctx, 0, 0, 0, ids.data(), ni), "svo_get_match_ids");
         matches_id.assign(ids.begin(), ids.end());
     }
+    /** Stage 1 (S1:47-85): what m_stereo_rectifier.setFromCamParams() precomputes, handed over as float maps [h][w] of
+     *  source coordinates (cv::initUndistortRectifyMap, CV_32FC1); empty vectors = areImagesRectified() (S1:61-65). */
+    void setRectifyMaps(int side, const std::vector<float>& map_x, const std::vector<float>& map_y, int w, int h) {
+        const bool clear = map_x.empty();
+        check(svo_set_rectify_map(m_ctx, 0, side, clear ? NULL : map_x.data(), clear ? NULL : map_y.data(), w, h), "svo_set_rectify_map");
+    }
     void resetIds() { check(svo_reset_ids(m_ctx, 0), "svo_reset_ids"); }                         // H:684
     void setThisFrameAsKF() { check(svo_set_this_frame_as_kf(m_ctx, 0), "svo_set_this_frame_as_kf"); }   // H:675-683
 

@@ -36,6 +36,10 @@ struct svo_ctx {
     std::vector<TimedSpan> spans; std::vector<hipEvent_t> free_events;
     double kt_total[KT_COUNT]; long long kt_calls[KT_COUNT];
     unsigned* d_ham_out; uint8_t* d_ham_q, *d_ham_t; int ham_cap_q, ham_cap_t;
+    // stage 1 (svo_set_rectify_map, SVO_FLAG_BGR_IMAGES): all allocated on first use
+    uint8_t* d_src; int src_pitch;                    // staging of host source images (grey or BGR)
+    uint2** d_map_ptrs; std::vector<uint2*> map_ptrs;  // per image: fixed-point map on the device or nullptr
+    int map_w, map_h, n_maps;
 };
 
 static int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -130,6 +134,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->fast_th = 20; ctx->orb_th = 60;                  // common.cpp:35-36
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
+    ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
     for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
     *out = ctx;                                           // so that the caller can read last_error and destroy
     HIPCHECK(hipSetDevice(cfg->device));
@@ -238,6 +243,45 @@ extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* c
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
         if (lane < 0 || lane == l) HIPCHECK(hipMemcpy(ctx->dc.cams + l, cam, sizeof(*cam), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
+extern "C" int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float* map_x, const float* map_y, int w, int h)
+{
+    if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes || side < 0 || side > 1 || ((map_x == nullptr) != (map_y == nullptr))) return SVO_ERR_ARG;
+    const int NI = 2 * ctx->cfg.n_lanes;
+    if (map_x && (w <= 0 || h <= 0 || w > ctx->cfg.max_w || h > ctx->cfg.max_h || (ctx->n_maps > 0 && (w != ctx->map_w || h != ctx->map_h)))) return SVO_ERR_ARG;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->map_ptrs.empty()) {
+        ctx->map_ptrs.assign(NI, nullptr);
+        HIPCHECK(dev_alloc(ctx, (uint2***)&ctx->d_map_ptrs, (size_t)NI));
+        HIPCHECK(hipMemset(ctx->d_map_ptrs, 0, sizeof(uint2*) * NI));
+    }
+    std::vector<uint2> fixed;
+    if (map_x) {
+        // cv::remap's fixed point (oracle: svo_oracle_map_fixed): cvRound(32 x) -> integer part + 5-bit fraction
+        fixed.resize((size_t)w * h);
+        for (size_t i = 0; i < fixed.size(); i++) {
+            const float mx = map_x[i], my = map_y[i];
+            uint2 e; e.x = 0xFFFFFFFFu; e.y = 0;
+            if (mx > -4.0f && mx < (float)(w + 4) && my > -4.0f && my < (float)(h + 4)) {
+                const long ix = lrintf(mx * 32.0f), iy = lrintf(my * 32.0f);
+                const int x = (int)(ix >> 5), y = (int)(iy >> 5);
+                if (x >= -1 && x < w && y >= -1 && y < h) { e.x = (uint32_t)(x + 1) | ((uint32_t)(y + 1) << 16); e.y = (uint32_t)(ix & 31) | ((uint32_t)(iy & 31) << 8); }
+            }
+            fixed[i] = e;
+        }
+    }
+    for (int l = 0; l < ctx->cfg.n_lanes; l++) {
+        if (lane >= 0 && lane != l) continue;
+        uint2*& mp = ctx->map_ptrs[2 * l + side];
+        if (map_x) {
+            if (!mp) { HIPCHECK(dev_alloc(ctx, &mp, (size_t)ctx->cfg.max_w * ctx->cfg.max_h)); ctx->n_maps++; }
+            HIPCHECK(hipMemcpy(mp, fixed.data(), fixed.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            ctx->map_w = w; ctx->map_h = h;
+        } else if (mp) { mp = nullptr; ctx->n_maps--; }     // the buffer stays in the context's allocation list until svo_destroy
+    }
+    HIPCHECK(hipMemcpy(ctx->d_map_ptrs, ctx->map_ptrs.data(), sizeof(uint2*) * NI, hipMemcpyHostToDevice));
     return SVO_OK;
 }
 
@@ -420,6 +464,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     DevCtx& d = ctx->dc;
     const hipStream_t st = ctx->stream;
     const uint8_t* ptrs[2 * SVO_MAX_LANES];
+    PrepArgs prep; memset(&prep, 0, sizeof(prep)); bool prepare = false;
     if (flags & SVO_RUN_DETECT) {
         if (!frames) return SVO_ERR_ARG;                    // P:81
         const int w = frames[0].left.w, h = frames[0].left.h;
@@ -428,6 +473,10 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             if (!f.left.data || !f.right.data || f.left.w != w || f.left.h != h || f.right.w != w || f.right.h != h) return SVO_ERR_ARG;
         }
         int rc = ensure_geometry(ctx, w, h); if (rc) return rc;
+        const int ch = (flags & SVO_FLAG_BGR_IMAGES) ? 3 : 1;
+        prepare = ch == 3 || ctx->n_maps > 0;
+        if (ctx->n_maps > 0 && (ctx->map_w != w || ctx->map_h != h)) return SVO_ERR_ARG;
+        const int ipitch = ctx->img0_pitch_internal;
         if (flags & SVO_FLAG_DEVICE_IMAGES) {
             const long long stride = frames[0].left.stride;
             for (int l = 0; l < d.n_lanes; l++) {
@@ -435,20 +484,37 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
                 ptrs[2 * l] = frames[l].left.data; ptrs[2 * l + 1] = frames[l].right.data;
             }
             d.img0_pitch = (int)stride;
-        } else {
-            const int pitch = ctx->img0_pitch_internal;
+            if (prepare) { for (int i = 0; i < 2 * d.n_lanes; i++) prep.src[i] = ptrs[i]; prep.src_stride = stride; }
+        } else if (!prepare) {
             for (int l = 0; l < d.n_lanes; l++)
                 for (int s = 0; s < 2; s++) {
                     const svo_image& im = s ? frames[l].right : frames[l].left;
-                    uint8_t* dst = ctx->d_img0 + (size_t)(2 * l + s) * pitch * ctx->cfg.max_h;
-                    HIPCHECK(hipMemcpy2DAsync(dst, pitch, im.data, (size_t)im.stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
+                    uint8_t* dst = ctx->d_img0 + (size_t)(2 * l + s) * ipitch * ctx->cfg.max_h;
+                    HIPCHECK(hipMemcpy2DAsync(dst, ipitch, im.data, (size_t)im.stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
                     ptrs[2 * l + s] = dst;
                 }
-            d.img0_pitch = pitch;
+            d.img0_pitch = ipitch;
+        } else {
+            if (!ctx->d_src) { ctx->src_pitch = align_up(3 * ctx->cfg.max_w, 64); HIPCHECK(dev_alloc(ctx, &ctx->d_src, (size_t)2 * ctx->cfg.n_lanes * ctx->src_pitch * ctx->cfg.max_h)); }
+            for (int l = 0; l < d.n_lanes; l++)
+                for (int s = 0; s < 2; s++) {
+                    const svo_image& im = s ? frames[l].right : frames[l].left;
+                    uint8_t* dst = ctx->d_src + (size_t)(2 * l + s) * ctx->src_pitch * ctx->cfg.max_h;
+                    HIPCHECK(hipMemcpy2DAsync(dst, ctx->src_pitch, im.data, (size_t)im.stride, (size_t)w * ch, (size_t)h, hipMemcpyHostToDevice, st));
+                    prep.src[2 * l + s] = dst;
+                }
+            prep.src_stride = ctx->src_pitch;
+        }
+        if (prepare) {       // stage 1 writes the context's own level-0 buffers; detection reads those
+            for (int i = 0; i < 2 * d.n_lanes; i++) ptrs[i] = ctx->d_img0 + (size_t)i * ipitch * ctx->cfg.max_h;
+            d.img0_pitch = ipitch;
+            prep.maps = ctx->n_maps > 0 ? (const uint2* const*)ctx->d_map_ptrs : nullptr;
+            prep.dst = ctx->d_img0; prep.dst_img_stride = (long long)ipitch * ctx->cfg.max_h; prep.dst_pitch = ipitch;
+            prep.channels = ch; prep.w = w; prep.h = h;
         }
     } else if (!ctx->geom_ready && (flags & (SVO_RUN_MATCH | SVO_RUN_OPTIMIZE))) return SVO_ERR_STATE;
     d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
-    { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); }
+    { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); if (prepare) launch_prepare(prep, 2 * d.n_lanes, st); }
     if (flags & SVO_RUN_DETECT) {
         if (d.fast_orb) {       // stage2_detect.cpp:502-515 on the x1/2 octave pyramid
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }

@@ -14,6 +14,14 @@ struct GNParams {
 };
 
 hipError_t svo_upload_tables();
+// stage 1 (k_prepare.hip)
+struct PrepArgs {
+    const uint8_t* src[2 * SVO_MAX_LANES];   // source image pointers (device memory), by value in the kernel arguments
+    const uint2* const* maps;         // device table [n_img] of fixed-point maps (nullptr entries: no rectification), or nullptr
+    uint8_t* dst; long long dst_img_stride; int dst_pitch;
+    long long src_stride; int channels, w, h;
+};
+void launch_prepare(const PrepArgs& a, int n_img, hipStream_t st);
 void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned flags, hipStream_t st);
 void launch_resize(const DevCtx& c, int level, hipStream_t st);
 void launch_fast(const DevCtx& c, hipStream_t st);

@@ -15,13 +15,13 @@ _LIB = None
 
 MAX_LANES = 64
 RUN_DETECT, RUN_MATCH, RUN_TRACK, RUN_OPTIMIZE, RUN_ALL = 1, 2, 4, 8, 15
-FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES = 16, 32, 64
+FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES = 16, 32, 64, 128
 
 # every entry point include/svo_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "svo_config_defaults", "svo_params_defaults", "svo_create", "svo_destroy", "svo_strerror", "svo_last_error",
     "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
-    "svo_get_orb_threshold", "svo_set_camera", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
+    "svo_get_orb_threshold", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_change_in_pose", "svo_hamming_match",
@@ -154,7 +154,10 @@ class Context:
             l = np.ascontiguousarray(l, np.uint8)
             r = np.ascontiguousarray(r, np.uint8)
             keep += [l, r]
-            h, w = l.shape
+            h, w = l.shape[:2]
+            if l.ndim == 3:
+                assert l.shape[2] == 3 and r.shape == l.shape
+                flags |= FLAG_BGR_IMAGES
             fr[i].left = Image(l.ctypes.data, w, h, l.strides[0])
             fr[i].right = Image(r.ctypes.data, w, h, r.strides[0])
         self._keep = keep
@@ -168,6 +171,15 @@ class Context:
             fr[i].left = Image(l, w, h, stride)
             fr[i].right = Image(r, w, h, stride)
         self._ck(self.L.svo_process(self.h, fr, C.c_uint32(flags | FLAG_DEVICE_IMAGES)), "svo_process")
+
+    def set_rectify_map(self, lane, side, map_x, map_y):
+        """Stage-1 rectification map of one camera (HxW float32 source coordinates); None, None clears it."""
+        if map_x is None:
+            self._ck(self.L.svo_set_rectify_map(self.h, lane, side, None, None, 0, 0), "svo_set_rectify_map")
+            return
+        mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+        assert mx.ndim == 2 and mx.shape == my.shape
+        self._ck(self.L.svo_set_rectify_map(self.h, lane, side, C.c_void_p(mx.ctypes.data), C.c_void_p(my.ctypes.data), mx.shape[1], mx.shape[0]), "svo_set_rectify_map")
 
     def run_stages(self, flags):
         """Run stages on data already in the context (svo_put_* / previous svo_process), no prev/cur shift."""

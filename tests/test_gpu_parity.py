@@ -418,3 +418,55 @@ def test_config5_high_res_three_octaves():
             assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD
     assert ro.valid
     ctx.close()
+
+
+def _distortion_maps(w, h, k1=0.08, shift=(2.3, -1.7), rot=0.01):
+    """A smooth radial + rigid rectification-like map (float32 source coordinates per output pixel), some of it
+    pointing outside the image."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    xn, yn = (xx - w / 2) / (w / 2), (yy - h / 2) / (w / 2)
+    r2 = xn * xn + yn * yn
+    xd, yd = xn * (1 + k1 * r2), yn * (1 + k1 * r2)
+    c, s = np.cos(rot), np.sin(rot)
+    mx = (c * xd - s * yd) * (w / 2) + w / 2 + shift[0]
+    my = (s * xd + c * yd) * (w / 2) + h / 2 + shift[1]
+    return mx.astype(np.float32), my.astype(np.float32)
+
+
+@pytest.mark.parametrize("w,h,bgr,device", [(320, 240, False, False), (317, 243, True, False), (640, 480, True, True), (1241, 376, False, True)])
+def test_stage1_grey_and_rectify_on_device(w, h, bgr, device):
+    """Stage 1 on the device (svo_set_rectify_map, SVO_FLAG_BGR_IMAGES) against the oracle's svo_oracle_prepare: the
+    prepared level-0 images bit-exact, and the whole frame computed from them identical to the oracle's on the
+    oracle-prepared images."""
+    import torch
+    rng = np.random.default_rng(7)
+    W0, H0 = (w + 7) // 8 * 8, (h + 7) // 8 * 8                 # the renderer wants friendly sizes; odd shapes are crops
+    world = SyntheticStereoWorld(W0, H0, 300.0 * w / 640.0, 0.12, seed=3, n_frames=2, device=torch.device("cpu"))
+    cam = StereoCamera.simple(300.0 * w / 640.0, w / 2.0, h / 2.0, 0.12, w, h)
+    p = north_star_params(hip.default_params(), orb_nfeats=300)
+    ctx = hip.Context(n_lanes=2, max_w=w, max_h=h, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    maps = [_distortion_maps(w, h), _distortion_maps(w, h, k1=-0.05, shift=(-3.25, 0.5), rot=-0.004)]
+    ctx.set_rectify_map(0, 0, *maps[0]); ctx.set_rectify_map(0, 1, *maps[1])       # lane 0 rectifies, lane 1 does not
+    orcs = [O().Oracle(p), O().Oracle(p)]
+    for t in range(2):
+        L, R = [x.numpy()[:h, :w] for x in world.render(t)]
+        if bgr:       # a colour image whose grey value is not just one of its channels
+            L = np.stack([L, np.roll(L, 3, 1), 255 - L // 2], -1); R = np.stack([R, np.roll(R, 2, 0), 255 - R // 2], -1)
+        L, R = np.ascontiguousarray(L), np.ascontiguousarray(R)
+        if device:
+            tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+            ctx.process_device([(tl.data_ptr(), tr.data_ptr())] * 2, w, h, L.strides[0], hip.RUN_ALL | (hip.FLAG_BGR_IMAGES if bgr else 0))
+        else:
+            ctx.process_host([(L, R)] * 2)
+        want = [[O().prepare(L, *maps[0]), O().prepare(R, *maps[1])], [O().prepare(L), O().prepare(R)]]
+        for lane in range(2):
+            for side in range(2):
+                assert (ctx.level(lane, side, 0) == want[lane][side]).all(), (t, lane, side)
+            r, ro = ctx.result(lane), orcs[lane].process(want[lane][0], want[lane][1], cam)
+            assert_same_frame(ctx, lane, orcs[lane], r, ro, "t=%d lane=%d" % (t, lane))
+    # clearing the map turns rectification off again
+    ctx.set_rectify_map(0, 0, None, None); ctx.set_rectify_map(0, 1, None, None)
+    L, R = [np.ascontiguousarray(x.numpy()[:h, :w]) for x in world.render(0)]
+    ctx.process_host([(L, R)] * 2)
+    assert (ctx.level(0, 0, 0) == L).all() and (ctx.level(1, 1, 0) == R).all()

@@ -304,3 +304,28 @@ def test_rbr_and_win_variants_run_and_agree_with_bf_on_easy_data():
     assert rr.tracked_feats_from_last_frame > 10 and rr.valid
     gt = w.gt_delta(1)[:3, 3]
     assert np.abs(np.array(rr.outPose)[:3] - gt).max() < 0.08 and np.abs(np.array(rb.outPose)[:3] - gt).max() < 0.08
+
+
+def test_stage1_prepare_known_answers():
+    """Stage 1 (stage1_rectify.cpp:47-85) as frozen by the oracle: 14-bit BGR2GRAY coefficients, cv::remap's 1/32-pixel
+    fixed point with exact 15-bit weights and a constant-0 border."""
+
+    img = np.zeros((4, 5, 3), np.uint8)
+    for ch, want in ((0, 29), (1, 150), (2, 76)):            # pure B, G, R at 255
+        img[:] = 0; img[..., ch] = 255
+        assert (O.prepare(img) == want).all()
+    img[:] = 255
+    assert (O.prepare(img) == 255).all()
+    g = (np.arange(20, dtype=np.uint8).reshape(4, 5) * 10)
+    yy, xx = np.mgrid[0:4, 0:5].astype(np.float32)
+    assert (O.prepare(g, xx, yy) == g).all()                  # identity map
+    half = O.prepare(g, xx + 0.5, yy)
+    assert (half[:, :4] == g[:, :4] + 5).all()                # midpoint of neighbours 10 apart
+    assert (half[:, 4] == (g[:, 4].astype(int) * 16384 + 16384) >> 15).all()      # right tap is the constant-0 border
+    out = O.prepare(g, xx - 1.0, yy + 3.5)
+    assert (out[1:] == 0).all() and out[0, 0] == 0 and (out[0, 1:] == (g[3, :4].astype(int) + 1) // 2).all()
+    nan = O.prepare(g, np.full_like(xx, np.nan), yy)
+    assert (nan == 0).all()
+    # 1/32-pixel rounding is round-half-even (cvRound): 1/64 rounds down to 0/32, 3/64 rounds up to 2/32
+    a = O.prepare(g, xx + 1.0 / 64.0, yy)[1, 1]; b = O.prepare(g, xx + 3.0 / 64.0, yy)[1, 1]
+    assert a == g[1, 1] and b == ((int(g[1, 1]) * 30 * 32 * 32 + int(g[1, 2]) * 2 * 32 * 32 + 16384) >> 15)
