@@ -232,6 +232,17 @@ def nms_copy(kps, min_distance, img_w, img_h, num_out):
     return order[:c].copy()
 
 
+def anms_copy(kps, num_out, min_radius_th=0.0):
+    """m_adaptive_non_max_sup (S2:141-215): indices of the kept keypoints in radius-descending order."""
+    kps = np.ascontiguousarray(kps, dtype=keypoint_dtype)
+    order = np.zeros(max(1, len(kps)), np.int32)
+    f = lib().svo_oracle_anms_copy
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    n = f(kps.ctypes.data, len(kps), int(num_out), float(min_radius_th), order.ctypes.data)
+    return order[:n].copy()
+
+
 def nms_mask(kps, min_distance, img_w, img_h, num_out):
     n = len(kps)
     m = np.zeros(max(n, 1), np.uint8)

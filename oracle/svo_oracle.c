@@ -495,6 +495,55 @@ void svo_oracle_nms_mask(const svo_keypoint* kps, int n, int min_distance, int i
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* m_adaptive_non_max_sup  (S2:141-215): suppression radius of every keypoint = squared distance to  */
+/* the nearest keypoint that is "robustly stronger" (response > it / 0.9), then keep by radius.      */
+/* ------------------------------------------------------------------------------------------------ */
+/* Kept quirks: the strongest keypoint bounds every radius whatever its response ratio (S2:176) and is skipped by
+ * the inner loop (k2 > 0, S2:179); the squared distance is evaluated in float (cv::Point2f arithmetic, S2:176/185)
+ * and compared as double; only the first min(num_out_points, N) entries of the radius order are looked at and those
+ * with radius <= min_radius_th^2 (default 0: exact duplicates of a stronger point) are dropped (S2:207-214).
+ * DEVIATION (appendix A #7): both std::sort calls are unstable; total orders (response desc, index asc) and
+ * (radius desc, index asc) are used instead. */
+int svo_oracle_anms_copy(const svo_keypoint* kps, int n, int num_out_points, double min_radius_th, int32_t* out_order)
+{
+    const int actual = num_out_points < n ? num_out_points : n;                      /* S2:151 */
+    if (actual <= 0) return 0;                                                      /* S2:152 */
+    const double CROB = 0.9;                                                        /* S2:154 */
+    uint64_t* keys = (uint64_t*)xmalloc(sizeof(uint64_t) * (size_t)n);
+    for (int i = 0; i < n; i++) keys[i] = ((uint64_t)ord32(kps[i].response) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64_desc);                         /* S2:160 */
+    int32_t* sorted = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)n);
+    for (int i = 0; i < n; i++) sorted[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFu));
+    float* radius = (float*)xmalloc(sizeof(float) * (size_t)n);
+    const svo_keypoint* s0 = &kps[sorted[0]];
+    radius[sorted[0]] = INFINITY;                                                   /* S2:167 */
+    for (int k1 = 1; k1 < n; k1++) {                                                /* S2:171-192 */
+        const svo_keypoint* a = &kps[sorted[k1]];
+        float dx = a->x - s0->x, dy = a->y - s0->y;
+        float min_ri = fabsf(dx * dx + dy * dy);                                    /* S2:176 */
+        for (int k2 = k1 - 1; k2 > 0; --k2) {                                       /* S2:179 */
+            const svo_keypoint* b = &kps[sorted[k2]];
+            if ((double)a->response < CROB * (double)b->response) {                 /* S2:183 */
+                dx = a->x - b->x; dy = a->y - b->y;
+                const float ri = fabsf(dx * dx + dy * dy);                          /* S2:185 */
+                if (ri < min_ri) min_ri = ri;
+            }
+        }
+        radius[sorted[k1]] = min_ri;
+    }
+    for (int i = 0; i < n; i++) keys[i] = ((uint64_t)ord32(radius[i]) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64_desc);                         /* S2:196 */
+    const double th2 = min_radius_th * min_radius_th;                               /* S2:194 */
+    int nk = 0;
+    for (int i = 0; i < actual; i++) {                                              /* S2:207-214 */
+        const int idx = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFu));
+        if ((double)radius[idx] > th2) out_order[nk++] = idx;
+    }
+    free(keys); free(sorted); free(radius);
+    return nk;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* m_update_indexes(order=true)  (S2:65-130)                                                         */
 /* ------------------------------------------------------------------------------------------------ */
 /* DEVIATION (appendix A #7): unstable sort on pt.y (S2:89) -> total order (pt.y asc, input index asc). */
@@ -1177,8 +1226,9 @@ static int stage2_detect(svo_oracle* o, pair_data* d, int side, const uint8_t* c
         int32_t* order = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
         int nk = n;
         if (p->non_maximal_suppression) {                                           /* S2:583-610 */
-            if (p->nmsMethod != SVO_NMS_STANDARD) { free(order); free(kv); free(dv); return -2; }   /* adaptive: out of scope */
-            nk = svo_oracle_nms_copy(kv, n, p->min_distance, W, H, (int)kps_to_detect[oc], order);
+            if (p->nmsMethod == SVO_NMS_STANDARD) nk = svo_oracle_nms_copy(kv, n, p->min_distance, W, H, (int)kps_to_detect[oc], order);    /* S2:585-597 */
+            else if (p->nmsMethod == SVO_NMS_ADAPTIVE) nk = svo_oracle_anms_copy(kv, n, (int)kps_to_detect[oc], 0.0, order);            /* S2:599-606 */
+            else { free(order); free(kv); free(dv); return -2; }                                                                      /* S2:608 */
         } else for (int i = 0; i < n; i++) order[i] = i;                            /* S2:613-614 */
         svo_keypoint* k2 = (svo_keypoint*)xmalloc(sizeof(svo_keypoint) * (size_t)(nk > 0 ? nk : 1));
         uint8_t* d2 = (uint8_t*)xmalloc((size_t)(nk > 0 ? nk : 1) * 32);

@@ -69,6 +69,7 @@ void svo_oracle_half_smooth(const uint8_t* src, int sw, int sh, int sstride, uin
 int svo_oracle_nms_copy(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h,
                         int num_out_points, int32_t* out_order);
 /* m_non_max_sup mask overload (S2:225-283) */
+int svo_oracle_anms_copy(const svo_keypoint* kps, int n, int num_out_points, double min_radius_th, int32_t* out_order); /* S2:141-215 */
 void svo_oracle_nms_mask(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h,
                          int num_out_points, uint8_t* survivors);
 /* m_update_indexes (S2:65-130): order[i] = input index of i-th output; idx has img_h entries */

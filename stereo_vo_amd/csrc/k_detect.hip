@@ -798,7 +798,53 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     auto slot_of = [&](int raw_i) { int l = l_first; for (int q = l_first + 1; q < SVO_MAX_LEVELS; q++) if (q < l_last && raw_i >= lvl_base[q]) l = q; return c.lv[l].slot_off + (raw_i - lvl_base[l]); };
     const int W = c.ow[oct], H = c.oh[oct], num_out_points = c.kps_to_detect[oct];
     int nacc = 0;
-    if (do_nms) {
+    if (do_nms == 2) {
+        // ---- m_adaptive_non_max_sup (stage2_detect.cpp:141-215; oracle: svo_oracle_anms_copy) ----
+        // keys[] holds the keypoints in (response desc, raw index asc) order.  radius^2 of rank i = min over the ranks
+        // k2 in [1, i) with resp_i < 0.9 * resp_k2 (double compare, S2:183) of the float squared distance, bounded by
+        // the distance to rank 0 whatever its response (S2:176).  0.9 * resp is non-increasing along the ranks, so the
+        // qualifying k2 are a prefix [1, t]: t by binary search, then a compare-free min loop.
+        float2* sxy = (float2*)hkey;                       // [NS_MAX]   (the grid-hash arrays are free in this mode)
+        double* thr = (double*)(hkey + 2 * NS_MAX);        // [NS_MAX]
+        float* rad = (float*)cellxy;                       // [NS_MAX]
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+            const svo_keypoint& k = rk[slot_of(raw_i)];
+            sxy[i] = make_float2(k.x, k.y);
+            thr[i] = 0.9 * (double)k.response;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) {
+            float r = __builtin_inff();                                               // S2:167
+            if (i > 0) {
+                const float2 a = sxy[i], s0 = sxy[0];
+                float dx = a.x - s0.x, dy = a.y - s0.y;
+                r = fabsf(dx * dx + dy * dy);                                         // S2:176
+                const double resp = (double)inv_ord32((uint32_t)(keys[i] >> 32));
+                int lo = 1, hi = i;                                                   // first k2 in [1, i) with !(resp < thr[k2])
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (resp < thr[mid]) lo = mid + 1; else hi = mid; }
+                for (int k2 = 1; k2 < lo; k2++) {                                     // S2:179-189
+                    const float2 b = sxy[k2];
+                    dx = a.x - b.x; dy = a.y - b.y;
+                    r = fminf(r, fabsf(dx * dx + dy * dy));
+                }
+            }
+            rad[i] = r;
+        }
+        __syncthreads();
+        for (int i = tid; i < P; i += blockDim.x) keys[i] = i < n ? (((unsigned long long)ord32(rad[i]) << 32) | (keys[i] & 0xFFFFFFFFull)) : 0ull;
+        bitonic_sort_lds<true>(keys, P);                                              // S2:196: (radius desc, raw index asc)
+        const int actual = min(num_out_points, n);                                    // S2:151
+        for (int base = 0; base < actual; base += blockDim.x) {                       // S2:207-214, min_radius_th = 0
+            const int i = base + tid;
+            const int keep = (i < actual && inv_ord32((uint32_t)(keys[i] >> 32)) > 0.0f) ? 1 : 0;
+            int tot;
+            const int off = block_exclusive_scan(keep, scan, &tot);
+            if (keep) acc_idx[nacc + off] = (unsigned short)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
+            nacc += tot;
+            __syncthreads();
+        }
+    } else if (do_nms) {
         const unsigned cell = (unsigned)((double)min_distance / 2.0);            // S2:331
         const float inv = 1.0f / (float)cell;                                    // S2:332
         const unsigned glx = (unsigned)(1 + (float)W * inv), gly = (unsigned)(1 + (float)H * inv);   // S2:334-335

@@ -459,7 +459,8 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if ((flags & SVO_RUN_DETECT) && p.detect_method != SVO_DM_ORB && p.detect_method != SVO_DM_FAST_ORB) return SVO_ERR_UNSUPPORTED;   // KLT / FASTER: out of scope
     if ((flags & SVO_RUN_MATCH) && p.match_method != SVO_SM_DESC_BF && p.match_method != SVO_SM_DESC_RBR) return SVO_ERR_UNSUPPORTED;   // smSAD: out of scope
     if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF && p.ifm_method != SVO_IFM_DESC_WIN) return SVO_ERR_UNSUPPORTED;      // ifmSAD / optical flow: out of scope
-    if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD) return SVO_ERR_UNSUPPORTED;
+    if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD && p.nmsMethod != SVO_NMS_ADAPTIVE) return SVO_ERR_ARG;          // S2:608
+    if (p.non_maximal_suppression && p.nmsMethod == SVO_NMS_ADAPTIVE && p.detect_method != SVO_DM_ORB) return SVO_ERR_UNSUPPORTED;  // adaptive NMS: ORB detector only
     if (p.min_distance < 2) return SVO_ERR_ARG;            // cell size 0 divides by zero in the reference (S2:331-332)
     DevCtx& d = ctx->dc;
     const hipStream_t st = ctx->stream;
@@ -527,7 +528,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             { Span s(ctx, KT_SELECT); launch_select(d, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
-            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression, p.min_distance, st); }
+            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0, p.min_distance, st); }
         }
     }
     const int nsplit = hamming_splits(ctx);

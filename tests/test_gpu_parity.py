@@ -470,3 +470,22 @@ def test_stage1_grey_and_rectify_on_device(w, h, bgr, device):
     L, R = [np.ascontiguousarray(x.numpy()[:h, :w]) for x in world.render(0)]
     ctx.process_host([(L, R)] * 2)
     assert (ctx.level(0, 0, 0) == L).all() and (ctx.level(1, 1, 0) == R).all()
+
+
+@pytest.mark.parametrize("w,h,nfe", [(640, 480, 500), (1280, 960, 2000)])
+def test_adaptive_nms_matches_oracle(w, h, nfe):
+    """nmsMethod = nmsmAdaptive (stage2_detect.cpp:599-606, 141-215) on the device against the oracle, whole frames."""
+    import torch
+    world = SyntheticStereoWorld(w, h, 800.0 * w / 1280.0, 0.12, seed=11, n_frames=3, device=torch.device("cpu"))
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=nfe)
+    p.nmsMethod = 1
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=4096)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        L, R = [x.numpy() for x in world.render(t)]
+        ctx.process_host([(L, R)])
+        r, ro = ctx.result(0), orc.process(L, R, cam)
+        assert_same_frame(ctx, 0, orc, r, ro, "anms t=%d" % t)
+    assert r.detected_left[0] > nfe // 2

@@ -329,3 +329,16 @@ def test_stage1_prepare_known_answers():
     # 1/32-pixel rounding is round-half-even (cvRound): 1/64 rounds down to 0/32, 3/64 rounds up to 2/32
     a = O.prepare(g, xx + 1.0 / 64.0, yy)[1, 1]; b = O.prepare(g, xx + 3.0 / 64.0, yy)[1, 1]
     assert a == g[1, 1] and b == ((int(g[1, 1]) * 30 * 32 * 32 + int(g[1, 2]) * 2 * 32 * 32 + 16384) >> 15)
+
+
+def test_adaptive_nms_hand_case():
+    """m_adaptive_non_max_sup (stage2_detect.cpp:141-215) on four points worked by hand, quirks included: the strongest
+    point bounds every radius whatever the response ratio, and a zero radius (exact duplicate of a stronger point) is dropped."""
+    k = np.zeros(4, keypoint_dtype)
+    k["x"] = [0, 3, 1, 3]; k["y"] = [0, 4, 0, 4]; k["response"] = [10, 5, 9.5, 4]
+    # ranks: A(10) C(9.5) B(5) D(4); radius^2: A inf, C 1 (distance to A although 9.5 !< 0.9 * 10), B 20 (C qualifies: 5 < 8.55),
+    # D 0 (same position as B, 4 < 4.5)
+    assert list(O.anms_copy(k, 10)) == [0, 1, 2]
+    assert list(O.anms_copy(k, 2)) == [0, 1]
+    assert list(O.anms_copy(k, 10, min_radius_th=2.0)) == [0, 1]             # radius^2 must exceed 4
+    assert list(O.anms_copy(k[:1], 5)) == [0] and len(O.anms_copy(k[:0], 5)) == 0
