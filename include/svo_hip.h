@@ -135,6 +135,18 @@ int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keyp
 int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n);
 int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n);
 
+/* saveStateToFile / loadStateFromFile (H:184-185, C:475-543, C:261-350): the state of one lane in the reference's
+ * binary layout -- npyr; then for PRE and CUR: left keypoints, right keypoints (count, then x y response size angle as
+ * float and octave class_id as int per keypoint, then rows cols type and the descriptor bytes), pairings (count,
+ * id count, then [id] queryIdx trainIdx distance imgIdx each); then m_reset (1 byte) and m_lastID,
+ * m_num_tracked_pairs_from_last_kf, m_num_tracked_pairs_from_last_frame, m_last_match_ID, m_kf_max_match_ID as
+ * 8-byte integers.  Octave-0 lists (single-octave contexts only).  svo_load_state reads what svo_save_state (and
+ * the reference's saveStateToFile) writes; the reference's own loader expects one more 8-byte word before
+ * m_last_match_ID that its saver never writes (C:342-343 vs C:533-539) -- deviation, see SURVEY.md appendix A #18.
+ * After a load both frames are present, m_error is cleared and the warm start is the identity. */
+int svo_save_state(svo_ctx* ctx, int lane, const char* path);
+int svo_load_state(svo_ctx* ctx, int lane, const char* path);
+
 /* getChangeInPose (H:162-172, C:355-413): stage 5 alone on caller arrays, lane 0 of the context.
  * residual: n_tracked doubles; outliers: n_tracked int32 (holds INLIER cur-match indices, S5:603-610).
  * init6 may be NULL.  Returns result.valid (0/1) or <0. */

@@ -175,6 +175,9 @@ public:
         const bool clear = map_x.empty();
         check(svo_set_rectify_map(m_ctx, 0, side, clear ? NULL : map_x.data(), clear ? NULL : map_y.data(), w, h), "svo_set_rectify_map");
     }
+    /** saveStateToFile / loadStateFromFile (H:184-185, C:475-543, C:261-350): false on error, like the reference */
+    bool saveStateToFile(const std::string& filename) { return svo_save_state(m_ctx, 0, filename.c_str()) == SVO_OK; }
+    bool loadStateFromFile(const std::string& filename) { return svo_load_state(m_ctx, 0, filename.c_str()) == SVO_OK; }
     void resetIds() { check(svo_reset_ids(m_ctx, 0), "svo_reset_ids"); }                         // H:684
     void setThisFrameAsKF() { check(svo_set_this_frame_as_kf(m_ctx, 0), "svo_set_this_frame_as_kf"); }   // H:675-683
 

@@ -770,6 +770,131 @@ extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, 
     return SVO_OK;
 }
 
+// ---- saveStateToFile / loadStateFromFile (common.cpp:475-543, 261-350; helpers :88-255) --------------------------
+namespace {
+struct StateList { std::vector<svo_keypoint> kps; std::vector<uint8_t> desc; };
+bool wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n; }
+bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
+bool dump_keypoints(FILE* f, const StateList& L)              // m_dump_keypoints_to_stream (C:88-133)
+{
+    const uint64_t n = L.kps.size();
+    if (!wr(f, &n, 8)) return false;
+    for (const svo_keypoint& k : L.kps) {
+        const float v[5] = { k.x, k.y, k.response, k.size, k.angle };
+        const int32_t w[2] = { k.octave, k.class_id };
+        if (!wr(f, v, sizeof(v)) || !wr(f, w, sizeof(w))) return false;
+    }
+    const int32_t hdr[3] = { (int32_t)n, n ? 32 : 0, 0 /* CV_8UC1 */ };
+    return wr(f, hdr, sizeof(hdr)) && (L.desc.empty() || wr(f, L.desc.data(), L.desc.size()));
+}
+bool load_keypoints(FILE* f, StateList& L, size_t cap)         // m_load_keypoints_from_stream (C:168-211)
+{
+    uint64_t n = 0;
+    if (!rd(f, &n, 8) || n > cap) return false;
+    L.kps.resize((size_t)n);
+    for (svo_keypoint& k : L.kps) {
+        float v[5]; int32_t w[2];
+        if (!rd(f, v, sizeof(v)) || !rd(f, w, sizeof(w))) return false;
+        k.x = v[0]; k.y = v[1]; k.response = v[2]; k.size = v[3]; k.angle = v[4]; k.octave = w[0]; k.class_id = w[1];
+    }
+    int32_t hdr[3];
+    if (!rd(f, hdr, sizeof(hdr)) || hdr[0] < 0 || hdr[1] < 0) return false;
+    if ((uint64_t)hdr[0] != n || (n && hdr[1] != 32)) return false;             // this path only knows 256-bit descriptors
+    L.desc.resize((size_t)n * 32);
+    return L.desc.empty() || rd(f, L.desc.data(), L.desc.size());
+}
+bool dump_matches(FILE* f, const std::vector<svo_dmatch>& m, const std::vector<int32_t>& ids)   // m_dump_matches_to_stream (C:138-163)
+{
+    const uint64_t n = m.size(), ni = ids.size();
+    if (!wr(f, &n, 8) || !wr(f, &ni, 8)) return false;
+    for (size_t i = 0; i < m.size(); i++) {
+        if (n == ni) { const uint64_t id = (uint64_t)(int64_t)ids[i]; if (!wr(f, &id, 8)) return false; }
+        if (!wr(f, &m[i].queryIdx, 4) || !wr(f, &m[i].trainIdx, 4) || !wr(f, &m[i].distance, 4) || !wr(f, &m[i].imgIdx, 4)) return false;
+    }
+    return true;
+}
+bool load_matches(FILE* f, std::vector<svo_dmatch>& m, std::vector<int32_t>& ids, size_t cap)    // m_load_matches_from_stream (C:216-255)
+{
+    uint64_t n = 0, ni = 0;
+    if (!rd(f, &n, 8) || !rd(f, &ni, 8) || n > cap || ni > cap) return false;
+    m.resize((size_t)n); ids.assign((size_t)ni, 0);
+    for (size_t i = 0; i < m.size(); i++) {
+        if (n == ni) { uint64_t id; if (!rd(f, &id, 8)) return false; ids[i] = (int32_t)id; }
+        if (!rd(f, &m[i].queryIdx, 4) || !rd(f, &m[i].trainIdx, 4) || !rd(f, &m[i].distance, 4) || !rd(f, &m[i].imgIdx, 4)) return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int svo_save_state(svo_ctx* ctx, int lane, const char* path)
+{
+    if (!ctx || !path || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    if (ctx->dc.n_oct > 1) return SVO_ERR_UNSUPPORTED;                 // the reference's format holds one list per eye
+    int rc = svo_wait(ctx); if (rc) return rc;
+    LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    StateList L[2][2]; std::vector<svo_dmatch> M[2]; std::vector<int32_t> I[2];           // [which: 0 cur, 1 prev]
+    for (int which = 0; which < 2; which++) {
+        for (int side = 0; side < 2; side++) {
+            const int n = svo_get_keypoints_oct(ctx, lane, which, side, 0, nullptr, nullptr, 0); if (n < 0) return n;
+            L[which][side].kps.resize(n); L[which][side].desc.resize((size_t)n * 32);
+            if (n) { rc = svo_get_keypoints_oct(ctx, lane, which, side, 0, L[which][side].kps.data(), L[which][side].desc.data(), n); if (rc < 0) return rc; }
+        }
+        int n = svo_get_matches_oct(ctx, lane, which, 0, nullptr, 0); if (n < 0) return n;
+        M[which].resize(n); if (n) { rc = svo_get_matches_oct(ctx, lane, which, 0, M[which].data(), n); if (rc < 0) return rc; }
+        n = svo_get_match_ids(ctx, lane, which, 0, nullptr, 0); if (n < 0) return n;
+        I[which].resize(n); if (n) { rc = svo_get_match_ids(ctx, lane, which, 0, I[which].data(), n); if (rc < 0) return rc; }
+    }
+    svo_result res; HIPCHECK(hipMemcpy(&res, ctx->dc.results + lane, sizeof(res), hipMemcpyDeviceToHost));
+    FILE* f = fopen(path, "wb");
+    if (!f) { ctx->last_error = std::string("cannot open ") + path; return SVO_ERR_ARG; }
+    const uint64_t npyr = 1;
+    bool ok = wr(f, &npyr, 8);
+    for (int which = 1; which >= 0 && ok; which--)                       // PRE first, then CUR (C:491-527)
+        ok = dump_keypoints(f, L[which][0]) && dump_keypoints(f, L[which][1]) && dump_matches(f, M[which], I[which]);
+    const uint8_t m_reset = s.reset_ids ? 1 : 0;
+    const uint64_t tail[5] = { 0 /* m_lastID: legacy, never used */, (uint64_t)s.num_tracked_last_kf, (uint64_t)res.tracked_feats_from_last_frame,
+                               (uint64_t)s.last_match_id, (uint64_t)s.last_kf_max_id };
+    ok = ok && wr(f, &m_reset, 1) && wr(f, tail, sizeof(tail));
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { ctx->last_error = std::string("short write to ") + path; return SVO_ERR_STATE; }
+    return SVO_OK;
+}
+
+extern "C" int svo_load_state(svo_ctx* ctx, int lane, const char* path)
+{
+    if (!ctx || !path || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    if (ctx->dc.oct_cap > 1 && ctx->dc.n_oct > 1) return SVO_ERR_UNSUPPORTED;
+    FILE* f = fopen(path, "rb");
+    if (!f) { ctx->last_error = std::string("cannot open ") + path; return SVO_ERR_ARG; }
+    StateList L[2][2]; std::vector<svo_dmatch> M[2]; std::vector<int32_t> I[2];
+    uint64_t npyr = 0, tail[5]; uint8_t m_reset = 0;
+    const size_t cap = (size_t)ctx->dc.max_kps;
+    bool ok = rd(f, &npyr, 8);
+    for (int which = 1; which >= 0 && ok; which--)
+        ok = load_keypoints(f, L[which][0], cap) && load_keypoints(f, L[which][1], cap) && load_matches(f, M[which], I[which], cap);
+    ok = ok && rd(f, &m_reset, 1) && rd(f, tail, sizeof(tail));
+    fclose(f);
+    if (!ok) { ctx->last_error = std::string("malformed or truncated state file ") + path; return SVO_ERR_ARG; }
+    // the file carries no image size: the geometry of the last frame, or the context's maximum for a fresh context
+    const int gw = ctx->geom_ready ? ctx->geom_w : ctx->cfg.max_w, gh = ctx->geom_ready ? ctx->geom_h : ctx->cfg.max_h;
+    int rc = svo_reset(ctx, lane); if (rc) return rc;
+    for (int which = 1; which >= 0; which--) {
+        for (int side = 0; side < 2; side++) {
+            rc = svo_put_features(ctx, lane, which, side, L[which][side].kps.data(), L[which][side].desc.data(), (int)L[which][side].kps.size(), gw, gh);
+            if (rc) return rc;
+        }
+        rc = svo_put_matches(ctx, lane, which, M[which].data(), (int)M[which].size()); if (rc) return rc;
+        LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
+        const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap, ni = (int)I[which].size();
+        if (ni > 0) HIPCHECK(hipMemcpy(ctx->dc.ids + ((long long)vl * 2 + slot) * ctx->dc.max_kps, I[which].data(), sizeof(int32_t) * ni, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(ctx->dc.n_ids + vl * 2 + slot, &ni, sizeof(int), hipMemcpyHostToDevice));
+    }
+    LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    s.reset_ids = m_reset; s.num_tracked_last_kf = (int)tail[1]; s.last_match_id = (int)tail[3]; s.last_kf_max_id = (int)tail[4];
+    HIPCHECK(hipMemcpy(ctx->dc.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
 // ---- getChangeInPose (common.cpp:355-413) -------------------------------------------------------------------
 extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, int n_tracked,
                                   const svo_dmatch* pre_matches, int n_pre, const svo_dmatch* cur_matches, int n_cur,

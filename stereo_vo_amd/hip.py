@@ -24,7 +24,7 @@ EXPORTS = [
     "svo_get_orb_threshold", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
-    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_change_in_pose", "svo_hamming_match",
+    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
 ]
@@ -180,6 +180,14 @@ class Context:
         mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
         assert mx.ndim == 2 and mx.shape == my.shape
         self._ck(self.L.svo_set_rectify_map(self.h, lane, side, C.c_void_p(mx.ctypes.data), C.c_void_p(my.ctypes.data), mx.shape[1], mx.shape[0]), "svo_set_rectify_map")
+
+    def save_state(self, lane, path):
+        """saveStateToFile (common.cpp:475-543) of one lane."""
+        self._ck(self.L.svo_save_state(self.h, lane, os.fsencode(path)), "svo_save_state")
+
+    def load_state(self, lane, path):
+        """loadStateFromFile (common.cpp:261-350) into one lane."""
+        self._ck(self.L.svo_load_state(self.h, lane, os.fsencode(path)), "svo_load_state")
 
     def run_stages(self, flags):
         """Run stages on data already in the context (svo_put_* / previous svo_process), no prev/cur shift."""

@@ -489,3 +489,49 @@ def test_adaptive_nms_matches_oracle(w, h, nfe):
         r, ro = ctx.result(0), orc.process(L, R, cam)
         assert_same_frame(ctx, 0, orc, r, ro, "anms t=%d" % t)
     assert r.detected_left[0] > nfe // 2
+
+
+def test_state_save_load_resumes_a_stream(golden_dir, tmp_path):
+    """saveStateToFile / loadStateFromFile (common.cpp:475-543, 261-350): the file written through the C-ABI reads back
+    through the independent Python reader with the lists the getters return, and a fresh context that loads it continues
+    the stream exactly like the one that kept running (and like the oracle)."""
+    from stereo_vo_amd.state_file import read_state
+    g, cam, p = load_small(golden_dir)
+    p.vo_use_matches_ids = 1
+    W, H = int(g["W"]), int(g["H"])
+    a = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    a.set_params(p); a.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        a.process_host([(g["L%d" % t], g["R%d" % t])]); a.result(0)
+        orc.process(g["L%d" % t], g["R%d" % t], cam)
+    path = str(tmp_path / "vo_state.bin")
+    a.save_state(0, path)
+    s = read_state(path)
+    for which, name in ((1, "pre"), (0, "cur")):
+        for side, sn in ((0, "left"), (1, "right")):
+            k, d = a.keypoints(0, which, side)
+            assert s[name][sn][0].tobytes() == k.tobytes() and (s[name][sn][1] == d).all()
+        assert s[name]["matches"].tobytes() == a.matches(0, which).tobytes()
+        assert list(s[name]["ids"]) == list(a.match_ids(0, which))
+    assert s["npyr"] == 1 and s["num_tracked_last_frame"] == a.result(0).tracked_feats_from_last_frame
+    b = hip.Context(n_lanes=2, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)       # a different context shape on purpose
+    b.set_params(p); b.set_camera(cam)
+    b.process_host([(g["L0"], g["R0"])] * 2); b.wait()                                 # lane 1 gets unrelated history first
+    b.load_state(1, path)
+    a.process_host([(g["L3"], g["R3"])]); b.process_host([(g["L3"], g["R3"])] * 2)
+    ra, rb, ro = a.result(0), b.result(1), orc.process(g["L3"], g["R3"], cam)
+    assert_same_frame(a, 0, orc, ra, ro, "kept running")
+    # the file does not carry m_last_computed_pose (neither does the reference's), so the resumed lane starts its
+    # Gauss-Newton from the identity: lists identical, pose equal to within the tolerance rather than bit for bit
+    for side in (0, 1):
+        assert b.keypoints(1, 0, side)[0].tobytes() == a.keypoints(0, 0, side)[0].tobytes()
+    assert b.matches(1).tobytes() == a.matches(0).tobytes() and b.tracked(1).tobytes() == a.tracked(0).tobytes()
+    assert (rb.valid, rb.error_code, rb.tracked_feats_from_last_frame) == (ra.valid, ra.error_code, ra.tracked_feats_from_last_frame)
+    dp = np.abs(np.array(rb.outPose) - np.array(ra.outPose))
+    assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD, dp
+    assert list(b.match_ids(1, 0)) == list(a.match_ids(0, 0)) == list(orc.match_ids(0))
+    # malformed input is refused, the lane is left as it was
+    bad = str(tmp_path / "bad.bin"); open(bad, "wb").write(open(path, "rb").read()[:100])
+    with pytest.raises(Exception):
+        b.load_state(0, bad)
