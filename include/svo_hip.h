@@ -135,6 +135,14 @@ int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keyp
 int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n);
 int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n);
 
+/* getProjectedCoords (H:175-182, C:415-466): pixel coordinates (uL vL uR vR, 4 floats each) that the previous
+ * pairings NOT marked as tracked (tracked_first[m] == -1, C:430-431) take after the change in pose: triangulation as
+ * in stage 5, then m_pinhole_stereo_projection with the inverse of change_pose (x y z yaw pitch roll).  Returns the
+ * number B of such pairings; nothing is written when pix is NULL or cap < B (size query). */
+int svo_projected_coords(svo_ctx* ctx, const svo_dmatch* pre_matches, int n_pre, const svo_keypoint* pre_left, int n_left,
+                         const svo_keypoint* pre_right, int n_right, const int32_t* tracked_first,
+                         const svo_stereo_camera* cam, const double* change_pose6, float* pix, int cap);
+
 /* saveStateToFile / loadStateFromFile (H:184-185, C:475-543, C:261-350): the state of one lane in the reference's
  * binary layout -- npyr; then for PRE and CUR: left keypoints, right keypoints (count, then x y response size angle as
  * float and octave class_id as int per keypoint, then rows cols type and the descriptor bytes), pairings (count,

@@ -344,6 +344,27 @@ def prepare(src, map_x=None, map_y=None):
     return dst
 
 
+def pose_to_delta(pose):
+    p = np.ascontiguousarray(pose, np.float64); d = np.zeros(6)
+    f = lib().svo_oracle_pose_to_delta
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    f(p.ctypes.data, d.ctypes.data)
+    return d
+
+
+def projected_coords(pre_matches, pre_left, pre_right, tracked_first, cam, change_pose):
+    """getProjectedCoords (C:415-466): (B, 4) float32 pixels uL vL uR vR of the pairings whose tracked_first is -1."""
+    m = np.ascontiguousarray(pre_matches, dmatch_dtype); kl = np.ascontiguousarray(pre_left, keypoint_dtype); kr = np.ascontiguousarray(pre_right, keypoint_dtype)
+    tf = np.ascontiguousarray(tracked_first, np.int32); pose = np.ascontiguousarray(change_pose, np.float64)
+    pix = np.zeros((max(1, len(m)), 4), np.float32)
+    f = lib().svo_oracle_projected_coords
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(m.ctypes.data, len(m), kl.ctypes.data, kr.ctypes.data, tf.ctypes.data, C.addressof(cam), pose.ctypes.data, pix.ctypes.data)
+    return pix[:n].copy()
+
+
 def sad8(l, r, lx, ly, rx, ry):
     l, r = _img(l), _img(r)
     return int(lib().svo_oracle_sad8(_ptr(l, u8p), _ptr(r, u8p), C.c_size_t(l.shape[1]), lx, ly, rx, ry))

@@ -1130,6 +1130,57 @@ void svo_oracle_delta_to_pose(const double* dp, double* pose)
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* getProjectedCoords  (H:175-182, C:415-466)                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+/* delta = [rotation vector, translation] of the INVERSE of the pose (x y z yaw pitch roll): CPose3D::inverse() then
+ * CPose3DRotVec(CPose3D) (C:456-461).  [frozen]: MRPT is absent; the log map goes through the unit quaternion
+ * (Shepperd's branch selection), theta = 2 atan2(|v|, q0), which is well conditioned at 0 and at pi. */
+void svo_oracle_pose_to_delta(const double* pose, double* dp)
+{
+    const double cy = cos(pose[3]), sy = sin(pose[3]), cp = cos(pose[4]), sp = sin(pose[4]), cr = cos(pose[5]), sr = sin(pose[5]);
+    /* R = Rz(yaw) Ry(pitch) Rx(roll) */
+    const double R[9] = { cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                          sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                          -sp, cp * sr, cp * cr };
+    const double Ri[9] = { R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8] };     /* inverse rotation */
+    dp[3] = -(Ri[0] * pose[0] + Ri[1] * pose[1] + Ri[2] * pose[2]);
+    dp[4] = -(Ri[3] * pose[0] + Ri[4] * pose[1] + Ri[5] * pose[2]);
+    dp[5] = -(Ri[6] * pose[0] + Ri[7] * pose[1] + Ri[8] * pose[2]);
+    double q0, q1, q2, q3;
+    const double tr = Ri[0] + Ri[4] + Ri[8];
+    if (tr > 0.0) { const double s = sqrt(tr + 1.0) * 2.0; q0 = 0.25 * s; q1 = (Ri[7] - Ri[5]) / s; q2 = (Ri[2] - Ri[6]) / s; q3 = (Ri[3] - Ri[1]) / s; }
+    else if (Ri[0] > Ri[4] && Ri[0] > Ri[8]) { const double s = sqrt(1.0 + Ri[0] - Ri[4] - Ri[8]) * 2.0; q0 = (Ri[7] - Ri[5]) / s; q1 = 0.25 * s; q2 = (Ri[1] + Ri[3]) / s; q3 = (Ri[2] + Ri[6]) / s; }
+    else if (Ri[4] > Ri[8]) { const double s = sqrt(1.0 + Ri[4] - Ri[0] - Ri[8]) * 2.0; q0 = (Ri[2] - Ri[6]) / s; q1 = (Ri[1] + Ri[3]) / s; q2 = 0.25 * s; q3 = (Ri[5] + Ri[7]) / s; }
+    else { const double s = sqrt(1.0 + Ri[8] - Ri[0] - Ri[4]) * 2.0; q0 = (Ri[3] - Ri[1]) / s; q1 = (Ri[2] + Ri[6]) / s; q2 = (Ri[5] + Ri[7]) / s; q3 = 0.25 * s; }
+    if (q0 < 0.0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+    const double vn = sqrt(q1 * q1 + q2 * q2 + q3 * q3);
+    if (vn < 1e-12) { dp[0] = 2.0 * q1; dp[1] = 2.0 * q2; dp[2] = 2.0 * q3; }
+    else { const double k = 2.0 * atan2(vn, q0) / vn; dp[0] = k * q1; dp[1] = k * q2; dp[2] = k * q3; }
+}
+
+/* tracked_first[m] != -1 marks pairing m as tracked elsewhere (skipped, C:430-431); the others are triangulated from
+ * the previous frame (C:436-455, the formula of S5:529-544) and projected after the change in pose (C:464).
+ * pix: 4 floats per emitted point (uL vL uR vR, the pair<TPixelCoordf,TPixelCoordf> of H:181).  Returns their number. */
+int svo_oracle_projected_coords(const svo_dmatch* pre_matches, int n_pre, const svo_keypoint* pre_left, const svo_keypoint* pre_right,
+                                const int32_t* tracked_first, const svo_stereo_camera* cam, const double* change_pose6, float* pix)
+{
+    double dp[6]; svo_oracle_pose_to_delta(change_pose6, dp);
+    rot_t R; rodrigues_with_derivs(dp, &R);
+    int nb = 0; double jac[24];
+    for (int m = 0; m < n_pre; m++) {
+        if (tracked_first[m] != -1) continue;
+        const double ul = pre_left[pre_matches[m].queryIdx].x, vl = pre_left[pre_matches[m].queryIdx].y, ur = pre_right[pre_matches[m].trainIdx].x;
+        const double cul = cam->l_cx, cvl = cam->l_cy, fl = cam->l_fx, cur = cam->r_cx, fr = cam->r_fx;
+        const double disparity = fl * (cur - ur) + fr * (ul - cul);
+        const double b_d = cam->baseline / disparity;
+        const double X[3] = { b_d * fr * (ul - cul), b_d * fr * (vl - cvl), b_d * fl * fr };
+        project_one(&R, dp, cam, X, pix + 4 * nb, jac);
+        nb++;
+    }
+    return nb;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* estimator state                                                                                   */
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct { svo_keypoint* kps; uint8_t* desc; int n; int64_t* row_index; int rows; } feat_set;

@@ -104,6 +104,10 @@ void svo_oracle_project(const double* lmks3, int n, const svo_stereo_camera* cam
                         float* pix, double* jac);
 /* CPose3D( CPose3DRotVec(delta).getInverse() ) -> x y z yaw pitch roll (S5:717-718) */
 void svo_oracle_delta_to_pose(const double* delta6, double* pose6);
+void svo_oracle_pose_to_delta(const double* pose6, double* delta6);      /* rotvec + translation of the inverse pose (C:456-461) */
+/* getProjectedCoords (H:175-182, C:415-466) */
+int svo_oracle_projected_coords(const svo_dmatch* pre_matches, int n_pre, const svo_keypoint* pre_left, const svo_keypoint* pre_right,
+                                const int32_t* tracked_first, const svo_stereo_camera* cam, const double* change_pose6, float* pix);
 /* compute_SAD8 (compute_SAD8.cpp:71-98) -- toolchain known-answer only */
 /* ---- stage 1 (stage1_rectify.cpp:47-85): grey conversion and rectification, the step before the hot path ---- */
 /* channels 1 or 3 (BGR, the colour order of cv::Mat / mrpt::utils::CImage); map_x / map_y: float source coordinates

@@ -497,3 +497,37 @@ void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
 {
     hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// getProjectedCoords (common.cpp:415-466): landmarks of the untracked previous pairings triangulated as in stage 5
+// (C:436-455) and projected after the change in pose through m_pinhole_stereo_projection (C:464, S5:180-195).
+// One thread per point; same expressions, in the same order, as oracle/svo_oracle.c (svo_oracle_projected_coords).
+// ------------------------------------------------------------------------------------------------------------
+struct Delta6 { double v[6]; };
+
+__global__ void __launch_bounds__(256) k_project_points(const float* uvu, int n, svo_stereo_camera cam, Delta6 dp, float* pix)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rot R; rodrigues_with_derivs(dp.v, R);
+    const double ul = (double)uvu[3 * i], vl = (double)uvu[3 * i + 1], ur = (double)uvu[3 * i + 2];
+    const double cul = cam.l_cx, cvl = cam.l_cy, fl = cam.l_fx, cur = cam.r_cx, fr = cam.r_fx;
+    const double disparity = fl * (cur - ur) + fr * (ul - cul);
+    const double b_d = cam.baseline / disparity;
+    const double X1p = b_d * fr * (ul - cul), Y1p = b_d * fr * (vl - cvl), Z1p = b_d * fl * fr;
+    const double* r = R.r;
+    const double X1c = r[0] * X1p + r[1] * Y1p + r[2] * Z1p + dp.v[3];
+    const double Y1c = r[3] * X1p + r[4] * Y1p + r[5] * Z1p + dp.v[4];
+    const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + dp.v[5];
+    const double X2c = X1c - cam.baseline;
+    pix[4 * i + 0] = (float)(cam.l_fx * X1c / Z1c + cam.l_cx);
+    pix[4 * i + 1] = (float)(cam.l_fy * Y1c / Z1c + cam.l_cy);
+    pix[4 * i + 2] = (float)(cam.r_fx * X2c / Z1c + cam.r_cx);
+    pix[4 * i + 3] = (float)(cam.r_fy * Y1c / Z1c + cam.r_cy);
+}
+
+void launch_project_points(const float* uvu, int n, const svo_stereo_camera& cam, const double* delta6, float* pix, hipStream_t st)
+{
+    Delta6 d; for (int k = 0; k < 6; k++) d.v[k] = delta6[k];
+    if (n > 0) hipLaunchKernelGGL(k_project_points, dim3((n + 255) / 256), dim3(256), 0, st, uvu, n, cam, d, pix);
+}

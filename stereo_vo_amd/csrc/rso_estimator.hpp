@@ -39,6 +39,9 @@ struct TStereoCamera {
     TStereoCamera() : leftCamera(), rightCamera() { for (double& v : rightCameraPose) v = 0; }
 };
 
+/** mrpt::utils::TPixelCoordf stand-in */
+struct TPixelCoordf { float x, y; TPixelCoordf() : x(0), y(0) {} TPixelCoordf(float x_, float y_) : x(x_), y(y_) {} };
+
 /** mrpt::poses::CPose3D stand-in: x y z yaw pitch roll, R = Rz(yaw) Ry(pitch) Rx(roll) */
 struct CPose3D {
     double m_coords[3]; double m_yaw, m_pitch, m_roll;
@@ -155,6 +158,22 @@ public:
         result.out_residual.assign(res.begin(), res.begin() + r.n_residual);
         result.outliers.assign(outl.begin(), outl.begin() + r.n_outliers);
         return result.valid;
+    }
+
+    /** getProjectedCoords (H:175-182, C:415-466): coordinates of the previous pairings that were NOT tracked elsewhere
+     *  (other_matches_tracked[m].first == -1) after the change in pose; pro_pre_feats gets (uL, vL), (uR, vR) pairs */
+    void getProjectedCoords(const TDMatchList& pre_matches, const TKeyPointList& pre_left_feats, const TKeyPointList& pre_right_feats,
+                            const std::vector<std::pair<int, float> >& other_matches_tracked, const TStereoCamera& stereo_camera,
+                            const CPose3D& change_pose, std::vector<std::pair<TPixelCoordf, TPixelCoordf> >& pro_pre_feats) {
+        std::vector<int32_t> first(other_matches_tracked.size());
+        for (size_t i = 0; i < first.size(); i++) first[i] = other_matches_tracked[i].first;
+        const svo_stereo_camera cam = to_cam(stereo_camera);
+        const double pose[6] = { change_pose.x(), change_pose.y(), change_pose.z(), change_pose.yaw(), change_pose.pitch(), change_pose.roll() };
+        std::vector<float> pix(4 * pre_matches.size() + 4);
+        const int n = check(svo_projected_coords(m_ctx, pre_matches.data(), (int)pre_matches.size(), pre_left_feats.data(), (int)pre_left_feats.size(),
+                                                 pre_right_feats.data(), (int)pre_right_feats.size(), first.data(), &cam, pose, pix.data(), (int)pre_matches.size() + 1), "svo_projected_coords");
+        pro_pre_feats.resize((size_t)n);
+        for (int i = 0; i < n; i++) { pro_pre_feats[i].first = TPixelCoordf(pix[4 * i], pix[4 * i + 1]); pro_pre_feats[i].second = TPixelCoordf(pix[4 * i + 2], pix[4 * i + 3]); }
     }
 
     /** getValues (H:704-724): copies of the current frame's octave-0 lists */

@@ -770,6 +770,59 @@ extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, 
     return SVO_OK;
 }
 
+// ---- getProjectedCoords (common.cpp:415-466) --------------------------------------------------------------------
+// delta = [rotation vector, translation] of the inverse of change_pose (C:456-461); same operations as
+// svo_oracle_pose_to_delta (log map through the unit quaternion)
+static void pose_to_delta(const double* pose, double* dp)
+{
+    const double cy = cos(pose[3]), sy = sin(pose[3]), cp = cos(pose[4]), sp = sin(pose[4]), cr = cos(pose[5]), sr = sin(pose[5]);
+    const double R[9] = { cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                          sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                          -sp, cp * sr, cp * cr };
+    const double Ri[9] = { R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8] };
+    dp[3] = -(Ri[0] * pose[0] + Ri[1] * pose[1] + Ri[2] * pose[2]);
+    dp[4] = -(Ri[3] * pose[0] + Ri[4] * pose[1] + Ri[5] * pose[2]);
+    dp[5] = -(Ri[6] * pose[0] + Ri[7] * pose[1] + Ri[8] * pose[2]);
+    double q0, q1, q2, q3;
+    const double tr = Ri[0] + Ri[4] + Ri[8];
+    if (tr > 0.0) { const double s = sqrt(tr + 1.0) * 2.0; q0 = 0.25 * s; q1 = (Ri[7] - Ri[5]) / s; q2 = (Ri[2] - Ri[6]) / s; q3 = (Ri[3] - Ri[1]) / s; }
+    else if (Ri[0] > Ri[4] && Ri[0] > Ri[8]) { const double s = sqrt(1.0 + Ri[0] - Ri[4] - Ri[8]) * 2.0; q0 = (Ri[7] - Ri[5]) / s; q1 = 0.25 * s; q2 = (Ri[1] + Ri[3]) / s; q3 = (Ri[2] + Ri[6]) / s; }
+    else if (Ri[4] > Ri[8]) { const double s = sqrt(1.0 + Ri[4] - Ri[0] - Ri[8]) * 2.0; q0 = (Ri[2] - Ri[6]) / s; q1 = (Ri[1] + Ri[3]) / s; q2 = 0.25 * s; q3 = (Ri[5] + Ri[7]) / s; }
+    else { const double s = sqrt(1.0 + Ri[8] - Ri[0] - Ri[4]) * 2.0; q0 = (Ri[3] - Ri[1]) / s; q1 = (Ri[2] + Ri[6]) / s; q2 = (Ri[5] + Ri[7]) / s; q3 = 0.25 * s; }
+    if (q0 < 0.0) { q0 = -q0; q1 = -q1; q2 = -q2; q3 = -q3; }
+    const double vn = sqrt(q1 * q1 + q2 * q2 + q3 * q3);
+    if (vn < 1e-12) { dp[0] = 2.0 * q1; dp[1] = 2.0 * q2; dp[2] = 2.0 * q3; }
+    else { const double k = 2.0 * atan2(vn, q0) / vn; dp[0] = k * q1; dp[1] = k * q2; dp[2] = k * q3; }
+}
+
+extern "C" int svo_projected_coords(svo_ctx* ctx, const svo_dmatch* pre_matches, int n_pre, const svo_keypoint* pre_left, int n_left,
+                                    const svo_keypoint* pre_right, int n_right, const int32_t* tracked_first,
+                                    const svo_stereo_camera* cam, const double* change_pose6, float* pix, int cap)
+{
+    if (!ctx || n_pre < 0 || (n_pre > 0 && (!pre_matches || !pre_left || !pre_right || !tracked_first)) || !cam || !change_pose6) return SVO_ERR_ARG;
+    std::vector<float> uvu;
+    for (int m = 0; m < n_pre; m++) {
+        if (tracked_first[m] != -1) continue;                                   // C:430-431
+        const int l = pre_matches[m].queryIdx, r = pre_matches[m].trainIdx;
+        if (l < 0 || l >= n_left || r < 0 || r >= n_right) return SVO_ERR_ARG;
+        uvu.push_back(pre_left[l].x); uvu.push_back(pre_left[l].y); uvu.push_back(pre_right[r].x);
+    }
+    const int nb = (int)(uvu.size() / 3);
+    if (!pix || cap < nb || nb == 0) return nb;                                 // size query / nothing to do
+    double dp[6]; pose_to_delta(change_pose6, dp);
+    float* d_in = nullptr, *d_out = nullptr;
+    HIPCHECK(hipMalloc((void**)&d_in, uvu.size() * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)nb * 4 * sizeof(float));
+    if (e != hipSuccess) { hipFree(d_in); HIPCHECK(e); }
+    const hipStream_t st = ctx->stream;
+    e = hipMemcpyAsync(d_in, uvu.data(), uvu.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { launch_project_points(d_in, nb, *cam, dp, d_out, st); e = hipMemcpyAsync(pix, d_out, (size_t)nb * 4 * sizeof(float), hipMemcpyDeviceToHost, st); }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_in); hipFree(d_out);
+    HIPCHECK(e);
+    return nb;
+}
+
 // ---- saveStateToFile / loadStateFromFile (common.cpp:475-543, 261-350; helpers :88-255) --------------------------
 namespace {
 struct StateList { std::vector<svo_keypoint> kps; std::vector<uint8_t> desc; };

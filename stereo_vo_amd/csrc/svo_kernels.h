@@ -42,4 +42,5 @@ void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st);
 void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st);
 void launch_hamming_plain(const uint8_t* q, int nq, const uint8_t* t, int nt, unsigned* out, int nsplit, hipStream_t st);
 hipError_t configure_gauss_newton(int pmax);
+void launch_project_points(const float* uvu, int n, const svo_stereo_camera& cam, const double* delta6, float* pix, hipStream_t st);
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st);

@@ -24,7 +24,7 @@ EXPORTS = [
     "svo_get_orb_threshold", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
-    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_hamming_match",
+    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
 ]
@@ -180,6 +180,14 @@ class Context:
         mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
         assert mx.ndim == 2 and mx.shape == my.shape
         self._ck(self.L.svo_set_rectify_map(self.h, lane, side, C.c_void_p(mx.ctypes.data), C.c_void_p(my.ctypes.data), mx.shape[1], mx.shape[0]), "svo_set_rectify_map")
+
+    def projected_coords(self, pre_matches, pre_left, pre_right, tracked_first, cam, change_pose):
+        """getProjectedCoords (common.cpp:415-466): (B, 4) float32 pixels of the pairings whose tracked_first is -1."""
+        m = np.ascontiguousarray(pre_matches, dmatch_dtype); kl = np.ascontiguousarray(pre_left, keypoint_dtype); kr = np.ascontiguousarray(pre_right, keypoint_dtype)
+        tf = np.ascontiguousarray(tracked_first, np.int32); pose = np.ascontiguousarray(change_pose, np.float64)
+        pix = np.zeros((max(1, len(m)), 4), np.float32)
+        n = self._ck(self.L.svo_projected_coords(self.h, _vp(m), len(m), _vp(kl), len(kl), _vp(kr), len(kr), _vp(tf), C.byref(cam), _vp(pose), _vp(pix), len(pix)), "svo_projected_coords")
+        return pix[:n].copy()
 
     def save_state(self, lane, path):
         """saveStateToFile (common.cpp:475-543) of one lane."""

@@ -535,3 +535,19 @@ def test_state_save_load_resumes_a_stream(golden_dir, tmp_path):
     bad = str(tmp_path / "bad.bin"); open(bad, "wb").write(open(path, "rb").read()[:100])
     with pytest.raises(Exception):
         b.load_state(0, bad)
+
+
+def test_projected_coords_match_oracle(golden_dir):
+    """getProjectedCoords (H:175-182, common.cpp:415-466) through the C-ABI against the oracle, bit for bit."""
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    for t in range(2):
+        ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+    r = ctx.result(0)
+    kl, _ = ctx.keypoints(0, 1, 0); kr, _ = ctx.keypoints(0, 1, 1); m = ctx.matches(0, 1)
+    tracked = np.full(len(m), -1, np.int32); tracked[ctx.tracked(0)["first"]] = 1
+    for pose in (list(r.outPose), [0.3, -0.1, 0.5, 0.2, -0.05, 0.1], [0, 0, 0, 0, 0, 0]):
+        a, b = ctx.projected_coords(m, kl, kr, tracked, cam, pose), O().projected_coords(m, kl, kr, tracked, cam, pose)
+        assert a.shape == b.shape == (int((tracked == -1).sum()), 4) and a.tobytes() == b.tobytes()
+    assert ctx.projected_coords(m[:0], kl, kr, tracked[:0], cam, [0] * 6).shape == (0, 4)
