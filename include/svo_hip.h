@@ -134,6 +134,9 @@ int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keyp
                      int img_w, int img_h);
 int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n);
 int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n);
+/* request_data.precomputed_matches_ID (H:218, P:233-244): the IDs of the octave-0 pairings put before; m_last_match_ID
+ * becomes their maximum (P:236-243).  Honoured by the pipeline only when vo_use_matches_ids is set (P:246-250). */
+int svo_put_match_ids(svo_ctx* ctx, int lane, int which, const int32_t* ids, int n);
 
 /* getProjectedCoords (H:175-182, C:415-466): pixel coordinates (uL vL uR vR, 4 floats each) that the previous
  * pairings NOT marked as tracked (tracked_first[m] == -1, C:430-431) take after the change in pose: triangulation as

@@ -758,6 +758,20 @@ extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmat
     return mark_present(ctx, lane, which);
 }
 
+extern "C" int svo_put_match_ids(svo_ctx* ctx, int lane, int which, const int32_t* ids, int n)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !ids)) return SVO_ERR_ARG;
+    if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
+    LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap;       // octave 0
+    if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.ids + ((long long)vl * 2 + slot) * ctx->dc.max_kps, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->dc.n_ids + vl * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
+    int mx = 0; for (int i = 0; i < n; i++) if (ids[i] > mx) mx = ids[i];                          // P:236, 243
+    s.last_match_id = mx;
+    HIPCHECK(hipMemcpy(ctx->dc.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
 extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n)
 {
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || n < 0 || (n > 0 && !t)) return SVO_ERR_ARG;

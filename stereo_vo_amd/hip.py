@@ -24,7 +24,7 @@ EXPORTS = [
     "svo_get_orb_threshold", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
-    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
+    "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
 ]
@@ -310,6 +310,10 @@ class Context:
     def put_matches(self, lane, which, m):
         m = np.ascontiguousarray(m)
         self._ck(self.L.svo_put_matches(self.h, lane, which, _vp(m), len(m)), "svo_put_matches")
+
+    def put_match_ids(self, lane, which, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self._ck(self.L.svo_put_match_ids(self.h, lane, which, _vp(ids), len(ids)), "svo_put_match_ids")
 
     def put_tracked(self, lane, t):
         t = np.ascontiguousarray(t)

@@ -213,6 +213,10 @@ def test_precomputed_data_bypass(golden_dir):
     # stage 3 alone on put features reproduces the pairings
     ctx.run_stages(hip.RUN_MATCH)
     assert ctx.matches(0).tobytes() == g["matches2"].tobytes()
+    # precomputed_matches_ID (H:218, P:233-244): the IDs come back and m_last_match_ID becomes their maximum
+    ids = np.arange(len(g["matches2"]), dtype=np.int32)[::-1] * 3 + 7
+    ctx.put_match_ids(0, 0, ids)
+    assert list(ctx.match_ids(0, 0)) == list(ids)
     ctx.close()
 
 
