@@ -6,7 +6,9 @@ torch.distributed.run, one rank per GPU.  A "step" advances every lane (independ
 one frame: value = N * lanes * K / t, t = max over ranks of the barrier-bracketed wall time of the K steps.
 All frames are rendered and resident in HBM before the timed region; nothing is copied host->device inside it.
 Workload at N=1: BASELINE.json configs[1] -- 1280x960 synthetic stereo streams, ~2000 ORB keypoints per image
-(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton.
+(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton; 128 streams per GPU held by two
+contexts of 64 on separate HIP streams (the per-stream latency-bound kernels of one context overlap the throughput
+kernels of the other; kernel times below are per launch = per context, measured while both run).
 Streams shard by independent stream across ranks with no data-path collective ("weak" scaling); the per-frame
 result records are all-gathered over RCCL as in configs[3] (512 B-class, latency only).
 
@@ -97,12 +99,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--lanes", type=int, default=64, help="independent stereo streams per GPU")
+    ap.add_argument("--lanes", type=int, default=128, help="independent stereo streams per GPU (all contexts together)")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
     ap.add_argument("--frames", type=int, default=6, help="distinct frames rendered per stream (played ping-pong)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--orb-nfeats", type=int, default=2000)
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of one stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
@@ -111,7 +115,7 @@ def main():
         args.width, args.height, args.orb_nfeats, kitti = 1241, 376, 900, True
     elif args.workload == "config5":
         args.width, args.height, args.orb_nfeats, detect_fast_orb, n_octaves = 2048, 1536, 3300, True, 3
-        args.lanes = min(args.lanes, 32)
+        args.lanes = min(args.lanes, 64)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,21 +141,61 @@ def main():
     cam = worlds[0].camera()
     torch.cuda.synchronize()
 
-    stream = torch.cuda.current_stream(dev)
     p = north_star_params(hip.default_params(), orb_nfeats=args.orb_nfeats)
     if detect_fast_orb:
         from stereo_vo_amd.abi import DM_FAST_ORB
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
-    ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=4096, device=local_rank, kernel_times=True, stream=stream.cuda_stream,
-                      max_octaves=n_octaves, max_cand=(1 << 18) if W * H > 2000000 else (1 << 17))
-    ctx.set_params(p)
-    ctx.set_camera(cam)
+    NC = max(1, args.contexts)
+    assert B % NC == 0 and B // NC <= 64, "--lanes must split evenly over --contexts, at most 64 streams per context"
+    Bc = B // NC
+    streams = [torch.cuda.Stream(dev) for _ in range(NC)]
+    ctxs = []
+    for k in range(NC):
+        c_ = hip.Context(n_lanes=Bc, max_w=W, max_h=H, max_kps=4096, device=local_rank, kernel_times=True, stream=streams[k].cuda_stream,
+                         max_octaves=n_octaves, max_cand=(1 << 18) if W * H > 2000000 else (1 << 17))
+        c_.set_params(p); c_.set_camera(cam)
+        ctxs.append(c_)
     rec = torch.zeros((B, C.sizeof(Result)), dtype=torch.uint8, device=dev)
+    done = [torch.cuda.Event() for _ in range(NC)]
+
+    # Schedule ("pipelined"): ONE normal-priority stream carries the detect phases (stage 2: resize / FAST / select /
+    # describe / NMS -- the throughput kernels) of all contexts back to back; ONE high-priority stream carries the rest
+    # of each frame (stages 3-5: mostly per-stream, latency-bound kernels), which therefore overlaps the next context's
+    # detect phase without being starved by it.  Events: rest(k) waits for detect(k); the next detect of context k waits
+    # for rest(k) (stage 4 reads the feature slot that detection overwrites next).
+    s_det = torch.cuda.Stream(dev, priority=0)
+    s_rest = torch.cuda.Stream(dev, priority=-1)
+    det_done = [torch.cuda.Event() for _ in range(NC)]
+    rest_done = [torch.cuda.Event() for _ in range(NC)]
+    REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE
+    state = {"first": True}
+    pipelined = NC > 1 and args.schedule == "pipelined"
 
     def step(i):
         t = frame_schedule(i, F)
-        ctx.process_device([(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)], W, H, W)
-        ctx.copy_results_async(rec.data_ptr(), rec.numel())
+        for k, c_ in enumerate(ctxs):
+            ptrs = [(frames[k * Bc + l][t][0].data_ptr(), frames[k * Bc + l][t][1].data_ptr()) for l in range(Bc)]
+            if pipelined:
+                if not state["first"]:
+                    s_det.wait_event(rest_done[k])
+                c_.set_stream(s_det.cuda_stream)
+                c_.process_device(ptrs, W, H, W, hip.RUN_DETECT)
+                det_done[k].record(s_det)
+                s_rest.wait_event(det_done[k])
+                c_.set_stream(s_rest.cuda_stream)
+                c_.run_stages(REST)
+                c_.copy_results_async(rec[k * Bc:(k + 1) * Bc].data_ptr(), Bc * C.sizeof(Result))
+                rest_done[k].record(s_rest)
+            else:
+                c_.process_device(ptrs, W, H, W)
+                c_.copy_results_async(rec[k * Bc:(k + 1) * Bc].data_ptr(), Bc * C.sizeof(Result))
+        state["first"] = False
+        if world > 1:          # the all-gather runs on torch's current stream: it waits for every context's last work
+            for k in range(NC):
+                if pipelined:
+                    torch.cuda.current_stream(dev).wait_event(rest_done[k])
+                else:
+                    done[k].record(streams[k]); torch.cuda.current_stream(dev).wait_event(done[k])
         return gather_records(rec, world)
 
     def barrier():
@@ -161,8 +205,10 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    ctx.wait()
-    ctx.kernel_times_reset()
+    torch.cuda.synchronize()
+    for c_ in ctxs:
+        c_.wait()
+        c_.kernel_times_reset()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     allrec = None
@@ -172,8 +218,12 @@ def main():
     dt = time.perf_counter() - t0
     dt = reduce_max(dt, dev, world)
 
-    kt = ctx.kernel_times()
-    results = ctx.results()
+    kt = {}
+    results = []
+    for c_ in ctxs:       # launches of all contexts pooled: ms and launch counts add up, a launch covers Bc streams
+        for kname, v in c_.kernel_times().items():
+            a_ = kt.setdefault(kname, [0.0, 0]); a_[0] += v[0]; a_[1] += v[1]
+        results += c_.results()
     n_valid = sum(1 for r in results if r.valid)
     mean_kps = float(np.mean([r.detected_left[0] for r in results]))
     mean_match = float(np.mean([r.stereo_matches[0] for r in results]))
@@ -190,8 +240,13 @@ def main():
         lv = list(zip(lw, lh))
         per_kernel = {k: {"ms_per_launch": v[0] / max(1, v[1]) / (7 if k == "resize" else 1), "ms_per_step": v[0] / max(1, v[1]), "launches": int(v[1]) * (7 if k == "resize" else 1)}
                       for k, v in kt.items() if v[1] > 0}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
-        abytes = algorithmic_bytes(dom, 2 * B, lv, mean_kps, mean_match, mean_track)
+        # The roofline kernel is the dominant one of the DETECT stream: in the pipelined schedule the kernels of stages 3-5
+        # run on the overlap stream while another context detects, so their event spans measure time-shared execution,
+        # not exclusive durations (those are in profiles/r01e_kernel_stats.csv: ransac_count 0.09 ms, gauss_newton 0.11 ms)
+        detect_kernels = ("resize", "fast", "select", "describe", "nms_rowsort")
+        pool = [k for k in per_kernel if k in detect_kernels] if pipelined else list(per_kernel)
+        dom = max(pool or list(per_kernel), key=lambda k: per_kernel[k]["ms_per_step"])
+        abytes = algorithmic_bytes(dom, 2 * Bc, lv, mean_kps, mean_match, mean_track)
         achieved = abytes / (per_kernel[dom]["ms_per_launch"] * 1e-3) / 1e9
         # HBM traffic of that kernel from the committed PMC passes (tools/pmc_traffic.py: L2 memory-side read / write
         # requests counted by size in separate rocprofv3 --pmc runs of this same command), scaled from the profiled
@@ -201,12 +256,14 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
             if pm.get("workload") == args.workload and kk in pm["read_bytes"]:
-                traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * B / pm["lanes"])
+                traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * Bc / pm["lanes"])
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4)}
+                    "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4),
+                    "streams_per_launch": Bc,
+                    "note": ("dominant kernel of the detect stream; stage 3-5 kernels run on the overlap stream and their spans are time-shared, not exclusive" if pipelined else "single stream: every span is an exclusive duration")}
         # end-to-end algorithmic traffic of the whole path (SURVEY.md 8d formula), for the DESIGN.md table
         P = sum(a * b for a, b in lv) / float(W * H)
         pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
@@ -228,19 +285,20 @@ def main():
             "metric": "stereo pairs/sec @%dx%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d synthetic stereo streams, %s, orb_nfeats %d (~%d kps/image in octave 0 after NMS), BF match, BF track, robust GN; %d independent streams per GPU, one frame per stream per step"
-                                   % (args.workload, W, H, "FAST+ORB on %d x1/2 octaves" % n_octaves if detect_fast_orb else "ORB x 8 levels", args.orb_nfeats, int(mean_kps), B),
-                       "lanes_per_gpu": B, "frames_per_stream": F, "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
+            "config": {"workload": "%s: %dx%d synthetic stereo streams, %s, orb_nfeats %d (~%d kps/image in octave 0 after NMS), BF match, BF track, robust GN; %d independent streams per GPU in %d contexts on separate HIP streams, one frame per stream per step"
+                                   % (args.workload, W, H, "FAST+ORB on %d x1/2 octaves" % n_octaves if detect_fast_orb else "ORB x 8 levels", args.orb_nfeats, int(mean_kps), B, NC),
+                       "lanes_per_gpu": B, "contexts_per_gpu": NC, "lanes_per_context": Bc, "frames_per_stream": F, "schedule": args.schedule if NC > 1 else "single stream", "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "path_hbm_frac": round(pair_bytes * value / 1e9 / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_pair": int(pair_bytes),
             "valid_last_step": "%d/%d" % (n_valid, B),
             "mean_kps": round(mean_kps, 1), "mean_matches": round(mean_match, 1), "mean_tracked": round(mean_track, 1),
-            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in per_kernel.items()},
+            "kernels_ms_per_context_step": {k: round(v["ms_per_step"], 4) for k, v in per_kernel.items()},
         }
         print(json.dumps(line))
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -84,6 +84,11 @@ int svo_set_fast_threshold(svo_ctx* ctx, int v);  /* setFASTThreshold, clamped (
 int svo_set_orb_threshold(svo_ctx* ctx, int v);   /* setORBThreshold, clamped (H:538) */
 int svo_get_fast_threshold(const svo_ctx* ctx);
 int svo_get_orb_threshold(const svo_ctx* ctx);
+/* Switch the HIP stream that later svo_process / svo_copy_results_async calls enqueue on (NULL: the context's own).
+ * Ordering between work already enqueued on the old stream and work on the new one is the caller's business (events):
+ * this is what lets a caller run stage 2 of one context on a normal-priority stream and stages 3-5 of another on a
+ * high-priority one (bench.py). */
+int svo_set_stream(svo_ctx* ctx, void* stream);
 /* request_data.stereo_cam (H:211), per lane; lane = -1 sets every lane */
 int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam);
 /* Stage 1 on the device (stage1_rectify.cpp:47-85).  Rectification maps of one camera of one lane (lane = -1: every

@@ -25,7 +25,7 @@ struct svo_ctx {
     svo_config cfg;
     svo_params params;
     int fast_th, orb_th;
-    hipStream_t stream; bool own_stream;
+    hipStream_t stream, stream0; bool own_stream;      // stream0: the stream the context was created with / owns
     DevCtx dc;
     bool geom_ready; int geom_w, geom_h, geom_nfe, geom_nlevels, geom_method, geom_noct;
     int raw_cap_alloc;
@@ -140,6 +140,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(hipSetDevice(cfg->device));
     if (cfg->stream) { ctx->stream = (hipStream_t)cfg->stream; ctx->own_stream = false; }
     else { HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    ctx->stream0 = ctx->stream;
     HIPCHECK(svo_upload_tables());
     DevCtx& d = ctx->dc;
     memset(&d, 0, sizeof(d));
@@ -206,7 +207,7 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     if (ctx->d_ham_t) hipFree(ctx->d_ham_t);
     for (auto& s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) hipEventDestroy(e);
-    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream0);
     delete ctx;
 }
 
@@ -236,6 +237,14 @@ extern "C" int svo_set_orb_threshold(svo_ctx* ctx, int v)
 }
 extern "C" int svo_get_fast_threshold(const svo_ctx* ctx) { return ctx ? ctx->fast_th : SVO_ERR_ARG; }
 extern "C" int svo_get_orb_threshold(const svo_ctx* ctx) { return ctx ? ctx->orb_th : SVO_ERR_ARG; }
+
+extern "C" int svo_set_stream(svo_ctx* ctx, void* stream)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    if (stream) ctx->stream = (hipStream_t)stream;
+    else ctx->stream = ctx->stream0;
+    return SVO_OK;
+}
 
 extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam)
 {
