@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--orb-nfeats", type=int, default=2000)
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of one stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
+    ap.add_argument("--det-priority", default="low", choices=["low", "high"])
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
@@ -163,8 +164,8 @@ def main():
     # of each frame (stages 3-5: mostly per-stream, latency-bound kernels), which therefore overlaps the next context's
     # detect phase without being starved by it.  Events: rest(k) waits for detect(k); the next detect of context k waits
     # for rest(k) (stage 4 reads the feature slot that detection overwrites next).
-    s_det = torch.cuda.Stream(dev, priority=0)
-    s_rest = torch.cuda.Stream(dev, priority=-1)
+    s_det = torch.cuda.Stream(dev, priority=-1 if args.det_priority == "high" else 0)
+    s_rest = torch.cuda.Stream(dev, priority=0 if args.det_priority == "high" else -1)
     det_done = [torch.cuda.Event() for _ in range(NC)]
     rest_done = [torch.cuda.Event() for _ in range(NC)]
     REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE

@@ -13,12 +13,11 @@
 // K7: Hamming brute force, first minimum.  mode 0: current left -> current right (stage 3).  mode 1: previous
 // pairings -> current pairings, blockIdx.z / nsplit = side (left-left / right-right) on the descriptor rows that
 // k_gather_mdesc laid out contiguously in pairing order (the gather of S4:105-131).
-// Each thread owns one query descriptor in registers (8 dwords).  The train row is the same for every lane of a
-// wave, so it never touches a vector register or LDS: the loop reads it with SCALAR loads (s_load_dwordx8 through
-// the constant cache) and xors it in as an SGPR operand.  That leaves 8 v_xor + 8 v_bcnt + 2 per pair -- the VALU
-// floor of a 256-bit popcount distance -- where the LDS-broadcast version spent as many LDS cycles again.
-// Distance and train index are packed (dist << 16 | idx) so that min() is the first-minimum rule of
-// cv::BFMatcher; partial results of the train splits merge by atomicMin.
+// The distances are computed on the MATRIX CORES (see "the brute force on the matrix cores" below): this is the one
+// genuinely GEMM-shaped piece of the path -- N x N x 256 -- and the VALU formulation (8 v_xor + 8 v_bcnt + 2 per pair,
+// ~80 cycles per 64 distances whether the train row comes from LDS, scalar loads or SGPR constants:
+// tools/ubench/ham_loop.hip) was its floor.  Partial results of the train splits merge by atomicMin on the packed
+// (distance << 16 | index) word, as before.
 // ------------------------------------------------------------------------------------------------------------
 #define HM_TILE 256
 
@@ -40,10 +39,36 @@ __global__ void __launch_bounds__(256) k_gather_mdesc(DevCtx c)
     dst[w] = src[w];
 }
 
-#define HM_QPT 2          // queries per thread: each scalar train load feeds two distances (tools/ubench/ham_real: ~8 % over 1)
+// ---- the brute force on the matrix cores ------------------------------------------------------------------------
+// Hamming(q, t) over 256 bits IS a dot product: with bit b encoded as q' = +64 / -64 (b = 0 / 1) for the query and
+// t' = -64 / +64 for the train row, sum_k t'_k q'_k = -4096 * (256 - 2 * ham).  v_mfma_i32_32x32x32_i8 accumulates
+// that on top of C, and C is initialised with the train index, so one accumulator of the chain over the 8 k-steps is
+//        D = t - 2^20 + 8192 * ham         (t < 8192)
+// -- already the packed first-minimum key: min over D = smallest distance, then smallest train index, exactly the
+// rule of cv::BFMatcher.  No popcount, no xor: the epilogue of a 32-train tile is 8 v_min3 per 32 queries.
+// Tile shapes: A = 32 train rows (M), B = 32 query columns (N), K = 32 bits expanded to bytes per MFMA, 8 MFMAs per
+// tile.  A wave keeps TWO sets of 32 queries expanded in registers (64 VGPRs) and streams train tiles from LDS, where
+// the block expands each 1 KB tile of packed rows once for its four waves (layout [k-step][half][row][16 B]: a wave's
+// ds_read_b128 is 1 KB contiguous).  Output layout of the 32x32 MFMA: lane l holds column l % 32, VGPR v holds row
+// 8 * (v / 4) + v % 4 + 4 * (l / 32)  (tools/ubench/mfma_layout.hip).
+typedef int hm_v4i __attribute__((ext_vector_type(4)));
+typedef int hm_v16i __attribute__((ext_vector_type(16)));
+#define HM_QB 256          // queries per block (4 waves x 2 sets x 32)
+
+// 4 bits -> 4 bytes of 0 / 1 (LSB first), then -> bytes of base ^ 0x80 where the bit is set
+__device__ __forceinline__ uint32_t hm_spread4(uint32_t nib, uint32_t base) { return base ^ (((nib * 0x00204081u) & 0x01010101u) << 7); }
+// 16 bits (low half of `bits`) -> 16 bytes
+__device__ __forceinline__ hm_v4i hm_expand16(uint32_t bits, uint32_t base)
+{
+    hm_v4i r;
+    r.x = (int)hm_spread4(bits & 15u, base); r.y = (int)hm_spread4((bits >> 4) & 15u, base);
+    r.z = (int)hm_spread4((bits >> 8) & 15u, base); r.w = (int)hm_spread4((bits >> 12) & 15u, base);
+    return r;
+}
 
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
 {
+    __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][16 * 32];          // [buffer][(k-step * 2 + half) * 32 + row]
     // grid = (lane-octave, query block, side x split): the query blocks past nq exit at once, and with the lane index
     // fastest they sit at the END of the dispatch order.  (With the query block fastest, live and dead workgroups
     // alternate, the dispatcher hands them to the two halves of each XCD in turn, and half the CUs idle: measured 2x.)
@@ -61,43 +86,85 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
         nq = c.n_matches[vl * 2 + prev]; nt = c.n_matches[vl * 2 + cur];
         qd = c.mdesc + feat_base(c, vl, prev, side) * 32; td = c.mdesc + feat_base(c, vl, cur, side) * 32;
     }
-    const int qbase = blockIdx.y * (256 * HM_QPT) + threadIdx.x;              // queries qbase + 256 * i
-    if ((int)(blockIdx.y * 256 * HM_QPT) >= nq || nt <= 0) return;            // block-uniform
-    uint32_t qw[HM_QPT][8];
+    if ((int)(blockIdx.y * HM_QB) >= nq || nt <= 0) return;                  // block-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    // ---- this wave's 2 x 32 queries, expanded once: Bq[set][k-step] = the 16 bits (k-step, half) of query column col ----
+    hm_v4i Bq[2][8];
 #pragma unroll
-    for (int i = 0; i < HM_QPT; i++) {
-        const int q = min(qbase + 256 * i, nq - 1);                           // out-of-range slots redo the last query, never stored
-        const uint4* p = (const uint4*)(qd + (long long)q * 32);
-        const uint4 a = p[0], b = p[1];
-        qw[i][0] = a.x; qw[i][1] = a.y; qw[i][2] = a.z; qw[i][3] = a.w; qw[i][4] = b.x; qw[i][5] = b.y; qw[i][6] = b.z; qw[i][7] = b.w;
+    for (int st = 0; st < 2; st++) {
+        const int q = min((int)blockIdx.y * HM_QB + wid * 64 + st * 32 + col, nq - 1);        // past-the-end columns redo the last query, never stored
+        const uint32_t* qp = (const uint32_t*)(qd + (long long)q * 32);
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = qp[k];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) Bq[st][s8] = hm_expand16(w[s8] >> (16 * half), 0x40404040u);       // chunk s8 * 2 + half = bytes 4 s8 + 2 half ..
     }
-    // this block's share of the train rows
-    const int per = (nt + nsplit - 1) / nsplit;
+    // ---- this block's share of the train rows, in tiles of 32 ----
+    const int per = ((nt + nsplit - 1) / nsplit + 31) & ~31;
     const int j_begin = split * per, j_end = min(nt, j_begin + per);
-    unsigned best[HM_QPT];
+    if (j_begin >= j_end) return;
+    // staging role of this thread: row sr of the tile, packed dword sg -> chunks 2 sg, 2 sg + 1
+    const int sr = tid >> 3, sg = tid & 7;
+    const uint32_t* tw = (const uint32_t*)td;
+    auto fetch = [&](int j0) -> uint32_t { return tw[(long long)min(j0 + sr, nt - 1) * 8 + sg]; };
+    auto stage = [&](int buf, uint32_t bits) {
+        tileA[buf][(2 * sg) * 32 + sr] = hm_expand16(bits, 0xC0C0C0C0u);
+        tileA[buf][(2 * sg + 1) * 32 + sr] = hm_expand16(bits >> 16, 0xC0C0C0C0u);
+    };
+    // C operand = train index of each accumulator row (advances by 32 per tile); running minima, 8 per set (v_min3 pairs)
+    int tc[16], best[2][8];
 #pragma unroll
-    for (int i = 0; i < HM_QPT; i++) best[i] = 0xFFFFFFFFu;
-    const uint32_t* __restrict__ tw = (const uint32_t*)td;
-#pragma unroll 4
-    for (int j = j_begin; j < j_end; j++) {
-        const uint32_t* __restrict__ t = tw + (long long)j * 8;             // wave-uniform address: scalar loads
-        uint32_t tv[8];
+    for (int v = 0; v < 16; v++) tc[v] = j_begin + 8 * (v >> 2) + (v & 3) + 4 * half;
 #pragma unroll
-        for (int k = 0; k < 8; k++) tv[k] = t[k];
+    for (int st = 0; st < 2; st++)
 #pragma unroll
-        for (int i = 0; i < HM_QPT; i++) {
-            unsigned d = 0;
+        for (int i = 0; i < 8; i++) best[st][i] = 0x7FFFFFFF;
+    uint32_t nxt = fetch(j_begin);
+    stage(0, nxt);
+    int buf = 0;
+    for (int j0 = j_begin; j0 < j_end; j0 += 32, buf ^= 1) {
+        __syncthreads();                                           // tile `buf` is staged; the other buffer is free again
+        const bool more = j0 + 32 < j_end;
+        if (more) nxt = fetch(j0 + 32);
+        hm_v16i cin;
+        if (j0 + 32 <= j_end) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) d += __popc(qw[i][k] ^ tv[k]);
-            best[i] = min(best[i], (d << 16) | (unsigned)j);
+            for (int v = 0; v < 16; v++) cin[v] = tc[v];
+        } else {                                                   // ragged last tile: rows past the end can never win
+#pragma unroll
+            for (int v = 0; v < 16; v++) cin[v] = tc[v] < j_end ? tc[v] : 0x3FFFFFFF;
         }
-    }
+        hm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
-    for (int i = 0; i < HM_QPT; i++) {
-        const int q = qbase + 256 * i;
-        if (q < nq && best[i] != 0xFFFFFFFFu) {
+        for (int s8 = 0; s8 < 8; s8++) {
+            const hm_v4i a = tileA[buf][(s8 * 2 + half) * 32 + col];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[0][s8], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[1][s8], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            best[0][i] = min(best[0][i], min(acc0[2 * i], acc0[2 * i + 1]));
+            best[1][i] = min(best[1][i], min(acc1[2 * i], acc1[2 * i + 1]));
+        }
+#pragma unroll
+        for (int v = 0; v < 16; v++) tc[v] += 32;
+        if (more) stage(buf ^ 1, nxt);
+    }
+    // ---- per query column: min over the 8 registers, then over the two lane halves; D -> (distance << 16 | index) ----
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        int m = best[st][0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) m = min(m, best[st][i]);
+        m = min(m, __shfl_xor(m, 32, 64));
+        const int q = (int)blockIdx.y * HM_QB + wid * 64 + st * 32 + col;
+        if (half == 0 && q < nq && m < 0x30000000) {
+            const unsigned u = (unsigned)(m + (1 << 20));
+            const unsigned packed = ((u >> 13) << 16) | (u & 8191u);
             unsigned* out = (unsigned*)c.bf_idx + ((long long)vl * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
-            if (nsplit > 1) atomicMin(out, best[i]); else *out = best[i];
+            if (nsplit > 1) atomicMin(out, packed); else *out = packed;
         }
     }
 }
@@ -745,7 +812,7 @@ __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_hamming, dim3(c.n_lanes * c.oct_cap, (c.max_kps + 256 * HM_QPT - 1) / (256 * HM_QPT), (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
+    hipLaunchKernelGGL(k_hamming, dim3(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)

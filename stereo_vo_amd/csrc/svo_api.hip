@@ -455,7 +455,7 @@ static int hamming_splits(const svo_ctx* ctx)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("SVO_HAM_SPLITS"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return forced;
-    int s = 8192 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 16 ? 16 : s);
+    int s = 2048 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 8 ? 8 : s);     // train splits: enough workgroups to fill the GPU, few enough to amortise the query expansion
 }
 
 // ---- processNewImagePair ---------------------------------------------------------------------------------
