@@ -531,14 +531,18 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
-            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, st); }
+            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, st); }
         } else {                // stage2_detect.cpp:458-497
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             { Span s(ctx, KT_SELECT); launch_select(d, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
-            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0, p.min_distance, st); }
+            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0, p.min_distance, st); }
         }
+    } else if (flags & SVO_RUN_DETECT_POST) {       // the post-processing a SVO_FLAG_DETECT_NO_POST call left out
+        if (!ctx->geom_ready) return SVO_ERR_STATE;
+        Span s(ctx, KT_NMS);
+        launch_nms_rowsort(d, d.fast_orb ? 0 : (p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0), p.min_distance, st);
     }
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {

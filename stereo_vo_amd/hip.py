@@ -15,7 +15,7 @@ _LIB = None
 
 MAX_LANES = 64
 RUN_DETECT, RUN_MATCH, RUN_TRACK, RUN_OPTIMIZE, RUN_ALL = 1, 2, 4, 8, 15
-FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES = 16, 32, 64, 128
+FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES, FLAG_DETECT_NO_POST, RUN_DETECT_POST = 16, 32, 64, 128, 256, 512
 
 # every entry point include/svo_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [

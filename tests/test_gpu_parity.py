@@ -555,3 +555,23 @@ def test_projected_coords_match_oracle(golden_dir):
         a, b = ctx.projected_coords(m, kl, kr, tracked, cam, pose), O().projected_coords(m, kl, kr, tracked, cam, pose)
         assert a.shape == b.shape == (int((tracked == -1).sum()), 4) and a.tobytes() == b.tobytes()
     assert ctx.projected_coords(m[:0], kl, kr, tracked[:0], cam, [0] * 6).shape == (0, 4)
+
+
+def test_split_detect_post_stage_equals_one_call(golden_dir):
+    """SVO_FLAG_DETECT_NO_POST + SVO_RUN_DETECT_POST (the NMS / row-sort block scheduled with stages 3-5, as bench.py does
+    on its overlap stream) gives exactly what one SVO_RUN_ALL call gives."""
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    a = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    b = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    for c in (a, b):
+        c.set_params(p); c.set_camera(cam)
+    for t in range(4):
+        a.process_host([(g["L%d" % t], g["R%d" % t])])
+        b.process_host([(g["L%d" % t], g["R%d" % t])], hip.RUN_DETECT | hip.FLAG_DETECT_NO_POST)
+        b.run_stages(hip.RUN_DETECT_POST | hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE)
+        ra, rb = a.result(0), b.result(0)
+        for side in (0, 1):
+            assert a.keypoints(0, 0, side)[0].tobytes() == b.keypoints(0, 0, side)[0].tobytes()
+        assert a.matches(0).tobytes() == b.matches(0).tobytes() and a.tracked(0).tobytes() == b.tracked(0).tobytes()
+        assert (ra.valid, ra.error_code) == (rb.valid, rb.error_code) and list(ra.outPose) == list(rb.outPose)
