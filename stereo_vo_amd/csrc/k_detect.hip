@@ -647,15 +647,23 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
     return __builtin_amdgcn_udot4(a, b, acc, false);
 }
 
-__global__ void __launch_bounds__(256) k_describe(DevCtx c)
+__global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div)
 {
     __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10 + 6];
     __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * 32];    // horizontal pass, 32 columns (31 used)
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int img = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wid;       // position in the level-segmented arrays
+    // XCD affinity by IMAGE: workgroup ids go round-robin over the 8 XCDs, so id -> (image, slot group) is laid out so
+    // that every XCD works through whole images (image = 8 * group + id % 8).  A keypoint window costs 37 rows x one or
+    // two 128-byte lines and neighbouring keypoints share most of them; with an image's keypoints spread over eight
+    // L2s each line was fetched again per XCD (1.32 GB per launch for 0.38 GB of windows), through one L2 the image's
+    // pyramid (3.8 MB < 4 MB) is fetched about once.
+    int img, bx;
+    if (c.debug_mode == 8) { img = blockIdx.x / gx_div.d; bx = blockIdx.x - img * gx_div.d; }
+    else { const uint32_t r = blockIdx.x >> 3, grp = fastdiv(r, gx_div); bx = (int)(r - grp * gx_div.d); img = (int)(grp * 8 + (blockIdx.x & 7)); }
+    if (img >= c.n_img) return;
+    const int slot = bx * 4 + wid;       // position in the level-segmented arrays
     if (slot >= c.n_slots) return;
     int level = 0;
 #pragma unroll
@@ -1130,7 +1138,8 @@ void launch_select(const DevCtx& c, hipStream_t st)
 void launch_describe(const DevCtx& c, hipStream_t st)
 {
     if (c.n_slots <= 0) return;
-    hipLaunchKernelGGL(k_describe, dim3((c.n_slots + 3) / 4, c.n_img), dim3(256), 0, st, c);
+    const int gx = (c.n_slots + 3) / 4, img8 = (c.n_img + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_describe, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx));
 }
 
 #define FO_PMAX 2048     // chunk size of k_fastorb_nms (LDS: 45 B per entry)
