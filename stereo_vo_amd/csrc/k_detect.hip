@@ -12,7 +12,7 @@
 // device copies of the frozen tables
 __constant__ int c_umax[16];
 __constant__ int c_gauss7[7];
-// steered BRIEF pairs as byte offsets into the 37x32 u16 horizontal-pass map: offA | offB << 16, off = ((y + 15) * 32 + x + 15) * 2
+// steered BRIEF pairs as byte offsets into the 31x32 blurred patch: offA | offB << 16, off = (y + 15) * 32 + x + 15
 __device__ __attribute__((aligned(16))) uint32_t g_brief_off[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS];
 // the radius-15 disc by rows of the describe window, for v_dot4_u32_u8: entry e = (v + 15) * 8 + d covers the window
 // bytes 4 + 4d .. 7 + 4d of row v + 18 (columns u = 4d - 15 .. 4d - 12); g_disc_m holds 1 per disc pixel,
@@ -31,7 +31,7 @@ hipError_t svo_upload_tables()
         for (int b = 0; b < SVO_BRIEF_NBINS; b++)
             for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) {
                 const int8_t* pr = svo_brief_rot[b][i];
-                const uint32_t oa = (uint32_t)(((pr[1] + 15) * 32 + pr[0] + 15) * 2), ob = (uint32_t)(((pr[3] + 15) * 32 + pr[2] + 15) * 2);
+                const uint32_t oa = (uint32_t)((pr[1] + 15) * 32 + pr[0] + 15), ob = (uint32_t)((pr[3] + 15) * 32 + pr[2] + 15);
                 off[b * SVO_BRIEF_NPAIRS + i] = oa | (ob << 16);
             }
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_off), off, sizeof(off));
@@ -621,8 +621,9 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
 //      248 lane-tasks, 4 per lane; wave sums by DPP + readlane;
 //   C  horizontal 7-tap pass by two v_dot4_u32_u8 per output (taps 18,33,49,56 | 49,33,18,0 on bytes funnel-shifted
 //      into place), 4 outputs per lane-task, 4 x u16 out as one b64;
-//   D  the vertical 7-tap pass is evaluated ONLY at the 512 sample points the 256 tests need (8 per lane);
-//   E  256 tests packed with four wave ballots.
+//   D  vertical 7-tap pass over the whole 31x32 patch, lane = (column pair, 8-row segment), 14 row reads in order,
+//      blurred BYTES written over the raw window;
+//   E  256 tests: one byte gather per sample point (LDS byte offsets from a per-bin table), four wave ballots.
 // ------------------------------------------------------------------------------------------------------------
 #define DP_P 40      // LDS row pitch of the raw window (10 dwords)
 
@@ -733,17 +734,39 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div)
         *(uint2*)&Hb[r * 32 + gq * 4] = pk;
     }
     wave_lds_sync();
-    // ---- D + E: vertical pass at the sample points only, then the tests ----
+    // ---- D: vertical 7-tap pass over the whole 31 x 32 patch -> blurred bytes Bl (aliases the raw window, no longer
+    //      needed).  LDS is what bounds this kernel (SQ_LDS_IDX_ACTIVE ~ 93 % of its duration, two thirds of it bank
+    //      conflicts, when the vertical pass was evaluated at the 512 sample points only: 56 scattered ds_read_u16 per
+    //      lane); the full pass reads each lane's 14 input rows once, in order, and leaves ONE byte gather per sample.
+    //      Exact: sum_r g[r] * Hb is the same integer whichever pass runs first; one rounding, (s + 32768) >> 16.
     const int G0 = c_gauss7[0], G1 = c_gauss7[1], G2 = c_gauss7[2], G3 = c_gauss7[3];
+    uint8_t* Bl = (uint8_t*)R32;
+    {
+        const int cp = lane & 15, sg = lane >> 4;                          // column pair 2cp, 2cp+1; output rows 8 sg .. 8 sg + 7
+        const uint32_t* H32 = (const uint32_t*)Hb;
+        int lo[14], hi[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const uint32_t w = H32[min(8 * sg + i, 36) * 16 + cp];
+            lo[i] = (int)(w & 0xFFFFu); hi[i] = (int)(w >> 16);
+        }
+        wave_lds_sync();                                                   // every lane has read: the raw window may be overwritten
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int sa = __mul24(G0, lo[i] + lo[i + 6]) + __mul24(G1, lo[i + 1] + lo[i + 5]) + __mul24(G2, lo[i + 2] + lo[i + 4]) + __mul24(G3, lo[i + 3]);
+            const int sb = __mul24(G0, hi[i] + hi[i + 6]) + __mul24(G1, hi[i + 1] + hi[i + 5]) + __mul24(G2, hi[i + 2] + hi[i + 4]) + __mul24(G3, hi[i + 3]);
+            const uint32_t v = (uint32_t)((sa + 32768) >> 16) | ((uint32_t)((sb + 32768) >> 16) << 8);
+            if (8 * sg + i < 31) *(unsigned short*)&Bl[(8 * sg + i) * 32 + 2 * cp] = (unsigned short)v;
+        }
+    }
+    wave_lds_sync();
+    // ---- E: 256 tests, one byte gather per sample point, packed with four wave ballots ----
     const uint32_t* pat = g_brief_off + bin * SVO_BRIEF_NPAIRS;
     unsigned long long bits[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t pr = pat[k * 64 + lane];
-        const unsigned short* pa = (const unsigned short*)((const uint8_t*)Hb + (pr & 0xFFFFu)), *pb2 = (const unsigned short*)((const uint8_t*)Hb + (pr >> 16));
-        const int sa = __mul24(G0, pa[0] + pa[6 * 32]) + __mul24(G1, pa[32] + pa[5 * 32]) + __mul24(G2, pa[2 * 32] + pa[4 * 32]) + __mul24(G3, pa[3 * 32]);
-        const int sb = __mul24(G0, pb2[0] + pb2[6 * 32]) + __mul24(G1, pb2[32] + pb2[5 * 32]) + __mul24(G2, pb2[2 * 32] + pb2[4 * 32]) + __mul24(G3, pb2[3 * 32]);
-        const int a = (sa + 32768) >> 16, b = (sb + 32768) >> 16;
+        const int a = Bl[pr & 0xFFFFu], b = Bl[pr >> 16];
         bits[k] = __ballot(a < b);
     }
     if (lane == 0) {
