@@ -235,9 +235,10 @@ __device__ __forceinline__ uint32_t quick_half(uint32_t c, uint32_t n, uint32_t 
     const u16x2 cc = as_u16x2(c), hi = __builtin_elementwise_add_sat(cc, t2), lo = __builtin_elementwise_sub_sat(cc, t2);
     const u16x2 N = as_u16x2(n), E = as_u16x2(e), S = as_u16x2(s), W = as_u16x2(w);
     // "two adjacent compass points bright" == (N or S bright) and (E or W bright): any N/S point is adjacent to any E/W point
-    const u16x2 bns = __builtin_elementwise_sub_sat(__builtin_elementwise_max(N, S), hi), bew = __builtin_elementwise_sub_sat(__builtin_elementwise_max(E, W), hi);
-    const u16x2 dns = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(N, S)), dew = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(E, W));
-    return as_u32(__builtin_elementwise_min(bns, bew) | __builtin_elementwise_min(dns, dew));
+    //   bright  <=>  min(max(N, S), max(E, W)) > c + t        dark  <=>  max(min(N, S), min(E, W)) < c - t
+    const u16x2 b = __builtin_elementwise_min(__builtin_elementwise_max(N, S), __builtin_elementwise_max(E, W));
+    const u16x2 d = __builtin_elementwise_max(__builtin_elementwise_min(N, S), __builtin_elementwise_min(E, W));
+    return as_u32(__builtin_elementwise_sub_sat(b, hi) | __builtin_elementwise_sub_sat(lo, d));
 }
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
