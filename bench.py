@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--orb-nfeats", type=int, default=2000)
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of one stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
+    ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
     ap.add_argument("--det-priority", default="low", choices=["low", "high"])
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
@@ -168,7 +169,7 @@ def main():
     s_rest = torch.cuda.Stream(dev, priority=0 if args.det_priority == "high" else -1)
     det_done = [torch.cuda.Event() for _ in range(NC)]
     rest_done = [torch.cuda.Event() for _ in range(NC)]
-    REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE
+    REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE | (hip.RUN_DETECT_POST if args.post_on_rest else 0)
     state = {"first": True}
     pipelined = NC > 1 and args.schedule == "pipelined"
 
@@ -180,7 +181,7 @@ def main():
                 if not state["first"]:
                     s_det.wait_event(rest_done[k])
                 c_.set_stream(s_det.cuda_stream)
-                c_.process_device(ptrs, W, H, W, hip.RUN_DETECT)
+                c_.process_device(ptrs, W, H, W, hip.RUN_DETECT | (hip.FLAG_DETECT_NO_POST if args.post_on_rest else 0))
                 det_done[k].record(s_det)
                 s_rest.wait_event(det_done[k])
                 c_.set_stream(s_rest.cuda_stream)
@@ -244,7 +245,7 @@ def main():
         # The roofline kernel is the dominant one of the DETECT stream: in the pipelined schedule the kernels of stages 3-5
         # run on the overlap stream while another context detects, so their event spans measure time-shared execution,
         # not exclusive durations (those are in profiles/r01e_kernel_stats.csv: ransac_count 0.09 ms, gauss_newton 0.11 ms)
-        detect_kernels = ("resize", "fast", "select", "describe", "nms_rowsort")
+        detect_kernels = ("resize", "fast", "select", "describe") + (() if args.post_on_rest else ("nms_rowsort",))
         pool = [k for k in per_kernel if k in detect_kernels] if pipelined else list(per_kernel)
         dom = max(pool or list(per_kernel), key=lambda k: per_kernel[k]["ms_per_step"])
         abytes = algorithmic_bytes(dom, 2 * Bc, lv, mean_kps, mean_match, mean_track)

@@ -825,8 +825,38 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         }
     }
     __syncthreads();
+    if (c.debug_mode == 21) return;
     int P = 64; while (P < n) P <<= 1;
-    if (do_nms) bitonic_sort_lds<true>(keys, P);
+    if (do_nms && !c.fast_orb) {
+        // (response desc, raw index asc) order WITHOUT a sort: every level's segment already is in that order (k_select
+        // emits a level by Harris rank, ties by position, and raw indices follow it), so the rank of a key = its offset
+        // in its own segment + the number of larger keys in each other segment (binary search; keys are unique).
+        // ~60 dependent LDS reads per keypoint and two barriers instead of a 78-stage bitonic network over 4096 keys.
+        unsigned long long* tmp = (unsigned long long*)hkey;              // the grid-hash arrays are free until the NMS
+        for (int i = tid; i < n; i += blockDim.x) {
+            const unsigned long long key = keys[i];
+            int own = l_first;
+            for (int q = l_first + 1; q < SVO_MAX_LEVELS; q++) if (q < l_last && i >= lvl_base[q]) own = q;
+            int rank = i - lvl_base[own];
+            // the searches of the (up to 7) other segments advance in lockstep: their LDS reads are independent
+            int lo[SVO_MAX_LEVELS], hi[SVO_MAX_LEVELS];
+#pragma unroll
+            for (int m = 0; m < SVO_MAX_LEVELS; m++) { const bool on = m >= l_first && m < l_last && m != own; lo[m] = on ? lvl_base[m] : 0; hi[m] = on ? lvl_base[m + 1] : 0; }
+            for (int it = 0; it < 13; it++) {                              // segments hold < 8192 keys
+#pragma unroll
+                for (int m = 0; m < SVO_MAX_LEVELS; m++) {
+                    if (lo[m] < hi[m]) { const int mid = (lo[m] + hi[m]) >> 1; if (keys[mid] > key) lo[m] = mid + 1; else hi[m] = mid; }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < SVO_MAX_LEVELS; m++) { const bool on = m >= l_first && m < l_last && m != own; if (on) rank += lo[m] - lvl_base[m]; }
+            tmp[rank] = key;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) keys[i] = tmp[i];
+        __syncthreads();
+    } else if (do_nms) bitonic_sort_lds<true>(keys, P);
+    if (c.debug_mode == 22) return;
     auto slot_of = [&](int raw_i) { int l = l_first; for (int q = l_first + 1; q < SVO_MAX_LEVELS; q++) if (q < l_last && raw_i >= lvl_base[q]) l = q; return c.lv[l].slot_off + (raw_i - lvl_base[l]); };
     const int W = c.ow[oct], H = c.oh[oct], num_out_points = c.kps_to_detect[oct];
     int nacc = 0;
@@ -887,7 +917,9 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
             cellxy[i] = (ux < glx && uy < gly) ? (((uint32_t)ux << 16) | (uint32_t)uy) : 0xFFFFFFFFu;
         }
         __syncthreads();
-        grid_nms_block(n, gly, cellxy, hkey, hval, NS_HASH, state, flag);
+        if (c.debug_mode == 26) return;
+        grid_nms_block<4>(n, gly, cellxy, hkey, hval, NS_HASH, state, flag);
+        if (c.debug_mode == 23) return;
         // survivors in rank order, at most num_out_points of them (S2:342)
         for (int base = 0; base < n && nacc < num_out_points; base += blockDim.x) {
             const int i = base + tid;
@@ -904,6 +936,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         nacc = n;
         __syncthreads();
     }
+    if (c.debug_mode == 24) return;
     if (nacc > c.max_kps) { nacc = c.max_kps; if (tid == 0) atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); }
     // row sort: (pt.y asc, survivor rank asc)
     __syncthreads();
@@ -913,6 +946,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     __syncthreads();
     P = 64; while (P < nacc) P <<= 1;
     bitonic_sort_lds<false>(keys, P);
+    if (c.debug_mode == 25) return;
     const int cur = 1 - c.lane[lane_id].prev_slot;
     const long long ob = feat_base(c, vl, cur, side);
     for (int i = tid; i < nacc; i += blockDim.x) {

@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
         }
         __syncthreads();
         int hsz = 128; while (hsz < 2 * T) hsz <<= 1;
-        grid_nms_block(T, gly, cellxy, hkey, hval, hsz, state, scan + 32);
+        grid_nms_block<0>(T, gly, cellxy, hkey, hval, hsz, state, scan + 32);
         int cnt = 0;
         for (int i = tid; i < T; i += blockDim.x) if (state[i] == 1) { mask[(int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull))] = 1; cnt++; }
         int tot; block_exclusive_scan(cnt, scan, &tot);

@@ -273,6 +273,9 @@ __device__ __forceinline__ uint32_t nms_lookup(const uint32_t* hkey, const uint3
     }
 }
 
+// ITEMS > 0: n <= ITEMS * blockDim.x is guaranteed by the caller and the neighbour lookups are cached in registers;
+// ITEMS = 0: any n, lookups repeated every round.
+template <int ITEMS>
 __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32_t* cellxy, uint32_t* hkey, uint32_t* hval, int HSZ,
                                                volatile unsigned char* state, volatile int* flag)
 {
@@ -299,22 +302,68 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
         state[i] = st;
     }
     __syncthreads();
-    for (;;) {
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        bool pending = false;
-        for (int i = tid; i < n; i += nt) {
-            if (state[i] != SVO_NMS_UNDECIDED) continue;
+    if constexpr (ITEMS == 0) {
+        for (;;) {
+            if (tid == 0) *flag = 0;
+            __syncthreads();
+            bool pending = false;
+            for (int i = tid; i < n; i += nt) {
+                if (state[i] != SVO_NMS_UNDECIDED) continue;
+                const uint32_t c = cellxy[i];
+                const int sx = (int)(c >> 16), sy = (int)(c & 0xFFFFu);
+                bool any_acc = false, any_und = false;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int cx = sx + (q == 0) - (q == 1), cy = sy + (q == 2) - (q == 3);
+                    if (cx < 0 || cy < 0 || cy >= (int)gly) continue;      // (cx, gly) would alias the key of (cx+1, 0)
+                    const uint32_t j = nms_lookup(hkey, hval, HSZ, (uint32_t)cx * gly + (uint32_t)cy);
+                    if (j < (uint32_t)i) { const unsigned char sj = state[j]; any_acc |= sj == 1; any_und |= sj == SVO_NMS_UNDECIDED; }
+                }
+                if (any_acc) state[i] = 0;
+                else if (!any_und) state[i] = 1;
+                else pending = true;
+            }
+            if (pending) *flag = 1;
+            __syncthreads();
+            const int again = *flag;
+            __syncthreads();
+            if (!again) break;
+        }
+        return;
+    }
+    // the lower-rank representatives of the 4 neighbour cells of each of this thread's undecided keypoints, looked up
+    // ONCE (the hash probes are the expensive part); the rounds below only re-read their states
+    constexpr int NI = ITEMS > 0 ? ITEMS : 1;
+    unsigned short nb[NI][4];
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+        const int i = tid + it * nt;
+#pragma unroll
+        for (int q = 0; q < 4; q++) nb[it][q] = 0xFFFFu;
+        if (i < n && state[i] == SVO_NMS_UNDECIDED) {
             const uint32_t c = cellxy[i];
             const int sx = (int)(c >> 16), sy = (int)(c & 0xFFFFu);
-            bool any_acc = false, any_und = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int cx = sx + (q == 0) - (q == 1), cy = sy + (q == 2) - (q == 3);
                 if (cx < 0 || cy < 0 || cy >= (int)gly) continue;      // (cx, gly) would alias the key of (cx+1, 0)
                 const uint32_t j = nms_lookup(hkey, hval, HSZ, (uint32_t)cx * gly + (uint32_t)cy);
-                if (j < (uint32_t)i) { const unsigned char sj = state[j]; any_acc |= sj == 1; any_und |= sj == SVO_NMS_UNDECIDED; }
+                if (j < (uint32_t)i) nb[it][q] = (unsigned short)j;
             }
+        }
+    }
+    for (;;) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        bool pending = false;
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            const int i = tid + it * nt;
+            if (i >= n || state[i] != SVO_NMS_UNDECIDED) continue;
+            bool any_acc = false, any_und = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (nb[it][q] != 0xFFFFu) { const unsigned char sj = state[nb[it][q]]; any_acc |= sj == 1; any_und |= sj == SVO_NMS_UNDECIDED; }
             if (any_acc) state[i] = 0;
             else if (!any_und) state[i] = 1;
             else pending = true;
