@@ -530,6 +530,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
         for (int u = 0; u < 8; u++) if (base + u * 512 < nc) atomicAdd(&hist[k[u] >> 24], 1u);
     }
     __syncthreads();
+    if (c.debug_mode == 31) return;
     unsigned prefix = 0, mask = 0, need = K;
     {
         const int mine = tid < 256 ? (int)hist[255 - tid] : 0;         // bins in DESCENDING order: thread t owns bin 255 - t
@@ -588,6 +589,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
         for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if (k >= cutoff) { const unsigned sl = atomicAdd(&s_sel, 1u); if (sl < SEL_MAX) sel[sl] = k; } }
         __syncthreads();
     }
+    if (c.debug_mode == 32) return;
     for (int i = tid; i < SEL_MAX; i += blockDim.x) keys[i] = 0;
     __syncthreads();
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
@@ -599,8 +601,10 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
         keys[i] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
     }
     __syncthreads();
+    if (c.debug_mode == 33) return;
     int P = 64; while (P < (int)K) P <<= 1;
     bitonic_sort_lds<true>(keys, P);
+    if (c.debug_mode == 34) return;
     const int nout = min((int)K, g.quota);
     for (int i = tid; i < nout; i += blockDim.x) {
         const unsigned long long k = keys[i];
