@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
 // select on the unique 32-bit keys, compute the Harris response of each, sort by (response desc, position asc)
 // and keep the best quota.  One 512-thread block per (image, level).
 // ------------------------------------------------------------------------------------------------------------
-#define SEL_MAX 2048     // >= 2 * quota[0]
+#define SEL_MAX SVO_SEL_MAX
 #define SEL_TIE_MAX (2 * SEL_MAX)      // LDS tie list: u32 entries aliasing the u64 key array
 
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x, int y)
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
     if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
     const unsigned K = min(nc, (unsigned)(2 * g.quota));
-    if (K == 0 || g.quota <= 0) { if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; return; }
+    if (K == 0 || g.quota <= 0) { if (tid == 0) { c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; c.sel_n[img * SVO_MAX_LEVELS + level] = 0; } return; }
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
     // ---- the K largest of the unique 32-bit keys (score << 24 | inverted position) ----
     // Two sweeps over the candidate list, eight independent loads in flight per thread (a one-load-per-iteration loop
@@ -589,23 +589,44 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
         for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if (k >= cutoff) { const unsigned sl = atomicAdd(&s_sel, 1u); if (sl < SEL_MAX) sel[sl] = k; } }
         __syncthreads();
     }
-    if (c.debug_mode == 32) return;
-    for (int i = tid; i < SEL_MAX; i += blockDim.x) keys[i] = 0;
-    __syncthreads();
+    // hand the K winners to k_harris: one CU gathering 868 x 9 scattered rows was bound by its own outstanding-request
+    // budget (55 us of this kernel's 108), the whole GPU does it in a few
+    uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX;
+    for (unsigned i = tid; i < K; i += blockDim.x) gsel[i] = sel[i];
+    if (tid == 0) c.sel_n[img * SVO_MAX_LEVELS + level] = (int)K;
+}
+
+// Harris response of every selected corner, one thread each, all (image, level) lists in one launch
+__global__ void __launch_bounds__(256) k_harris(DevCtx c)
+{
+    const int img = blockIdx.x, level = blockIdx.z, i = blockIdx.y * 256 + threadIdx.x;
+    const LevelGeom& g = c.lv[level];
+    const int K = g.quota > 0 ? c.sel_n[img * SVO_MAX_LEVELS + level] : 0;
+    if ((int)(blockIdx.y * 256) >= K) return;
+    if (i >= K) return;
+    const long long o = ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX + i;
+    const uint32_t pos = 0xFFFFFFu - (c.sel_keys[o] & 0xFFFFFFu);
+    const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     const bool aligned = (((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0;
-    for (unsigned i = tid; i < K; i += blockDim.x) {
-        const uint32_t pos = 0xFFFFFFu - (sel[i] & 0xFFFFFFu);
-        const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
-        const float r = aligned ? harris_at_dw(lim, pitch, x, y) : harris_at(lim, pitch, x, y);
-        keys[i] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
-    }
-    __syncthreads();
-    if (c.debug_mode == 33) return;
-    int P = 64; while (P < (int)K) P <<= 1;
+    const float r = aligned ? harris_at_dw(lim, pitch, x, y) : harris_at(lim, pitch, x, y);
+    c.sel_resp[o] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
+}
+
+// sort the K (Harris response desc, position asc) keys of one (image, level) and keep the best quota
+__global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
+{
+    __shared__ unsigned long long keys[SEL_MAX];
+    const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
+    const LevelGeom& g = c.lv[level];
+    if (g.quota <= 0) return;
+    const int K = c.sel_n[img * SVO_MAX_LEVELS + level];
+    if (K <= 0) return;                                      // lvl_n was zeroed by k_select
+    int P = 64; while (P < K) P <<= 1;
+    const unsigned long long* gk = c.sel_resp + ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX;
+    for (int i = tid; i < P; i += blockDim.x) keys[i] = i < K ? gk[i] : 0ull;
     bitonic_sort_lds<true>(keys, P);
-    if (c.debug_mode == 34) return;
-    const int nout = min((int)K, g.quota);
+    const int nout = min(K, g.quota);
     for (int i = tid; i < nout; i += blockDim.x) {
         const unsigned long long k = keys[i];
         const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
@@ -1195,6 +1216,8 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 void launch_select(const DevCtx& c, hipStream_t st)
 {
     hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
+    hipLaunchKernelGGL(k_harris, dim3(c.n_img, SEL_MAX / 256, c.n_levels), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_select_sort, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
 }
 
 void launch_describe(const DevCtx& c, hipStream_t st)

@@ -161,6 +161,9 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS * SVO_CNT_STRIDE));
     HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * ctx->raw_cap_alloc));
+    HIPCHECK(dev_alloc(ctx, &d.sel_keys, (size_t)NI * SVO_MAX_LEVELS * SVO_SEL_MAX));
+    HIPCHECK(dev_alloc(ctx, &d.sel_resp, (size_t)NI * SVO_MAX_LEVELS * SVO_SEL_MAX));
+    HIPCHECK(dev_alloc(ctx, &d.sel_n, (size_t)NI * SVO_MAX_LEVELS));
     HIPCHECK(dev_alloc(ctx, &d.lvl_n, (size_t)NI * SVO_MAX_LEVELS));
     HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.raw_desc, (size_t)NI * ctx->raw_cap_alloc * 32));

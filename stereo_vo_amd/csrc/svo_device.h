@@ -16,6 +16,7 @@
 
 #define SVO_EDGE 31
 #define SVO_RANSAC_HYP 256
+#define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) that get a Harris response
 #define SVO_FT_W 64          // k_fast tile (interior pixels)
 #define SVO_FT_H 28
 #define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each
@@ -95,6 +96,9 @@ struct DevCtx {
     uint32_t* cand_cnt;       // [n_img][SVO_MAX_LEVELS] counters, ONE PER 128-BYTE LINE (atomics to one L2 line serialise)
     uint32_t* lvl_pos;
     float* lvl_resp;
+    uint32_t* sel_keys;             // [n_img][SVO_MAX_LEVELS][SVO_SEL_MAX]  k_select's winners (FAST key), input of k_harris
+    unsigned long long* sel_resp;   // same shape: (Harris response, position) keys, input of k_select_sort
+    int* sel_n;                     // [n_img][SVO_MAX_LEVELS]
     int* lvl_n;               // [n_img][SVO_MAX_LEVELS]
     svo_keypoint* raw_kps;
     uint8_t* raw_desc;
@@ -183,7 +187,8 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int P
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
                 const unsigned long long a = keys[i], b = keys[ixj];
                 const bool up = ((i & k) == 0);
-                const bool sw = DESC ? (up ? a < b : a > b) : (up ? a > b : a < b);
+                const bool lt = a < b;                                  // one 64-bit compare: for a != b, a > b == !lt; swapping equal keys is harmless
+                const bool sw = DESC ? (lt == up) : (lt != up);
                 if (sw) { keys[i] = b; keys[ixj] = a; }
             }
         }
