@@ -469,8 +469,10 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
     int px[9][9];
 #pragma unroll
     for (int r = 0; r < 9; r++) {
-        const uint32_t* p = (const uint32_t*)(img + (long long)(y - 4 + r) * pitch + xa);
-        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        // one 12-byte load per row: three dword loads of 64 scattered lanes are three passes over the same 64 cache lines,
+        // and with other waves in between the L1 has dropped them by then
+        const uint3 pw = *(const uint3*)(img + (long long)(y - 4 + r) * pitch + xa);
+        const uint32_t w0 = pw.x, w1 = pw.y, w2 = pw.z;
         const uint32_t A = __builtin_amdgcn_alignbyte(w1, w0, o), B = __builtin_amdgcn_alignbyte(w2, w1, o), C = w2 >> (8 * o);
 #pragma unroll
         for (int k = 0; k < 4; k++) { px[r][k] = (A >> (8 * k)) & 0xFF; px[r][4 + k] = (B >> (8 * k)) & 0xFF; }
