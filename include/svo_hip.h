@@ -191,6 +191,9 @@ int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w);   /* capacit
  * total_ms[i] / calls[i] accumulate since the last svo_kernel_times_reset. Returns number of kernels. */
 int svo_kernel_times(svo_ctx* ctx, const char** names, double* total_ms, int64_t* calls, int cap);
 int svo_kernel_times_reset(svo_ctx* ctx);
+/* time only the kernel of that name from now on (NULL or "": all again): two events per kernel cost a few percent of
+ * a step, a benchmark that needs the live duration of one kernel need not pay for the others */
+int svo_kernel_times_select(svo_ctx* ctx, const char* name);
 
 /* sizeof() of the ABI records as this library was compiled: out[0..5] = keypoint, dmatch, stereo_camera,
  * params, result, config.  Lets a binding verify its mirror of svo_types.h. */

@@ -34,7 +34,7 @@ struct svo_ctx {
     std::vector<void*> allocs;
     std::string last_error;
     std::vector<TimedSpan> spans; std::vector<hipEvent_t> free_events;
-    double kt_total[KT_COUNT]; long long kt_calls[KT_COUNT];
+    double kt_total[KT_COUNT]; long long kt_calls[KT_COUNT]; unsigned kt_mask;
     unsigned* d_ham_out; uint8_t* d_ham_q, *d_ham_t; int ham_cap_q, ham_cap_t;
     // stage 1 (svo_set_rectify_map, SVO_FLAG_BGR_IMAGES): all allocated on first use
     uint8_t* d_src; int src_pitch;                    // staging of host source images (grey or BGR)
@@ -136,6 +136,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
     for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
+    ctx->kt_mask = 0xFFFFFFFFu;
     *out = ctx;                                           // so that the caller can read last_error and destroy
     HIPCHECK(hipSetDevice(cfg->device));
     if (cfg->stream) { ctx->stream = (hipStream_t)cfg->stream; ctx->own_stream = false; }
@@ -415,7 +416,7 @@ static hipEvent_t get_event(svo_ctx* ctx)
 }
 struct Span {
     svo_ctx* ctx; int id; hipEvent_t a, b; bool on;
-    Span(svo_ctx* c, int i) : ctx(c), id(i), on(c->cfg.kernel_times != 0) { if (on) { a = get_event(ctx); b = get_event(ctx); hipEventRecord(a, ctx->stream); } }
+    Span(svo_ctx* c, int i) : ctx(c), id(i), on(c->cfg.kernel_times != 0 && ((c->kt_mask >> i) & 1u)) { if (on) { a = get_event(ctx); b = get_event(ctx); hipEventRecord(a, ctx->stream); } }
     ~Span() { if (on) { hipEventRecord(b, ctx->stream); ctx->spans.push_back({ id, a, b }); } }
 };
 static void collect_spans(svo_ctx* ctx)
@@ -443,6 +444,14 @@ extern "C" int svo_kernel_times(svo_ctx* ctx, const char** names, double* total_
     for (int i = 0; i < KT_COUNT && i < cap; i++) { if (names) names[i] = kt_names[i]; if (total_ms) total_ms[i] = ctx->kt_total[i]; if (calls) calls[i] = ctx->kt_calls[i]; }
     return KT_COUNT;
 }
+extern "C" int svo_kernel_times_select(svo_ctx* ctx, const char* name)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    if (!name || !*name) { ctx->kt_mask = 0xFFFFFFFFu; return SVO_OK; }
+    for (int i = 0; i < KT_COUNT; i++) if (!strcmp(name, kt_names[i])) { ctx->kt_mask = 1u << i; return SVO_OK; }
+    return SVO_ERR_ARG;
+}
+
 extern "C" int svo_kernel_times_reset(svo_ctx* ctx)
 {
     if (!ctx) return SVO_ERR_ARG;

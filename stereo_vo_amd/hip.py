@@ -26,7 +26,7 @@ EXPORTS = [
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
-    "svo_kernel_times", "svo_kernel_times_reset", "svo_abi_sizes",
+    "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
 ]
 
 
@@ -351,6 +351,9 @@ class Context:
         calls = (C.c_int64 * 32)()
         n = self._ck(self.L.svo_kernel_times(self.h, names, tot, calls, 32), "svo_kernel_times")
         return {names[i].decode(): (tot[i], calls[i]) for i in range(n)}
+
+    def kernel_times_select(self, name=None):
+        self._ck(self.L.svo_kernel_times_select(self.h, name.encode() if name else None), "svo_kernel_times_select")
 
     def kernel_times_reset(self):
         self._ck(self.L.svo_kernel_times_reset(self.h), "svo_kernel_times_reset")

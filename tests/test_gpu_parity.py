@@ -575,3 +575,37 @@ def test_split_detect_post_stage_equals_one_call(golden_dir):
             assert a.keypoints(0, 0, side)[0].tobytes() == b.keypoints(0, 0, side)[0].tobytes()
         assert a.matches(0).tobytes() == b.matches(0).tobytes() and a.tracked(0).tobytes() == b.tracked(0).tobytes()
         assert (ra.valid, ra.error_code) == (rb.valid, rb.error_code) and list(ra.outPose) == list(rb.outPose)
+
+
+def test_scheduling_hooks_streams_and_selective_timing(golden_dir):
+    """svo_set_stream + the split detect stage on two HIP streams ordered by events (what bench.py's pipelined schedule
+    does) reproduces the single-stream results; svo_kernel_times_select restricts the event spans to one kernel."""
+    import torch
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    a = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    b = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15, kernel_times=True, stream=s1.cuda_stream)
+    for c in (a, b):
+        c.set_params(p); c.set_camera(cam)
+    imgs = [(torch.from_numpy(g["L%d" % t]).cuda(), torch.from_numpy(g["R%d" % t]).cuda()) for t in range(4)]
+    torch.cuda.synchronize()
+    det, rest = torch.cuda.Event(), torch.cuda.Event()
+    for t in range(4):
+        a.process_host([(g["L%d" % t], g["R%d" % t])])
+        if t:
+            s1.wait_event(rest)
+        b.set_stream(s1.cuda_stream)
+        b.process_device([(imgs[t][0].data_ptr(), imgs[t][1].data_ptr())], W, H, W, hip.RUN_DETECT)
+        det.record(s1); s2.wait_event(det)
+        b.set_stream(s2.cuda_stream)
+        b.run_stages(hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE)
+        rest.record(s2)
+        if t == 1:
+            s2.synchronize(); b.wait(); b.kernel_times_select("fast"); b.kernel_times_reset()
+    ra, rb = a.result(0), b.result(0)
+    assert a.keypoints(0, 0, 0)[0].tobytes() == b.keypoints(0, 0, 0)[0].tobytes() and a.tracked(0).tobytes() == b.tracked(0).tobytes()
+    assert (ra.valid, list(ra.outPose)) == (rb.valid, list(rb.outPose))
+    kt = {k: v for k, v in b.kernel_times().items() if v[1] > 0}
+    assert list(kt) == ["fast"] and kt["fast"][1] == 2
+    b.kernel_times_select(None)
