@@ -609,3 +609,26 @@ def test_scheduling_hooks_streams_and_selective_timing(golden_dir):
     kt = {k: v for k, v in b.kernel_times().items() if v[1] > 0}
     assert list(kt) == ["fast"] and kt["fast"][1] == 2
     b.kernel_times_select(None)
+
+
+def test_sixty_four_lanes_each_match_their_own_oracle():
+    """The batched configuration bench.py runs (64 estimators per context): every kernel's lane indexing, XCD-aware tile
+    orders and the MFMA matcher's per-lane tiles, checked on lanes 0, 17, 40 and 63 against independent oracles."""
+    import torch
+    W, H, B = 640, 480, 64
+    worlds = [SyntheticStereoWorld(W, H, 400.0, 0.12, seed=100 + s, n_frames=3, device=torch.device("cuda"), scene_seed=s % 4) for s in range(B)]
+    cam = worlds[0].camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=500)
+    ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    probe = (0, 17, 40, 63)
+    orcs = {l: O().Oracle(p) for l in probe}
+    for t in range(3):
+        fr = [w.render(t) for w in worlds]
+        torch.cuda.synchronize()
+        ctx.process_device([(a.data_ptr(), b.data_ptr()) for a, b in fr], W, H, W)
+        res = ctx.results()
+        for l in probe:
+            ro = orcs[l].process(fr[l][0].cpu().numpy(), fr[l][1].cpu().numpy(), cam)
+            assert_same_frame(ctx, l, orcs[l], res[l], ro, "t=%d lane=%d" % (t, l))
+    assert sum(1 for r in res if r.valid) >= B - 2
