@@ -165,12 +165,18 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
     __syncthreads();
     const int gx = (tid & 31) * 4, x4 = dx0 + gx;                       // 4 adjacent pixels per row, 4 rows per thread
     if (x4 >= d.w || c.debug_mode == 6) return;
-    uint32_t wx[4], sel[4]; int wi[4];
+    // The taps of the thread's 4 adjacent pixels lie within 8 source bytes (3 x 1.2 px apart + the second tap): per source
+    // row ONE 12-byte fetch from the aligned dword of the first tap, funnel-shifted to an 8-byte window starting at that
+    // tap, serves all four -- LDS reads were what bounded this kernel (16 dword gathers per pixel quad before).
+    uint32_t wx[4], sel[4];
+    const uint32_t rx0 = xr[gx];
+    const int wi0 = (int)(rx0 >> 2);
+    const uint32_t sh0 = rx0 & 3u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t rx = xr[gx + k];
-        wx[k] = xw[gx + k]; wi[k] = (int)(rx >> 2);
-        sel[k] = 0x0c010c00u + (rx & 3u) * 0x00010001u;                 // bytes (rx & 3, rx & 3 + 1) of {hi, lo} -> u16 pair
+        const uint32_t o = xr[gx + k] - rx0;                            // 0 .. 5 (< 7: both taps inside the window)
+        wx[k] = xw[gx + k];
+        sel[k] = 0x0c010c00u + o * 0x00010001u;                         // bytes (o, o + 1) of the 8-byte window -> u16 pair
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -178,12 +184,15 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
         if (y >= d.h) continue;
         const uint32_t wy = yw[gy];
         const uint32_t wy0 = wy & 0xFFFFu, wy1 = wy >> 16;
-        const uint32_t* r0 = win + yr[gy] * (RZ_SP / 4), *r1 = r0 + RZ_SP / 4;
+        const uint32_t* r0 = win + yr[gy] * (RZ_SP / 4) + wi0, *r1 = r0 + RZ_SP / 4;
+        const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        const uint32_t w0lo = __builtin_amdgcn_alignbyte(a1, a0, sh0), w0hi = __builtin_amdgcn_alignbyte(a2, a1, sh0);
+        const uint32_t w1lo = __builtin_amdgcn_alignbyte(b1, b0, sh0), w1hi = __builtin_amdgcn_alignbyte(b2, b1, sh0);
         uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t t0 = __builtin_amdgcn_perm(r0[wi[k] + 1], r0[wi[k]], sel[k]);
-            const uint32_t t1 = __builtin_amdgcn_perm(r1[wi[k] + 1], r1[wi[k]], sel[k]);
+            const uint32_t t0 = __builtin_amdgcn_perm(w0hi, w0lo, sel[k]);
+            const uint32_t t1 = __builtin_amdgcn_perm(w1hi, w1lo, sel[k]);
             const uint32_t top = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t0), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
             const uint32_t bot = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t1), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
             v[k] = __umul24(bot, wy1) + (__umul24(top, wy0) + (1u << 23));                       // result in byte 3
