@@ -980,8 +980,54 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     __syncthreads();
     for (int i = tid; i < nacc; i += blockDim.x) keys[i] = ((unsigned long long)ord32(rk[slot_of(acc_idx[i])].y) << 32) | (unsigned)i;
     __syncthreads();
-    P = 64; while (P < nacc) P <<= 1;
-    bitonic_sort_lds<false>(keys, P);
+    if (H <= NS_MAX) {
+        // counting sort on the integer row (pt.y >= 0, so ord32 order == numeric order and the row is monotone in the key):
+        // bucket sizes by LDS atomics, exclusive scan over the rows, scatter, then each key ranks itself inside its (tiny)
+        // bucket.  Six barriers instead of the 66 stages of a 2048-key bitonic network.
+        int* rcnt = (int*)hkey, *roff = rcnt + H;                         // the grid-hash arrays are free again
+        unsigned long long* tmp = (unsigned long long*)hval;
+        for (int r = tid; r < H; r += blockDim.x) rcnt[r] = 0;
+        __syncthreads();
+        int myrow[4], mypos[4];                                           // nacc <= 4096 keys, 1024 threads
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = tid + it * (int)blockDim.x;
+            myrow[it] = -1; mypos[it] = 0;
+            if (i < nacc) { const int r = min(max((int)inv_ord32((uint32_t)(keys[i] >> 32)), 0), H - 1); myrow[it] = r; mypos[it] = atomicAdd(&rcnt[r], 1); }
+        }
+        __syncthreads();
+        int run = 0;
+        for (int base = 0; base < H; base += blockDim.x) {
+            const int r = base + tid;
+            const int v = r < H ? rcnt[r] : 0;
+            int tot;
+            const int off = block_exclusive_scan(v, scan, &tot);
+            if (r < H) roff[r] = run + off;
+            run += tot;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = tid + it * (int)blockDim.x;
+            if (i < nacc) tmp[roff[myrow[it]] + mypos[it]] = keys[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int i = tid + it * (int)blockDim.x;
+            if (i < nacc) {
+                const int r = myrow[it], b0 = roff[r], n_r = rcnt[r];
+                const unsigned long long key = tmp[b0 + mypos[it]];
+                int less = 0;
+                for (int q = 0; q < n_r; q++) less += tmp[b0 + q] < key ? 1 : 0;
+                keys[b0 + less] = key;
+            }
+        }
+        __syncthreads();
+    } else {
+        P = 64; while (P < nacc) P <<= 1;
+        bitonic_sort_lds<false>(keys, P);
+    }
     if (c.debug_mode == 25) return;
     const int cur = 1 - c.lane[lane_id].prev_slot;
     const long long ob = feat_base(c, vl, cur, side);
