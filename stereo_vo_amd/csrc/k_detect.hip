@@ -624,19 +624,89 @@ __global__ void __launch_bounds__(256) k_harris(DevCtx c)
     c.sel_resp[o] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
 }
 
-// sort the K (Harris response desc, position asc) keys of one (image, level) and keep the best quota
+// order the K (Harris response desc, position asc) keys of one (image, level) and keep the best quota.
+// Bucket sort instead of a bitonic network (1024 of these blocks run at once and the network was instruction bound,
+// 29 us): 1024 buckets over [min, max] of the response's order-preserving bit pattern (float bit patterns are log
+// spaced, which suits the heavy-tailed Harris response), bucket sizes by LDS atomics, scan, scatter, and each key ranks
+// itself inside its bucket by full 64-bit compares.  Any bucket function monotone in the key gives the exact order.
+#define SS_NB 1024
 __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
 {
-    __shared__ unsigned long long keys[SEL_MAX];
+    __shared__ unsigned long long keys[SEL_MAX], tmp[SEL_MAX];
+    __shared__ int cnt[SS_NB], off[SS_NB], scan_s[32];
+    __shared__ unsigned s_mn, s_mx, s_mnp; __shared__ int s_np;
     const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
     const LevelGeom& g = c.lv[level];
     if (g.quota <= 0) return;
     const int K = c.sel_n[img * SVO_MAX_LEVELS + level];
     if (K <= 0) return;                                      // lvl_n was zeroed by k_select
-    int P = 64; while (P < K) P <<= 1;
     const unsigned long long* gk = c.sel_resp + ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX;
-    for (int i = tid; i < P; i += blockDim.x) keys[i] = i < K ? gk[i] : 0ull;
-    bitonic_sort_lds<true>(keys, P);
+    if (tid == 0) { s_mn = 0xFFFFFFFFu; s_mx = 0u; s_mnp = 0xFFFFFFFFu; s_np = 0; }
+    for (int i = tid; i < SS_NB; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    unsigned long long mykey[SEL_MAX / 512]; int mypos[SEL_MAX / 512], myb[SEL_MAX / 512];
+    // Only the best `quota` keys are emitted, so only they need their exact order: the buckets span the POSITIVE responses
+    // (corners; the order-preserving pattern of a positive float is >= 0x80000000) when there are at least quota of them,
+    // and everything below shares the last bucket, which then starts past the output range and is never ranked.
+    unsigned lmn = 0xFFFFFFFFu, lmx = 0u, lmnp = 0xFFFFFFFFu; int lnp = 0;
+#pragma unroll
+    for (int it = 0; it < SEL_MAX / 512; it++) {
+        const int i = tid + it * 512;
+        mykey[it] = i < K ? gk[i] : 0ull;
+        if (i < K) {
+            const unsigned h = (unsigned)(mykey[it] >> 32);
+            lmn = min(lmn, h); lmx = max(lmx, h);
+            if (h >= 0x80000000u) { lmnp = min(lmnp, h); lnp++; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lmn = min(lmn, (unsigned)__shfl_xor((int)lmn, o, 64)); lmx = max(lmx, (unsigned)__shfl_xor((int)lmx, o, 64));
+        lmnp = min(lmnp, (unsigned)__shfl_xor((int)lmnp, o, 64)); lnp += __shfl_xor(lnp, o, 64);
+    }
+    if (c.debug_mode == 41) return;
+    if ((tid & 63) == 0) { atomicMin(&s_mn, lmn); atomicMax(&s_mx, lmx); atomicMin(&s_mnp, lmnp); atomicAdd(&s_np, lnp); }
+    __syncthreads();
+    const unsigned mn = s_np >= g.quota ? s_mnp : s_mn;
+    const float scale = (float)(SS_NB - 1) / ((float)(s_mx - mn) + 1.0f);
+#pragma unroll
+    for (int it = 0; it < SEL_MAX / 512; it++) {
+        const int i = tid + it * 512;
+        if (i < K) {
+            // descending order: bucket 0 holds the largest responses; keys below mn all go to the last bucket
+            const unsigned h = (unsigned)(mykey[it] >> 32);
+            const int b = h < mn ? SS_NB - 1 : SS_NB - 1 - min((int)((float)(h - mn) * scale), SS_NB - 1);
+            myb[it] = b; mypos[it] = atomicAdd(&cnt[b], 1);
+        }
+    }
+    __syncthreads();
+    if (c.debug_mode == 42) return;
+    int run = 0;
+    for (int base = 0; base < SS_NB; base += 512) {
+        int tot;
+        const int o = block_exclusive_scan(cnt[base + tid], scan_s, &tot);
+        off[base + tid] = run + o;
+        run += tot;
+        __syncthreads();
+    }
+    if (c.debug_mode == 43) return;
+#pragma unroll
+    for (int it = 0; it < SEL_MAX / 512; it++) { const int i = tid + it * 512; if (i < K) tmp[off[myb[it]] + mypos[it]] = mykey[it]; }
+    __syncthreads();
+    if (c.debug_mode == 44) return;
+#pragma unroll
+    for (int it = 0; it < SEL_MAX / 512; it++) {
+        const int i = tid + it * 512;
+        if (i < K) {
+            const int b0 = off[myb[it]], nb = cnt[myb[it]];
+            if (b0 >= min(K, g.quota)) continue;                   // past the output range: order irrelevant, never read
+            int greater = 0;
+            for (int q = 0; q < nb; q++) greater += tmp[b0 + q] > mykey[it] ? 1 : 0;
+            keys[b0 + greater] = mykey[it];
+        }
+    }
+    __syncthreads();
+    if (c.debug_mode == 45) return;
     const int nout = min(K, g.quota);
     for (int i = tid; i < nout; i += blockDim.x) {
         const unsigned long long k = keys[i];
