@@ -41,9 +41,10 @@ enum {
     SVO_FLAG_NO_SHIFT = 32, /* do not run the prev/cur shift of P:86-100 (staged tests and the
                                precomputed-data bypass of P:131-162 / P:219-251 after svo_put_*) */
     SVO_FLAG_DEVICE_IMAGES = 64, /* svo_image.data are device pointers (already resident in HBM) */
-    SVO_FLAG_DETECT_NO_POST = 256, /* with SVO_RUN_DETECT: stop after the descriptors; the reference's own post-processing of the
-                                    detector output (m_non_max_sup + m_update_indexes, S2:583-618: one latency-bound block per
-                                    image) is left to a later call with SVO_RUN_DETECT_POST, e.g. on another stream */
+    SVO_FLAG_DETECT_NO_POST = 256, /* with SVO_RUN_DETECT: stop before the reference's own post-processing of the detector output
+                                    (m_non_max_sup + m_update_indexes, S2:583-618: one latency-bound block per image) and the
+                                    description of its survivors; both are left to a later call with SVO_RUN_DETECT_POST,
+                                    e.g. on another stream */
     SVO_RUN_DETECT_POST = 512,   /* that post-processing alone, ahead of the other stages of the call */
     SVO_FLAG_BGR_IMAGES = 128    /* svo_image.data are 8-bit 3-channel BGR (stride in bytes): stage 1's grey conversion runs
                                     on the device (stage1_rectify.cpp:50-51) */

@@ -755,7 +755,7 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
     return __builtin_amdgcn_udot4(a, b, acc, false);
 }
 
-__global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div)
+__global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int pre)
 {
     __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10 + 6];
     __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * 32];    // horizontal pass, 32 columns (31 used)
@@ -771,14 +771,24 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div)
     if (c.debug_mode == 8) { img = blockIdx.x / gx_div.d; bx = blockIdx.x - img * gx_div.d; }
     else { const uint32_t r = blockIdx.x >> 3, grp = fastdiv(r, gx_div); bx = (int)(r - grp * gx_div.d); img = (int)(grp * 8 + (blockIdx.x & 7)); }
     if (img >= c.n_img) return;
-    const int slot = bx * 4 + wid;       // position in the level-segmented arrays
+    // pre != 0: the NMS ran first (k_nms_rowsort, pre mode); work item = final keypoint fi of the image's current list,
+    // final_slot names the detector slot it came from, and only the angle and the descriptor are left to fill in
+    int slot = bx * 4 + wid;             // position in the level-segmented arrays
+    long long fo = 0;
+    if (pre) {
+        const int lane_id = img >> 1, vl0 = lane_id * c.oct_cap;
+        const int cur = 1 - c.lane[lane_id].prev_slot;
+        if (slot >= c.n_kps[feat_cnt_idx(vl0, cur, img & 1)]) return;
+        fo = feat_base(c, vl0, cur, img & 1) + slot;
+        slot = __builtin_amdgcn_readfirstlane(c.final_slot[fo]);
+    }
     if (slot >= c.n_slots) return;
     int level = 0;
 #pragma unroll
     for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
     const LevelGeom& g = c.lv[level];
     const int rank = slot - g.slot_off;
-    if (rank >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
+    if (!pre && rank >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
     const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
@@ -877,6 +887,12 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div)
         bits[k] = __ballot(a < b);
     }
     if (lane == 0) {
+        if (pre) {
+            unsigned long long* d = (unsigned long long*)(c.desc + fo * 32);
+            d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+            c.kps[fo].angle = angle;
+            return;
+        }
         const long long o = (long long)img * c.raw_cap + slot;
         unsigned long long* d = (unsigned long long*)(c.raw_desc + o * 32);
         d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
@@ -895,7 +911,7 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div)
 //   m_update_indexes(order=true) (stage2_detect.cpp:65-130): re-sort by (pt.y asc, rank asc).
 // Writes the final keypoints + descriptors of the lane's current slot.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX)
+__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX, int pre)
 {
     // dynamic LDS only (G17): keys[NS_MAX] u64 | hkey[2*NS_MAX] | hval[2*NS_MAX] | cellxy[NS_MAX] | acc_idx[NS_MAX] u16 | state[NS_MAX] u8 | scan[32] | flag
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -911,6 +927,24 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     const int img = blockIdx.x, oct = blockIdx.y, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
     const int vl = lane_id * c.oct_cap + oct;
     const svo_keypoint* rk = c.raw_kps + (long long)img * c.raw_cap;
+    // pre != 0 (ORB mode): this kernel runs BEFORE the describe kernel -- the reference's NMS needs positions and
+    // responses only -- so that only its survivors are oriented and described (a third of the detector's output is
+    // dropped here).  The keypoint attributes then come from k_select_sort's lists with the expressions the describe
+    // kernel uses, the final records are written with a placeholder angle, and final_slot tells k_describe what to fill in.
+    const uint32_t* lpos = c.lvl_pos + (long long)img * c.raw_cap;
+    const float* lresp = c.lvl_resp + (long long)img * c.raw_cap;
+    auto kp_at = [&](int slot) -> svo_keypoint {
+        if (!pre) return rk[slot];
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < SVO_MAX_LEVELS; q++) if (q < c.n_levels && slot >= c.lv[q].slot_off) l = q;
+        const uint32_t pos = lpos[slot];
+        const float sc = c.lv[l].scale;
+        svo_keypoint k;
+        k.x = (float)(pos & 0xFFFFu) * sc; k.y = (float)(pos >> 16) * sc; k.size = 31.0f * sc; k.angle = 0.0f;
+        k.response = lresp[slot]; k.octave = l; k.class_id = -1;
+        return k;
+    };
     // ORB mode (one octave): all pyramid levels are gathered, level 0 first, each level by Harris rank, and the
     // reference's grid NMS runs here.  FAST+ORB mode: level == octave, the NMS already ran before the describe kernel
     // (k_fastorb_nms), so only this octave's segment is taken, in its accepted (response-descending) order.
@@ -926,7 +960,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         const int nl = lvl_base[l + 1] - lvl_base[l];
         for (int i = tid; i < nl; i += blockDim.x) {
             const int raw_i = lvl_base[l] + i;
-            const float resp = rk[c.lv[l].slot_off + i].response;
+            const float resp = pre ? lresp[c.lv[l].slot_off + i] : rk[c.lv[l].slot_off + i].response;
             keys[raw_i] = ((unsigned long long)ord32(resp) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)raw_i);
         }
     }
@@ -977,7 +1011,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         float* rad = (float*)cellxy;                       // [NS_MAX]
         for (int i = tid; i < n; i += blockDim.x) {
             const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
-            const svo_keypoint& k = rk[slot_of(raw_i)];
+            const svo_keypoint k = kp_at(slot_of(raw_i));
             sxy[i] = make_float2(k.x, k.y);
             thr[i] = 0.9 * (double)k.response;
         }
@@ -1018,7 +1052,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         const unsigned glx = (unsigned)(1 + (float)W * inv), gly = (unsigned)(1 + (float)H * inv);   // S2:334-335
         for (int i = tid; i < n; i += blockDim.x) {
             const int raw_i = (int)(0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFull));
-            const svo_keypoint& k = rk[slot_of(raw_i)];
+            const svo_keypoint k = kp_at(slot_of(raw_i));
             const size_t ux = (size_t)(k.x * inv), uy = (size_t)(k.y * inv);     // S2:348-349
             cellxy[i] = (ux < glx && uy < gly) ? (((uint32_t)ux << 16) | (uint32_t)uy) : 0xFFFFFFFFu;
         }
@@ -1048,7 +1082,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     __syncthreads();
     for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = ~0ull;
     __syncthreads();
-    for (int i = tid; i < nacc; i += blockDim.x) keys[i] = ((unsigned long long)ord32(rk[slot_of(acc_idx[i])].y) << 32) | (unsigned)i;
+    for (int i = tid; i < nacc; i += blockDim.x) keys[i] = ((unsigned long long)ord32(kp_at(slot_of(acc_idx[i])).y) << 32) | (unsigned)i;
     __syncthreads();
     if (H <= NS_MAX) {
         // counting sort on the integer row (pt.y >= 0, so ord32 order == numeric order and the row is monotone in the key):
@@ -1103,7 +1137,8 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     const long long ob = feat_base(c, vl, cur, side);
     for (int i = tid; i < nacc; i += blockDim.x) {
         const int s = slot_of(acc_idx[(int)(keys[i] & 0xFFFFFFFFull)]);
-        c.kps[ob + i] = rk[s];
+        c.kps[ob + i] = kp_at(s);
+        if (pre) { c.final_slot[ob + i] = s; continue; }
         const uint4* sd = (const uint4*)(c.raw_desc + ((long long)img * c.raw_cap + s) * 32);
         uint4* dd = (uint4*)(c.desc + (ob + i) * 32);
         dd[0] = sd[0]; dd[1] = sd[1];
@@ -1347,11 +1382,11 @@ void launch_select(const DevCtx& c, hipStream_t st)
     hipLaunchKernelGGL(k_select_sort, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
 }
 
-void launch_describe(const DevCtx& c, hipStream_t st)
+void launch_describe(const DevCtx& c, int pre, hipStream_t st)
 {
     if (c.n_slots <= 0) return;
     const int gx = (c.n_slots + 3) / 4, img8 = (c.n_img + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_describe, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx));
+    hipLaunchKernelGGL(k_describe, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0);
 }
 
 #define FO_PMAX 2048     // chunk size of k_fastorb_nms (LDS: 45 B per entry)
@@ -1372,10 +1407,10 @@ hipError_t configure_nms_rowsort(const DevCtx& c)
     return hipFuncSetAttribute((const void*)k_nms_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(nms_pmax(c)));
 }
 
-void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, hipStream_t st)
+void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st)
 {
     const int pmax = nms_pmax(c);
-    hipLaunchKernelGGL(k_nms_rowsort, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax);
+    hipLaunchKernelGGL(k_nms_rowsort, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0);
 }
 
 void launch_half(const DevCtx& c, int level, hipStream_t st)

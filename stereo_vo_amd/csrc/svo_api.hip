@@ -172,6 +172,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.kps, (size_t)NV * 4 * MK));
     HIPCHECK(dev_alloc(ctx, &d.desc, (size_t)NV * 4 * MK * 32));
     HIPCHECK(dev_alloc(ctx, &d.mdesc, (size_t)NV * 4 * MK * 32));
+    HIPCHECK(dev_alloc(ctx, &d.final_slot, (size_t)NV * 4 * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_kps, (size_t)NV * 4));
     HIPCHECK(dev_alloc(ctx, &d.matches, (size_t)NV * 2 * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_matches, (size_t)NV * 2));
@@ -542,19 +543,32 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
-            { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
-            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, st); }
+            { Span s(ctx, KT_DESCRIBE); launch_describe(d, 0, st); }
+            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, 0, st); }
         } else {                // stage2_detect.cpp:458-497
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             { Span s(ctx, KT_SELECT); launch_select(d, st); }
-            { Span s(ctx, KT_DESCRIBE); launch_describe(d, st); }
-            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0, p.min_distance, st); }
+            // The reference's NMS needs positions and responses only, so it runs BEFORE orientation + description and only
+            // its survivors are described (debug mode 9 keeps the detector's order: describe everything, then NMS --
+            // that is what svo_debug_get_raw_keypoints shows)
+            const int nms_mode = p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0;
+            if (d.debug_mode == 9) {
+                { Span s(ctx, KT_DESCRIBE); launch_describe(d, 0, st); }
+                if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, nms_mode, p.min_distance, 0, st); }
+            } else if (!(flags & SVO_FLAG_DETECT_NO_POST)) {
+                { Span s(ctx, KT_NMS); launch_nms_rowsort(d, nms_mode, p.min_distance, 1, st); }
+                { Span s(ctx, KT_DESCRIBE); launch_describe(d, 1, st); }
+            }
         }
     } else if (flags & SVO_RUN_DETECT_POST) {       // the post-processing a SVO_FLAG_DETECT_NO_POST call left out
         if (!ctx->geom_ready) return SVO_ERR_STATE;
-        Span s(ctx, KT_NMS);
-        launch_nms_rowsort(d, d.fast_orb ? 0 : (p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0), p.min_distance, st);
+        const int nms_mode = p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0;
+        if (d.fast_orb || d.debug_mode == 9) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, d.fast_orb ? 0 : nms_mode, p.min_distance, 0, st); }
+        else {
+            { Span s(ctx, KT_NMS); launch_nms_rowsort(d, nms_mode, p.min_distance, 1, st); }
+            { Span s(ctx, KT_DESCRIBE); launch_describe(d, 1, st); }
+        }
     }
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {

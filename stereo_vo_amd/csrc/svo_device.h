@@ -105,6 +105,7 @@ struct DevCtx {
     int* raw_n;               // [n_img]
     svo_keypoint* kps;
     uint8_t* desc;
+    int* final_slot;          // same index space as kps: detector slot of each final keypoint (describe-after-NMS path)
     uint8_t* mdesc;           // same shape as desc: descriptors of the paired features in pairing order (stage-4 BF input)
     int* n_kps;               // [n_lanes][2][2]
     svo_dmatch* matches;

@@ -26,9 +26,9 @@ void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned fl
 void launch_resize(const DevCtx& c, int level, hipStream_t st);
 void launch_fast(const DevCtx& c, hipStream_t st);
 void launch_select(const DevCtx& c, hipStream_t st);
-void launch_describe(const DevCtx& c, hipStream_t st);
+void launch_describe(const DevCtx& c, int pre, hipStream_t st);
 hipError_t configure_nms_rowsort(const DevCtx& c);
-void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, hipStream_t st);
+void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st);
 void launch_half(const DevCtx& c, int level, hipStream_t st);
 void launch_fastorb_nms(const DevCtx& c, int do_nms, int min_distance, hipStream_t st);
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st);

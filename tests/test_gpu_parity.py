@@ -69,7 +69,10 @@ def test_small_sequence_against_golden_and_oracle(golden_dir):
     ctx.close()
 
 
-def test_pyramid_and_detector_stage_outputs(golden_dir):
+def test_pyramid_and_detector_stage_outputs(golden_dir, monkeypatch):
+    # debug mode 9 = the detector's own order (describe every detected keypoint, then the reference's NMS), the only
+    # mode in which the pre-NMS list carries angles and descriptors; the product default describes the survivors only
+    monkeypatch.setenv("SVO_DEBUG_MODE", "9")
     g, cam, p = load_small(golden_dir)
     ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
     ctx.set_params(p); ctx.set_camera(cam)
@@ -84,7 +87,16 @@ def test_pyramid_and_detector_stage_outputs(golden_dir):
         k, d = ctx.raw_keypoints(0, side)
         ko, do = O().orb_detect(img, int(1.5 * int(g["orb_nfeats"])), 8, 20)
         assert k.tobytes() == ko.tobytes() and (d == do).all()
-    ctx.close()
+    # ... and that order gives the same final lists as the default one
+    monkeypatch.delenv("SVO_DEBUG_MODE")
+    ctx2 = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx2.set_params(p); ctx2.set_camera(cam)
+    ctx2.process_host([(g["L0"], g["R0"])], hip.RUN_DETECT)
+    ctx.process_host([(g["L0"], g["R0"])], hip.RUN_DETECT | hip.FLAG_REPEAT)
+    for side in (0, 1):
+        (k1, d1), (k2, d2) = ctx.keypoints(0, 0, side), ctx2.keypoints(0, 0, side)
+        assert k1.tobytes() == k2.tobytes() and (d1 == d2).all()
+    ctx.close(); ctx2.close()
 
 
 @pytest.mark.parametrize("w,h,f,cx,cy,B,nfe", [(1280, 960, 800.0, None, None, 0.12, 2000), (1241, 376, 718.856, 607.19, 185.22, 0.537, 900)])

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """First-contact diagnostic for the GPU box: runs the small golden sequence through the HIP path and prints where
 (if anywhere) it departs from the oracle, stage by stage.  Not a test; tests/ holds the assertions."""
+import os
+os.environ.setdefault("SVO_DEBUG_MODE", "9")    # raw (pre-NMS) keypoints carry angles / descriptors only in this mode
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
