@@ -6,9 +6,9 @@ torch.distributed.run, one rank per GPU.  A "step" advances every lane (independ
 one frame: value = N * lanes * K / t, t = max over ranks of the barrier-bracketed wall time of the K steps.
 All frames are rendered and resident in HBM before the timed region; nothing is copied host->device inside it.
 Workload at N=1: BASELINE.json configs[1] -- 1280x960 synthetic stereo streams, ~2000 ORB keypoints per image
-(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton; 128 streams per GPU held by two
-contexts of 64 on separate HIP streams (the per-stream latency-bound kernels of one context overlap the throughput
-kernels of the other; kernel times below are per launch = per context, measured while both run).
+(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton; 192 streams per GPU held by three
+contexts of 64 (the per-stream latency-bound kernels of stages 3-5 of one context overlap the throughput kernels of
+stage 2 of the next on a second HIP stream; kernel times below are per launch = per context of 64 streams).
 Streams shard by independent stream across ranks with no data-path collective ("weak" scaling); the per-frame
 result records are all-gathered over RCCL as in configs[3] (512 B-class, latency only).
 
@@ -99,8 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--lanes", type=int, default=128, help="independent stereo streams per GPU (all contexts together)")
-    ap.add_argument("--contexts", type=int, default=2, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
+    ap.add_argument("--lanes", type=int, default=192, help="independent stereo streams per GPU (all contexts together)")
+    ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
     ap.add_argument("--frames", type=int, default=6, help="distinct frames rendered per stream (played ping-pong)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
@@ -117,7 +117,7 @@ def main():
         args.width, args.height, args.orb_nfeats, kitti = 1241, 376, 900, True
     elif args.workload == "config5":
         args.width, args.height, args.orb_nfeats, detect_fast_orb, n_octaves = 2048, 1536, 3300, True, 3
-        args.lanes = min(args.lanes, 64)
+        args.lanes = min(args.lanes, 64); args.contexts = min(args.contexts, 2)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
