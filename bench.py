@@ -283,21 +283,44 @@ def main():
         P = sum(a * b for a, b in lv) / float(W * H)
         pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
         cpu_baseline = None
+        pose_rmse = None
         if world == 1 and args.cpu_frames > 0:
             from oracle import oracle as O      # checker / baseline only; never on the product path
             orc = O.Oracle(p)
             host = [(frames[0][t][0].cpu().numpy(), frames[0][t][1].cpu().numpy()) for t in range(F)]
             orc.process(host[0][0], host[0][1], cam)
             c0 = time.perf_counter()
+            cpu_poses = []
             for i in range(args.cpu_frames):
                 t = frame_schedule(1 + i, F)
-                orc.process(host[t][0], host[t][1], cam)
+                ro = orc.process(host[t][0], host[t][1], cam)
+                cpu_poses.append((ro.valid, list(ro.outPose)))
             cdt = time.perf_counter() - c0
+            # BASELINE.json's metric is "pairs/sec + pose RMSE vs CPU ref": the same frames of stream 0 through a fresh
+            # one-stream HIP context (untimed), pose by pose against the oracle's
+            chk = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=4096, device=local_rank, max_octaves=n_octaves,
+                              max_cand=(1 << 18) if W * H > 2000000 else (1 << 17))
+            chk.set_params(p); chk.set_camera(cam)
+            err_t, err_r, n_cmp, n_flag = [], [], 0, 0
+            for i in range(-1, args.cpu_frames):
+                t = frame_schedule(1 + i, F)
+                chk.process_device([(frames[0][t][0].data_ptr(), frames[0][t][1].data_ptr())], W, H, W)
+                rg = chk.result(0)
+                if i < 0:
+                    continue
+                ok_c, pc = cpu_poses[i]
+                n_flag += int(bool(rg.valid) != bool(ok_c))
+                if rg.valid and ok_c:
+                    dpz = np.array(rg.outPose) - np.array(pc)
+                    err_t.append(float(np.sum(dpz[:3] ** 2))); err_r.append(float(np.sum(dpz[3:] ** 2))); n_cmp += 1
+            chk.close()
+            pose_rmse = {"translation_m": float(np.sqrt(np.mean(err_t))) if err_t else None, "rotation_rad": float(np.sqrt(np.mean(err_r))) if err_r else None,
+                         "frames": n_cmp, "valid_flag_mismatches": n_flag, "tolerance": "1e-3 m / 1e-4 rad per frame (tests/test_gpu_parity.py)"}
             cpu_baseline = {"value": round(args.cpu_frames / cdt, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
                             "sample": "%d frames of stream 0 (%dx%d, orb_nfeats=%d) on the single-threaded C oracle, host has %d cores"
                                       % (args.cpu_frames, W, H, args.orb_nfeats, os.cpu_count() or 0)}
         line = {
-            "metric": "stereo pairs/sec @%dx%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
+            "metric": "stereo pairs/sec @%d\u00d7%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d synthetic stereo streams, %s, orb_nfeats %d (~%d kps/image in octave 0 after NMS), BF match, BF track, robust GN; %d independent streams per GPU in %d contexts on separate HIP streams, one frame per stream per step"
@@ -305,6 +328,7 @@ def main():
                        "lanes_per_gpu": B, "contexts_per_gpu": NC, "lanes_per_context": Bc, "frames_per_stream": F, "schedule": args.schedule if NC > 1 else "single stream", "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "pose_rmse_vs_cpu": pose_rmse,
             "path_hbm_frac": round(pair_bytes * value / 1e9 / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_pair": int(pair_bytes),
             "valid_last_step": "%d/%d" % (n_valid, B),
