@@ -171,6 +171,7 @@ def main():
     rest_done = [torch.cuda.Event() for _ in range(NC)]
     REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE | (hip.RUN_DETECT_POST if args.post_on_rest else 0)
     state = {"first": True}
+    gathered = torch.cuda.Event()
     pipelined = NC > 1 and args.schedule == "pipelined"
 
     def step(i):
@@ -198,7 +199,14 @@ def main():
                     torch.cuda.current_stream(dev).wait_event(rest_done[k])
                 else:
                     done[k].record(streams[k]); torch.cuda.current_stream(dev).wait_event(done[k])
-        return gather_records(rec, world)
+        out = gather_records(rec, world)
+        if world > 1:          # the next step's result copies must not overwrite `rec` while the all-gather still reads it
+            gathered.record(torch.cuda.current_stream(dev))
+            (s_rest if pipelined else torch.cuda.current_stream(dev)).wait_event(gathered)
+            if not pipelined:
+                for k in range(NC):
+                    streams[k].wait_event(gathered)
+        return out
 
     def barrier():
         if world > 1:
