@@ -122,6 +122,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (one-GPU boxes): BENCH_FORCE_DEVICE puts every rank on that device, BENCH_DIST_BACKEND=gloo replaces RCCL,
+    # so that the N > 1 code path (sharding, event ordering, all-gather, MAX-time) can be exercised without N GPUs
+    if os.environ.get("BENCH_FORCE_DEVICE"):
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -129,7 +133,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     W, H, B, F = args.width, args.height, args.lanes, args.frames
