@@ -266,9 +266,13 @@ def main():
         pairs = world * B * args.steps
         value = pairs / dt
         lw, lh = [], []
-        for l in range(8):
-            sf = np.float32(1.2 ** l)
-            lw.append(int(np.rint(np.float32(W) / sf))); lh.append(int(np.rint(np.float32(H) / sf)))
+        if detect_fast_orb:       # FAST+ORB works on the x1/2 octave images (S1:80-83), not on ORB's x1/1.2 levels
+            for o in range(n_octaves):
+                lw.append(W >> o); lh.append(H >> o)
+        else:
+            for l in range(8):
+                sf = np.float32(1.2 ** l)
+                lw.append(int(np.rint(np.float32(W) / sf))); lh.append(int(np.rint(np.float32(H) / sf)))
         lv = list(zip(lw, lh))
         def table(tt):
             return {k: {"ms_per_launch": v[0] / max(1, v[1]) / (7 if k == "resize" else 1), "ms_per_step": v[0] / max(1, v[1]), "launches": int(v[1]) * (7 if k == "resize" else 1)}
