@@ -82,3 +82,17 @@ def test_config1_plumbing_sequence_tracks_ground_truth():
     assert np.median(errs[:, 0]) < 3e-3 and np.median(errs[:, 1]) < 0.03
     er, et = pose_error(pose, w.poses[19])
     assert er < 0.03 and et < 0.35
+
+
+def test_oracle_extras_against_frozen_vectors(golden_dir):
+    """Stage 1, adaptive NMS and getProjectedCoords against tests/golden/oracle_extras.npz (minted by
+    tests/golden/make_oracle_extras.py from the same seeded inputs): the oracle must not drift."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_extras", os.path.join(golden_dir, "make_oracle_extras.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    g = np.load(os.path.join(golden_dir, "oracle_extras.npz"))
+    out = mod.outputs(*mod.inputs())
+    assert set(out) == set(g.files)
+    for name, v in out.items():
+        assert v.shape == g[name].shape and v.tobytes() == g[name].tobytes(), name
+    assert len(out["anms_all"]) > len(out["anms_r3"]) >= 1 and len(out["anms_100"]) <= 100
