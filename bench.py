@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 from stereo_vo_amd import hip  # noqa: E402
 from stereo_vo_amd.abi import Result, north_star_params  # noqa: E402
 from stereo_vo_amd.synth import SyntheticStereoWorld  # noqa: E402
+from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 
 import ctypes as C  # noqa: E402
 
@@ -105,7 +106,8 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--orb-nfeats", type=int, default=2000)
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of one stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="upper bound on the frames per probe stream replayed on the CPU oracle (baseline timing + parity probe; 0 = skip)")
+    ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
     ap.add_argument("--det-priority", default="low", choices=["low", "high"])
@@ -156,64 +158,21 @@ def main():
         from stereo_vo_amd.abi import DM_FAST_ORB
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
     NC = max(1, args.contexts)
-    assert B % NC == 0 and B // NC <= 64, "--lanes must split evenly over --contexts, at most 64 streams per context"
-    Bc = B // NC
-    streams = [torch.cuda.Stream(dev) for _ in range(NC)]
-    ctxs = []
-    for k in range(NC):
-        c_ = hip.Context(n_lanes=Bc, max_w=W, max_h=H, max_kps=4096, device=local_rank, kernel_times=True, stream=streams[k].cuda_stream,
-                         max_octaves=n_octaves, max_cand=(1 << 18) if W * H > 2000000 else (1 << 17))
-        c_.set_params(p); c_.set_camera(cam)
-        ctxs.append(c_)
-    rec = torch.zeros((B, C.sizeof(Result)), dtype=torch.uint8, device=dev)
-    done = [torch.cuda.Event() for _ in range(NC)]
-
-    # Schedule ("pipelined"): ONE normal-priority stream carries the detect phases (stage 2: resize / FAST / select /
-    # describe / NMS -- the throughput kernels) of all contexts back to back; ONE high-priority stream carries the rest
-    # of each frame (stages 3-5: mostly per-stream, latency-bound kernels), which therefore overlaps the next context's
-    # detect phase without being starved by it.  Events: rest(k) waits for detect(k); the next detect of context k waits
-    # for rest(k) (stage 4 reads the feature slot that detection overwrites next).
-    s_det = torch.cuda.Stream(dev, priority=-1 if args.det_priority == "high" else 0)
-    s_rest = torch.cuda.Stream(dev, priority=0 if args.det_priority == "high" else -1)
-    det_done = [torch.cuda.Event() for _ in range(NC)]
-    rest_done = [torch.cuda.Event() for _ in range(NC)]
-    REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE | (hip.RUN_DETECT_POST if args.post_on_rest else 0)
-    state = {"first": True}
+    batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=bool(args.post_on_rest),
+                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves)
+    Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
+    ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
     gathered = torch.cuda.Event()
-    pipelined = NC > 1 and args.schedule == "pipelined"
 
     def step(i):
-        t = frame_schedule(i, F)
-        for k, c_ in enumerate(ctxs):
-            ptrs = [(frames[k * Bc + l][t][0].data_ptr(), frames[k * Bc + l][t][1].data_ptr()) for l in range(Bc)]
-            if pipelined:
-                if not state["first"]:
-                    s_det.wait_event(rest_done[k])
-                c_.set_stream(s_det.cuda_stream)
-                c_.process_device(ptrs, W, H, W, hip.RUN_DETECT | (hip.FLAG_DETECT_NO_POST if args.post_on_rest else 0))
-                det_done[k].record(s_det)
-                s_rest.wait_event(det_done[k])
-                c_.set_stream(s_rest.cuda_stream)
-                c_.run_stages(REST)
-                c_.copy_results_async(rec[k * Bc:(k + 1) * Bc].data_ptr(), Bc * C.sizeof(Result))
-                rest_done[k].record(s_rest)
-            else:
-                c_.process_device(ptrs, W, H, W)
-                c_.copy_results_async(rec[k * Bc:(k + 1) * Bc].data_ptr(), Bc * C.sizeof(Result))
-        state["first"] = False
+        """One frame of every stream of this rank (stereo_vo_amd/pipeline.py), then the all-gather of the result records."""
+        batch.step(ptrs_at[frame_schedule(i, F)])
         if world > 1:          # the all-gather runs on torch's current stream: it waits for every context's last work
-            for k in range(NC):
-                if pipelined:
-                    torch.cuda.current_stream(dev).wait_event(rest_done[k])
-                else:
-                    done[k].record(streams[k]); torch.cuda.current_stream(dev).wait_event(done[k])
-        out = gather_records(rec, world)
+            batch.make_wait(torch.cuda.current_stream(dev))
+        out = gather_records(batch.rec, world)
         if world > 1:          # the next step's result copies must not overwrite `rec` while the all-gather still reads it
             gathered.record(torch.cuda.current_stream(dev))
-            (s_rest if pipelined else torch.cuda.current_stream(dev)).wait_event(gathered)
-            if not pipelined:
-                for k in range(NC):
-                    streams[k].wait_event(gathered)
+            batch.hold_for(gathered)
         return out
 
     def barrier():
@@ -225,18 +184,11 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
-    def pooled_times():      # launches of all contexts pooled: ms and launch counts add up, a launch covers Bc streams
-        acc = {}
-        for c_ in ctxs:
-            for kname, v in c_.kernel_times().items():
-                a_ = acc.setdefault(kname, [0.0, 0]); a_[0] += v[0]; a_[1] += v[1]
-        return acc
-
     # The warm-up steps time every kernel (the per-kernel table and the choice of the roofline kernel); the timed region
     # keeps the two events per launch only around that one kernel, whose duration it has to measure live.
     for c_ in ctxs:
         c_.wait()
-    kt_warm = pooled_times()
+    kt_warm = batch.pooled_kernel_times()
     detect_kernels = ("resize", "fast", "select", "describe") + (() if args.post_on_rest else ("nms_rowsort",))
     pool = [k for k in kt_warm if kt_warm[k][1] > 0 and (k in detect_kernels or not pipelined)]
     dom = max(pool, key=lambda k: kt_warm[k][0] / kt_warm[k][1]) if pool else "fast"
@@ -252,15 +204,16 @@ def main():
     dt = time.perf_counter() - t0
     dt = reduce_max(dt, dev, world)
 
-    kt = pooled_times()
-    results = []
-    for c_ in ctxs:
-        results += c_.results()
+    kt = batch.pooled_kernel_times()
+    results = batch.results()
     n_valid = sum(1 for r in results if r.valid)
     mean_kps = float(np.mean([r.detected_left[0] for r in results]))
     mean_match = float(np.mean([r.stereo_matches[0] for r in results]))
     mean_track = float(np.mean([r.tracked_feats_from_last_frame for r in results]))
     assert allrec is not None and allrec.shape[0] == world * B
+    if args.dump_records:      # tests/test_gpu_parity.py: every rank's own records and what the all-gather handed it
+        np.savez(args.dump_records + ".rank%d.npz" % rank, local=batch.rec.cpu().numpy(), gathered=allrec.cpu().numpy(), rank=rank, world=world,
+                 own=np.frombuffer(b"".join(bytes(r) for r in results), np.uint8).reshape(B, -1))
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -283,64 +236,34 @@ def main():
             per_kernel[dom] = per_kernel_warm[dom]
         abytes = algorithmic_bytes(dom, 2 * Bc, lv, mean_kps, mean_match, mean_track)
         achieved = abytes / (per_kernel[dom]["ms_per_launch"] * 1e-3) / 1e9
-        # HBM traffic of that kernel from the committed PMC passes (tools/pmc_traffic.py: L2 memory-side read / write
-        # requests counted by size in separate rocprofv3 --pmc runs of this same command), scaled from the profiled
-        # lane count to this run's; None when the profile does not cover this workload
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
-            if pm.get("workload") == args.workload and kk in pm["read_bytes"]:
-                traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * Bc / pm["lanes"])
-        except Exception:
-            traffic = None
+        # HBM traffic of that kernel: NOT measured in this run -- read from the committed PMC passes (tools/pmc_traffic.py:
+        # L2 memory-side read / write requests counted by size in separate rocprofv3 --pmc runs of this same command),
+        # scaled from the profiled lane count to this run's; None when the profile does not cover this workload.
+        # `traffic_source` names the file so that a reader can tell a carried-over constant from a live counter.
+        traffic, traffic_source = None, None
+        for prof in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
+                if pm.get("workload") == args.workload and kk in pm["read_bytes"]:
+                    traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * Bc / pm["lanes"])
+                    traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)" % prof
+                    break
+            except Exception:
+                pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4),
                     "streams_per_launch": Bc,
                     "note": ("dominant kernel of the detect stream; stage 3-5 kernels run on the overlap stream and their spans are time-shared, not exclusive" if pipelined else "single stream: every span is an exclusive duration")}
         # end-to-end algorithmic traffic of the whole path (SURVEY.md 8d formula), for the DESIGN.md table
         P = sum(a * b for a, b in lv) / float(W * H)
         pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
-        cpu_baseline = None
-        pose_rmse = None
+        cpu_baseline, pose_rmse, parity_probe = None, None, None
         if world == 1 and args.cpu_frames > 0:
-            from oracle import oracle as O      # checker / baseline only; never on the product path
-            orc = O.Oracle(p)
-            host = [(frames[0][t][0].cpu().numpy(), frames[0][t][1].cpu().numpy()) for t in range(F)]
-            orc.process(host[0][0], host[0][1], cam)
-            c0 = time.perf_counter()
-            cpu_poses = []
-            for i in range(args.cpu_frames):
-                t = frame_schedule(1 + i, F)
-                ro = orc.process(host[t][0], host[t][1], cam)
-                cpu_poses.append((ro.valid, list(ro.outPose)))
-            cdt = time.perf_counter() - c0
-            # BASELINE.json's metric is "pairs/sec + pose RMSE vs CPU ref": the same frames of stream 0 through a fresh
-            # one-stream HIP context (untimed), pose by pose against the oracle's
-            chk = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=4096, device=local_rank, max_octaves=n_octaves,
-                              max_cand=(1 << 18) if W * H > 2000000 else (1 << 17))
-            chk.set_params(p); chk.set_camera(cam)
-            err_t, err_r, n_cmp, n_flag = [], [], 0, 0
-            for i in range(-1, args.cpu_frames):
-                t = frame_schedule(1 + i, F)
-                chk.process_device([(frames[0][t][0].data_ptr(), frames[0][t][1].data_ptr())], W, H, W)
-                rg = chk.result(0)
-                if i < 0:
-                    continue
-                ok_c, pc = cpu_poses[i]
-                n_flag += int(bool(rg.valid) != bool(ok_c))
-                if rg.valid and ok_c:
-                    dpz = np.array(rg.outPose) - np.array(pc)
-                    err_t.append(float(np.sum(dpz[:3] ** 2))); err_r.append(float(np.sum(dpz[3:] ** 2))); n_cmp += 1
-            chk.close()
-            pose_rmse = {"translation_m": float(np.sqrt(np.mean(err_t))) if err_t else None, "rotation_rad": float(np.sqrt(np.mean(err_r))) if err_r else None,
-                         "frames": n_cmp, "valid_flag_mismatches": n_flag, "tolerance": "1e-3 m / 1e-4 rad per frame (tests/test_gpu_parity.py)"}
-            cpu_baseline = {"value": round(args.cpu_frames / cdt, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
-                            "sample": "%d frames of stream 0 (%dx%d, orb_nfeats=%d) on the single-threaded C oracle, host has %d cores"
-                                      % (args.cpu_frames, W, H, args.orb_nfeats, os.cpu_count() or 0)}
+            cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
         line = {
-            "metric": "stereo pairs/sec @%d\u00d7%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
+            "metric": "stereo pairs/sec @%d×%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d synthetic stereo streams, %s, orb_nfeats %d (~%d kps/image in octave 0 after NMS), BF match, BF track, robust GN; %d independent streams per GPU in %d contexts on separate HIP streams, one frame per stream per step"
@@ -349,6 +272,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_cpu": pose_rmse,
+            "parity_probe": parity_probe,
             "path_hbm_frac": round(pair_bytes * value / 1e9 / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_pair": int(pair_bytes),
             "valid_last_step": "%d/%d" % (n_valid, B),
@@ -357,11 +281,131 @@ def main():
             "kernels_ms_note": "all kernels: HIP-event spans of the %d warm-up steps; roofline kernel: spans of the timed region" % args.warmup,
         }
         print(json.dumps(line))
-    for c_ in ctxs:
-        c_.close()
+    batch.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec):
+    """N=1 only, after the timed region.  The oracle (CHECKER / BASELINE, never the thing measured) replays the first
+    n frames of the run's own frame schedule for a few probe streams of every context:
+      * leg (i): stream 0 alone on one host thread, timed          -> cpu_baseline.value (mirrors the single-threaded reference)
+      * leg (ii): the other probe streams on min(S, cores) threads -> cpu_baseline.multi_thread
+    Then the SAME batch object (same contexts, lane count, image size, streams and event schedule the timed region used)
+    is reset and driven through those frames again, untimed, with a synchronisation after every step, and every probe
+    lane's keypoints / descriptors / pairings / tracked pairs / inlier list are compared with the oracle's bit for bit,
+    its pose within 1e-3 m / 1e-4 rad -> parity_probe, pose_rmse_vs_cpu."""
+    from oracle import oracle as O      # checker / baseline only; never on the product path
+    from oracle import probe as PR
+    from stereo_vo_amd.abi import Result
+    F, B, Bc, NC = args.frames, batch.B, batch.Bc, batch.NC
+    total = args.warmup + args.steps
+    n = min(total, args.cpu_frames)
+    order = [frame_schedule(i, F) for i in range(n)]
+    want = sorted(set(k * Bc + l for k in range(NC) for l in (0, Bc // 2 - 1 if Bc > 1 else 0, Bc - 1)))
+    host = {g: [(frames[g][t][0].cpu().numpy(), frames[g][t][1].cpu().numpy()) for t in range(F)] for g in want}
+    # the timing legs use a -march=native build of the same oracle source made on this host, if gcc is here; it must agree
+    # with the portable checker build bit for bit before its digests are trusted
+    native = False
+    try:
+        a, _ = PR.replay(p, cam, host[0], order[:2])
+        O.lib(native=True)
+        orc_n = O.Oracle(p, native=True)
+        b = []
+        for t in order[:2]:
+            r = orc_n.process(host[0][t][0], host[0][t][1], cam); b.append(PR.digest_of(orc_n, 0, r))
+        orc_n.close()
+        native = all(x == y and np.array_equal(x.pose, y.pose) for x, y in zip(a, b))
+    except Exception:
+        native = False
+
+    def replay_one(frs):
+        orc = O.Oracle(p, native=native)
+        out = []
+        c0 = time.perf_counter()
+        for t in order:
+            r = orc.process(frs[t][0], frs[t][1], cam); out.append(PR.digest_of(orc, 0, r))
+        d = time.perf_counter() - c0
+        orc.close()
+        return out, d
+    ref = {}
+    ref[0], dt1 = replay_one(host[0])
+    others = [g for g in want if g != 0]
+    threads = max(1, min(len(others), os.cpu_count() or 1))
+    import threading
+    lock, todo = threading.Lock(), list(others)
+    def work():
+        while True:
+            with lock:
+                if not todo: return
+                g = todo.pop()
+            d, _ = replay_one(host[g])
+            with lock:
+                ref[g] = d
+    c0 = time.perf_counter()
+    ts = [threading.Thread(target=work) for _ in range(threads)]
+    for t_ in ts: t_.start()
+    for t_ in ts: t_.join()
+    dtm = time.perf_counter() - c0
+    cpu_baseline = {"value": round(n / dt1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                    "sample": "first %d frames of stream 0's schedule (%dx%d, orb_nfeats=%d) on ONE thread of the C oracle (%s build); host has %d cores"
+                              % (n, args.width, args.height, args.orb_nfeats, "-O3 -march=native, made on this host" if native else "-O3 -msse4.2 portable", os.cpu_count() or 0),
+                    "multi_thread": {"value": round(len(others) * n / dtm, 3) if others else None, "unit": "stereo pairs/s", "cores": threads, "streams": len(others),
+                                     "sample": "%d independent oracle instances (one per stream, %d frames each) on %d host threads" % (len(others), n, threads)}}
+    # final state of the timed run itself against the oracle's state after the same history (only when the whole history was replayed)
+    final_checked, final_ok = False, None
+    if n == total:
+        final_checked = True
+        rec_cpu = allrec.cpu().numpy()
+        final_ok = True
+        for g in want:
+            ctx, l = batch.lane(g)
+            res = Result.from_buffer_copy(rec_cpu[g].tobytes())
+            lists, flags, et, er = PR.compare(PR.digest_of(ctx, l, res), ref[g][-1])
+            final_ok = final_ok and lists and flags and et < 1e-3 and er < 1e-4
+    batch.reset()
+    for c_ in batch.ctxs:
+        c_.kernel_times_select(None)
+    bad, max_t, max_r, se_t, se_r, n_pose, n_flag = [], 0.0, 0.0, 0.0, 0.0, 0, 0
+    for i in range(n):
+        batch.step(ptrs_at[order[i]])
+        batch.synchronize()
+        rec_cpu = batch.rec.cpu().numpy()
+        for g in want:
+            ctx, l = batch.lane(g)
+            res = Result.from_buffer_copy(rec_cpu[g].tobytes())
+            dg = PR.digest_of(ctx, l, res)
+            lists, flags, et, er = PR.compare(dg, ref[g][i])
+            if not lists and len(bad) < 8:
+                bad.append({"lane": g, "frame": i, "gpu_counts": list(dg.n), "cpu_counts": list(ref[g][i].n)})
+            n_flag += int(not flags)
+            if dg.valid and ref[g][i].valid:
+                dpz = dg.pose - ref[g][i].pose
+                se_t += float(np.sum(dpz[:3] ** 2)); se_r += float(np.sum(dpz[3:] ** 2)); n_pose += 1
+                max_t, max_r = max(max_t, et), max(max_r, er)
+    # accuracy against the synthetic ground truth (stream 0): translation / rotation error of the estimated frame-to-frame pose
+    from stereo_vo_amd.synth import pose6_to_matrix, pose_error
+    gt_t, gt_r = [], []
+    for i in range(1, n):
+        d = ref[0][i]
+        if not d.valid or abs(order[i] - order[i - 1]) != 1:
+            continue
+        fwd = order[i] > order[i - 1]
+        G = worlds[0].gt_delta(order[i] if fwd else order[i - 1])
+        G = G if fwd else np.linalg.inv(G)
+        er_, et_ = pose_error(pose6_to_matrix(d.pose), G)
+        gt_t.append(et_); gt_r.append(er_)
+    pose_rmse = {"translation_m": float(np.sqrt(se_t / n_pose)) if n_pose else None, "rotation_rad": float(np.sqrt(se_r / n_pose)) if n_pose else None,
+                 "frames": n_pose, "valid_flag_mismatches": n_flag, "tolerance": "1e-3 m / 1e-4 rad per frame (tests/test_gpu_parity.py)",
+                 "vs_ground_truth_stream0": {"translation_rmse_m": float(np.sqrt(np.mean(np.square(gt_t)))) if gt_t else None,
+                                             "rotation_rmse_rad": float(np.sqrt(np.mean(np.square(gt_r)))) if gt_r else None, "frames": len(gt_t),
+                                             "note": "oracle poses of stream 0 (identical to the HIP poses within the error above) against the renderer's ground-truth motion"}}
+    parity_probe = {"lanes": want, "frames": n, "shape": "%d contexts x %d lanes x %dx%d, %s schedule -- the timed configuration, same contexts, reset and replayed untimed with a sync per step"
+                                                         % (NC, Bc, args.width, args.height, args.schedule if NC > 1 else "single-stream"),
+                    "lists_bit_exact": len(bad) == 0, "flags_equal": n_flag == 0, "pose_max_err_m": max_t, "pose_max_err_rad": max_r,
+                    "first_mismatches": bad, "final_state_of_timed_run_checked": final_checked, "final_state_of_timed_run_ok": final_ok}
+    return cpu_baseline, pose_rmse, parity_probe
 
 
 if __name__ == "__main__":

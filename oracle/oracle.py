@@ -10,7 +10,7 @@ import numpy as np
 from stereo_vo_amd.abi import (Params, Result, StereoCamera, keypoint_dtype, dmatch_dtype, index_pair_dtype)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIB = {}
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int32)
@@ -23,24 +23,26 @@ def _ptr(a, ty):
     return a.ctypes.data_as(ty) if a is not None else None
 
 
-def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+def build(native=False):
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["native"] if native else []))
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        path = os.path.join(_HERE, "libsvo_oracle.so")
-        if not os.path.exists(path):
-            build()
+def lib(native=False):
+    """native=True: the same source built -march=native ON THIS HOST (oracle/_native/, never shipped): the timing leg of
+    bench.py's cpu_baseline.  The portable build is the checker everywhere else; -ffp-contract=off and no fast-math in
+    both, so they agree bit for bit (bench.py checks that before it uses the native one)."""
+    if native not in _LIB:
+        path = os.path.join(_HERE, "_native", "libsvo_oracle.so") if native else os.path.join(_HERE, "libsvo_oracle.so")
+        if native or not os.path.exists(path):
+            build(native)
         L = C.CDLL(path)
         L.svo_oracle_create.restype = C.c_void_p
         L.svo_oracle_sad8.restype = C.c_uint32
         for name in ("svo_oracle_destroy", "svo_oracle_set_params", "svo_oracle_get_params", "svo_oracle_set_fast_threshold",
                      "svo_oracle_set_orb_threshold", "svo_oracle_reset_ids", "svo_oracle_set_this_frame_as_kf"):
             getattr(L, name).restype = None
-        _LIB = L
-    return _LIB
+        _LIB[native] = L
+    return _LIB[native]
 
 
 def default_params() -> Params:
@@ -58,8 +60,8 @@ def _img(a):
 class Oracle:
     """One rso::CStereoOdometryEstimator worth of state, CPU side."""
 
-    def __init__(self, params: Params = None):
-        self.L = lib()
+    def __init__(self, params: Params = None, native=False):
+        self.L = lib(native)
         self.h = C.c_void_p(self.L.svo_oracle_create())
         if params is not None:
             self.set_params(params)

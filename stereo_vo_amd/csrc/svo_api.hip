@@ -40,7 +40,29 @@ struct svo_ctx {
     uint8_t* d_src; int src_pitch;                    // staging of host source images (grey or BGR)
     uint2** d_map_ptrs; std::vector<uint2*> map_ptrs;  // per image: fixed-point map on the device or nullptr
     int map_w, map_h, n_maps;
+    std::vector<uint2*> map_bufs;                      // per image: the allocation behind map_ptrs (kept across clear / set cycles)
+    // getChangeInPose works on temporaries (common.cpp:362-400): a one-lane scratch view of the device context
+    DevCtx cip; bool cip_ready;
+    // every stream that has had work of this context enqueued since the last full synchronisation (svo_set_stream)
+    std::vector<hipStream_t> used_streams;
 };
+
+static void note_stream(svo_ctx* ctx)
+{
+    for (hipStream_t s : ctx->used_streams) if (s == ctx->stream) return;
+    ctx->used_streams.push_back(ctx->stream);
+}
+// wait for everything this context has enqueued, on whichever stream (a caller that switched streams with
+// svo_set_stream may have left work on the earlier ones)
+static hipError_t sync_all(svo_ctx* ctx)
+{
+    hipError_t first = hipSuccess;
+    for (hipStream_t s : ctx->used_streams) { if (s == ctx->stream) continue; const hipError_t e = hipStreamSynchronize(s); if (first == hipSuccess) first = e; }
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (first == hipSuccess) first = e;
+    ctx->used_streams.clear();
+    return first;
+}
 
 static int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
@@ -96,7 +118,7 @@ static hipError_t dev_alloc(svo_ctx* ctx, T** p, size_t n)
     hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
     if (e != hipSuccess) return e;
     e = hipMemset(q, 0, n * sizeof(T) + 256);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { hipFree(q); return e; }
     ctx->allocs.push_back(q);
     *p = (T*)q;
     return hipSuccess;
@@ -135,6 +157,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
+    ctx->cip_ready = false;
     for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
     ctx->kt_mask = 0xFFFFFFFFu;
     *out = ctx;                                           // so that the caller can read last_error and destroy
@@ -205,7 +228,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
 extern "C" void svo_destroy(svo_ctx* ctx)
 {
     if (!ctx) return;
-    hipStreamSynchronize(ctx->stream);
+    sync_all(ctx);                                        // work may still be running on a stream the caller switched away from
     for (void* p : ctx->allocs) hipFree(p);
     if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
     if (ctx->d_ham_q) hipFree(ctx->d_ham_q);
@@ -254,7 +277,7 @@ extern "C" int svo_set_stream(svo_ctx* ctx, void* stream)
 extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam)
 {
     if (!ctx || !cam || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
         if (lane < 0 || lane == l) HIPCHECK(hipMemcpy(ctx->dc.cams + l, cam, sizeof(*cam), hipMemcpyHostToDevice));
     return SVO_OK;
@@ -265,9 +288,9 @@ extern "C" int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float
     if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes || side < 0 || side > 1 || ((map_x == nullptr) != (map_y == nullptr))) return SVO_ERR_ARG;
     const int NI = 2 * ctx->cfg.n_lanes;
     if (map_x && (w <= 0 || h <= 0 || w > ctx->cfg.max_w || h > ctx->cfg.max_h || (ctx->n_maps > 0 && (w != ctx->map_w || h != ctx->map_h)))) return SVO_ERR_ARG;
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     if (ctx->map_ptrs.empty()) {
-        ctx->map_ptrs.assign(NI, nullptr);
+        ctx->map_ptrs.assign(NI, nullptr); ctx->map_bufs.assign(NI, nullptr);
         HIPCHECK(dev_alloc(ctx, (uint2***)&ctx->d_map_ptrs, (size_t)NI));
         HIPCHECK(hipMemset(ctx->d_map_ptrs, 0, sizeof(uint2*) * NI));
     }
@@ -290,10 +313,14 @@ extern "C" int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float
         if (lane >= 0 && lane != l) continue;
         uint2*& mp = ctx->map_ptrs[2 * l + side];
         if (map_x) {
-            if (!mp) { HIPCHECK(dev_alloc(ctx, &mp, (size_t)ctx->cfg.max_w * ctx->cfg.max_h)); ctx->n_maps++; }
+            if (!mp) {                                       // a cleared camera's buffer is reused, not allocated again
+                uint2*& buf = ctx->map_bufs[2 * l + side];
+                if (!buf) HIPCHECK(dev_alloc(ctx, &buf, (size_t)ctx->cfg.max_w * ctx->cfg.max_h));
+                mp = buf; ctx->n_maps++;
+            }
             HIPCHECK(hipMemcpy(mp, fixed.data(), fixed.size() * sizeof(uint2), hipMemcpyHostToDevice));
             ctx->map_w = w; ctx->map_h = h;
-        } else if (mp) { mp = nullptr; ctx->n_maps--; }     // the buffer stays in the context's allocation list until svo_destroy
+        } else if (mp) { mp = nullptr; ctx->n_maps--; }     // the buffer stays in map_bufs for the next set
     }
     HIPCHECK(hipMemcpy(ctx->d_map_ptrs, ctx->map_ptrs.data(), sizeof(uint2*) * NI, hipMemcpyHostToDevice));
     return SVO_OK;
@@ -302,7 +329,7 @@ extern "C" int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float
 extern "C" int svo_reset(svo_ctx* ctx, int lane)
 {
     if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
         if (lane < 0 || lane == l) {
             HIPCHECK(hipMemset(ctx->dc.lane + l, 0, sizeof(LaneState)));
@@ -352,7 +379,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     if (w > ctx->cfg.max_w || h > ctx->cfg.max_h || w < 64 || h < 64) return SVO_ERR_CAPACITY;
     if (nlev > SVO_MAX_LEVELS) return SVO_ERR_UNSUPPORTED;
     if (noct > ctx->dc.oct_cap) return SVO_ERR_CAPACITY;       // svo_config.max_octaves
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     DevCtx& d = ctx->dc;
     int lw[SVO_MAX_LEVELS], lh[SVO_MAX_LEVELS], quota[SVO_MAX_LEVELS]; float sc[SVO_MAX_LEVELS];
     d.fast_orb = fast_orb ? 1 : 0; d.n_oct = noct;
@@ -433,7 +460,7 @@ static void collect_spans(svo_ctx* ctx)
 extern "C" int svo_wait(svo_ctx* ctx)
 {
     if (!ctx) return SVO_ERR_ARG;
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     collect_spans(ctx);
     return SVO_OK;
 }
@@ -486,6 +513,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if (p.min_distance < 2) return SVO_ERR_ARG;            // cell size 0 divides by zero in the reference (S2:331-332)
     DevCtx& d = ctx->dc;
     const hipStream_t st = ctx->stream;
+    note_stream(ctx);
     const uint8_t* ptrs[2 * SVO_MAX_LANES];
     PrepArgs prep; memset(&prep, 0, sizeof(prep)); bool prepare = false;
     if (flags & SVO_RUN_DETECT) {
@@ -628,6 +656,7 @@ extern "C" int svo_get_results(svo_ctx* ctx, svo_result* res)
 extern "C" int svo_copy_results_async(svo_ctx* ctx, void* dst, size_t bytes)
 {
     if (!ctx || !dst || bytes < sizeof(svo_result) * (size_t)ctx->cfg.n_lanes) return SVO_ERR_ARG;
+    note_stream(ctx);
     HIPCHECK(hipMemcpyAsync(dst, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToDevice, ctx->stream));
     return SVO_OK;
 }
@@ -1002,6 +1031,38 @@ extern "C" int svo_load_state(svo_ctx* ctx, int lane, const char* path)
 }
 
 // ---- getChangeInPose (common.cpp:355-413) -------------------------------------------------------------------
+// The reference packs the caller's arrays into TEMPORARY TImagePairData / TTrackingData (C:362-400) and runs
+// stage5_optimize on them: m_prev_imgpair / m_current_imgpair are not touched.  The only estimator members the call
+// shares with the pipeline are the ones stage 5 itself reads and writes: m_last_computed_pose (S5:506-507, 720-721)
+// and m_error (S5:380-386).  Same here: the Gauss-Newton kernel runs on a ONE-LANE SCRATCH VIEW of the device context
+// (its own keypoint / pairing / track / residual buffers and lane record); lane 0's warm start and m_error are copied
+// into it before the launch and back afterwards, nothing else of the live lanes is read or written.
+static int ensure_cip(svo_ctx* ctx)
+{
+    if (ctx->cip_ready) return SVO_OK;
+    DevCtx& s = ctx->cip;
+    s = ctx->dc;
+    const int MK = ctx->dc.max_kps;
+    s.n_lanes = 1; s.n_img = 2; s.oct_cap = 1; s.n_oct = 1;
+    HIPCHECK(dev_alloc(ctx, &s.kps, (size_t)4 * MK));
+    HIPCHECK(dev_alloc(ctx, &s.n_kps, (size_t)4));
+    HIPCHECK(dev_alloc(ctx, &s.matches, (size_t)2 * MK));
+    HIPCHECK(dev_alloc(ctx, &s.n_matches, (size_t)2));
+    HIPCHECK(dev_alloc(ctx, &s.tracked, (size_t)MK));
+    HIPCHECK(dev_alloc(ctx, &s.n_tracked, (size_t)1));
+    HIPCHECK(dev_alloc(ctx, &s.trk_kq, (size_t)MK));
+    HIPCHECK(dev_alloc(ctx, &s.gn_lmk, (size_t)MK * 3));
+    HIPCHECK(dev_alloc(ctx, &s.gn_obs, (size_t)MK * 8));
+    HIPCHECK(dev_alloc(ctx, &s.residual, (size_t)MK));
+    HIPCHECK(dev_alloc(ctx, &s.outliers, (size_t)MK));
+    HIPCHECK(dev_alloc(ctx, &s.cams, (size_t)1));
+    HIPCHECK(dev_alloc(ctx, &s.lane, (size_t)1));
+    HIPCHECK(dev_alloc(ctx, &s.results, (size_t)1));
+    HIPCHECK(dev_alloc(ctx, &s.status, (size_t)1));
+    ctx->cip_ready = true;
+    return SVO_OK;
+}
+
 extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, int n_tracked,
                                   const svo_dmatch* pre_matches, int n_pre, const svo_dmatch* cur_matches, int n_cur,
                                   const svo_keypoint* pre_left, int n_pl, const svo_keypoint* pre_right, int n_pr,
@@ -1009,45 +1070,55 @@ extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, i
                                   const svo_stereo_camera* cam, const double* init6,
                                   svo_result* res, double* residual, int32_t* outliers)
 {
-    if (!ctx || !cam || !res || n_tracked < 0) return SVO_ERR_ARG;
+    if (!ctx || !cam || !res || n_tracked < 0 || n_pre < 0 || n_cur < 0 || n_pl < 0 || n_pr < 0 || n_cl < 0 || n_cr < 0) return SVO_ERR_ARG;
+    if ((n_tracked > 0 && !tracked) || (n_pre > 0 && !pre_matches) || (n_cur > 0 && !cur_matches) || (n_pl > 0 && !pre_left) ||
+        (n_pr > 0 && !pre_right) || (n_cl > 0 && !cur_left) || (n_cr > 0 && !cur_right)) return SVO_ERR_ARG;
     if (cam->ncols < 1 || cam->nrows < 1) return SVO_ERR_ARG;
     const svo_params& p = ctx->params;
-    DevCtx& d = ctx->dc;
+    const int MK = ctx->dc.max_kps;
+    if (n_tracked > MK || n_pre > MK || n_cur > MK || n_pl > MK || n_pr > MK || n_cl > MK || n_cr > MK) return SVO_ERR_CAPACITY;
     int rc = svo_wait(ctx); if (rc) return rc;
-    if (!ctx->geom_ready) { d.W = cam->ncols; d.H = cam->nrows; d.ow[0] = cam->ncols; d.oh[0] = cam->nrows; }
-    const int lane = 0;
-    const int saved_noct = d.n_oct; d.n_oct = 1;          // getChangeInPose packs everything into octave 0 (common.cpp:367)
-    HIPCHECK(hipMemcpy(d.cams + lane, cam, sizeof(*cam), hipMemcpyHostToDevice));
-    LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
-    s.has_prev = 1; s.has_cur = 1;
-    HIPCHECK(hipMemcpy(d.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
-    auto put_k = [&](int which, int side, const svo_keypoint* k, int n) -> int {
-        if (n > d.max_kps) return SVO_ERR_CAPACITY;
-        const int slot = slot_of(s, which);
-        const int vl = lane * d.oct_cap;
-        const long long base = (((long long)vl * 2 + slot) * 2 + side) * d.max_kps;
-        if (n > 0 && hipMemcpy(d.kps + base, k, sizeof(svo_keypoint) * n, hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
-        if (hipMemcpy(d.n_kps + (vl * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return SVO_ERR_HIP;
-        return SVO_OK;
-    };
-    if ((rc = put_k(1, 0, pre_left, n_pl)) || (rc = put_k(1, 1, pre_right, n_pr)) || (rc = put_k(0, 0, cur_left, n_cl)) || (rc = put_k(0, 1, cur_right, n_cr))) return rc;
-    if ((rc = svo_put_matches(ctx, lane, 1, pre_matches, n_pre)) || (rc = svo_put_matches(ctx, lane, 0, cur_matches, n_cur))) return rc;
-    launch_begin_frame(d, nullptr, SVO_FLAG_NO_SHIFT, ctx->stream);
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
-    if ((rc = svo_put_tracked(ctx, lane, tracked, n_tracked))) return rc;
+    if ((rc = ensure_cip(ctx))) return rc;
+    DevCtx& s = ctx->cip;
+    s.debug_mode = ctx->dc.debug_mode;
+    s.W = cam->ncols; s.H = cam->nrows; s.ow[0] = cam->ncols; s.oh[0] = cam->nrows;      // common.cpp:402-403
+    // lane record of the scratch lane: slot 0 = previous, slot 1 = current, both present; warm start and m_error of lane 0
+    LaneState live; HIPCHECK(hipMemcpy(&live, ctx->dc.lane, sizeof(live), hipMemcpyDeviceToHost));
+    LaneState ls = live; ls.prev_slot = 0; ls.has_prev = 1; ls.has_cur = 1;
+    HIPCHECK(hipMemcpy(s.lane, &ls, sizeof(ls), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(s.cams, cam, sizeof(*cam), hipMemcpyHostToDevice));
+    const svo_keypoint* kp[4] = { pre_left, pre_right, cur_left, cur_right };        // (slot 0: prev | slot 1: cur) x (left, right)
+    const int nk[4] = { n_pl, n_pr, n_cl, n_cr };
+    for (int i = 0; i < 4; i++) if (nk[i] > 0) HIPCHECK(hipMemcpy(s.kps + (size_t)i * MK, kp[i], sizeof(svo_keypoint) * nk[i], hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(s.n_kps, nk, sizeof(nk), hipMemcpyHostToDevice));
+    if (n_pre > 0) HIPCHECK(hipMemcpy(s.matches, pre_matches, sizeof(svo_dmatch) * n_pre, hipMemcpyHostToDevice));
+    if (n_cur > 0) HIPCHECK(hipMemcpy(s.matches + MK, cur_matches, sizeof(svo_dmatch) * n_cur, hipMemcpyHostToDevice));
+    const int nm[2] = { n_pre, n_cur };
+    HIPCHECK(hipMemcpy(s.n_matches, nm, sizeof(nm), hipMemcpyHostToDevice));
+    if (n_tracked > 0) HIPCHECK(hipMemcpy(s.tracked, tracked, sizeof(svo_index_pair) * n_tracked, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(s.n_tracked, &n_tracked, sizeof(int), hipMemcpyHostToDevice));
+    svo_result r0; memset(&r0, 0, sizeof(r0)); r0.n_octaves = 1;                         // what k_begin_frame leaves in a result record
+    HIPCHECK(hipMemcpy(s.results, &r0, sizeof(r0), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(s.status, 0, sizeof(uint32_t)));
     GNParams g; memset(&g, 0, sizeof(g));
     g.use_robust_kernel = p.use_robust_kernel; g.max_iters = p.max_iters; g.initial_max_iters = p.initial_max_iters; g.max_incr_cost = p.max_incr_cost;
     g.use_previous_pose_as_initial = p.use_previous_pose_as_initial; g.use_custom_initial_pose = p.use_custom_initial_pose;
     g.min_distance = p.min_distance; g.img_w = cam->ncols; g.img_h = cam->nrows;      // common.cpp:402-403
-    g.pmax = d.max_kps; g.standalone = 1;
+    g.pmax = MK; g.standalone = 1;
     g.kernel_param = p.kernel_param; g.min_mod_out_vector = p.min_mod_out_vector; g.residual_threshold = p.residual_threshold;
     for (int k = 0; k < 6; k++) g.init[k] = init6 ? init6[k] : 0.0;
-    // only lane 0 carries data; the other lanes see n_tracked == 0 and return invalid
-    { Span sp(ctx, KT_GN); launch_gauss_newton(d, g, ctx->stream); }
-    d.n_oct = saved_noct;
-    if ((rc = svo_get_result(ctx, lane, res))) return rc;
-    if (residual && res->n_residual > 0) HIPCHECK(hipMemcpy(residual, d.residual, sizeof(double) * res->n_residual, hipMemcpyDeviceToHost));
-    if (outliers && res->n_outliers > 0) HIPCHECK(hipMemcpy(outliers, d.outliers, sizeof(int32_t) * res->n_outliers, hipMemcpyDeviceToHost));
+    note_stream(ctx);
+    { Span sp(ctx, KT_GN); launch_gauss_newton(s, g, ctx->stream); }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(hipMemcpy(res, s.results, sizeof(*res), hipMemcpyDeviceToHost));
+    if (residual && res->n_residual > 0) HIPCHECK(hipMemcpy(residual, s.residual, sizeof(double) * res->n_residual, hipMemcpyDeviceToHost));
+    if (outliers && res->n_outliers > 0) HIPCHECK(hipMemcpy(outliers, s.outliers, sizeof(int32_t) * res->n_outliers, hipMemcpyDeviceToHost));
+    // m_last_computed_pose and m_error are the estimator's own members: hand them back to lane 0
+    HIPCHECK(hipMemcpy(&ls, s.lane, sizeof(ls), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; k++) live.last_pose[k] = ls.last_pose[k];
+    live.m_error = ls.m_error;
+    HIPCHECK(hipMemcpy(ctx->dc.lane, &live, sizeof(live), hipMemcpyHostToDevice));
     return res->valid;
 }
 

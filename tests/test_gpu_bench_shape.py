@@ -1,0 +1,114 @@
+"""The configuration bench.py times, checked against the oracle AT ITS OWN SHAPE, and bench.py's N > 1 path run for real.
+
+test_benchmark_shape_*: 3 contexts x 64 lanes x 1280x960 through stereo_vo_amd.pipeline.StreamBatch -- the object
+bench.py's step() drives -- on the pipelined two-stream schedule; probe lanes {0, 31, 63} of every context against
+independent oracle instances, every list bit for bit.  The XCD-chunked tile orders, fastdiv helpers and the matcher's
+train splits all depend on lane count x image size; no smaller test exercises these values.
+
+test_bench_two_ranks_*: `bench.py --gpus 2` under torch.distributed.run with both ranks on device 0 (this box has one
+GPU): sharding, event ordering around the all-gather, MAX-time reduction and the gather itself on REAL result records.
+RCCL refuses two ranks on one device, so the collective backend is gloo there; the 8-GPU driver run uses nccl.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from stereo_vo_amd import hip
+from stereo_vo_amd.abi import north_star_params, Result
+from stereo_vo_amd.synth import SyntheticStereoWorld
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("schedule", ["pipelined"])
+def test_benchmark_shape_three_contexts_of_64_lanes_match_oracle(schedule):
+    import torch
+    from oracle import probe as PR
+    from stereo_vo_amd.pipeline import StreamBatch
+    import bench
+    W, H, B, NC, F, STEPS = 1280, 960, 192, 3, 3, 4
+    dev = torch.device("cuda", 0)
+    worlds = [SyntheticStereoWorld(W, H, 800.0, 0.12, seed=s, n_frames=F, device=dev, scene_seed=s % 4) for s in bench.lane_seeds(0, 1, B)]
+    frames = [[w.render(t) for t in range(F)] for w in worlds]
+    cam = worlds[0].camera()
+    torch.cuda.synchronize()
+    p = north_star_params(hip.default_params(), orb_nfeats=2000)
+    batch = StreamBatch(p, cam, W, H, B, NC, schedule=schedule)
+    Bc = batch.Bc
+    probe = sorted(k * Bc + l for k in range(NC) for l in (0, 31, 63))
+    order = [bench.frame_schedule(i, F) for i in range(STEPS)]           # 0 1 2 1: the ping-pong bench.py plays
+    host = {g: [(frames[g][t][0].cpu().numpy(), frames[g][t][1].cpu().numpy()) for t in range(F)] for g in probe}
+    ref, _ = PR.replay_many(p, cam, host, order, threads=min(8, os.cpu_count() or 1))
+    ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
+    # enqueue the steps back to back first (the schedule as timed: no host synchronisation between steps) ...
+    for i in range(STEPS):
+        batch.step(ptrs_at[order[i]])
+    batch.synchronize()
+    rec = batch.rec.cpu().numpy()
+    for g in probe:
+        ctx, l = batch.lane(g)
+        res = Result.from_buffer_copy(rec[g].tobytes())
+        lists, flags, et, er = PR.compare(PR.digest_of(ctx, l, res), ref[g][-1])
+        assert lists and flags and et < 1e-3 and er < 1e-4, ("back-to-back", g, et, er)
+        assert ctx.status_word(l) == 0
+    # ... then frame by frame after a reset, every probe lane at every step
+    batch.reset()
+    n_valid = 0
+    for i in range(STEPS):
+        batch.step(ptrs_at[order[i]])
+        batch.synchronize()
+        rec = batch.rec.cpu().numpy()
+        for g in probe:
+            ctx, l = batch.lane(g)
+            res = Result.from_buffer_copy(rec[g].tobytes())
+            dg = PR.digest_of(ctx, l, res)
+            lists, flags, et, er = PR.compare(dg, ref[g][i])
+            assert lists, ("lists differ", g, i, dg.n, ref[g][i].n)
+            assert flags and et < 1e-3 and er < 1e-4, (g, i, et, er)
+            if i:
+                assert np.allclose(dg.residual[dg.residual < 1e300], ref[g][i].residual[ref[g][i].residual < 1e300], rtol=1e-6, atol=1e-9)
+            n_valid += int(dg.valid)
+            if i:
+                assert dg.n[0] > 1500 and dg.n[3] > 100, dg.n
+    assert n_valid >= (STEPS - 1) * len(probe) - 1
+    assert sum(1 for r in batch.results() if r.valid) >= B - 4
+    batch.close()
+
+
+def _run_bench_2ranks(backend, tmp, extra_env=None):
+    env = dict(os.environ)
+    env.update({"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": backend, "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env or {})
+    dump = os.path.join(tmp, "rec_" + backend)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--lanes", "8", "--contexts", "2", "--frames", "3",
+           "--width", "640", "--height", "480", "--orb-nfeats", "500", "--cpu-frames", "0", "--dump-records", dump]
+    try:
+        pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return None, dump, "timeout"
+    return pr, dump, pr.stdout[-2000:] + pr.stderr[-2000:]
+
+
+def test_bench_two_ranks_on_one_gpu_gather_real_records(tmp_path):
+    import json
+    pr, dump, log = _run_bench_2ranks("gloo", str(tmp_path))
+    assert pr is not None and pr.returncode == 0, log
+    line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["lanes_per_gpu"] == 8
+    r0, r1 = np.load(dump + ".rank0.npz"), np.load(dump + ".rank1.npz")
+    # every rank holds the same gathered array = rank 0's records followed by rank 1's (stream s -> rank s // lanes)
+    assert r0["gathered"].tobytes() == r1["gathered"].tobytes()
+    assert r0["gathered"].shape[0] == 16
+    assert r0["gathered"][:8].tobytes() == r0["local"].tobytes() and r0["gathered"][8:].tobytes() == r1["local"].tobytes()
+    # ... and those records are what svo_get_results returns on the rank that computed them
+    assert r0["own"].tobytes() == r0["local"].tobytes() and r1["own"].tobytes() == r1["local"].tobytes()
+    # different streams (seeds) on the two ranks: their poses differ, and they are real (valid) results
+    recs = [Result.from_buffer_copy(r0["gathered"][i].tobytes()) for i in range(16)]
+    assert sum(r.valid for r in recs) >= 14
+    assert list(recs[0].outPose) != list(recs[8].outPose)
