@@ -21,7 +21,7 @@
 
 #define EDGE_THRESHOLD 31          /* S2:486 */
 #define HARRIS_BLOCK 7
-#define RANSAC_MAX_HYP 256         /* [frozen] */
+#define RANSAC_MAX_HYP 1000        /* [frozen]  cv::findFundamentalMat's maxIters default of OpenCV >= 3.4 (2.4 sized its schedule from the confidence alone) */
 #define RANSAC_SEED 0x5EEDF00DCAFE1234ULL
 #define MAXOCT SVO_MAX_OCTAVES
 

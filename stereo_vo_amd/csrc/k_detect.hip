@@ -64,7 +64,15 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
     const bool detect = flags & SVO_RUN_DETECT, do_shift = !(flags & SVO_FLAG_NO_SHIFT), repeat = flags & SVO_FLAG_REPEAT;
     if (detect) {
         if (t < c.n_img) { c.img0[t] = ptrs.p[t]; c.raw_n[t] = 0; }
-        if (t < c.n_img * SVO_MAX_LEVELS) { c.cand_cnt[t * SVO_CNT_STRIDE] = 0; c.lvl_n[t] = 0; }
+        if (t < c.n_img * SVO_MAX_LEVELS) {
+            c.cand_cnt[t * SVO_CNT_STRIDE] = 0; c.lvl_n[t] = 0;
+            // this frame's FAST threshold per (image, level): the speculated one when there is one (ORB mode only; debug
+            // mode 12 switches the speculation off), never below the caller's threshold
+            const uint32_t dyn = (c.fast_orb || c.debug_mode == 12) ? 0u : c.fast_th_dyn[t];
+            c.fast_th_used[t] = max((uint32_t)c.fast_th, min(dyn, 250u));
+            c.redo_flag[t] = 0;
+        }
+        if (t == 0) *c.redo_n = 0;
     }
     if (t < c.n_lanes) {
         LaneState& s = c.lane[t];
@@ -291,29 +299,21 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* win, int off, int t
     return best > th ? best - 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_fast(DevCtx c)
+struct FastSmem {
+    __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
+    __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 16];
+    unsigned short list[FT_SH * FT_SW];
+    uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
+    unsigned s_count, s_nout;
+};
+
+// one 64x28 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
+__device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, int t, int th_fast)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
-    __shared__ __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 16];
-    __shared__ unsigned short list[FT_SH * FT_SW];
-    __shared__ unsigned s_count;
-    __shared__ uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
-    __shared__ unsigned s_nout;
-    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The global work list
-    // (image-major, then the image's tiles of all levels) is cut into chunks of FT_CHUNK consecutive tiles and chunk k
-    // goes to XCD k % 8, so the halo columns / rows that neighbouring tiles share are re-read from that XCD's L2 rather
-    // than through another one.  (One contiguous eighth of every image per XCD shares more, but gives each XCD a
-    // fixed set of pyramid levels -- their corner densities differ and the launch waits for the slowest XCD: measured.)
+    uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = sm.out_keys;
+    unsigned& s_count = sm.s_count; unsigned& s_nout = sm.s_nout;
     const int tid = threadIdx.x;
-    const uint32_t slot = blockIdx.x >> 3;
-    const uint32_t work = c.debug_mode == 8 ? blockIdx.x : (((slot / FT_CHUNK) * 8 + (blockIdx.x & 7)) * FT_CHUNK + slot % FT_CHUNK);
-    const int img = (int)fastdiv(work, c.div_tiles), tile_id = (int)work - img * c.n_tiles;
-    if (img >= c.n_img) return;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && tile_id >= c.lv[l].tile_off) level = l;
     const LevelGeom& g = c.lv[level];
-    const int t = tile_id - g.tile_off;
     const int by = t / g.tiles_x, bx = t - by * g.tiles_x;
     const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
     int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     if (c.debug_mode == 1) return;
     // ---- (1) packed cardinal test: 30 rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + 15, gq) ----
     const uint32_t* T32 = (const uint32_t*)tile;
-    const uint32_t th = (uint32_t)c.fast_th;
+    const uint32_t th = (uint32_t)th_fast;
     const u16x2 t2 = { (unsigned short)th, (unsigned short)th }, t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
     const int r0 = tid / FT_NG, gq = tid - r0 * FT_NG;
     uint32_t pe[2] = { 0, 0 }, po[2] = { 0, 0 };                        // nonzero halves = passing positions
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     // ---- (2) score on the survivors only ----
     for (int i = tid; i < ns; i += 256) {
         const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
-        score[pos] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), c.fast_th);
+        score[pos] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
     }
     __syncthreads();
     if (c.debug_mode == 3) return;
@@ -427,16 +427,58 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     __syncthreads();
     // only the first wave publishes: the other three retire here, so the returning global atomic (a ~2-3 us round trip)
     // stalls one wave per tile instead of the whole workgroup
-    if (tid >= 64) return;
-    const unsigned nout = s_nout;
-    if (nout == 0 || c.debug_mode == 4) return;
-    unsigned gbase = 0;
-    if (tid == 0) gbase = atomicAdd(&c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE], nout);
-    gbase = __shfl(gbase, 0, 64);
-    uint32_t* dst = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
-    for (unsigned i = tid; i < nout; i += 64) {
-        if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
-        else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
+    if (tid < 64) {
+        const unsigned nout = s_nout;
+        if (nout != 0 && c.debug_mode != 4) {
+            unsigned gbase = 0;
+            if (tid == 0) gbase = atomicAdd(&c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE], nout);
+            gbase = __shfl(gbase, 0, 64);
+            uint32_t* dst = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
+            for (unsigned i = tid; i < nout; i += 64) {
+                if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
+                else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fast(DevCtx c)
+{
+    __shared__ FastSmem sm;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The global work list
+    // (image-major, then the image's tiles of all levels) is cut into chunks of FT_CHUNK consecutive tiles and chunk k
+    // goes to XCD k % 8, so the halo columns / rows that neighbouring tiles share are re-read from that XCD's L2 rather
+    // than through another one.  (One contiguous eighth of every image per XCD shares more, but gives each XCD a
+    // fixed set of pyramid levels -- their corner densities differ and the launch waits for the slowest XCD: measured.)
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t work = c.debug_mode == 8 ? blockIdx.x : (((slot / FT_CHUNK) * 8 + (blockIdx.x & 7)) * FT_CHUNK + slot % FT_CHUNK);
+    const int img = (int)fastdiv(work, c.div_tiles), tile_id = (int)work - img * c.n_tiles;
+    if (img >= c.n_img) return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && tile_id >= c.lv[l].tile_off) level = l;
+    fast_tile(c, sm, img, level, tile_id - c.lv[level].tile_off, (int)c.fast_th_used[img * SVO_MAX_LEVELS + level]);
+}
+
+// The (image, level) pairs whose speculated threshold found fewer than 2 * quota corners (k_select) again, with the
+// caller's threshold.  Normally the list is empty and the launch retires at once; otherwise the workgroups stride over
+// the concatenated tile lists of the listed pairs.
+__global__ void __launch_bounds__(256) k_fast_redo(DevCtx c)
+{
+    __shared__ FastSmem sm;
+    const unsigned n = *c.redo_n;
+    if (n == 0) return;
+    int first = (int)blockIdx.x;                                             // this workgroup's next tile, relative to entry e
+    for (unsigned e = 0; e < n; e++) {
+        const uint32_t il = c.redo_list[e];
+        const int img = (int)(il / SVO_MAX_LEVELS), level = (int)(il % SVO_MAX_LEVELS);
+        const int nt = c.lv[level].tiles_x * c.lv[level].tiles_y;
+        int t = first;
+        for (; t < nt; t += (int)gridDim.x) {
+            fast_tile(c, sm, img, level, t, c.fast_th);
+            __syncthreads();                                                 // the tile's LDS is reused by the next one
+        }
+        first = t - nt;
     }
 }
 
@@ -507,7 +549,17 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
     return (det - k) * s4;
 }
 
-__global__ void __launch_bounds__(512) k_select(DevCtx c)
+// Speculative FAST threshold (exact, with fallback).  Only the 2 * quota best corners of a level survive this kernel, and
+// on a textured scene they are a small fraction of what FAST finds at the caller's threshold (1 300 of 12 000 at level 0
+// of a 1280x960 frame at th = 20: the cut-off score sits near 80).  A corner's score, and whether it survives the 3x3
+// NMS against weaker neighbours, do not depend on the threshold it was found with (a neighbour that a higher threshold
+// misses has a lower score than anything it finds), so k_fast run with th' >= th yields exactly the candidates with
+// score >= th' -- and if there are at least 2 * quota of them, the 2 * quota best of those ARE the 2 * quota best of
+// all.  Each (image, level) therefore carries its own th' from frame to frame: this kernel sets the next frame's th' to
+// the score that 1.5 x (2 * quota) + 32 of this frame's candidates reach, and when a frame's th' turns out too high
+// (fewer than 2 * quota found) it discards the list and queues the pair for k_fast_redo at the caller's threshold,
+// after which pass 1 of this kernel selects from the complete list.  Same lists as the oracle, bit for bit, either way.
+__global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
 {
     __shared__ unsigned long long keys[SEL_MAX];
     __shared__ uint32_t sel[SEL_MAX];
@@ -519,10 +571,21 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     const int level = blockIdx.y, img = blockIdx.x;
     const LevelGeom& g = c.lv[level];
     const int tid = threadIdx.x;
-    unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
+    const int il = img * SVO_MAX_LEVELS + level;
+    if (redo_pass && !c.redo_flag[il]) return;
+    unsigned nc = c.cand_cnt[il * SVO_CNT_STRIDE];
     if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
     const unsigned K = min(nc, (unsigned)(2 * g.quota));
-    if (K == 0 || g.quota <= 0) { if (tid == 0) { c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; c.sel_n[img * SVO_MAX_LEVELS + level] = 0; } return; }
+    const uint32_t th_used = c.fast_th_used[il], th_base = (uint32_t)c.fast_th;
+    if (!redo_pass && g.quota > 0 && th_used > th_base && nc < (unsigned)(2 * g.quota)) {
+        // the speculated threshold found too few corners: start this pair over at the caller's threshold
+        if (tid == 0) {
+            c.redo_flag[il] = 1; c.redo_list[atomicAdd(c.redo_n, 1u)] = (uint32_t)il;
+            c.cand_cnt[il * SVO_CNT_STRIDE] = 0; c.fast_th_used[il] = th_base; c.fast_th_dyn[il] = 0;
+        }
+        return;
+    }
+    if (K == 0 || g.quota <= 0) { if (tid == 0) { c.lvl_n[il] = 0; c.sel_n[il] = 0; c.fast_th_dyn[il] = 0; } return; }
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
     // ---- the K largest of the unique 32-bit keys (score << 24 | inverted position) ----
     // Two sweeps over the candidate list, eight independent loads in flight per thread (a one-load-per-iteration loop
@@ -548,6 +611,15 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
         int tot;
         const int before = block_exclusive_scan(mine, scan_s, &tot);
         if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { s_prefix = (unsigned)(255 - tid) << 24; s_need = need - (unsigned)before; s_ntie = (unsigned)mine; }
+        // the next frame's threshold for this pair: the largest score s that M candidates reach (k_fast at th' = s finds
+        // exactly the corners with score >= s); with fewer than M in sight, step below this frame's threshold by the
+        // deficit over the density at the visible edge.  0 = do not speculate.
+        const unsigned M = 3u * (unsigned)g.quota + 32u;
+        if (tid < 256 && (unsigned)before < M && M <= (unsigned)(before + mine)) c.fast_th_dyn[il] = (uint32_t)(255 - tid) > th_base ? (uint32_t)(255 - tid) : 0u;
+        if (tid == 0 && (unsigned)tot < M) {
+            const unsigned dens = max(hist[min(th_used, 255u)], 1u), lower = (M - (unsigned)tot) / dens + 1u;
+            c.fast_th_dyn[il] = th_used > th_base + lower ? th_used - lower : 0u;
+        }
         __syncthreads();
         prefix = s_prefix; need = s_need; mask = 0xFF000000u;
     }
@@ -604,7 +676,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c)
     // budget (55 us of this kernel's 108), the whole GPU does it in a few
     uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX;
     for (unsigned i = tid; i < K; i += blockDim.x) gsel[i] = sel[i];
-    if (tid == 0) c.sel_n[img * SVO_MAX_LEVELS + level] = (int)K;
+    if (tid == 0) c.sel_n[il] = (int)K;
 }
 
 // Harris response of every selected corner, one thread each, all (image, level) lists in one launch
@@ -1422,7 +1494,10 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 
 void launch_select(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
+    hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
+    // the pairs whose speculated FAST threshold was too high (normally none: both launches retire at once)
+    hipLaunchKernelGGL(k_fast_redo, dim3(4096), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
     hipLaunchKernelGGL(k_harris, dim3(c.n_img, SEL_MAX / 256, c.n_levels), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_select_sort, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
 }

@@ -501,13 +501,51 @@ __device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
 
 // one thread per hypothesis: sample 8 pairs, normalised linear 8-point solution through the null vector of the
 // 8x9 system (Gauss-Jordan, full pivoting).  The 8x9 matrix lives in LDS, one column of doubles per thread slot.
-__global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c)
+// The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): scan the inlier counts in hypothesis
+// order; a count above the best so far (and above 7) becomes the model and shrinks the iteration budget to the smallest K
+// with (1 - w^8)^K <= 0.01, w = count / n.  Returns the budget after the first `upto` hypotheses; *best_k / *best_cnt
+// receive the model so far.  `niters` can only shrink, so the value after the first chunk bounds what is ever scanned.
+__device__ __forceinline__ int ransac_scan(const int* cnts, int upto, int n, int* best_k_out, int* best_cnt_out)
+{
+    int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP;
+    for (int k = 0; k < niters && k < upto; k++) {
+        const int cnt = cnts[k];
+        if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
+            best_cnt = cnt; best_k = k;
+            const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
+            // the oracle's stop is the sequential product below; when even x^1024 (by squaring, with a 10 % margin for the
+            // different rounding) stays above the bound the loop cannot stop early and is skipped
+            double pbig = x; for (int sq = 0; sq < 10; sq++) pbig = pbig * pbig;
+            if (pbig <= 0.011) {
+                double acc = 1.0; int K = 0;
+                while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
+                niters = K;
+            }
+        }
+    }
+    if (best_k_out) *best_k_out = best_k;
+    if (best_cnt_out) *best_cnt_out = best_cnt;
+    return niters;
+}
+
+// chunk 0: hypotheses [0, CHUNK0); chunk 1: [CHUNK0, bound) where bound = the iteration budget the first chunk leaves
+__global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c, int chunk)
 {
     __shared__ double As[72][64];     // As[r*9+col][thread]: conflict-free (consecutive threads, consecutive banks)
-    const int h = blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z, tx = threadIdx.x;
+    __shared__ int s_bound;
+    const int h = (chunk ? SVO_RANSAC_CHUNK0 : 0) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z, tx = threadIdx.x;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 8) return;
+    if (chunk) {
+        if (tx == 0) {
+            const int b = ransac_scan(c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_PAD, SVO_RANSAC_CHUNK0, n, nullptr, nullptr);
+            s_bound = b;
+            if (blockIdx.x == 0) c.rs_bound[vl * 2 + side] = b;          // for k_ransac_count(chunk 1), launched after this kernel
+        }
+        __syncthreads();
+        if (h >= s_bound) return;
+    } else if (h >= SVO_RANSAC_CHUNK0) return;
     const float* pts = c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4;
     int s[8];
     {
@@ -571,7 +609,7 @@ __global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c)
         M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
         M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
     }
-    double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_HYP + h) * 9;
+    double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
         F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
@@ -603,16 +641,17 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
 
 // inlier counts: 16 hypotheses per 256-thread block, F matrices broadcast from LDS, points streamed once per thread
 #define RC_HB 16
-__global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
+__global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 {
     __shared__ double Fs[RC_HB][9];
     __shared__ int cnt_s[RC_HB];
-    const int side = blockIdx.y, vl = blockIdx.z, h0 = blockIdx.x * RC_HB, tid = threadIdx.x;
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = (chunk ? SVO_RANSAC_CHUNK0 : 0) + blockIdx.x * RC_HB, tid = threadIdx.x;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 8) return;
+    if (chunk && h0 >= c.rs_bound[vl * 2 + side]) return;               // hypotheses the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
-    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_HYP + h0) * 9;
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 9;
     if (tid < RC_HB * 9) Fs[tid / 9][tid % 9] = F[tid];
     if (tid < RC_HB) cnt_s[tid] = 0;
     __syncthreads();
@@ -627,7 +666,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c)
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) { const int v = wave_sum_uniform(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
     __syncthreads();
-    if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_HYP + h0 + tid] = cnt_s[tid];
+    if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0 + tid] = cnt_s[tid];
 }
 
 // pick the model a sequential RANSAC with the 0.99-confidence stop would have returned, apply both masks
@@ -645,41 +684,27 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
     LaneState& ls = c.lane[lane_id];
     if (!ls.has_prev) { if (tid == 0) c.n_tracked[vl] = 0; return; }
     const int n = c.trk_nk[vl];
-    __shared__ int cnt_lds[2 * SVO_RANSAC_HYP];
+    __shared__ int cnt_lds[2 * SVO_RANSAC_PAD];
     // the hypothesis scan below is serial and data dependent: stage the counts in LDS so that every step is an LDS
-    // read instead of a dependent global load
-    for (int i = tid; i < 2 * SVO_RANSAC_HYP; i += blockDim.x) cnt_lds[i] = n >= 8 ? c.rs_cnt[(long long)vl * 2 * SVO_RANSAC_HYP + i] : 0;
+    // read instead of a dependent global load (only the first rs_bound counts of a side exist; the scan never goes further)
+    for (int i = tid; i < 2 * SVO_RANSAC_PAD; i += blockDim.x) {
+        const int side = i / SVO_RANSAC_PAD, k = i - side * SVO_RANSAC_PAD;
+        const int lim = n >= 8 ? max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0) : 0;
+        cnt_lds[i] = k < lim ? c.rs_cnt[(long long)vl * 2 * SVO_RANSAC_PAD + i] : 0;
+    }
     __syncthreads();
     if (tid == 0 || tid == 64) {
         const int side = tid >> 6;
         int best_k = -1, best_cnt = 0;
-        if (n >= 8) {
-            const int* cnts = cnt_lds + side * SVO_RANSAC_HYP;
-            int niters = SVO_RANSAC_HYP;
-            for (int k = 0; k < niters; k++) {
-                const int cnt = cnts[k];
-                if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
-                    best_cnt = cnt; best_k = k;
-                    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
-                    // the oracle's stop is the sequential product below; when even x^256 (by squaring, with a 10 % margin
-                    // for the different rounding) stays above the bound the loop cannot stop early and is skipped
-                    double p256 = x; for (int sq = 0; sq < 8; sq++) p256 = p256 * p256;
-                    if (p256 <= 0.011) {
-                        double acc = 1.0; int K = 0;
-                        while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
-                        niters = K;
-                    }
-                }
-            }
-        }
+        if (n >= 8) ransac_scan(cnt_lds + side * SVO_RANSAC_PAD, SVO_RANSAC_HYP, n, &best_k, &best_cnt);
         s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
     }
     __syncthreads();
     const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
     const bool use_f = goodFL && goodFR;                             // S4:243
     if (use_f) {
-        const double* FL = c.rs_F + (((long long)vl * 2 + 0) * SVO_RANSAC_HYP + s_best[0]) * 9;
-        const double* FR = c.rs_F + (((long long)vl * 2 + 1) * SVO_RANSAC_HYP + s_best[1]) * 9;
+        const double* FL = c.rs_F + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + s_best[0]) * 9;
+        const double* FR = c.rs_F + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + s_best[1]) * 9;
         double fl[9], fr[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) { fl[i] = FL[i]; fr[i] = FR[i]; }
@@ -838,13 +863,15 @@ void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
     hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes * c.oct_cap), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 3 * sizeof(unsigned), st, c);
 }
-void launch_ransac_hyp(const DevCtx& c, hipStream_t st)
+void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ransac_hyp, dim3(SVO_RANSAC_HYP / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c);
+    const int nh = chunk ? SVO_RANSAC_HYP - SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK0;
+    hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
 }
-void launch_ransac_count(const DevCtx& c, hipStream_t st)
+void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_ransac_count, dim3(SVO_RANSAC_HYP / RC_HB, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c);
+    const int nh = chunk ? SVO_RANSAC_HYP - SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK0;
+    hipLaunchKernelGGL(k_ransac_count, dim3((nh + RC_HB - 1) / RC_HB, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {

@@ -15,9 +15,10 @@
 #define HIPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); return SVO_ERR_HIP; } } while (0)
 
 enum { KT_BEGIN, KT_RESIZE, KT_FAST, KT_SELECT, KT_DESCRIBE, KT_NMS, KT_HAM_LR, KT_LR_FILTER, KT_HAM_TRK, KT_TRK_FILTER,
-       KT_RANSAC_HYP, KT_RANSAC_CNT, KT_TRK_FINAL, KT_GN, KT_COUNT };
+       KT_RANSAC_HYP, KT_RANSAC_CNT, KT_TRK_FINAL, KT_GN, KT_RANSAC_HYP1, KT_RANSAC_CNT1, KT_COUNT };
 static const char* kt_names[KT_COUNT] = { "begin_frame", "resize", "fast", "select", "describe", "nms_rowsort", "hamming_lr",
-    "match_lr_filter", "hamming_track", "track_filter", "ransac_hyp", "ransac_count", "track_finalize", "gauss_newton" };
+    "match_lr_filter", "hamming_track", "track_filter", "ransac_hyp", "ransac_count", "track_finalize", "gauss_newton",
+    "ransac_hyp_rest", "ransac_count_rest" };
 
 struct TimedSpan { int id; hipEvent_t a, b; };
 
@@ -183,6 +184,9 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rtab, (size_t)ctx->rtab_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_keys, (size_t)NI * ctx->cand_total_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS * SVO_CNT_STRIDE));
+    HIPCHECK(dev_alloc(ctx, &d.fast_th_dyn, (size_t)NI * SVO_MAX_LEVELS * 4 + 32));
+    d.fast_th_used = d.fast_th_dyn + (size_t)NI * SVO_MAX_LEVELS; d.redo_flag = d.fast_th_used + (size_t)NI * SVO_MAX_LEVELS;
+    d.redo_list = d.redo_flag + (size_t)NI * SVO_MAX_LEVELS; d.redo_n = d.redo_list + (size_t)NI * SVO_MAX_LEVELS;
     HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.sel_keys, (size_t)NI * SVO_MAX_LEVELS * SVO_SEL_MAX));
@@ -207,8 +211,9 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.trk_kq, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.trk_pts, (size_t)NV * 2 * MK * 4));
-    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)NV * 2 * SVO_RANSAC_HYP * 9));
-    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)NV * 2 * SVO_RANSAC_HYP));
+    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)NV * 2 * SVO_RANSAC_PAD * 9));
+    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)NV * 2 * SVO_RANSAC_PAD));
+    HIPCHECK(dev_alloc(ctx, &d.rs_bound, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.gn_lmk, (size_t)L * MK * 3));
@@ -339,6 +344,7 @@ extern "C" int svo_reset(svo_ctx* ctx, int lane)
             HIPCHECK(hipMemset(ctx->dc.n_tracked + (size_t)l * OC, 0, (size_t)OC * sizeof(int)));
             HIPCHECK(hipMemset(ctx->dc.n_ids + (size_t)l * OC * 2, 0, (size_t)OC * 2 * sizeof(int)));
             HIPCHECK(hipMemset(ctx->dc.results + l, 0, sizeof(svo_result)));
+            HIPCHECK(hipMemset(ctx->dc.fast_th_dyn + (size_t)2 * l * SVO_MAX_LEVELS, 0, (size_t)2 * SVO_MAX_LEVELS * sizeof(uint32_t)));   // a fresh estimator speculates nothing
         }
     return SVO_OK;
 }
@@ -619,8 +625,12 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         } else {                                                // ifmDescWin (stage4_match_consecutive.cpp:435-738)
             Span s(ctx, KT_TRK_FILTER); launch_track_win(d, p.ifm_win_w, p.ifm_win_h, st);
         }
-        { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, st); }
-        { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, st); }
+        // F-matrix RANSAC: the first SVO_RANSAC_CHUNK0 hypotheses of the fixed schedule, then only as many of the remaining
+        // ones as the 0.99-confidence stop of the sequential algorithm can still reach given the best of the first chunk
+        { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, 0, st); }
+        { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, 0, st); }
+        { Span s(ctx, KT_RANSAC_HYP1); launch_ransac_hyp(d, 1, st); }
+        { Span s(ctx, KT_RANSAC_CNT1); launch_ransac_count(d, 1, st); }
         { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, win, st); }
     }
     if (p.vo_use_matches_ids && (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK))) { Span s(ctx, KT_TRK_FINAL); launch_match_ids(d, flags, st); }

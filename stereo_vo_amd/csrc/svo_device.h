@@ -15,7 +15,9 @@
 #include "../../include/svo_hip.h"
 
 #define SVO_EDGE 31
-#define SVO_RANSAC_HYP 256
+#define SVO_RANSAC_HYP 1000         // hypothesis schedule of one F-matrix RANSAC (oracle: RANSAC_MAX_HYP)
+#define SVO_RANSAC_PAD 1024         // stride of the per-(lane, side) hypothesis arrays
+#define SVO_RANSAC_CHUNK0 32        // hypotheses evaluated unconditionally; the rest only as far as the 0.99-confidence stop can still reach
 #define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) that get a Harris response
 #define SVO_FT_W 64          // k_fast tile (interior pixels)
 #define SVO_FT_H 28
@@ -94,6 +96,13 @@ struct DevCtx {
     int* rtab;                // resize tables: for level l: idx_x[w], frac_x[w], idx_y[h], frac_y[h]
     uint32_t* cand_keys;
     uint32_t* cand_cnt;       // [n_img][SVO_MAX_LEVELS] counters, ONE PER 128-BYTE LINE (atomics to one L2 line serialise)
+    // speculative per-(image, level) FAST threshold (see k_select): th_dyn = what the next frame should try, th_used = what
+    // this frame's k_fast ran with, redo_flag / redo_list / redo_n = the (image, level) pairs whose speculation failed
+    uint32_t* fast_th_dyn;    // [n_img][SVO_MAX_LEVELS]   0 = no speculation (base threshold)
+    uint32_t* fast_th_used;   // [n_img][SVO_MAX_LEVELS]
+    uint32_t* redo_flag;      // [n_img][SVO_MAX_LEVELS]
+    uint32_t* redo_list;      // [n_img * SVO_MAX_LEVELS]  img * SVO_MAX_LEVELS + level
+    uint32_t* redo_n;         // [1]
     uint32_t* lvl_pos;
     float* lvl_resp;
     uint32_t* sel_keys;             // [n_img][SVO_MAX_LEVELS][SVO_SEL_MAX]  k_select's winners (FAST key), input of k_harris
@@ -120,8 +129,9 @@ struct DevCtx {
     int* trk_kq;              // [n_lanes][max_kps]  indices k that survive the joint filter (S4:145-160)
     int* trk_nk;              // [n_lanes]
     float* trk_pts;           // [n_lanes][2 sides][max_kps][4]  (x1,y1,x2,y2) for the F-matrix RANSAC
-    double* rs_F;             // [n_lanes][2][HYP][9]
-    int* rs_cnt;              // [n_lanes][2][HYP]
+    double* rs_F;             // [n_lanes][2][PAD][9]
+    int* rs_cnt;              // [n_lanes][2][PAD]
+    int* rs_bound;            // [n_lanes][2]  hypotheses the sequential stop can still reach after the first chunk
     svo_index_pair* tracked;  // [n_lanes][max_kps]
     int* n_tracked;           // [n_lanes]
     // stage 5

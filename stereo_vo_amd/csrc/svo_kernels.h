@@ -34,8 +34,8 @@ void launch_fastorb_nms(const DevCtx& c, int do_nms, int min_distance, hipStream
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st);
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st);
 void launch_track_filter(const DevCtx& c, hipStream_t st);
-void launch_ransac_hyp(const DevCtx& c, hipStream_t st);
-void launch_ransac_count(const DevCtx& c, hipStream_t st);
+void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st);
+void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st);
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st);
 void launch_match_lr_rbr(const DevCtx& c, int one_to_one, double max_y_diff, double minimum_response, int max_distance, hipStream_t st);
 void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st);

@@ -644,3 +644,33 @@ def test_sixty_four_lanes_each_match_their_own_oracle():
             ro = orcs[l].process(fr[l][0].cpu().numpy(), fr[l][1].cpu().numpy(), cam)
             assert_same_frame(ctx, l, orcs[l], res[l], ro, "t=%d lane=%d" % (t, l))
     assert sum(1 for r in res if r.valid) >= B - 2
+
+
+def test_change_in_pose_leaves_the_live_lanes_alone(golden_dir):
+    """getChangeInPose works on temporaries (common.cpp:362-400): calling it between two frames must not disturb the
+    estimator's previous / current frame; only m_last_computed_pose (the warm start, S5:506-507, 720-721) is shared --
+    exactly as in the oracle, which shares it the same way."""
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    ctx = hip.Context(n_lanes=2, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orcs = [O().Oracle(p), O().Oracle(p)]
+    cam2 = StereoCamera.simple(800.0, 639.5, 479.5, 0.12, 1280, 960)
+    t_, m_, pl, pr, cl, cr = _tracks(cam2, np.array([0.004, -0.009, 0.002, 0.02, -0.01, -0.25]), n=300, noise=0.2, n_out=10)
+    for t in range(4):
+        pair = (g["L%d" % t], g["R%d" % t]); mirrored = (g["R%d" % t][:, ::-1].copy(), g["L%d" % t][:, ::-1].copy())
+        ctx.process_host([pair, mirrored])
+        for lane, fr in ((0, pair), (1, mirrored)):
+            ro = orcs[lane].process(fr[0], fr[1], cam)
+            assert_same_frame(ctx, lane, orcs[lane], ctx.result(lane), ro, "t=%d lane=%d" % (t, lane))
+        if t in (1, 2):
+            before = [(ctx.keypoints(l, w_, s)[0].tobytes(), ctx.matches(l, w_).tobytes()) for l in (0, 1) for w_ in (0, 1) for s in (0, 1)]
+            res_before = [bytes(ctx.result(l)) for l in (0, 1)]
+            v, r, resid, outl = ctx.change_in_pose(t_, m_, m_, pl, pr, cl, cr, cam2)
+            vo, ro, resid_o, outl_o = orcs[0].change_in_pose(t_, m_, m_, pl, pr, cl, cr, cam2)
+            assert v == vo and (r.n_residual, r.n_outliers) == (ro.n_residual, ro.n_outliers) and (outl == outl_o).all()
+            assert np.abs(np.array(r.delta) - np.array(ro.delta)).max() < 1e-7
+            after = [(ctx.keypoints(l, w_, s)[0].tobytes(), ctx.matches(l, w_).tobytes()) for l in (0, 1) for w_ in (0, 1) for s in (0, 1)]
+            assert before == after
+            assert res_before == [bytes(ctx.result(l)) for l in (0, 1)]          # the live result records too
+    ctx.close()
