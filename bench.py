@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--orb-nfeats", type=int, default=2000)
     ap.add_argument("--cpu-frames", type=int, default=64, help="upper bound on the frames per probe stream replayed on the CPU oracle (baseline timing + parity probe; 0 = skip)")
+    ap.add_argument("--host-fed-steps", type=int, default=16, help="steps of the host-fed leg (page-locked host frames uploaded per step on the contexts' copy streams; 0 = skip); N=1 only")
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
@@ -259,9 +260,11 @@ def main():
         # end-to-end algorithmic traffic of the whole path (SURVEY.md 8d formula), for the DESIGN.md table
         P = sum(a * b for a, b in lv) / float(W * H)
         pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
-        cpu_baseline, pose_rmse, parity_probe = None, None, None
+        cpu_baseline, pose_rmse, parity_probe, host_fed = None, None, None, None
         if world == 1 and args.cpu_frames > 0:
             cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
+        if world == 1 and args.host_fed_steps > 0:
+            host_fed = host_fed_leg(args, batch, frames, dev)
         line = {
             "metric": "stereo pairs/sec @%d×%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -273,6 +276,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_cpu": pose_rmse,
             "parity_probe": parity_probe,
+            "host_fed": host_fed,
             "path_hbm_frac": round(pair_bytes * value / 1e9 / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_pair": int(pair_bytes),
             "valid_last_step": "%d/%d" % (n_valid, B),
@@ -285,6 +289,40 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def host_fed_leg(args, batch, frames, dev):
+    """The reference's own contract is host images per call (process_new_image_pair.cpp:100-120).  Same batch, same
+    schedule, but every step hands PAGE-LOCKED HOST frames to svo_process (SVO_FLAG_PINNED_IMAGES): each context uploads
+    on its own copy stream into a two-slot device ring, so the upload of a step overlaps the kernels of the one before.
+    PCIe-bound by construction (2 * W * H bytes per pair); never part of `value`."""
+    F, B, W, H = args.frames, batch.B, args.width, args.height
+    try:
+        host = torch.empty((F, B, 2, H, W), dtype=torch.uint8, pin_memory=True)
+    except Exception as e:                                   # not enough lockable memory on this host
+        return {"error": "pinned allocation failed: %s" % e}
+    for l in range(B):
+        for t in range(F):
+            host[t, l, 0].copy_(frames[l][t][0]); host[t, l, 1].copy_(frames[l][t][1])
+    torch.cuda.synchronize()
+    hptr = [[(host[t, l, 0].data_ptr(), host[t, l, 1].data_ptr()) for l in range(B)] for t in range(F)]
+    for c_ in batch.ctxs:
+        c_.kernel_times_select("fast")
+    batch.reset()
+    n_warm, K = 3, args.host_fed_steps
+    for i in range(n_warm):
+        batch.step(hptr[frame_schedule(i, F)], pinned_host=True)
+    batch.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        batch.step(hptr[frame_schedule(n_warm + i, F)], pinned_host=True)
+    batch.synchronize()
+    dt = time.perf_counter() - t0
+    res = batch.results()
+    rate = B * K / dt
+    return {"pairs_per_s": round(rate, 1), "ms_per_step": round(1e3 * dt / K, 3), "steps": K, "pcie_GBps": round(rate * 2 * W * H / 1e9, 2),
+            "bytes_per_pair": 2 * W * H, "valid_last_step": "%d/%d" % (sum(1 for r in res if r.valid), B),
+            "note": "page-locked host frames, one contiguous upload of %d pairs per context per step on the context's copy stream, two-slot device ring; the resident figure `value` excludes this copy" % batch.Bc}
 
 
 def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec):

@@ -46,8 +46,13 @@ enum {
                                     description of its survivors; both are left to a later call with SVO_RUN_DETECT_POST,
                                     e.g. on another stream */
     SVO_RUN_DETECT_POST = 512,   /* that post-processing alone, ahead of the other stages of the call */
-    SVO_FLAG_BGR_IMAGES = 128    /* svo_image.data are 8-bit 3-channel BGR (stride in bytes): stage 1's grey conversion runs
+    SVO_FLAG_BGR_IMAGES = 128,   /* svo_image.data are 8-bit 3-channel BGR (stride in bytes): stage 1's grey conversion runs
                                     on the device (stage1_rectify.cpp:50-51) */
+    SVO_FLAG_PINNED_IMAGES = 1024 /* svo_image.data are PAGE-LOCKED host pointers (svo_host_alloc / svo_host_register): the upload is
+                                    enqueued on the context's copy stream and svo_process returns without waiting for it; the
+                                    images must stay untouched until svo_wait_upload (or svo_wait) returns.  Without this flag host
+                                    images are copied into the context's own page-locked staging first, so they are only borrowed
+                                    for the duration of the call, as in the reference (P:111-120) */
 };
 
 typedef struct svo_ctx svo_ctx;
@@ -111,6 +116,16 @@ int svo_reset(svo_ctx* ctx, int lane);
 int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags);
 /* block until every enqueued frame has finished */
 int svo_wait(svo_ctx* ctx);
+/* Host-fed frames (the reference's contract: P:100-120 takes host images per call).  Uploads go through a ring of two
+ * device buffers on a dedicated copy stream, so the upload of frame t+1 overlaps the kernels of frame t; stage 2 of a
+ * frame waits for its own upload only.  svo_wait_upload blocks until every enqueued upload has left the host buffers.
+ * svo_host_alloc / svo_host_free hand out page-locked memory to callers that have no HIP headers; svo_host_register /
+ * svo_host_unregister page-lock memory the caller already owns (e.g. a camera driver's frame buffers). */
+int svo_wait_upload(svo_ctx* ctx);
+int svo_host_alloc(size_t bytes, void** out);
+int svo_host_free(void* p);
+int svo_host_register(void* p, size_t bytes);
+int svo_host_unregister(void* p);
 /* TStereoOdometryResult of the last frame, per lane (H:235-264); implies svo_wait */
 int svo_get_result(svo_ctx* ctx, int lane, svo_result* res);
 int svo_get_results(svo_ctx* ctx, svo_result* res /* n_lanes entries */);

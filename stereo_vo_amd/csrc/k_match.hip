@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
         np_total += tot;
         __syncthreads();
     }
-    if (tid == 0) c.trk_nk[vl] = np_total;
+    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
         const svo_keypoint e = pkr[mp.trainIdx], f = ckr[cm[tr].trainIdx];
         ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
     }
-    if (lane == 0) c.trk_nk[vl] = nk;
+    if (lane == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -501,51 +501,37 @@ __device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
 
 // one thread per hypothesis: sample 8 pairs, normalised linear 8-point solution through the null vector of the
 // 8x9 system (Gauss-Jordan, full pivoting).  The 8x9 matrix lives in LDS, one column of doubles per thread slot.
-// The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): scan the inlier counts in hypothesis
-// order; a count above the best so far (and above 7) becomes the model and shrinks the iteration budget to the smallest K
-// with (1 - w^8)^K <= 0.01, w = count / n.  Returns the budget after the first `upto` hypotheses; *best_k / *best_cnt
-// receive the model so far.  `niters` can only shrink, so the value after the first chunk bounds what is ever scanned.
-__device__ __forceinline__ int ransac_scan(const int* cnts, int upto, int n, int* best_k_out, int* best_cnt_out)
+// The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): hypotheses are visited in order; a count
+// above the best so far (and above 7) becomes the model and shrinks the iteration budget to the smallest K with
+// (1 - w^8)^K <= 0.01, w = count / n, K never above the budget before.  ransac_budget is that K for one count.
+__device__ __forceinline__ int ransac_budget(int cnt, int n, int cap)
 {
-    int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP;
-    for (int k = 0; k < niters && k < upto; k++) {
-        const int cnt = cnts[k];
-        if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
-            best_cnt = cnt; best_k = k;
-            const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
-            // the oracle's stop is the sequential product below; when even x^1024 (by squaring, with a 10 % margin for the
-            // different rounding) stays above the bound the loop cannot stop early and is skipped
-            double pbig = x; for (int sq = 0; sq < 10; sq++) pbig = pbig * pbig;
-            if (pbig <= 0.011) {
-                double acc = 1.0; int K = 0;
-                while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
-                niters = K;
-            }
-        }
-    }
-    if (best_k_out) *best_k_out = best_k;
-    if (best_cnt_out) *best_cnt_out = best_cnt;
-    return niters;
+    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
+    // the oracle's stop is the sequential product below; when even x^1024 (by squaring, with a 10 % margin for the
+    // different rounding) stays above the bound the loop cannot stop before `cap` <= 1000 and is skipped
+    double pbig = x; for (int sq = 0; sq < 10; sq++) pbig = pbig * pbig;
+    if (pbig > 0.011) return cap;
+    double acc = 1.0; int K = 0;
+    while (K < cap) { acc = acc * x; ++K; if (acc <= 0.01) break; }
+    return K;
 }
 
-// chunk 0: hypotheses [0, CHUNK0); chunk 1: [CHUNK0, bound) where bound = the iteration budget the first chunk leaves
+// Evaluating hypotheses OUT OF ORDER still bounds the sequential budget N*: hypothesis h with count c > 7 is either never
+// reached by the sequential scan (N* <= h) or, reached, leaves a budget <= K(c) whether it is a record or not (a record
+// before it had a count >= c, and K falls with the count).  So N* <= max(h, K(c)) for EVERY evaluated h, and the minimum of
+// those over whatever has been evaluated so far (rs_bound) is a safe upper limit: hypotheses at or beyond it are never read.
+#define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1))
+#define RS_CHUNK_END(ch) ((ch) == 0 ? SVO_RANSAC_CHUNK0 : ((ch) == 1 ? SVO_RANSAC_CHUNK1 : SVO_RANSAC_HYP))
+
+// chunk 0: hypotheses [0, CHUNK0) always; chunks 1, 2: only below rs_bound
 __global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c, int chunk)
 {
     __shared__ double As[72][64];     // As[r*9+col][thread]: conflict-free (consecutive threads, consecutive banks)
-    __shared__ int s_bound;
-    const int h = (chunk ? SVO_RANSAC_CHUNK0 : 0) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z, tx = threadIdx.x;
+    const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z, tx = threadIdx.x;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 8) return;
-    if (chunk) {
-        if (tx == 0) {
-            const int b = ransac_scan(c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_PAD, SVO_RANSAC_CHUNK0, n, nullptr, nullptr);
-            s_bound = b;
-            if (blockIdx.x == 0) c.rs_bound[vl * 2 + side] = b;          // for k_ransac_count(chunk 1), launched after this kernel
-        }
-        __syncthreads();
-        if (h >= s_bound) return;
-    } else if (h >= SVO_RANSAC_CHUNK0) return;
+    if (h >= RS_CHUNK_END(chunk) || (chunk && h >= c.rs_bound[vl * 2 + side])) return;
     const float* pts = c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4;
     int s[8];
     {
@@ -639,20 +625,21 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
     return e <= 1.0;
 }
 
-// inlier counts: 16 hypotheses per 256-thread block, F matrices broadcast from LDS, points streamed once per thread
+// inlier counts: 16 hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
+// a wave-uniform address (scalar loads into SGPRs: a VALU operand each, no LDS round trip per use).  The block's best
+// hypothesis then tightens rs_bound (see above), so that later blocks of the launch and the next chunk stop earlier.
 #define RC_HB 16
 __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 {
-    __shared__ double Fs[RC_HB][9];
     __shared__ int cnt_s[RC_HB];
-    const int side = blockIdx.y, vl = blockIdx.z, h0 = (chunk ? SVO_RANSAC_CHUNK0 : 0) + blockIdx.x * RC_HB, tid = threadIdx.x;
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 8) return;
-    if (chunk && h0 >= c.rs_bound[vl * 2 + side]) return;               // hypotheses the sequential stop never reaches
+    int* bound = c.rs_bound + vl * 2 + side;
+    if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 9;
-    if (tid < RC_HB * 9) Fs[tid / 9][tid % 9] = F[tid];
     if (tid < RC_HB) cnt_s[tid] = 0;
     __syncthreads();
     int cnt[RC_HB];
@@ -661,12 +648,21 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
     for (int i = tid; i < n; i += blockDim.x) {
         const float4 p = pts[i];
 #pragma unroll
-        for (int h = 0; h < RC_HB; h++) cnt[h] += fm_inlier(Fs[h], p.x, p.y, p.z, p.w);
+        for (int h = 0; h < RC_HB; h++) cnt[h] += fm_inlier(F + 9 * h, p.x, p.y, p.z, p.w);
     }
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) { const int v = wave_sum_uniform(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
     __syncthreads();
     if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0 + tid] = cnt_s[tid];
+    if (tid == 0) {
+        int best = 0, best_h = 0;
+        for (int h = 0; h < RC_HB; h++) if (cnt_s[h] > best && h0 + h < SVO_RANSAC_HYP) { best = cnt_s[h]; best_h = h0 + h; }
+        const int cur = *(volatile int*)bound;
+        if (best > 7 && best_h < cur) {
+            const int K = ransac_budget(best, n, cur);
+            if (max(best_h, K) < cur) atomicMin(bound, max(best_h, K));
+        }
+    }
 }
 
 // pick the model a sequential RANSAC with the 0.99-confidence stop would have returned, apply both masks
@@ -684,22 +680,60 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
     LaneState& ls = c.lane[lane_id];
     if (!ls.has_prev) { if (tid == 0) c.n_tracked[vl] = 0; return; }
     const int n = c.trk_nk[vl];
-    __shared__ int cnt_lds[2 * SVO_RANSAC_PAD];
-    // the hypothesis scan below is serial and data dependent: stage the counts in LDS so that every step is an LDS
-    // read instead of a dependent global load (only the first rs_bound counts of a side exist; the scan never goes further)
-    for (int i = tid; i < 2 * SVO_RANSAC_PAD; i += blockDim.x) {
-        const int side = i / SVO_RANSAC_PAD, k = i - side * SVO_RANSAC_PAD;
-        const int lim = n >= 8 ? max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0) : 0;
-        cnt_lds[i] = k < lim ? c.rs_cnt[(long long)vl * 2 * SVO_RANSAC_PAD + i] : 0;
+    // The sequential scan (records in hypothesis order, each shrinking the budget) without its serial cost: the counts
+    // below rs_bound are all there; a hypothesis is a RECORD when its count exceeds every earlier one (and 7); only records
+    // can change the model or the budget.  Waves 0-1 / 2-3 take the two sides: strict prefix maxima by a wave scan over
+    // chunks of 128, the records' budgets K(count) computed in parallel (each is a chain of up to 1000 multiplications), then
+    // one thread walks the handful of records in order.
+    __shared__ int rec_k[2][64], rec_c[2][64], rec_K[2][64], rec_n[2];
+    {
+        const int side = tid >> 7, t = tid & 127, wv = (tid >> 6) & 1, ln = tid & 63;
+        __shared__ int run_max[2], wave_max[2][2];
+        if (tid < 2) { rec_n[tid] = 0; run_max[tid] = 7; }
+        __syncthreads();
+        const int lim = n >= 8 ? min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP) : 0;
+        const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_PAD;
+        for (int base = 0; base < SVO_RANSAC_PAD; base += 128) {            // uniform trip count: barriers inside
+            const int k = base + t;
+            const int v = k < lim ? gc[k] : 0;
+            // inclusive prefix max inside the wave, then across the side's two waves
+            int m = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(m, o, 64); if (ln >= o) m = max(m, u); }
+            if (ln == 63) wave_max[side][wv] = m;
+            __syncthreads();
+            const int before_wave = wv ? max(run_max[side], wave_max[side][0]) : run_max[side];
+            int prev = __shfl_up(m, 1, 64); if (ln == 0) prev = 0;
+            const int excl = max(before_wave, prev);                         // max of everything before k (and 7)
+            if (v > excl) { const int slot = atomicAdd(&rec_n[side], 1); if (slot < 64) { rec_k[side][slot] = k; rec_c[side][slot] = v; } }
+            __syncthreads();
+            if (t == 0) run_max[side] = max(run_max[side], max(wave_max[side][0], wave_max[side][1]));
+            __syncthreads();
+        }
+        // records are few (each at least one more inlier than the last; in practice ~ln(lim)); sort the <= 64 by index
+        const int nr = min(rec_n[side], 64);
+        if (t < nr) rec_K[side][t] = ransac_budget(rec_c[side][t], n, SVO_RANSAC_HYP);
+        __syncthreads();
+        if (t == 0 && rec_n[side] > 64) {                                   // more records than slots (a count creeping up one by one): the plain scan
+            int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP;
+            for (int k = 0; k < niters && k < lim; k++) {
+                const int cnt = gc[k];
+                if (cnt > (best_cnt > 7 ? best_cnt : 7)) { best_cnt = cnt; best_k = k; niters = ransac_budget(cnt, n, niters); }
+            }
+            s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
+        } else if (t == 0) {
+            int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1;
+            for (int r = 0; r < nr; r++) {                                   // next record in index order = smallest index above `last`
+                int sel = -1, selk = 0x7FFFFFFF;
+                for (int q = 0; q < nr; q++) if (rec_k[side][q] > last && rec_k[side][q] < selk) { selk = rec_k[side][q]; sel = q; }
+                if (sel < 0 || selk >= niters) break;
+                last = selk; best_k = selk; best_cnt = rec_c[side][sel];
+                niters = min(niters, rec_K[side][sel]);
+            }
+            s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0 || tid == 64) {
-        const int side = tid >> 6;
-        int best_k = -1, best_cnt = 0;
-        if (n >= 8) ransac_scan(cnt_lds + side * SVO_RANSAC_PAD, SVO_RANSAC_HYP, n, &best_k, &best_cnt);
-        s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
-    }
-    __syncthreads();
     const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
     const bool use_f = goodFL && goodFR;                             // S4:243
     if (use_f) {
@@ -865,12 +899,12 @@ void launch_track_filter(const DevCtx& c, hipStream_t st)
 }
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
-    const int nh = chunk ? SVO_RANSAC_HYP - SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK0;
+    const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
     hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
 }
 void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {
-    const int nh = chunk ? SVO_RANSAC_HYP - SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK0;
+    const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
     hipLaunchKernelGGL(k_ransac_count, dim3((nh + RC_HB - 1) / RC_HB, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)

@@ -15,10 +15,10 @@
 #define HIPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); return SVO_ERR_HIP; } } while (0)
 
 enum { KT_BEGIN, KT_RESIZE, KT_FAST, KT_SELECT, KT_DESCRIBE, KT_NMS, KT_HAM_LR, KT_LR_FILTER, KT_HAM_TRK, KT_TRK_FILTER,
-       KT_RANSAC_HYP, KT_RANSAC_CNT, KT_TRK_FINAL, KT_GN, KT_RANSAC_HYP1, KT_RANSAC_CNT1, KT_COUNT };
+       KT_RANSAC_HYP, KT_RANSAC_CNT, KT_TRK_FINAL, KT_GN, KT_RANSAC_HYP1, KT_RANSAC_CNT1, KT_RANSAC_HYP2, KT_RANSAC_CNT2, KT_COUNT };
 static const char* kt_names[KT_COUNT] = { "begin_frame", "resize", "fast", "select", "describe", "nms_rowsort", "hamming_lr",
     "match_lr_filter", "hamming_track", "track_filter", "ransac_hyp", "ransac_count", "track_finalize", "gauss_newton",
-    "ransac_hyp_rest", "ransac_count_rest" };
+    "ransac_hyp_1", "ransac_count_1", "ransac_hyp_2", "ransac_count_2" };
 
 struct TimedSpan { int id; hipEvent_t a, b; };
 
@@ -31,6 +31,10 @@ struct svo_ctx {
     bool geom_ready; int geom_w, geom_h, geom_nfe, geom_nlevels, geom_method, geom_noct;
     int raw_cap_alloc;
     uint8_t* d_img0; int img0_pitch_internal;
+    // host-fed frames (process_new_image_pair.cpp:100-120 hands over host images): a ring of two device level-0 buffers
+    // filled by a dedicated copy stream, so that the upload of frame t+1 overlaps the kernels of frame t
+    uint8_t* d_img0_ring[2]; uint8_t* h_stage[2]; size_t slot_bytes;
+    hipStream_t s_copy; hipEvent_t ev_h2d[2], ev_det[2]; bool ev_det_valid[2], ev_h2d_valid[2], up_ready; int up_slot, det_slot;
     long long pyr_bytes_alloc; int cand_total_alloc, rtab_alloc;
     std::vector<void*> allocs;
     std::string last_error;
@@ -59,6 +63,7 @@ static hipError_t sync_all(svo_ctx* ctx)
 {
     hipError_t first = hipSuccess;
     for (hipStream_t s : ctx->used_streams) { if (s == ctx->stream) continue; const hipError_t e = hipStreamSynchronize(s); if (first == hipSuccess) first = e; }
+    if (ctx->up_ready) { const hipError_t e2 = hipStreamSynchronize(ctx->s_copy); if (first == hipSuccess) first = e2; }
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (first == hipSuccess) first = e;
     ctx->used_streams.clear();
@@ -159,6 +164,8 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
     ctx->cip_ready = false;
+    ctx->up_ready = false; ctx->up_slot = 0; ctx->det_slot = -1; ctx->s_copy = nullptr; ctx->slot_bytes = 0;
+    for (int i = 0; i < 2; i++) { ctx->d_img0_ring[i] = nullptr; ctx->h_stage[i] = nullptr; ctx->ev_det_valid[i] = ctx->ev_h2d_valid[i] = false; }
     for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
     ctx->kt_mask = 0xFFFFFFFFu;
     *out = ctx;                                           // so that the caller can read last_error and destroy
@@ -238,6 +245,11 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
     if (ctx->d_ham_q) hipFree(ctx->d_ham_q);
     if (ctx->d_ham_t) hipFree(ctx->d_ham_t);
+    if (ctx->up_ready) {
+        hipStreamSynchronize(ctx->s_copy);
+        for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_h2d[i]); hipEventDestroy(ctx->ev_det[i]); if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]); }
+        hipStreamDestroy(ctx->s_copy);
+    }
     for (auto& s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream0);
@@ -504,6 +516,82 @@ static int hamming_splits(const svo_ctx* ctx)
     int s = 2048 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 8 ? 8 : s);     // train splits: enough workgroups to fill the GPU, few enough to amortise the query expansion
 }
 
+// ---- host-fed frames ------------------------------------------------------------------------------------------
+static int ensure_upload(svo_ctx* ctx)
+{
+    if (ctx->up_ready) return SVO_OK;
+    HIPCHECK(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { HIPCHECK(hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&ctx->ev_det[i], hipEventDisableTiming)); }
+    ctx->slot_bytes = (size_t)2 * ctx->cfg.n_lanes * ctx->img0_pitch_internal * ctx->cfg.max_h;
+    ctx->d_img0_ring[0] = ctx->d_img0;
+    HIPCHECK(dev_alloc(ctx, &ctx->d_img0_ring[1], ctx->slot_bytes));
+    ctx->up_ready = true;
+    return SVO_OK;
+}
+
+// Enqueue the upload of one frame of every lane (8-bit grey, host memory) into the next slot of the device ring, on the
+// copy stream; the compute stream `st` is made to wait for it.  No host synchronisation when the images are
+// page-locked (SVO_FLAG_PINNED_IMAGES): the call returns while the copy is in flight and the caller keeps the images
+// valid until svo_wait_upload / svo_wait.  Pageable images are first copied into the context's own page-locked
+// staging slot (that is the cost of "borrowed for the duration of the call", P:111-120), then uploaded the same way.
+static int upload_frames(svo_ctx* ctx, const svo_frame* frames, int w, int h, bool pinned, hipStream_t st, const uint8_t** ptrs)
+{
+    int rc = ensure_upload(ctx); if (rc) return rc;
+    const int L = ctx->cfg.n_lanes, ipitch = ctx->img0_pitch_internal, slot = ctx->up_slot;
+    const size_t img_bytes = (size_t)ipitch * ctx->cfg.max_h;
+    uint8_t* dbase = ctx->d_img0_ring[slot];
+    // the slot's previous frame must be through stage 2 (the only stage that reads level 0) before it is overwritten
+    if (ctx->ev_det_valid[slot]) HIPCHECK(hipStreamWaitEvent(ctx->s_copy, ctx->ev_det[slot], 0));
+    const uint8_t* src0 = frames[0].left.data;
+    bool contiguous = (w == ipitch) && (h == ctx->cfg.max_h);
+    for (int l = 0; l < L && contiguous; l++)
+        for (int sd = 0; sd < 2; sd++) {
+            const svo_image& im = sd ? frames[l].right : frames[l].left;
+            if (im.stride != (int64_t)w || im.data != src0 + (size_t)(2 * l + sd) * img_bytes) contiguous = false;
+        }
+    if (pinned) {
+        if (contiguous) HIPCHECK(hipMemcpyAsync(dbase, src0, img_bytes * 2 * L, hipMemcpyHostToDevice, ctx->s_copy));       // [lane][side][h][w] in one piece
+        else for (int l = 0; l < L; l++)
+            for (int sd = 0; sd < 2; sd++) {
+                const svo_image& im = sd ? frames[l].right : frames[l].left;
+                HIPCHECK(hipMemcpy2DAsync(dbase + (size_t)(2 * l + sd) * img_bytes, ipitch, im.data, (size_t)im.stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->s_copy));
+            }
+    } else {
+        if (!ctx->h_stage[slot]) HIPCHECK(hipHostMalloc((void**)&ctx->h_stage[slot], ctx->slot_bytes, hipHostMallocDefault));
+        if (ctx->ev_h2d_valid[slot]) HIPCHECK(hipEventSynchronize(ctx->ev_h2d[slot]));          // the staging slot's last upload has left it
+        for (int l = 0; l < L; l++)
+            for (int sd = 0; sd < 2; sd++) {
+                const svo_image& im = sd ? frames[l].right : frames[l].left;
+                uint8_t* hs = ctx->h_stage[slot] + (size_t)(2 * l + sd) * img_bytes;
+                if (im.stride == (int64_t)ipitch && w == ipitch) memcpy(hs, im.data, (size_t)ipitch * h);
+                else for (int y = 0; y < h; y++) memcpy(hs + (size_t)y * ipitch, im.data + (size_t)y * im.stride, (size_t)w);
+            }
+        if (h == ctx->cfg.max_h) HIPCHECK(hipMemcpyAsync(dbase, ctx->h_stage[slot], img_bytes * 2 * L, hipMemcpyHostToDevice, ctx->s_copy));
+        else for (int i = 0; i < 2 * L; i++) HIPCHECK(hipMemcpyAsync(dbase + (size_t)i * img_bytes, ctx->h_stage[slot] + (size_t)i * img_bytes, (size_t)ipitch * h, hipMemcpyHostToDevice, ctx->s_copy));
+    }
+    HIPCHECK(hipEventRecord(ctx->ev_h2d[slot], ctx->s_copy)); ctx->ev_h2d_valid[slot] = true;
+    HIPCHECK(hipStreamWaitEvent(st, ctx->ev_h2d[slot], 0));
+    for (int i = 0; i < 2 * L; i++) ptrs[i] = dbase + (size_t)i * img_bytes;
+    ctx->det_slot = slot; ctx->up_slot = slot ^ 1;
+    return SVO_OK;
+}
+
+extern "C" int svo_wait_upload(svo_ctx* ctx)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    if (ctx->up_ready) HIPCHECK(hipStreamSynchronize(ctx->s_copy));
+    return SVO_OK;
+}
+extern "C" int svo_host_alloc(size_t bytes, void** out)
+{
+    if (!out || !bytes) return SVO_ERR_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? SVO_OK : SVO_ERR_HIP;
+}
+extern "C" int svo_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? SVO_OK : SVO_ERR_HIP; }
+extern "C" int svo_host_register(void* p, size_t bytes) { return (p && bytes && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) ? SVO_OK : SVO_ERR_HIP; }
+extern "C" int svo_host_unregister(void* p) { return (p && hipHostUnregister(p) == hipSuccess) ? SVO_OK : SVO_ERR_HIP; }
+
 // ---- processNewImagePair ---------------------------------------------------------------------------------
 extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags)
 {
@@ -543,13 +631,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             d.img0_pitch = (int)stride;
             if (prepare) { for (int i = 0; i < 2 * d.n_lanes; i++) prep.src[i] = ptrs[i]; prep.src_stride = stride; }
         } else if (!prepare) {
-            for (int l = 0; l < d.n_lanes; l++)
-                for (int s = 0; s < 2; s++) {
-                    const svo_image& im = s ? frames[l].right : frames[l].left;
-                    uint8_t* dst = ctx->d_img0 + (size_t)(2 * l + s) * ipitch * ctx->cfg.max_h;
-                    HIPCHECK(hipMemcpy2DAsync(dst, ipitch, im.data, (size_t)im.stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, st));
-                    ptrs[2 * l + s] = dst;
-                }
+            rc = upload_frames(ctx, frames, w, h, (flags & SVO_FLAG_PINNED_IMAGES) != 0, st, ptrs); if (rc) return rc;
             d.img0_pitch = ipitch;
         } else {
             if (!ctx->d_src) { ctx->src_pitch = align_up(3 * ctx->cfg.max_w, 64); HIPCHECK(dev_alloc(ctx, &ctx->d_src, (size_t)2 * ctx->cfg.n_lanes * ctx->src_pitch * ctx->cfg.max_h)); }
@@ -625,12 +707,14 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         } else {                                                // ifmDescWin (stage4_match_consecutive.cpp:435-738)
             Span s(ctx, KT_TRK_FILTER); launch_track_win(d, p.ifm_win_w, p.ifm_win_h, st);
         }
-        // F-matrix RANSAC: the first SVO_RANSAC_CHUNK0 hypotheses of the fixed schedule, then only as many of the remaining
-        // ones as the 0.99-confidence stop of the sequential algorithm can still reach given the best of the first chunk
+        // F-matrix RANSAC: the first SVO_RANSAC_CHUNK0 hypotheses of the fixed schedule, then two more chunks, each only
+        // as far as the 0.99-confidence stop of the sequential algorithm can still reach given what has been counted so far
         { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, 0, st); }
         { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, 0, st); }
         { Span s(ctx, KT_RANSAC_HYP1); launch_ransac_hyp(d, 1, st); }
         { Span s(ctx, KT_RANSAC_CNT1); launch_ransac_count(d, 1, st); }
+        { Span s(ctx, KT_RANSAC_HYP2); launch_ransac_hyp(d, 2, st); }
+        { Span s(ctx, KT_RANSAC_CNT2); launch_ransac_count(d, 2, st); }
         { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, win, st); }
     }
     if (p.vo_use_matches_ids && (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK))) { Span s(ctx, KT_TRK_FINAL); launch_match_ids(d, flags, st); }
@@ -642,6 +726,10 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         g.kernel_param = p.kernel_param; g.min_mod_out_vector = p.min_mod_out_vector; g.residual_threshold = p.residual_threshold;
         if (p.use_custom_initial_pose) g.use_custom_initial_pose = 1;        // deltaPose = initial_estimation = zeros (S5:504-505, default argument H:1045)
         { Span s(ctx, KT_GN); launch_gauss_newton(d, g, st); }
+    }
+    // stage 2 is the only reader of the level-0 images: once it is through, the ring slot may take the next upload
+    if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) {
+        HIPCHECK(hipEventRecord(ctx->ev_det[ctx->det_slot], st)); ctx->ev_det_valid[ctx->det_slot] = true;
     }
     HIPCHECK(hipGetLastError());
     return SVO_OK;

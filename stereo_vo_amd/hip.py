@@ -15,7 +15,7 @@ _LIB = None
 
 MAX_LANES = 64
 RUN_DETECT, RUN_MATCH, RUN_TRACK, RUN_OPTIMIZE, RUN_ALL = 1, 2, 4, 8, 15
-FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES, FLAG_DETECT_NO_POST, RUN_DETECT_POST = 16, 32, 64, 128, 256, 512
+FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES, FLAG_DETECT_NO_POST, RUN_DETECT_POST, FLAG_PINNED_IMAGES = 16, 32, 64, 128, 256, 512, 1024
 
 # every entry point include/svo_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
@@ -27,6 +27,7 @@ EXPORTS = [
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
+    "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
 ]
 
 
@@ -171,6 +172,19 @@ class Context:
             fr[i].left = Image(l, w, h, stride)
             fr[i].right = Image(r, w, h, stride)
         self._ck(self.L.svo_process(self.h, fr, C.c_uint32(flags | FLAG_DEVICE_IMAGES)), "svo_process")
+
+    def process_pinned(self, ptr_pairs, w, h, stride, flags=RUN_ALL):
+        """ptr_pairs: (left_ptr, right_ptr) PAGE-LOCKED host addresses per lane (torch pin_memory() tensors, svo_host_alloc):
+        the upload is enqueued on the context's copy stream; the buffers must stay untouched until wait_upload()."""
+        assert len(ptr_pairs) == self.n_lanes
+        fr = (Frame * self.n_lanes)()
+        for i, (l, r) in enumerate(ptr_pairs):
+            fr[i].left = Image(l, w, h, stride)
+            fr[i].right = Image(r, w, h, stride)
+        self._ck(self.L.svo_process(self.h, fr, C.c_uint32((flags | FLAG_PINNED_IMAGES) & ~FLAG_DEVICE_IMAGES)), "svo_process")
+
+    def wait_upload(self):
+        self._ck(self.L.svo_wait_upload(self.h), "svo_wait_upload")
 
     def set_stream(self, stream):
         """Later process / copy calls enqueue on this raw HIP stream (None: the stream the context was created with)."""

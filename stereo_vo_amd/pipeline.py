@@ -47,20 +47,22 @@ class StreamBatch:
         self.first = True
         self.REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE | (hip.RUN_DETECT_POST if post_on_rest else 0)
 
-    def step(self, ptrs, stride=None):
-        """Enqueue one frame of every lane.  ptrs[lane] = (left, right) device addresses of 8-bit grey images of the
-        batch's size, lane = context * lanes_per_context + lane_in_context.  Returns at once; the result records land
-        in self.rec (device) in lane order."""
+    def step(self, ptrs, stride=None, pinned_host=False):
+        """Enqueue one frame of every lane.  ptrs[lane] = (left, right) addresses of 8-bit grey images of the batch's
+        size -- device memory, or page-locked host memory with pinned_host=True (the upload then runs on each context's
+        copy stream and overlaps the kernels of the frames before it) -- lane = context * lanes_per_context +
+        lane_in_context.  Returns at once; the result records land in self.rec (device) in lane order."""
         assert len(ptrs) == self.B
         stride = self.W if stride is None else stride
         Bc, rsz = self.Bc, C.sizeof(Result)
         for k, c in enumerate(self.ctxs):
             pk = ptrs[k * Bc:(k + 1) * Bc]
+            proc = c.process_pinned if pinned_host else c.process_device
             if self.pipelined:
                 if not self.first:
                     self.s_det.wait_event(self.rest_done[k])
                 c.set_stream(self.s_det.cuda_stream)
-                c.process_device(pk, self.W, self.H, stride, hip.RUN_DETECT | (hip.FLAG_DETECT_NO_POST if self.post_on_rest else 0))
+                proc(pk, self.W, self.H, stride, hip.RUN_DETECT | (hip.FLAG_DETECT_NO_POST if self.post_on_rest else 0))
                 self.det_done[k].record(self.s_det)
                 self.s_rest.wait_event(self.det_done[k])
                 c.set_stream(self.s_rest.cuda_stream)
@@ -68,7 +70,7 @@ class StreamBatch:
                 c.copy_results_async(self.rec[k * Bc:(k + 1) * Bc].data_ptr(), Bc * rsz)
                 self.rest_done[k].record(self.s_rest)
             else:
-                c.process_device(pk, self.W, self.H, stride)
+                proc(pk, self.W, self.H, stride)
                 c.copy_results_async(self.rec[k * Bc:(k + 1) * Bc].data_ptr(), Bc * rsz)
                 self.done[k].record(self.streams[k])
         self.first = False

@@ -112,3 +112,48 @@ def test_bench_two_ranks_on_one_gpu_gather_real_records(tmp_path):
     recs = [Result.from_buffer_copy(r0["gathered"][i].tobytes()) for i in range(16)]
     assert sum(r.valid for r in recs) >= 14
     assert list(recs[0].outPose) != list(recs[8].outPose)
+
+
+def test_host_fed_path_64_lanes_matches_oracle():
+    """Frames handed over as HOST images (the reference's own contract, P:100-120) at the batched shape: page-locked
+    contiguous frames (one upload per step), page-locked non-contiguous frames (per-image 2-D uploads) and pageable
+    frames (staged through the context's pinned slot) all give the oracle's lists; five steps enqueued back to back
+    without waiting walk the two-slot device ring more than twice."""
+    import torch
+    from oracle import probe as PR
+    from stereo_vo_amd.pipeline import StreamBatch
+    import bench
+    W, H, B, F = 640, 480, 64, 3
+    dev = torch.device("cuda", 0)
+    worlds = [SyntheticStereoWorld(W, H, 400.0, 0.12, seed=300 + s, n_frames=F, device=dev, scene_seed=s % 4) for s in range(B)]
+    cam = worlds[0].camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=500)
+    host = torch.empty((F, B, 2, H, W), dtype=torch.uint8, pin_memory=True)
+    padded = torch.empty((F, B, 2, H, W + 64), dtype=torch.uint8, pin_memory=True)          # row stride != width: 2-D copies
+    for l, w in enumerate(worlds):
+        for t in range(F):
+            a, b = w.render(t)
+            host[t, l, 0].copy_(a); host[t, l, 1].copy_(b)
+    torch.cuda.synchronize()
+    padded[..., :W] = host
+    order = [bench.frame_schedule(i, F) for i in range(5)]
+    probe = [0, 21, 42, 63]
+    ref, _ = PR.replay_many(p, cam, {g: [(host[t, g, 0].numpy(), host[t, g, 1].numpy()) for t in range(F)] for g in probe}, order, threads=4)
+    for mode in ("pinned", "pinned-2d", "pageable"):
+        batch = StreamBatch(p, cam, W, H, B, 1, max_kps=1024, max_cand=1 << 15)
+        ctx = batch.ctxs[0]
+        for i, t in enumerate(order):
+            if mode == "pinned":
+                batch.step([(host[t, l, 0].data_ptr(), host[t, l, 1].data_ptr()) for l in range(B)], pinned_host=True)
+            elif mode == "pinned-2d":
+                batch.step([(padded[t, l, 0].data_ptr(), padded[t, l, 1].data_ptr()) for l in range(B)], stride=W + 64, pinned_host=True)
+            else:
+                ctx.process_host([(host[t, l, 0].numpy(), host[t, l, 1].numpy()) for l in range(B)])
+            if i in (1, 4):                       # steps 0-1 and 2-4 run back to back; check after each burst
+                batch.synchronize()
+                res = ctx.results()
+                for g in probe:
+                    lists, flags, et, er = PR.compare(PR.digest_of(ctx, g, res[g]), ref[g][i])
+                    assert lists and flags and et < 1e-3 and er < 1e-4, (mode, i, g)
+        ctx.wait_upload()
+        batch.close()

@@ -674,3 +674,34 @@ def test_change_in_pose_leaves_the_live_lanes_alone(golden_dir):
             assert before == after
             assert res_before == [bytes(ctx.result(l)) for l in (0, 1)]          # the live result records too
     ctx.close()
+
+
+def test_speculative_fast_threshold_and_its_fallback_match_oracle(golden_dir):
+    """k_select carries a per-(image, level) FAST threshold from frame to frame and k_fast_redo starts a level over at
+    the caller's threshold when the speculation found too few corners.  A sequence whose corner count collapses and
+    recovers (textured -> low contrast -> textured -> blank -> textured ...) drives both paths; every list must equal
+    the oracle's, which knows no speculation."""
+    import torch
+    W, H = 640, 480
+    w = SyntheticStereoWorld(W, H, 400.0, 0.12, seed=21, n_frames=6)
+    cam = w.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=500)
+    ctx = hip.Context(n_lanes=2, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 16)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orcs = [O().Oracle(p), O().Oracle(p)]
+    def low(img, k):      # contrast / k around mid-grey: most corners fall below the FAST threshold
+        return (128.0 + (img.astype(np.float32) - 128.0) / k).round().clip(0, 255).astype(np.uint8)
+    n_redo_like = 0
+    for t, k in enumerate([1, 1, 4, 1, 1.5, 0, 1, 2.5, 1, 1]):
+        L, R = [x.numpy() for x in w.render(t % 6)]
+        if k == 0: L, R = np.full_like(L, 128), np.full_like(R, 128)
+        elif k != 1: L, R = low(L, k), low(R, k)
+        other = (R[:, ::-1].copy(), L[:, ::-1].copy()) if t % 3 else (L, R)        # lane 1 sees a different stream
+        ctx.process_host([(L, R), other])
+        for lane, fr in ((0, (L, R)), (1, other)):
+            ro = orcs[lane].process(fr[0], fr[1], cam)
+            assert_same_frame(ctx, lane, orcs[lane], ctx.result(lane), ro, "t=%d lane=%d k=%s" % (t, lane, k))
+            assert ctx.status_word(lane) == 0
+        n_redo_like += int(k not in (1,))
+    assert n_redo_like >= 4
+    ctx.close()
