@@ -799,6 +799,43 @@ static int fm_inlier(const double* F, float fx1, float fy1, float fx2, float fy2
     return e <= 1.0;   /* threshold 1.0 px, squared */
 }
 
+/* natural logarithm from IEEE +, -, *, / only, one operation per operator (the HIP kernels repeat it verbatim, so
+ * both sides get the same bits; libm's and the device library's log may differ in the last place).  x normal, > 0.
+ * ln x = e ln 2 + 2 atanh(s), s = (m - 1) / (m + 1), m in [sqrt(1/2), sqrt(2)]: |s| <= 0.1716, series to s^17. */
+static double svo_ln(double x)
+{
+    union { double d; uint64_t u; } v; v.d = x;
+    int e = (int)((v.u >> 52) & 0x7FF) - 1023;
+    v.u = (v.u & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+    double p = 0.058823529411764705;                 /* 1/17 */
+    p = p * s2 + 0.066666666666666666;               /* 1/15 */
+    p = p * s2 + 0.076923076923076927;               /* 1/13 */
+    p = p * s2 + 0.090909090909090912;               /* 1/11 */
+    p = p * s2 + 0.1111111111111111;                 /* 1/9 */
+    p = p * s2 + 0.14285714285714285;                /* 1/7 */
+    p = p * s2 + 0.2;
+    p = p * s2 + 0.33333333333333331;
+    p = p * s2 + 1.0;
+    return (double)e * 0.69314718055994529 + 2.0 * (s * p);
+}
+
+/* cv::RANSACUpdateNumIters(p = 0.99, ep = 1 - cnt / n, modelPoints = 8, maxIters) as OpenCV's ptsetreg.cpp writes it
+ * [frozen; recalled, the source is not in /root/reference]: 0 when every point is an inlier, maxIters when the
+ * estimate is no smaller, else cvRound(log(1 - p) / log(1 - (1 - ep)^modelPoints)). */
+static int ransac_update_niters(int cnt, int n, int max_iters)
+{
+    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
+    const double denom = 1.0 - w8;
+    if (denom < 2.2250738585072014e-308) return 0;
+    const double num = -4.6051701859880909;          /* log(1 - 0.99) */
+    const double d = svo_ln(denom);
+    if (d >= 0.0 || -num >= (double)max_iters * (-d)) return max_iters;
+    return (int)rint(num / d);
+}
+
 int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9, int* best_hyp, int* n_hyp_used)
 {
     for (int i = 0; i < n; i++) mask[i] = 0;
@@ -816,11 +853,7 @@ int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8
         for (int i = 0; i < n; i++) cnt += fm_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
         if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
             best_cnt = cnt; best_k = k; memcpy(Fbest, F, sizeof(F));
-            /* confidence 0.99: smallest K with (1 - w^8)^K <= 0.01, by repeated multiplication (no log) */
-            const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
-            double acc = 1.0; int K = 0;
-            while (K < niters) { acc = acc * x; ++K; if (acc <= 0.01) break; }
-            niters = K;
+            niters = ransac_update_niters(cnt, n, niters);      /* confidence 0.99 */
         }
     }
     if (n_hyp_used) *n_hyp_used = k;

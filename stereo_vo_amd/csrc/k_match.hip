@@ -502,104 +502,191 @@ __device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
 // one thread per hypothesis: sample 8 pairs, normalised linear 8-point solution through the null vector of the
 // 8x9 system (Gauss-Jordan, full pivoting).  The 8x9 matrix lives in LDS, one column of doubles per thread slot.
 // The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): hypotheses are visited in order; a count
-// above the best so far (and above 7) becomes the model and shrinks the iteration budget to the smallest K with
-// (1 - w^8)^K <= 0.01, w = count / n, K never above the budget before.  ransac_budget is that K for one count.
-__device__ __forceinline__ int ransac_budget(int cnt, int n, int cap)
+// above the best so far (and above 7) becomes the model and shrinks the iteration budget to
+// cv::RANSACUpdateNumIters(0.99, 1 - count / n, 8, budget).  svo_ln / ransac_niters repeat the oracle's functions operation
+// by operation (+, -, *, / only, no contraction), so both sides round alike.
+__device__ __forceinline__ double svo_ln(double x)
 {
-    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4, x = 1.0 - w8;
-    // the oracle's stop is the sequential product below; when even x^1024 (by squaring, with a 10 % margin for the
-    // different rounding) stays above the bound the loop cannot stop before `cap` <= 1000 and is skipped
-    double pbig = x; for (int sq = 0; sq < 10; sq++) pbig = pbig * pbig;
-    if (pbig > 0.011) return cap;
-    double acc = 1.0; int K = 0;
-    while (K < cap) { acc = acc * x; ++K; if (acc <= 0.01) break; }
-    return K;
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFULL) | 0x3FF0000000000000ULL;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+    double p = 0.058823529411764705;
+    p = p * s2 + 0.066666666666666666;
+    p = p * s2 + 0.076923076923076927;
+    p = p * s2 + 0.090909090909090912;
+    p = p * s2 + 0.1111111111111111;
+    p = p * s2 + 0.14285714285714285;
+    p = p * s2 + 0.2;
+    p = p * s2 + 0.33333333333333331;
+    p = p * s2 + 1.0;
+    return (double)e * 0.69314718055994529 + 2.0 * (s * p);
+}
+__device__ __forceinline__ int ransac_niters(int cnt, int n, int max_iters)
+{
+    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
+    const double denom = 1.0 - w8;
+    if (denom < 2.2250738585072014e-308) return 0;
+    const double num = -4.6051701859880909;
+    const double d = svo_ln(denom);
+    if (d >= 0.0 || -num >= (double)max_iters * (-d)) return max_iters;
+    return (int)rint(num / d);
 }
 
 // Evaluating hypotheses OUT OF ORDER still bounds the sequential budget N*: hypothesis h with count c > 7 is either never
 // reached by the sequential scan (N* <= h) or, reached, leaves a budget <= K(c) whether it is a record or not (a record
 // before it had a count >= c, and K falls with the count).  So N* <= max(h, K(c)) for EVERY evaluated h, and the minimum of
 // those over whatever has been evaluated so far (rs_bound) is a safe upper limit: hypotheses at or beyond it are never read.
+// (The tightening uses K(c - 1): one inlier less moves num / d by far more than svo_ln's rounding error, so the
+// "K falls with the count" step holds for the computed values too, not only in exact arithmetic.)
 #define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1))
 #define RS_CHUNK_END(ch) ((ch) == 0 ? SVO_RANSAC_CHUNK0 : ((ch) == 1 ? SVO_RANSAC_CHUNK1 : SVO_RANSAC_HYP))
 
-// chunk 0: hypotheses [0, CHUNK0) always; chunks 1, 2: only below rs_bound
-__global__ void __launch_bounds__(64) k_ransac_hyp(DevCtx c, int chunk)
+// chunk 0: hypotheses [0, CHUNK0) always; chunks 1, 2: only below rs_bound.
+//
+// One hypothesis = 16 lanes (a DPP row), four hypotheses per wave, sixteen per 256-thread block.  Lane c < 9 of a group holds
+// COLUMN c of the 8x9 system in registers; the oracle's Gauss-Jordan with full pivoting (eight_point) then runs without any
+// memory traffic: the pivot search is a per-lane scan plus a 16-lane all-reduce on the DPP network, rows are swapped in
+// registers, columns are swapped VIRTUALLY (vcol = a lane's current column position; the data never moves), the pivot
+// column's entries reach the other lanes by ds_bpermute.  Every arithmetic step is element-wise and uses the oracle's
+// expression, so the matrices agree bit for bit; ties in the pivot search resolve to the oracle's scan order (row, then
+// column position).  The one-thread-per-hypothesis version this replaces walked ~1500 dependent LDS accesses per hypothesis:
+// ~45 us of latency per launch whatever the hypothesis count, three launches per frame.
+typedef struct { double v; int key; } PivotCand;
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_tag)
 {
-    __shared__ double As[72][64];     // As[r*9+col][thread]: conflict-free (consecutive threads, consecutive banks)
-    const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z, tx = threadIdx.x;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_tag) {
+        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int dpp_i32(int v, const int ctrl_tag)
+{
+    switch (ctrl_tag) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    }
+}
+// value of `v` in lane `src` (0..15) of this lane's group of 16
+__device__ __forceinline__ double group_bcast(double v, int src) { return __shfl(v, src, 16); }
+
+__global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
+{
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16 + grp, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 8) return;
-    if (h >= RS_CHUNK_END(chunk) || (chunk && h >= c.rs_bound[vl * 2 + side])) return;
-    const float* pts = c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4;
+    // rs_bound is stable while this kernel runs (only k_ransac_count lowers it, and the previous chunk's has finished): what
+    // this chunk generates is [begin, gen) with gen = min(end, rs_bound); k_ransac_count must not trust anything beyond it
+    const int gen = chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk);
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
+    if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 16 >= gen) return;          // block-uniform; inside a live block every lane stays (DPP)
+    const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
+    // ---- the sample (oracle: ransac_sample), computed redundantly by the 16 lanes of the group ----
     int s[8];
     {
         unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
         if (!st) st = 1;
+#pragma unroll
         for (int j = 0; j < 8; j++) {
             int v; bool dup;
-            do { v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false; for (int k = 0; k < j; k++) if (s[k] == v) dup = true; } while (dup);
+            do {
+                v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < j && s[k] == v) dup = true;
+            } while (dup);
             s[j] = v;
         }
     }
+    float4 P[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) P[i] = pts[s[i]];
     double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
-    for (int i = 0; i < 8; i++) { const float4 p = ((const float4*)pts)[s[i]]; c1x += (double)p.x; c1y += (double)p.y; c2x += (double)p.z; c2y += (double)p.w; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
     c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
     double d1 = 0, d2 = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float4 p = ((const float4*)pts)[s[i]];
-        const double ax = (double)p.x - c1x, ay = (double)p.y - c1y, bx = (double)p.z - c2x, by = (double)p.w - c2y;
+        const double ax = (double)P[i].x - c1x, ay = (double)P[i].y - c1y, bx = (double)P[i].z - c2x, by = (double)P[i].w - c2y;
         d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
     }
     const double s1 = 11.313708498984761 / d1, s2 = 11.313708498984761 / d2;
-#define A(r, cc) As[(r) * 9 + (cc)][tx]
+    // ---- column gl of the system: A[i][0..8] = x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1 ----
+    double col[8];
+    const int cu = gl / 3, cv = gl - 3 * cu;                                  // column = (x2 | y2 | 1) * (x1 | y1 | 1)
+#pragma unroll
     for (int i = 0; i < 8; i++) {
-        const float4 p = ((const float4*)pts)[s[i]];
-        const double x1 = ((double)p.x - c1x) * s1, y1 = ((double)p.y - c1y) * s1, x2 = ((double)p.z - c2x) * s2, y2 = ((double)p.w - c2y) * s2;
-        A(i, 0) = x2 * x1; A(i, 1) = x2 * y1; A(i, 2) = x2; A(i, 3) = y2 * x1; A(i, 4) = y2 * y1; A(i, 5) = y2; A(i, 6) = x1; A(i, 7) = y1; A(i, 8) = 1.0;
+        const double x1 = ((double)P[i].x - c1x) * s1, y1 = ((double)P[i].y - c1y) * s1, x2 = ((double)P[i].z - c2x) * s2, y2 = ((double)P[i].w - c2y) * s2;
+        const double u = cu == 0 ? x2 : (cu == 1 ? y2 : 1.0), v = cv == 0 ? x1 : (cv == 1 ? y1 : 1.0);
+        col[i] = gl < 9 ? u * v : 0.0;                                          // x * 1.0 == x exactly: same entries as the oracle's
     }
-    int perm[9];
+    int vcol = gl < 9 ? gl : 64;                                              // lanes 9..15 hold no column
 #pragma unroll
-    for (int j = 0; j < 9; j++) perm[j] = j;
     for (int k = 0; k < 8; k++) {
-        double best = -1.0; int pi = k, pj = k;
-        for (int i = k; i < 8; i++) for (int j = k; j < 9; j++) { const double v = fabs(A(i, j)); if (v > best) { best = v; pi = i; pj = j; } }
-        if (pi != k) for (int j = 0; j < 9; j++) { const double t = A(k, j); A(k, j) = A(pi, j); A(pi, j) = t; }
-        if (pj != k) {
-            for (int i = 0; i < 8; i++) { const double t = A(i, k); A(i, k) = A(i, pj); A(i, pj) = t; }
-            // perm[k] <-> perm[pj] without dynamic register indexing
-            int pk = 0, pp = 0;
+        // pivot = first maximum of |A[i][j]|, i >= k, j >= k, in (i, j) scan order
+        double bv = -1.0; int bi = k;
 #pragma unroll
-            for (int j = 0; j < 9; j++) { if (j == k) pk = perm[j]; if (j == pj) pp = perm[j]; }
+        for (int i = k; i < 8; i++) { const double a = fabs(col[i]); if (a > bv) { bv = a; bi = i; } }
+        const bool active = vcol >= k && vcol <= 8;
+        if (!active) bv = -2.0;
+        int bkey = (bi << 8) | ((vcol & 63) << 4) | gl;
 #pragma unroll
-            for (int j = 0; j < 9; j++) { if (j == k) perm[j] = pp; else if (j == pj) perm[j] = pk; }
+        for (int st = 0; st < 4; st++) {
+            const double ov = dpp_f64(bv, st); const int ok = dpp_i32(bkey, st);
+            const bool take = ov > bv || (ov == bv && ok < bkey);
+            bv = take ? ov : bv; bkey = take ? ok : bkey;
         }
-        const double piv = A(k, k);
-        for (int j = k; j < 9; j++) A(k, j) = A(k, j) / piv;
-        for (int i = 0; i < 8; i++) { if (i == k) continue; const double f = A(i, k); for (int j = k; j < 9; j++) A(i, j) = A(i, j) - f * A(k, j); }
+        const int pi = bkey >> 8, pjv = (bkey >> 4) & 15, plane = bkey & 15;
+        // row swap k <-> pi in every column
+#pragma unroll
+        for (int i = k + 1; i < 8; i++) if (i == pi) { const double t = col[i]; col[i] = col[k]; col[k] = t; }
+        // column swap k <-> pjv, virtual
+        if (vcol == pjv) vcol = k; else if (vcol == k) vcol = pjv;
+        const double piv = group_bcast(col[k], plane);
+        const bool act2 = vcol >= k && vcol <= 8;
+        if (act2) col[k] = col[k] / piv;
+        double f[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) f[i] = i == k ? 0.0 : group_bcast(col[i], plane);       // A[i][k], read before anything below changes it
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i != k && act2) col[i] = col[i] - f[i] * col[k];
     }
-    double f[9];
+    // f[perm[8]] = 1, f[perm[i]] = -A[i][8]: lane L (original column L) sits at position vcol, the lane at position 8 holds A[.][8]
+    const unsigned long long at8 = __ballot(vcol == 8);
+    const int lane8 = __ffs((unsigned)((at8 >> (16 * (threadIdx.x >> 4 & 3))) & 0xFFFFu)) - 1;
+    double a8[8];
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
-        double v = 0;
+    for (int i = 0; i < 8; i++) a8[i] = group_bcast(col[i], lane8);
+    double fmine = 1.0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) if (perm[i] == j) v = (i == 8) ? 1.0 : -A(i, 8);
-        f[j] = v;
-    }
-#undef A
-    const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
-    double M[3][3];
+    for (int i = 0; i < 8; i++) if (vcol == i) fmine = -a8[i];
+    double fv[9];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
-        M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
-    }
-    double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
+    for (int j = 0; j < 9; j++) fv[j] = group_bcast(fmine, j);
+    if (gl == 0 && h < gen) {
+        const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
+        double M[3][3];
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) {
-        F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
-        F[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+        for (int r = 0; r < 3; r++) {
+            M[r][0] = fv[3 * r] * s1; M[r][1] = fv[3 * r + 1] * s1;
+            M[r][2] = (fv[3 * r] * t1x + fv[3 * r + 1] * t1y) + fv[3 * r + 2];
+        }
+        double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
+            F[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+        }
     }
 }
 
@@ -645,21 +732,34 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
     int cnt[RC_HB];
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) cnt[h] = 0;
-    for (int i = tid; i < n; i += blockDim.x) {
-        const float4 p = pts[i];
+    // four points per thread in registers, hypotheses in the outer loop: one scalar fetch of a hypothesis' matrix serves 1024
+    // point tests (with the points outermost the sixteen matrices, 288 SGPRs' worth, were fetched again for every point)
+    for (int base = 0; base < n; base += 4 * 256) {
+        float4 p[4];
 #pragma unroll
-        for (int h = 0; h < RC_HB; h++) cnt[h] += fm_inlier(F + 9 * h, p.x, p.y, p.z, p.w);
+        for (int q = 0; q < 4; q++) { const int i = base + q * 256 + tid; p[q] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        const int live = min(4, (n - base - tid + 255) / 256);            // this thread's points of the tile
+#pragma unroll
+        for (int h = 0; h < RC_HB; h++) {
+            const double* Fh = F + 9 * h;
+            int a = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int v = fm_inlier(Fh, p[q].x, p[q].y, p[q].z, p[q].w); a += q < live ? v : 0; }
+            cnt[h] += a;
+        }
     }
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) { const int v = wave_sum_uniform(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
     __syncthreads();
     if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0 + tid] = cnt_s[tid];
     if (tid == 0) {
+        // only hypotheses this chunk really generated count: beyond rs_gen the F matrices are leftovers of an earlier frame
+        const int gen = c.rs_gen[vl * 2 + side];
         int best = 0, best_h = 0;
-        for (int h = 0; h < RC_HB; h++) if (cnt_s[h] > best && h0 + h < SVO_RANSAC_HYP) { best = cnt_s[h]; best_h = h0 + h; }
+        for (int h = 0; h < RC_HB; h++) if (cnt_s[h] > best && h0 + h < gen) { best = cnt_s[h]; best_h = h0 + h; }
         const int cur = *(volatile int*)bound;
-        if (best > 7 && best_h < cur) {
-            const int K = ransac_budget(best, n, cur);
+        if (best > 8 && best_h < cur) {
+            const int K = ransac_niters(best - 1, n, cur);
             if (max(best_h, K) < cur) atomicMin(bound, max(best_h, K));
         }
     }
@@ -683,7 +783,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
     // The sequential scan (records in hypothesis order, each shrinking the budget) without its serial cost: the counts
     // below rs_bound are all there; a hypothesis is a RECORD when its count exceeds every earlier one (and 7); only records
     // can change the model or the budget.  Waves 0-1 / 2-3 take the two sides: strict prefix maxima by a wave scan over
-    // chunks of 128, the records' budgets K(count) computed in parallel (each is a chain of up to 1000 multiplications), then
+    // chunks of 128, the records' budgets K(count) computed in parallel, then
     // one thread walks the handful of records in order.
     __shared__ int rec_k[2][64], rec_c[2][64], rec_K[2][64], rec_n[2];
     {
@@ -712,13 +812,13 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
         }
         // records are few (each at least one more inlier than the last; in practice ~ln(lim)); sort the <= 64 by index
         const int nr = min(rec_n[side], 64);
-        if (t < nr) rec_K[side][t] = ransac_budget(rec_c[side][t], n, SVO_RANSAC_HYP);
+        if (t < nr) rec_K[side][t] = ransac_niters(rec_c[side][t], n, SVO_RANSAC_HYP);
         __syncthreads();
         if (t == 0 && rec_n[side] > 64) {                                   // more records than slots (a count creeping up one by one): the plain scan
             int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP;
             for (int k = 0; k < niters && k < lim; k++) {
                 const int cnt = gc[k];
-                if (cnt > (best_cnt > 7 ? best_cnt : 7)) { best_cnt = cnt; best_k = k; niters = ransac_budget(cnt, n, niters); }
+                if (cnt > (best_cnt > 7 ? best_cnt : 7)) { best_cnt = cnt; best_k = k; niters = ransac_niters(cnt, n, niters); }
             }
             s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
         } else if (t == 0) {
@@ -900,7 +1000,7 @@ void launch_track_filter(const DevCtx& c, hipStream_t st)
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
     const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
-    hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
+    hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {

@@ -132,7 +132,8 @@ struct DevCtx {
     float* trk_pts;           // [n_lanes][2 sides][max_kps][4]  (x1,y1,x2,y2) for the F-matrix RANSAC
     double* rs_F;             // [n_lanes][2][PAD][9]
     int* rs_cnt;              // [n_lanes][2][PAD]
-    int* rs_bound;            // [n_lanes][2]  hypotheses the sequential stop can still reach after the first chunk
+    int* rs_bound;            // [n_lanes][2]  upper limit of the hypotheses the sequential stop can still reach
+    int* rs_gen;              // [n_lanes][2]  end of the hypotheses the current chunk generated
     svo_index_pair* tracked;  // [n_lanes][max_kps]
     int* n_tracked;           // [n_lanes]
     // stage 5
