@@ -857,6 +857,7 @@ int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8
         }
     }
     if (n_hyp_used) *n_hyp_used = k;
+    if (getenv("SVO_ORACLE_TRACE")) fprintf(stderr, "ransac n=%d visited=%d best_k=%d best_cnt=%d budget=%d\n", n, k, best_k, best_cnt, niters);
     if (best_k < 0) return 0;
     int cnt = 0;
     for (int i = 0; i < n; i++) { mask[i] = (uint8_t)fm_inlier(Fbest, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]); cnt += mask[i]; }

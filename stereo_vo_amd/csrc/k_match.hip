@@ -535,10 +535,12 @@ __device__ __forceinline__ int ransac_niters(int cnt, int n, int max_iters)
     return (int)rint(num / d);
 }
 
-// Evaluating hypotheses OUT OF ORDER still bounds the sequential budget N*: hypothesis h with count c > 7 is either never
-// reached by the sequential scan (N* <= h) or, reached, leaves a budget <= K(c) whether it is a record or not (a record
-// before it had a count >= c, and K falls with the count).  So N* <= max(h, K(c)) for EVERY evaluated h, and the minimum of
-// those over whatever has been evaluated so far (rs_bound) is a safe upper limit: hypotheses at or beyond it are never read.
+// Evaluating hypotheses OUT OF ORDER still bounds what the sequential scan visits.  The scan visits [0, E), E = the first k
+// that is no longer below the budget (a record at k may cut the budget below k itself: k is still visited, so E can exceed the
+// final budget).  A visited hypothesis h with count c > 7 leaves a budget <= K(c) whether it is a record or not (a record
+// before it had a count >= c, and K falls with the count), so the scan ends by max(h + 1, K(c)); an unvisited one has
+// E <= h.  Hence E <= max(h + 1, K(c)) for EVERY evaluated h, and the minimum of those over whatever has been evaluated so
+// far (rs_bound) is a safe limit: hypotheses at or beyond it are never visited, everything below it is evaluated.
 // (The tightening uses K(c - 1): one inlier less moves num / d by far more than svo_ln's rounding error, so the
 // "K falls with the count" step holds for the computed values too, not only in exact arithmetic.)
 #define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1))
@@ -758,9 +760,9 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
         int best = 0, best_h = 0;
         for (int h = 0; h < RC_HB; h++) if (cnt_s[h] > best && h0 + h < gen) { best = cnt_s[h]; best_h = h0 + h; }
         const int cur = *(volatile int*)bound;
-        if (best > 8 && best_h < cur) {
+        if (best > 8 && best_h + 1 < cur) {
             const int K = ransac_niters(best - 1, n, cur);
-            if (max(best_h, K) < cur) atomicMin(bound, max(best_h, K));
+            if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
         }
     }
 }
