@@ -150,6 +150,19 @@ int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int octave, int
 /* match-ID bookkeeping of params_general.vo_use_matches_ids: matches_IDs (H:794, getRefCurrentIDs H:701),
  * resetIds (H:684) and setThisFrameAsKF (H:675-683); result.tracked_feats_from_last_KF counts against the key frame */
 int svo_get_match_ids(svo_ctx* ctx, int lane, int which, int octave, int32_t* ids, int cap);
+/* getValues (H:704-724) in ONE device synchronisation: every list of one octave of one frame of one lane.  The caller
+ * fills the array pointers (any may be NULL) and the two capacities; the call fills the four counts (the full list
+ * lengths, possibly above the capacities; min(length, capacity) entries are written).  The lists are packed on the
+ * device, copied to the context's page-locked staging in one transfer, and unpacked on the host: one stream
+ * synchronisation per call where the individual getters above pay one or two each. */
+typedef struct svo_values {
+    svo_keypoint* left_kps;  uint8_t* left_desc;      /* cap_kps entries / cap_kps * 32 bytes */
+    svo_keypoint* right_kps; uint8_t* right_desc;
+    svo_dmatch* matches;     int32_t* match_ids;      /* cap_matches entries each */
+    int32_t cap_kps, cap_matches;
+    int32_t n_left, n_right, n_matches, n_ids;        /* out */
+} svo_values;
+int svo_get_values(svo_ctx* ctx, int lane, int which, int octave, svo_values* v);
 int svo_reset_ids(svo_ctx* ctx, int lane);
 int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane);
 
@@ -162,6 +175,13 @@ int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n);
 /* request_data.precomputed_matches_ID (H:218, P:233-244): the IDs of the octave-0 pairings put before; m_last_match_ID
  * becomes their maximum (P:236-243).  Honoured by the pipeline only when vo_use_matches_ids is set (P:246-250). */
 int svo_put_match_ids(svo_ctx* ctx, int lane, int which, const int32_t* ids, int n);
+/* the same per OCTAVE (P:141-161 and P:219-244 loop over params_rectify.nOctaves lists): octave < svo_config.max_octaves and,
+ * in the FAST+ORB mode, < nOctaves.  img_w / img_h stay the size of the octave-0 image.  svo_put_match_ids_oct: octave 0
+ * restarts m_last_match_ID at its maximum ID, higher octaves raise it (call in ascending octave order, as P:236-243 does). */
+int svo_put_features_oct(svo_ctx* ctx, int lane, int which, int side, int octave, const svo_keypoint* kps, const uint8_t* desc, int n,
+                         int img_w, int img_h);
+int svo_put_matches_oct(svo_ctx* ctx, int lane, int which, int octave, const svo_dmatch* m, int n);
+int svo_put_match_ids_oct(svo_ctx* ctx, int lane, int which, int octave, const int32_t* ids, int n);
 
 /* getProjectedCoords (H:175-182, C:415-466): pixel coordinates (uL vL uR vR, 4 floats each) that the previous
  * pairings NOT marked as tracked (tracked_first[m] == -1, C:430-431) take after the change in pose: triangulation as

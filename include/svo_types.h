@@ -105,7 +105,8 @@ typedef struct svo_result {
     int32_t n_octaves;
     int32_t n_outliers;      /* size of result.outliers (which holds INLIER cur-match indices, S5:603-610) */
     int32_t n_residual;      /* size of result.out_residual */
-    int32_t _pad;
+    int32_t status;          /* 0, or capacity bits: 1 = a level's FAST candidate list overflowed svo_config.max_cand, 2 = a keypoint /
+                                track list was cut at svo_config.max_kps (the reference has no such limits: stage2_detect.cpp:461-464) */
 } svo_result;
 
 #define SVO_MAX_OCTAVES 4

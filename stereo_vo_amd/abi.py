@@ -61,7 +61,7 @@ class Result(C.Structure):
         ("num_it", C.c_int32), ("num_it_final", C.c_int32), ("valid", C.c_int32), ("error_code", C.c_int32),
         ("tracked_feats_from_last_KF", C.c_int32), ("tracked_feats_from_last_frame", C.c_int32),
         ("detected_left", C.c_int32 * 4), ("detected_right", C.c_int32 * 4), ("stereo_matches", C.c_int32 * 4),
-        ("n_octaves", C.c_int32), ("n_outliers", C.c_int32), ("n_residual", C.c_int32), ("_pad", C.c_int32),
+        ("n_octaves", C.c_int32), ("n_outliers", C.c_int32), ("n_residual", C.c_int32), ("status", C.c_int32),
     ]
 
 

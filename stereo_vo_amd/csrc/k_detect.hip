@@ -95,9 +95,41 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
         svo_result& r = c.results[t];
         r.error_code = SVO_VOEC_NONE;                                                  // P:50
         r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = c.n_oct;
+        if (detect) r.status = 0;
         r.tracked_feats_from_last_frame = 0; r.tracked_feats_from_last_KF = 0;
         for (int k = 0; k < 6; k++) { r.outPose[k] = 0; r.delta[k] = 0; }
     }
+}
+
+// getValues (H:704-724) packed for ONE transfer: header {n_left, n_right, n_matches, n_ids} at byte 0, then at byte 64 the
+// six lists at max_kps-strided offsets (left kps | right kps | left desc | right desc | pairings | pairing IDs); the
+// previous / current slot is resolved here, on the device, so that the host needs no round trip to learn it.
+__global__ void __launch_bounds__(256) k_pack_values(DevCtx c, int lane, int which, int octave, uint8_t* dst)
+{
+    const LaneState& s = c.lane[lane];
+    const int slot = which ? s.prev_slot : 1 - s.prev_slot, vl = lane * c.oct_cap + octave;
+    const bool present = which ? s.has_prev != 0 : s.has_cur != 0;
+    const int nl = present ? c.n_kps[feat_cnt_idx(vl, slot, 0)] : 0, nr = present ? c.n_kps[feat_cnt_idx(vl, slot, 1)] : 0;
+    const int nm = present ? c.n_matches[vl * 2 + slot] : 0, ni = present ? c.n_ids[vl * 2 + slot] : 0;
+    const size_t MK = (size_t)c.max_kps;
+    uint4* out = (uint4*)(dst + 64);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (t == 0) { int32_t* h = (int32_t*)dst; h[0] = nl; h[1] = nr; h[2] = nm; h[3] = ni; }
+    // everything is copied as 4-byte words (28-byte keypoints are not 16-byte multiples)
+    auto copy_words = [&](const void* src, size_t dst_off, size_t nbytes) {
+        const uint32_t* sp = (const uint32_t*)src; uint32_t* dp = (uint32_t*)((uint8_t*)out + dst_off);
+        for (size_t i = (size_t)t; i < nbytes / 4; i += (size_t)nt) dp[i] = sp[i];
+    };
+    copy_words(c.kps + feat_base(c, vl, slot, 0), 0, (size_t)nl * sizeof(svo_keypoint));
+    copy_words(c.kps + feat_base(c, vl, slot, 1), MK * sizeof(svo_keypoint), (size_t)nr * sizeof(svo_keypoint));
+    copy_words(c.desc + feat_base(c, vl, slot, 0) * 32, 2 * MK * sizeof(svo_keypoint), (size_t)nl * 32);
+    copy_words(c.desc + feat_base(c, vl, slot, 1) * 32, 2 * MK * sizeof(svo_keypoint) + MK * 32, (size_t)nr * 32);
+    copy_words(c.matches + match_base(c, vl, slot), 2 * MK * (sizeof(svo_keypoint) + 32), (size_t)nm * sizeof(svo_dmatch));
+    copy_words(c.ids + match_base(c, vl, slot), 2 * MK * (sizeof(svo_keypoint) + 32) + MK * sizeof(svo_dmatch), (size_t)ni * 4);
+}
+void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_t* dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pack_values, dim3(64), dim3(256), 0, st, c, lane, which, octave, dst);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -436,7 +468,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             uint32_t* dst = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
             for (unsigned i = tid; i < nout; i += 64) {
                 if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
-                else atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW);
+                else { atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW); atomicOr(&c.results[img >> 1].status, (int)SVO_ST_CAND_OVERFLOW); }
             }
         }
     }
@@ -1194,7 +1226,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         __syncthreads();
     }
     if (c.debug_mode == 24) return;
-    if (nacc > c.max_kps) { nacc = c.max_kps; if (tid == 0) atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); }
+    if (nacc > c.max_kps) { nacc = c.max_kps; if (tid == 0) { atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); atomicOr(&c.results[lane_id].status, (int)SVO_ST_KPS_OVERFLOW); } }
     // row sort: (pt.y asc, survivor rank asc)
     __syncthreads();
     for (int i = tid; i < NS_MAX; i += blockDim.x) keys[i] = ~0ull;

@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     toff[0] = 0;
     for (int o = 0; o < SVO_MAX_OCTAVES; o++) toff[o + 1] = toff[o] + (o < c.n_oct ? c.n_tracked[lane_id * c.oct_cap + o] : 0);
     int T = toff[SVO_MAX_OCTAVES];
-    if (T > P.pmax) { T = P.pmax; if (tid == 0) atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); }
+    if (T > P.pmax) { T = P.pmax; if (tid == 0) { atomicOr(&c.status[lane_id], SVO_ST_KPS_OVERFLOW); atomicOr(&res.status, (int)SVO_ST_KPS_OVERFLOW); } }
     auto oct_of = [&](int i) { int o = 0; for (int q = 1; q < SVO_MAX_OCTAVES; q++) if (i >= toff[q] && q < c.n_oct) o = q; return o; };
     float* obs = c.gn_obs + (long long)lane_id * c.max_kps * 8;
     double* lmk = c.gn_lmk + (long long)lane_id * c.max_kps * 3;

@@ -73,9 +73,11 @@ public:
         std::vector<TKeyPointList>* precomputed_left_feats, *precomputed_right_feats;
         std::vector<std::vector<uint8_t> >* precomputed_left_desc, *precomputed_right_desc;   // N x 32 bytes per octave
         std::vector<TDMatchList>* precomputed_matches;
+        std::vector<std::vector<size_t> >* precomputed_matches_ID;                         // H:218, honoured when vo_use_matches_ids (P:233-250)
         bool repeat;
         TStereoOdometryRequest() : imageLeft(), imageRight(), stereo_cam(), use_precomputed_data(false), precomputed_left_feats(NULL),
-            precomputed_right_feats(NULL), precomputed_left_desc(NULL), precomputed_right_desc(NULL), precomputed_matches(NULL), repeat(false) {}
+            precomputed_right_feats(NULL), precomputed_left_desc(NULL), precomputed_right_desc(NULL), precomputed_matches(NULL),
+            precomputed_matches_ID(NULL), repeat(false) {}
     };
     struct TStereoOdometryResult {                // H:235-264
         CPose3D outPose;
@@ -123,14 +125,28 @@ public:
         if (request_data.use_precomputed_data) {                                         // P:131-162, 219-251
             if (!request_data.precomputed_left_feats || !request_data.precomputed_right_feats || !request_data.precomputed_left_desc ||
                 !request_data.precomputed_right_desc || !request_data.precomputed_matches) throw std::runtime_error("precomputed data pointers must be set");   // P:137, 157, 221
-            // shift prev/cur first (P:86-100), then load the caller's lists into the new current frame
-            check(svo_process(m_ctx, NULL, 0), "svo_process(shift)");
+            // shift prev/cur first (P:86-100; request_data.repeat and the recovery rule apply here as in the full path), then
+            // load the caller's lists, octave by octave (P:141-161, 219-244), into the new current frame
+            check(svo_process(m_ctx, NULL, request_data.repeat ? SVO_FLAG_REPEAT : 0), "svo_process(shift)");
             const int w = request_data.imageLeft.w, h = request_data.imageLeft.h;
-            const TKeyPointList& kl = (*request_data.precomputed_left_feats)[0], &kr = (*request_data.precomputed_right_feats)[0];
-            check(svo_put_features(m_ctx, 0, 0, 0, kl.data(), (*request_data.precomputed_left_desc)[0].data(), (int)kl.size(), w, h), "svo_put_features");
-            check(svo_put_features(m_ctx, 0, 0, 1, kr.data(), (*request_data.precomputed_right_desc)[0].data(), (int)kr.size(), w, h), "svo_put_features");
-            const TDMatchList& m = (*request_data.precomputed_matches)[0];
-            check(svo_put_matches(m_ctx, 0, 0, m.data(), (int)m.size()), "svo_put_matches");
+            const size_t nOct = request_data.precomputed_left_feats->size();
+            if (request_data.precomputed_right_feats->size() != nOct || request_data.precomputed_left_desc->size() != nOct ||
+                request_data.precomputed_right_desc->size() != nOct || request_data.precomputed_matches->size() != nOct)
+                throw std::runtime_error("Number of octaves in precomputed data does not match");                          // P:138-139
+            if (params.vo_use_matches_ids && (!request_data.precomputed_matches_ID || request_data.precomputed_matches_ID->size() != nOct))
+                throw std::runtime_error("precomputed_matches_ID must be set when vo_use_matches_ids is on");                // P:235
+            for (size_t o = 0; o < nOct; o++) {
+                const TKeyPointList& kl = (*request_data.precomputed_left_feats)[o], &kr = (*request_data.precomputed_right_feats)[o];
+                check(svo_put_features_oct(m_ctx, 0, 0, 0, (int)o, kl.data(), (*request_data.precomputed_left_desc)[o].data(), (int)kl.size(), w, h), "svo_put_features_oct");
+                check(svo_put_features_oct(m_ctx, 0, 0, 1, (int)o, kr.data(), (*request_data.precomputed_right_desc)[o].data(), (int)kr.size(), w, h), "svo_put_features_oct");
+                const TDMatchList& m = (*request_data.precomputed_matches)[o];
+                check(svo_put_matches_oct(m_ctx, 0, 0, (int)o, m.data(), (int)m.size()), "svo_put_matches_oct");
+                if (params.vo_use_matches_ids) {
+                    const std::vector<size_t>& idv = (*request_data.precomputed_matches_ID)[o];
+                    std::vector<int32_t> ids(idv.begin(), idv.end());
+                    check(svo_put_match_ids_oct(m_ctx, 0, 0, (int)o, ids.data(), (int)ids.size()), "svo_put_match_ids_oct");
+                }
+            }
             check(svo_process(m_ctx, NULL, SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_FLAG_NO_SHIFT), "svo_process");
         } else {
             if (!f.left.data || !f.right.data) throw std::runtime_error("Pointer 'request_data.stereo_imgs' must be set to stereo observation data!");   // P:81
@@ -179,14 +195,19 @@ public:
     /** getValues (H:704-724): copies of the current frame's octave-0 lists */
     void getValues(TKeyPointList& leftKP, TKeyPointList& rightKP, std::vector<uint8_t>& leftDesc, std::vector<uint8_t>& rightDesc, TDMatchList& matches,
                    std::vector<size_t>& matches_id) {
-        fetch_kps(0, leftKP, leftDesc); fetch_kps(1, rightKP, rightDesc);
-        const int n = check(svo_get_matches(m_ctx, 0, 0, NULL, 0), "svo_get_matches");
-        matches.resize(n);
-        if (n) check(svo_get_matches(m_ctx, 0, 0, matches.data(), n), "svo_get_matches");
-        const int ni = check(svo_get_match_ids(m_ctx, 0, 0, 0, NULL, 0), "svo_get_match_ids");
-        std::vector<int32_t> ids((size_t)ni);
-        if (ni) check(svo_get_match_ids(m_ctx, 0, 0, 0, ids.data(), ni), "svo_get_match_ids");
-        matches_id.assign(ids.begin(), ids.end());
+        // one device synchronisation for all six lists (svo_get_values); a second call only if a list outgrew the guess
+        int cap_k = 4096, cap_m = 4096;
+        for (int pass = 0; pass < 2; pass++) {
+            leftKP.resize(cap_k); rightKP.resize(cap_k); leftDesc.resize((size_t)cap_k * 32); rightDesc.resize((size_t)cap_k * 32); matches.resize(cap_m);
+            std::vector<int32_t> ids((size_t)cap_m);
+            svo_values v; v.left_kps = leftKP.data(); v.left_desc = leftDesc.data(); v.right_kps = rightKP.data(); v.right_desc = rightDesc.data();
+            v.matches = matches.data(); v.match_ids = ids.data(); v.cap_kps = cap_k; v.cap_matches = cap_m;
+            check(svo_get_values(m_ctx, 0, 0, 0, &v), "svo_get_values");
+            if (v.n_left > cap_k || v.n_right > cap_k || v.n_matches > cap_m || v.n_ids > cap_m) { cap_k = v.n_left > v.n_right ? v.n_left : v.n_right; cap_m = v.n_matches > v.n_ids ? v.n_matches : v.n_ids; continue; }
+            leftKP.resize(v.n_left); leftDesc.resize((size_t)v.n_left * 32); rightKP.resize(v.n_right); rightDesc.resize((size_t)v.n_right * 32);
+            matches.resize(v.n_matches); matches_id.assign(ids.begin(), ids.begin() + v.n_ids);
+            break;
+        }
     }
     /** Stage 1 (S1:47-85): what m_stereo_rectifier.setFromCamParams() precomputes, handed over as float maps [h][w] of
      *  source coordinates (cv::initUndistortRectifyMap, CV_32FC1); empty vectors = areImagesRectified() (S1:61-65). */
@@ -222,8 +243,9 @@ private:
         result.outPose = CPose3D(r.outPose[0], r.outPose[1], r.outPose[2], r.outPose[3], r.outPose[4], r.outPose[5]);
         result.num_it = r.num_it; result.num_it_final = r.num_it_final; result.valid = r.valid != 0; result.error_code = (VOErrorCode)r.error_code;
         result.tracked_feats_from_last_KF = (size_t)r.tracked_feats_from_last_KF; result.tracked_feats_from_last_frame = (size_t)r.tracked_feats_from_last_frame;
-        result.detected_feats.assign(1, std::make_pair((size_t)r.detected_left[0], (size_t)r.detected_right[0]));
-        result.stereo_matches.assign(1, (size_t)r.stereo_matches[0]);
+        const int no = r.n_octaves > 0 ? (r.n_octaves < 4 ? r.n_octaves : 4) : 1;
+        result.detected_feats.clear(); result.stereo_matches.clear();
+        for (int o = 0; o < no; o++) { result.detected_feats.push_back(std::make_pair((size_t)r.detected_left[o], (size_t)r.detected_right[o])); result.stereo_matches.push_back((size_t)r.stereo_matches[o]); }
     }
     void fill_result(TStereoOdometryResult& result) {
         svo_result r; check(svo_get_result(m_ctx, 0, &r), "svo_get_result");

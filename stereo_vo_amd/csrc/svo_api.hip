@@ -48,6 +48,8 @@ struct svo_ctx {
     std::vector<uint2*> map_bufs;                      // per image: the allocation behind map_ptrs (kept across clear / set cycles)
     // getChangeInPose works on temporaries (common.cpp:362-400): a one-lane scratch view of the device context
     DevCtx cip; bool cip_ready;
+    // svo_get_values: device packing buffer and its page-locked host mirror
+    uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
     // every stream that has had work of this context enqueued since the last full synchronisation (svo_set_stream)
     std::vector<hipStream_t> used_streams;
 };
@@ -163,7 +165,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
-    ctx->cip_ready = false;
+    ctx->cip_ready = false; ctx->d_vals = nullptr; ctx->h_vals = nullptr; ctx->vals_bytes = 0;
     ctx->up_ready = false; ctx->up_slot = 0; ctx->det_slot = -1; ctx->s_copy = nullptr; ctx->slot_bytes = 0;
     for (int i = 0; i < 2; i++) { ctx->d_img0_ring[i] = nullptr; ctx->h_stage[i] = nullptr; ctx->ev_det_valid[i] = ctx->ev_h2d_valid[i] = false; }
     for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
@@ -243,6 +245,7 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     if (!ctx) return;
     sync_all(ctx);                                        // work may still be running on a stream the caller switched away from
     for (void* p : ctx->allocs) hipFree(p);
+    if (ctx->h_vals) hipHostFree(ctx->h_vals);
     if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
     if (ctx->d_ham_q) hipFree(ctx->d_ham_q);
     if (ctx->d_ham_t) hipFree(ctx->d_ham_t);
@@ -810,6 +813,40 @@ extern "C" int svo_get_matches_oct(svo_ctx* ctx, int lane, int which, int octave
 }
 extern "C" int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* mm, int cap) { return svo_get_matches_oct(ctx, lane, which, 0, mm, cap); }
 
+// ---- getValues in one synchronisation (H:704-724) ---------------------------------------------------------------
+extern "C" int svo_get_values(svo_ctx* ctx, int lane, int which, int octave, svo_values* v)
+{
+    if (!ctx || !v || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap || v->cap_kps < 0 || v->cap_matches < 0) return SVO_ERR_ARG;
+    const int MK = ctx->dc.max_kps;
+    if (!ctx->d_vals) {
+        ctx->vals_bytes = 64 + (size_t)MK * (2 * (sizeof(svo_keypoint) + 32) + sizeof(svo_dmatch) + sizeof(int32_t));
+        HIPCHECK(dev_alloc(ctx, &ctx->d_vals, ctx->vals_bytes));
+        HIPCHECK(hipHostMalloc((void**)&ctx->h_vals, ctx->vals_bytes, hipHostMallocDefault));
+    }
+    // whatever the context still has in flight on other streams must be done; the pack + copy below then run on the
+    // current stream and the single synchronisation of this call waits for them
+    for (hipStream_t st : ctx->used_streams) if (st != ctx->stream) HIPCHECK(hipStreamSynchronize(st));
+    note_stream(ctx);
+    launch_pack_values(ctx->dc, lane, which, octave, ctx->d_vals, ctx->stream);
+    HIPCHECK(hipMemcpyAsync(ctx->h_vals, ctx->d_vals, ctx->vals_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));                                      // THE synchronisation
+    collect_spans(ctx);
+    const int32_t* hdr = (const int32_t*)ctx->h_vals;
+    v->n_left = hdr[0]; v->n_right = hdr[1]; v->n_matches = hdr[2]; v->n_ids = hdr[3];
+    const uint8_t* b = ctx->h_vals + 64;
+    const uint8_t* kl = b, *kr = kl + (size_t)MK * sizeof(svo_keypoint), *dl = kr + (size_t)MK * sizeof(svo_keypoint), *dr = dl + (size_t)MK * 32;
+    const uint8_t* mm = dr + (size_t)MK * 32, *ii = mm + (size_t)MK * sizeof(svo_dmatch);
+    const int nl = v->n_left < v->cap_kps ? v->n_left : v->cap_kps, nr = v->n_right < v->cap_kps ? v->n_right : v->cap_kps;
+    const int nm = v->n_matches < v->cap_matches ? v->n_matches : v->cap_matches, ni = v->n_ids < v->cap_matches ? v->n_ids : v->cap_matches;
+    if (v->left_kps && nl > 0) memcpy(v->left_kps, kl, sizeof(svo_keypoint) * nl);
+    if (v->right_kps && nr > 0) memcpy(v->right_kps, kr, sizeof(svo_keypoint) * nr);
+    if (v->left_desc && nl > 0) memcpy(v->left_desc, dl, (size_t)32 * nl);
+    if (v->right_desc && nr > 0) memcpy(v->right_desc, dr, (size_t)32 * nr);
+    if (v->matches && nm > 0) memcpy(v->matches, mm, sizeof(svo_dmatch) * nm);
+    if (v->match_ids && ni > 0) memcpy(v->match_ids, ii, sizeof(int32_t) * ni);
+    return SVO_OK;
+}
+
 extern "C" int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int octave, int32_t* idx, int cap)
 {
     if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
@@ -900,44 +937,57 @@ static int mark_present(svo_ctx* ctx, int lane, int which)
     return SVO_OK;
 }
 
-extern "C" int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keypoint* kps, const uint8_t* desc, int n, int img_w, int img_h)
+extern "C" int svo_put_features_oct(svo_ctx* ctx, int lane, int which, int side, int octave, const svo_keypoint* kps, const uint8_t* desc, int n, int img_w, int img_h)
 {
-    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || n < 0 || (n > 0 && !kps)) return SVO_ERR_ARG;
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || n < 0 || (n > 0 && !kps) || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     int rc = ensure_geometry(ctx, img_w, img_h); if (rc) return rc;
+    if (octave >= ctx->dc.n_oct) return SVO_ERR_ARG;                       // P:139: the octave count of the data must match the system's
     LaneState s; rc = lane_state(ctx, lane, &s); if (rc) return rc;
-    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap;       // octave 0
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave;
     const long long base = (((long long)vl * 2 + slot) * 2 + side) * ctx->dc.max_kps;
     if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.kps + base, kps, sizeof(svo_keypoint) * n, hipMemcpyHostToDevice));
     if (n > 0 && desc) HIPCHECK(hipMemcpy(ctx->dc.desc + base * 32, desc, (size_t)32 * n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->dc.n_kps + (vl * 2 + slot) * 2 + side, &n, sizeof(int), hipMemcpyHostToDevice));
+    if (which == 0) {                                                      // result.detected_feats[octave] (P:171-176)
+        int32_t* cnt = side ? ctx->dc.results[lane].detected_right : ctx->dc.results[lane].detected_left;
+        HIPCHECK(hipMemcpy(cnt + octave, &n, sizeof(int), hipMemcpyHostToDevice));
+    }
     return mark_present(ctx, lane, which);
 }
-
-extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n)
+extern "C" int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keypoint* kps, const uint8_t* desc, int n, int img_w, int img_h)
 {
-    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !m)) return SVO_ERR_ARG;
+    return svo_put_features_oct(ctx, lane, which, side, 0, kps, desc, n, img_w, img_h);
+}
+
+extern "C" int svo_put_matches_oct(svo_ctx* ctx, int lane, int which, int octave, const svo_dmatch* m, int n)
+{
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !m) || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
-    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap;       // octave 0
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave;
     if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.matches + ((long long)vl * 2 + slot) * ctx->dc.max_kps, m, sizeof(svo_dmatch) * n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->dc.n_matches + vl * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
+    if (which == 0) HIPCHECK(hipMemcpy(ctx->dc.results[lane].stereo_matches + octave, &n, sizeof(int), hipMemcpyHostToDevice));   // P:274-276
     return mark_present(ctx, lane, which);
 }
+extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n) { return svo_put_matches_oct(ctx, lane, which, 0, m, n); }
 
-extern "C" int svo_put_match_ids(svo_ctx* ctx, int lane, int which, const int32_t* ids, int n)
+extern "C" int svo_put_match_ids_oct(svo_ctx* ctx, int lane, int which, int octave, const int32_t* ids, int n)
 {
-    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !ids)) return SVO_ERR_ARG;
+    if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !ids) || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
-    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap;       // octave 0
+    const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave;
     if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.ids + ((long long)vl * 2 + slot) * ctx->dc.max_kps, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->dc.n_ids + vl * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
-    int mx = 0; for (int i = 0; i < n; i++) if (ids[i] > mx) mx = ids[i];                          // P:236, 243
+    int mx = octave == 0 ? 0 : s.last_match_id;                                                    // P:236: m_last_match_ID = 0, then the maximum over the octaves (P:243)
+    for (int i = 0; i < n; i++) if (ids[i] > mx) mx = ids[i];
     s.last_match_id = mx;
     HIPCHECK(hipMemcpy(ctx->dc.lane + lane, &s, sizeof(s), hipMemcpyHostToDevice));
     return SVO_OK;
 }
+extern "C" int svo_put_match_ids(svo_ctx* ctx, int lane, int which, const int32_t* ids, int n) { return svo_put_match_ids_oct(ctx, lane, which, 0, ids, n); }
 
 extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n)
 {

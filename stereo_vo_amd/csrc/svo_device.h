@@ -19,7 +19,7 @@
 #define SVO_RANSAC_PAD 1024         // stride of the per-(lane, side) hypothesis arrays
 #define SVO_RANSAC_CHUNK0 32        // hypotheses [0, CHUNK0) are evaluated unconditionally, [CHUNK0, CHUNK1) and [CHUNK1, HYP) only as far as
 #define SVO_RANSAC_CHUNK1 288       // the 0.99-confidence stop of the sequential algorithm can still reach (rs_bound)
-#define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) that get a Harris response
+#define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) ranked by their Harris response
 #define SVO_FT_W 64          // k_fast tile (interior pixels)
 #define SVO_FT_H 28
 #define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each

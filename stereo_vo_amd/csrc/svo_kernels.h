@@ -22,6 +22,7 @@ struct PrepArgs {
     long long src_stride; int channels, w, h;
 };
 void launch_prepare(const PrepArgs& a, int n_img, hipStream_t st);
+void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_t* dst, hipStream_t st);
 void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned flags, hipStream_t st);
 void launch_resize(const DevCtx& c, int level, hipStream_t st);
 void launch_fast(const DevCtx& c, hipStream_t st);

@@ -27,6 +27,7 @@ EXPORTS = [
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
+    "svo_get_values", "svo_put_features_oct", "svo_put_matches_oct", "svo_put_match_ids_oct",
     "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
 ]
 
@@ -43,6 +44,12 @@ class Image(C.Structure):
 
 class Frame(C.Structure):
     _fields_ = [("left", Image), ("right", Image)]
+
+
+class Values(C.Structure):
+    _fields_ = [("left_kps", C.c_void_p), ("left_desc", C.c_void_p), ("right_kps", C.c_void_p), ("right_desc", C.c_void_p),
+                ("matches", C.c_void_p), ("match_ids", C.c_void_p), ("cap_kps", C.c_int32), ("cap_matches", C.c_int32),
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("n_matches", C.c_int32), ("n_ids", C.c_int32)]
 
 
 class SvoError(RuntimeError):
@@ -319,19 +326,29 @@ class Context:
             self._ck(self.L.svo_get_outliers(self.h, lane, _vp(r), n), "svo_get_outliers")
         return r
 
+    def values(self, lane=0, which=0, octave=0):
+        """getValues (H:704-724) in one device synchronisation: (left_kps, left_desc, right_kps, right_desc, matches, ids)."""
+        mk = self.max_kps
+        kl, kr = np.zeros(mk, keypoint_dtype), np.zeros(mk, keypoint_dtype)
+        dl, dr = np.zeros((mk, 32), np.uint8), np.zeros((mk, 32), np.uint8)
+        m, ids = np.zeros(mk, dmatch_dtype), np.zeros(mk, np.int32)
+        v = Values(kl.ctypes.data, dl.ctypes.data, kr.ctypes.data, dr.ctypes.data, m.ctypes.data, ids.ctypes.data, mk, mk, 0, 0, 0, 0)
+        self._ck(self.L.svo_get_values(self.h, lane, which, octave, C.byref(v)), "svo_get_values")
+        return kl[:v.n_left].copy(), dl[:v.n_left].copy(), kr[:v.n_right].copy(), dr[:v.n_right].copy(), m[:v.n_matches].copy(), ids[:v.n_ids].copy()
+
     # -- precomputed-data bypass -------------------------------------------------------------------------
-    def put_features(self, lane, which, side, kps, desc, img_w, img_h):
+    def put_features(self, lane, which, side, kps, desc, img_w, img_h, octave=0):
         kps = np.ascontiguousarray(kps)
         desc = None if desc is None else np.ascontiguousarray(desc, np.uint8)
-        self._ck(self.L.svo_put_features(self.h, lane, which, side, _vp(kps), _vp(desc), len(kps), img_w, img_h), "svo_put_features")
+        self._ck(self.L.svo_put_features_oct(self.h, lane, which, side, octave, _vp(kps), _vp(desc), len(kps), img_w, img_h), "svo_put_features_oct")
 
-    def put_matches(self, lane, which, m):
+    def put_matches(self, lane, which, m, octave=0):
         m = np.ascontiguousarray(m)
-        self._ck(self.L.svo_put_matches(self.h, lane, which, _vp(m), len(m)), "svo_put_matches")
+        self._ck(self.L.svo_put_matches_oct(self.h, lane, which, octave, _vp(m), len(m)), "svo_put_matches_oct")
 
-    def put_match_ids(self, lane, which, ids):
+    def put_match_ids(self, lane, which, ids, octave=0):
         ids = np.ascontiguousarray(ids, np.int32)
-        self._ck(self.L.svo_put_match_ids(self.h, lane, which, _vp(ids), len(ids)), "svo_put_match_ids")
+        self._ck(self.L.svo_put_match_ids_oct(self.h, lane, which, octave, _vp(ids), len(ids)), "svo_put_match_ids_oct")
 
     def put_tracked(self, lane, t):
         t = np.ascontiguousarray(t)

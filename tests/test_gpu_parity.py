@@ -705,3 +705,71 @@ def test_speculative_fast_threshold_and_its_fallback_match_oracle(golden_dir):
         n_redo_like += int(k not in (1,))
     assert n_redo_like >= 4
     ctx.close()
+
+
+def test_get_values_and_per_octave_precomputed_bypass():
+    """getValues in one synchronisation (svo_get_values) equals the individual getters; the precomputed-data bypass
+    (P:131-162, 219-251) per OCTAVE: a FAST+ORB context with two octaves fed another context's lists octave by octave
+    tracks and optimises to the same result."""
+    from stereo_vo_amd.abi import DM_FAST_ORB
+    W, H = 640, 480
+    w = SyntheticStereoWorld(W, H, 400.0, 0.12, seed=31, n_frames=3)
+    cam = w.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=600)
+    p.detect_method = DM_FAST_ORB; p.nOctaves = 2; p.vo_use_matches_ids = 1
+    a = hip.Context(n_lanes=2, max_w=W, max_h=H, max_kps=2048, max_cand=1 << 16, max_octaves=2)
+    b = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=2048, max_cand=1 << 16, max_octaves=2)
+    for c in (a, b):
+        c.set_params(p); c.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        L, R = [x.numpy() for x in w.render(t)]
+        a.process_host([(L, R), (R[:, ::-1].copy(), L[:, ::-1].copy())])
+        ro = orc.process(L, R, cam)
+        ra = a.result(0)
+        assert ra.status == 0 and ra.n_octaves == 2
+        for o in range(2):
+            kl, dl, kr, dr, m, ids = a.values(0, 0, o)
+            assert kl.tobytes() == a.keypoints(0, 0, 0, o)[0].tobytes() and (dl == a.keypoints(0, 0, 0, o)[1]).all()
+            assert kr.tobytes() == a.keypoints(0, 0, 1, o)[0].tobytes() and (dr == a.keypoints(0, 0, 1, o)[1]).all()
+            assert m.tobytes() == a.matches(0, 0, o).tobytes() and (ids == a.match_ids(0, 0, o)).all()
+            assert kl.tobytes() == orc.keypoints(0, 0, o)[0].tobytes() and m.tobytes() == orc.matches(0, o).tobytes()
+            assert len(kl) == ra.detected_left[o] and len(m) == ra.stereo_matches[o] and len(kl) > 50
+            if t:
+                pk = a.values(0, 1, o)
+                assert pk[0].tobytes() == a.keypoints(0, 1, 0, o)[0].tobytes() and pk[4].tobytes() == a.matches(0, 1, o).tobytes()
+            # hand this octave's lists to the other context
+            if o == 0:
+                b.L.svo_process(b.h, None, 0)                  # the shift of P:86-100
+            b.put_features(0, 0, 0, kl, dl, W, H, octave=o); b.put_features(0, 0, 1, kr, dr, W, H, octave=o)
+            b.put_matches(0, 0, m, octave=o); b.put_match_ids(0, 0, ids, octave=o)
+        b.run_stages(hip.RUN_TRACK | hip.RUN_OPTIMIZE)
+        rb = b.result(0)
+        assert (rb.valid, rb.error_code) == (ra.valid, ra.error_code) == (ro.valid, ro.error_code)
+        assert [rb.detected_left[o] for o in range(2)] == [ra.detected_left[o] for o in range(2)] and [rb.stereo_matches[o] for o in range(2)] == [ra.stereo_matches[o] for o in range(2)]
+        for o in range(2):
+            assert b.tracked(0, o).tobytes() == a.tracked(0, o).tobytes() == orc.tracked(o).tobytes()
+        if ra.valid:
+            assert np.abs(np.array(rb.outPose) - np.array(ra.outPose)).max() < 1e-9
+    a.close(); b.close()
+
+
+def test_capacity_overflow_is_reported_in_the_result_record(golden_dir):
+    """svo_result.status carries the capacity bits (the reference has no caps, stage2_detect.cpp:461-464): a context too
+    small for the requested keypoints says so in every result record instead of leaving it to a debug probe."""
+    g, cam, p = load_small(golden_dir)
+    q = p.copy(); q.orb_nfeats = 220
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=64, max_cand=1 << 15)
+    ctx.set_params(q); ctx.set_camera(cam)
+    try:
+        ctx.process_host([(g["L0"], g["R0"])])
+        r = ctx.result(0)
+        assert r.status & 2 and ctx.status_word(0) & 2
+    except hip.SvoError as e:          # or the geometry is refused outright: also an explicit error, not a silent cut
+        assert "capacity" in str(e)
+    ctx.close()
+    ok = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ok.set_params(p); ok.set_camera(cam)
+    ok.process_host([(g["L0"], g["R0"])])
+    assert ok.result(0).status == 0
+    ok.close()
