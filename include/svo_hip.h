@@ -191,6 +191,22 @@ int svo_projected_coords(svo_ctx* ctx, const svo_dmatch* pre_matches, int n_pre,
                          const svo_keypoint* pre_right, int n_right, const int32_t* tracked_first,
                          const svo_stereo_camera* cam, const double* change_pose6, float* pix, int cap);
 
+/* Frame-parallelism WITHIN one stream: consecutive frames of a stream dealt round-robin to several
+ * contexts (one GPU or several).  Stages 2-3 of a frame need only its images; stages 4-5 need the previous frame's lists
+ * and the members a call inherits from the one before (m_error for the recovery rule P:86-95, m_last_computed_pose
+ * S5:506-507, the match-ID counters H:735-742).  The owner of frame t-1 exports them once its stages 4-5 are enqueued,
+ * the owner of frame t imports them after its own stages 2-3 and before its stages 4-5:
+ *     owner(t):   svo_process(frames, SVO_RUN_DETECT | SVO_RUN_MATCH);            // overlaps owner(t-1)'s stages 4-5
+ *                 <wait for owner(t-1)'s export>  svo_import_frame(blob);
+ *                 svo_process(NULL, SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_FLAG_NO_SHIFT);  svo_export_frame(blob');
+ * The record is one flat DEVICE buffer of svo_handover_bytes() bytes (all lanes): hand it over device-to-device, or with
+ * ncclSend / ncclRecv between GPUs.  Both calls only enqueue on the context's stream; ordering between the two
+ * contexts' streams is the caller's (an event, or the send/recv pair).  The run equals the sequential one list for
+ * list and pose for pose: nothing is dropped, not even the warm start. */
+size_t svo_handover_bytes(const svo_ctx* ctx);
+int svo_export_frame(svo_ctx* ctx, void* dev_blob, size_t bytes);
+int svo_import_frame(svo_ctx* ctx, const void* dev_blob, size_t bytes);
+
 /* saveStateToFile / loadStateFromFile (H:184-185, C:475-543, C:261-350): the state of one lane in the reference's
  * binary layout -- npyr; then for PRE and CUR: left keypoints, right keypoints (count, then x y response size angle as
  * float and octave class_id as int per keypoint, then rows cols type and the descriptor bytes), pairings (count,

@@ -50,6 +50,7 @@ struct svo_ctx {
     DevCtx cip; bool cip_ready;
     // svo_get_values: device packing buffer and its page-locked host mirror
     uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
+    bool imported_pending;                             // svo_import_frame ran since the last svo_process
     // every stream that has had work of this context enqueued since the last full synchronisation (svo_set_stream)
     std::vector<hipStream_t> used_streams;
 };
@@ -165,6 +166,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
+    ctx->imported_pending = false;
     ctx->cip_ready = false; ctx->d_vals = nullptr; ctx->h_vals = nullptr; ctx->vals_bytes = 0;
     ctx->up_ready = false; ctx->up_slot = 0; ctx->det_slot = -1; ctx->s_copy = nullptr; ctx->slot_bytes = 0;
     for (int i = 0; i < 2; i++) { ctx->d_img0_ring[i] = nullptr; ctx->h_stage[i] = nullptr; ctx->ev_det_valid[i] = ctx->ev_h2d_valid[i] = false; }
@@ -721,7 +723,10 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         { Span s(ctx, KT_RANSAC_CNT2); launch_ransac_count(d, 2, st); }
         { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, win, st); }
     }
-    if (p.vo_use_matches_ids && (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK))) { Span s(ctx, KT_TRK_FINAL); launch_match_ids(d, flags, st); }
+    // (after svo_import_frame the lane may turn out to be at its stream's FIRST frame: the first-frame ID rule of S3:172-173
+    // then applies in this call although stage 3 ran in an earlier one)
+    if (p.vo_use_matches_ids && (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK))) { Span s(ctx, KT_TRK_FINAL); launch_match_ids(d, flags | (ctx->imported_pending ? SVO_RUN_MATCH : 0), st); }
+    ctx->imported_pending = false;
     if (flags & SVO_RUN_OPTIMIZE) {
         GNParams g; memset(&g, 0, sizeof(g));
         g.use_robust_kernel = p.use_robust_kernel; g.max_iters = p.max_iters; g.initial_max_iters = p.initial_max_iters; g.max_incr_cost = p.max_incr_cost;
@@ -1052,6 +1057,31 @@ extern "C" int svo_projected_coords(svo_ctx* ctx, const svo_dmatch* pre_matches,
     hipFree(d_in); hipFree(d_out);
     HIPCHECK(e);
     return nb;
+}
+
+// ---- frame hand-over between contexts (k_handover.hip) ----------------------------------------------------------
+extern "C" size_t svo_handover_bytes(const svo_ctx* ctx)
+{
+    return ctx ? handover_record_bytes(ctx->dc) * (size_t)ctx->dc.n_lanes * (size_t)ctx->dc.oct_cap : 0;
+}
+extern "C" int svo_export_frame(svo_ctx* ctx, void* dev_blob, size_t bytes)
+{
+    if (!ctx || !dev_blob || bytes < svo_handover_bytes(ctx)) return SVO_ERR_ARG;
+    if (!ctx->geom_ready) return SVO_ERR_STATE;
+    note_stream(ctx);
+    launch_export_frame(ctx->dc, (uint8_t*)dev_blob, ctx->stream);
+    HIPCHECK(hipGetLastError());
+    return SVO_OK;
+}
+extern "C" int svo_import_frame(svo_ctx* ctx, const void* dev_blob, size_t bytes)
+{
+    if (!ctx || !dev_blob || bytes < svo_handover_bytes(ctx)) return SVO_ERR_ARG;
+    if (!ctx->geom_ready) return SVO_ERR_STATE;
+    note_stream(ctx);
+    launch_import_frame(ctx->dc, (const uint8_t*)dev_blob, ctx->stream);
+    ctx->imported_pending = true;
+    HIPCHECK(hipGetLastError());
+    return SVO_OK;
 }
 
 // ---- saveStateToFile / loadStateFromFile (common.cpp:475-543, 261-350; helpers :88-255) --------------------------

@@ -22,6 +22,10 @@ struct PrepArgs {
     long long src_stride; int channels, w, h;
 };
 void launch_prepare(const PrepArgs& a, int n_img, hipStream_t st);
+// frame hand-over between contexts (k_handover.hip)
+size_t handover_record_bytes(const DevCtx& c);
+void launch_export_frame(const DevCtx& c, uint8_t* blob, hipStream_t st);
+void launch_import_frame(const DevCtx& c, const uint8_t* blob, hipStream_t st);
 void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_t* dst, hipStream_t st);
 void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned flags, hipStream_t st);
 void launch_resize(const DevCtx& c, int level, hipStream_t st);

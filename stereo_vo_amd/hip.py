@@ -28,6 +28,7 @@ EXPORTS = [
     "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
     "svo_get_values", "svo_put_features_oct", "svo_put_matches_oct", "svo_put_match_ids_oct",
+    "svo_handover_bytes", "svo_export_frame", "svo_import_frame",
     "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
 ]
 
@@ -189,6 +190,17 @@ class Context:
             fr[i].left = Image(l, w, h, stride)
             fr[i].right = Image(r, w, h, stride)
         self._ck(self.L.svo_process(self.h, fr, C.c_uint32((flags | FLAG_PINNED_IMAGES) & ~FLAG_DEVICE_IMAGES)), "svo_process")
+
+    def handover_bytes(self):
+        self.L.svo_handover_bytes.restype = C.c_size_t
+        return int(self.L.svo_handover_bytes(self.h))
+
+    def export_frame(self, dev_ptr, nbytes):
+        """Enqueue the hand-over record ("what the next call finds as its previous frame", all lanes) into device memory."""
+        self._ck(self.L.svo_export_frame(self.h, C.c_void_p(dev_ptr), C.c_size_t(nbytes)), "svo_export_frame")
+
+    def import_frame(self, dev_ptr, nbytes):
+        self._ck(self.L.svo_import_frame(self.h, C.c_void_p(dev_ptr), C.c_size_t(nbytes)), "svo_import_frame")
 
     def wait_upload(self):
         self._ck(self.L.svo_wait_upload(self.h), "svo_wait_upload")

@@ -123,3 +123,63 @@ class StreamBatch:
         for c in self.ctxs:
             c.close()
         self.ctxs = []
+
+
+class FrameParallelStream:
+    """ONE stereo stream (or one batch of `lanes` streams advancing together) whose consecutive frames are dealt
+    round-robin to `contexts` contexts (SURVEY.md 8e "Within ONE stream").  Context g = t % G runs stages 2-3 of frame t
+    on its own HIP stream as soon as it is free -- overlapping stages 2-5 of frame t-1 on the context before it -- then
+    imports the previous owner's hand-over record (svo_export_frame / svo_import_frame), runs stages 4-5 and exports its
+    own.  Same results as one context fed sequentially, bit for bit; frames per second are bounded by
+    max(stages 4-5 of one frame, a whole frame / G) instead of a whole frame.
+
+    On several GPUs the same protocol runs with one context per rank and the record sent rank g -> rank g + 1 with
+    torch.distributed send / recv (RCCL over xGMI): see tools/frame_parallel_ranks.py."""
+
+    def __init__(self, params, cam, width, height, lanes=1, contexts=2, device=0, max_kps=4096, max_cand=None, max_octaves=1):
+        self.W, self.H, self.G, self.lanes = width, height, contexts, lanes
+        self.dev = torch.device("cuda", device)
+        if max_cand is None:
+            max_cand = (1 << 18) if width * height > 2000000 else (1 << 17)
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(contexts)]
+        self.ctxs = []
+        for g in range(contexts):
+            c = hip.Context(n_lanes=lanes, max_w=width, max_h=height, max_kps=max_kps, device=device, stream=self.streams[g].cuda_stream,
+                            max_octaves=max_octaves, max_cand=max_cand)
+            c.set_params(params); c.set_camera(cam)
+            self.ctxs.append(c)
+        self.nbytes = self.ctxs[0].handover_bytes()
+        self.blobs = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.dev) for _ in range(contexts)]
+        self.exported = [torch.cuda.Event() for _ in range(contexts)]
+        self.rec = torch.zeros((contexts, lanes, C.sizeof(Result)), dtype=torch.uint8, device=self.dev)
+        self.t = 0
+
+    def push(self, ptrs, stride=None):
+        """Enqueue the next frame (ptrs[lane] = (left, right) device addresses).  Returns the context that owns it."""
+        stride = self.W if stride is None else stride
+        g, t = self.t % self.G, self.t
+        c, s = self.ctxs[g], self.streams[g]
+        c.process_device(ptrs, self.W, self.H, stride, hip.RUN_DETECT | hip.RUN_MATCH)            # stages 2-3: independent of every other frame
+        if t > 0:
+            gp = (t - 1) % self.G
+            s.wait_event(self.exported[gp])
+            c.import_frame(self.blobs[gp].data_ptr(), self.nbytes)
+        c.run_stages(hip.RUN_TRACK | hip.RUN_OPTIMIZE)
+        c.export_frame(self.blobs[g].data_ptr(), self.nbytes)
+        self.exported[g].record(s)
+        c.copy_results_async(self.rec[g].data_ptr(), self.lanes * C.sizeof(Result))
+        self.t += 1
+        return c
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.dev)
+        for c in self.ctxs:
+            c.wait()
+
+    def last_owner(self):
+        return self.ctxs[(self.t - 1) % self.G]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []

@@ -157,3 +157,75 @@ def test_host_fed_path_64_lanes_matches_oracle():
                     assert lists and flags and et < 1e-3 and er < 1e-4, (mode, i, g)
         ctx.wait_upload()
         batch.close()
+
+
+def test_frame_parallel_within_one_stream_equals_the_sequential_run(golden_dir):
+    """SURVEY.md 8e "Within ONE stream": frames dealt round-robin to two (and three) contexts, hand-over of the previous
+    frame's lists + inherited estimator members between them.  Every frame's lists, inlier lists and POSES equal the
+    sequential context's and the oracle's -- including across a failed frame (blank images -> voecBadTracking), after
+    which the recovery rule (P:86-89) makes the OLDER frame the previous one on whichever context comes next -- with
+    match-ID bookkeeping on."""
+    import torch
+    from stereo_vo_amd.pipeline import FrameParallelStream
+    from oracle import probe as PR
+    W, H = 640, 480
+    w = SyntheticStereoWorld(W, H, 400.0, 0.12, seed=41, n_frames=7, device=torch.device("cuda"))
+    cam = w.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=500)
+    p.vo_use_matches_ids = 1
+    frames = [w.render(t) for t in range(7)]
+    blank = (torch.full((H, W), 128, dtype=torch.uint8, device="cuda"), torch.full((H, W), 128, dtype=torch.uint8, device="cuda"))
+    seq_frames = [frames[0], frames[1], frames[2], blank, frames[3], frames[4], blank, blank, frames[5], frames[6]]
+    torch.cuda.synchronize()
+    orc = O_().Oracle(p)
+    seq = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    seq.set_params(p); seq.set_camera(cam)
+    ref = []
+    for (L, R) in seq_frames:
+        seq.process_device([(L.data_ptr(), R.data_ptr())], W, H, W)
+        r = seq.result(0)
+        ro = orc.process(L.cpu().numpy(), R.cpu().numpy(), cam)
+        d = PR.digest_of(seq, 0, r)
+        assert d == PR.digest_of(orc, 0, ro)
+        ref.append((d, list(r.outPose), seq.match_ids(0).tobytes(), r.tracked_feats_from_last_KF))
+    assert [d.error_code for d, _, _, _ in ref].count(5) >= 3 and sum(d.valid for d, _, _, _ in ref) >= 5
+    for G in (2, 3):
+        fp = FrameParallelStream(p, cam, W, H, lanes=1, contexts=G, max_kps=1024, max_cand=1 << 15)
+        # (a) pushed back to back, checked at the end ...
+        for (L, R) in seq_frames:
+            c = fp.push([(L.data_ptr(), R.data_ptr())])
+        fp.synchronize()
+        r = c.result(0)
+        assert PR.digest_of(c, 0, r) == ref[-1][0] and list(r.outPose) == ref[-1][1]
+        fp.close()
+        # (b) ... and frame by frame
+        fp = FrameParallelStream(p, cam, W, H, lanes=1, contexts=G, max_kps=1024, max_cand=1 << 15)
+        for i, (L, R) in enumerate(seq_frames):
+            c = fp.push([(L.data_ptr(), R.data_ptr())])
+            fp.synchronize()
+            r = c.result(0)
+            d = PR.digest_of(c, 0, r)
+            assert d == ref[i][0], (G, i, d.n, ref[i][0].n, d.error_code, ref[i][0].error_code)
+            assert list(r.outPose) == ref[i][1], (G, i)                     # the warm start travels with the record: identical poses
+            assert c.match_ids(0).tobytes() == ref[i][2] and r.tracked_feats_from_last_KF == ref[i][3], (G, i)
+        fp.close()
+    seq.close()
+
+
+def O_():
+    from oracle import oracle
+    return oracle
+
+
+def test_frame_parallel_across_two_ranks():
+    """The same hand-over between RANKS (torch.distributed send / recv of the record): two processes on this box's one
+    GPU, gloo (the nccl path needs one GPU per rank); rank 0 checks every frame against a sequential context."""
+    import json
+    env = dict(os.environ)
+    env.update({"FP_FORCE_DEVICE": "0", "FP_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+           os.path.join(ROOT, "tools", "frame_parallel_ranks.py"), "--frames", "9"]
+    pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+    line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["identical_to_sequential"] is True and line["frame_parallel_ranks"] == 2 and line["valid_frames"] >= 7
