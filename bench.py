@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--orb-nfeats", type=int, default=2000)
     ap.add_argument("--cpu-frames", type=int, default=64, help="upper bound on the frames per probe stream replayed on the CPU oracle (baseline timing + parity probe; 0 = skip)")
     ap.add_argument("--host-fed-steps", type=int, default=16, help="steps of the host-fed leg (page-locked host frames uploaded per step on the contexts' copy streams; 0 = skip); N=1 only")
+    ap.add_argument("--single-stream", type=int, default=1, help="1: also time ONE stream alone (plain launches, hipGraph replay, frames dealt to 2 / 3 contexts); N=1, config2 only")
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
@@ -265,6 +266,15 @@ def main():
             cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
         if world == 1 and args.host_fed_steps > 0:
             host_fed = host_fed_leg(args, batch, frames, dev)
+        single_stream = None
+        if world == 1 and args.single_stream and args.workload == "config2":
+            batch.synchronize()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                import single_stream_bench as SSB
+                single_stream = SSB.measure(W, H, args.orb_nfeats, n=120, device=local_rank)
+            except Exception as e:
+                single_stream = {"error": str(e)}
         line = {
             "metric": "stereo pairs/sec @%d×%d" % (W, H), "value": round(value, 2), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -277,6 +287,7 @@ def main():
             "pose_rmse_vs_cpu": pose_rmse,
             "parity_probe": parity_probe,
             "host_fed": host_fed,
+            "single_stream": single_stream,
             "path_hbm_frac": round(pair_bytes * value / 1e9 / HBM_PEAK_GBS, 5),
             "algorithmic_bytes_per_pair": int(pair_bytes),
             "valid_last_step": "%d/%d" % (n_valid, B),

@@ -122,6 +122,12 @@ int svo_wait(svo_ctx* ctx);
  * svo_host_alloc / svo_host_free hand out page-locked memory to callers that have no HIP headers; svo_host_register /
  * svo_host_unregister page-lock memory the caller already owns (e.g. a camera driver's frame buffers). */
 int svo_wait_upload(svo_ctx* ctx);
+/* One stream alone is bound by launch latency, not by its kernels (~30 launches per frame).  With graphs enabled, the
+ * kernel sequence of a svo_process call is captured once into a hipGraph -- per combination of stage flags, image ring slot
+ * and dynamic thresholds -- and replayed by one graph launch afterwards.  Images (host or device) then always pass
+ * through the context's two-slot ring, which gives the captured kernels fixed addresses.  Calls that run stage 1 on the
+ * device (rectification maps / BGR input) or have kernel timing on fall back to plain launches.  Same results. */
+int svo_use_graphs(svo_ctx* ctx, int enable);
 int svo_host_alloc(size_t bytes, void** out);
 int svo_host_free(void* p);
 int svo_host_register(void* p, size_t bytes);

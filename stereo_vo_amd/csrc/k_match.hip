@@ -395,94 +395,105 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K8b: the tracker's joint sequential filter (S4:145-160), exact, one wave per lane.
-// k is kept iff dL <= th and dR <= th and neither its left nor its right train index was taken by an EARLIER
-// KEPT k.  Earlier chunks of 64 are remembered in two LDS bitmaps; inside a chunk the chain is resolved in rank
-// order with ballot masks (same scheme as grid_nms_wave).  Also gathers the pixel pairs for the two RANSACs
-// (S4:181-189, 216-224).
+// K8b: the tracker's joint sequential filter (S4:145-160), exact, one 256-thread block per lane-octave.
+// Reference: walk k = 0, 1, ...; k is kept iff dL <= th and dR <= th and neither its left nor its right train index was
+// taken by an EARLIER KEPT k.  That is a greedy matching in index order, and it parallelises by rounds: among the still
+// undecided candidates, every k that is the smallest undecided claimant of BOTH its train indices (and whose train indices
+// are free) is kept at once -- everything earlier that competes for them has been decided, and decided means rejected,
+// or the index would not be free -- then every undecided k whose left or right index was just taken is rejected (by a
+// smaller kept k, as in the walk).  The smallest undecided k overall always qualifies, so a round always makes progress;
+// chains of conflicts are a handful long.  A thread owns k = tid, tid + 256, ... in registers; the per-train-index
+// minima live in LDS.  (One wave walking 64 entries at a time took 70 us; the rounds take a few.)
+// Also gathers the pixel pairs for the two RANSACs (S4:181-189, 216-224).
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_track_filter(DevCtx c)
+#define TF_ITEMS 16          // 256 threads x 16 >= max_kps (4096)
+__global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned* ltaken = (unsigned*)smem;                 // max_kps/32 words
-    unsigned* rtaken = ltaken + c.max_kps / 32;
-    __shared__ int chunk_tl[64], chunk_tr[64];
-    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, lane = threadIdx.x;
+    unsigned* firstL = (unsigned*)smem;                    // max_kps: smallest undecided k claiming left train index i
+    unsigned* firstR = firstL + c.max_kps;                 // max_kps
+    unsigned* takenL = firstR + c.max_kps;                 // max_kps / 32 bits
+    unsigned* takenR = takenL + c.max_kps / 32;
+    __shared__ int scan[40];
+    __shared__ int s_und;
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap, tid = threadIdx.x;
     if (vl % c.oct_cap >= c.n_oct) return;
     const LaneState& ls = c.lane[lane_id];
-    if (!ls.has_prev) { if (lane == 0) c.trk_nk[vl] = 0; return; }
+    if (!ls.has_prev) { if (tid == 0) c.trk_nk[vl] = 0; return; }
     const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
     const int npm = c.n_matches[vl * 2 + prev], ncm = c.n_matches[vl * 2 + cur];
-    if (npm <= 0 || ncm <= 0) { if (lane == 0) c.trk_nk[vl] = 0; return; }
-    for (int i = lane; i < c.max_kps / 32; i += 64) { ltaken[i] = 0; rtaken[i] = 0; }
-    // the walk below is sequential: stage the packed matcher results in LDS first so that no step of it waits on HBM
-    unsigned* pL = rtaken + c.max_kps / 32, *pR = pL + c.max_kps;
-    int* kq_l = (int*)(pR + c.max_kps);      // kept list, LDS copy: a global store inside the walk would make every
-                                             // workgroup-scope fence wait ~2 us for its write acknowledgement
-    {
-        const unsigned* gL = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 1) * c.max_kps;
-        const unsigned* gR = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 2) * c.max_kps;
-        for (int i = lane; i < npm; i += 64) { pL[i] = gL[i]; pR[i] = gR[i]; }
+    if (npm <= 0 || ncm <= 0) { if (tid == 0) c.trk_nk[vl] = 0; return; }
+    const unsigned* gL = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 1) * c.max_kps;
+    const unsigned* gR = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 2) * c.max_kps;
+    // state per owned k: 0 rejected, 1 kept, 2 undecided
+    unsigned tlr[TF_ITEMS]; unsigned char st[TF_ITEMS];
+#pragma unroll
+    for (int j = 0; j < TF_ITEMS; j++) {
+        const int k = tid + 256 * j;
+        tlr[j] = 0; st[j] = 0;
+        if (k < npm) {
+            const unsigned a = gL[k], b = gR[k];
+            tlr[j] = (a & 0xFFFFu) | (b << 16);                                   // tl | tr << 16
+            st[j] = ((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th) ? 0 : 2;      // S4:149
+        }
     }
-    __syncthreads();
+    for (int i = tid; i < c.max_kps / 32; i += 256) { takenL[i] = 0; takenR[i] = 0; }
+    const int n_items = (npm + 255) / 256;
+    for (;;) {
+        for (int i = tid; i < ncm; i += 256) { firstL[i] = 0xFFFFFFFFu; firstR[i] = 0xFFFFFFFFu; }
+        if (tid == 0) s_und = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TF_ITEMS; j++)
+            if (j < n_items && st[j] == 2) { atomicMin(&firstL[tlr[j] & 0xFFFFu], (unsigned)(tid + 256 * j)); atomicMin(&firstR[tlr[j] >> 16], (unsigned)(tid + 256 * j)); }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TF_ITEMS; j++)
+            if (j < n_items && st[j] == 2) {
+                const unsigned k = (unsigned)(tid + 256 * j), tl = tlr[j] & 0xFFFFu, tr = tlr[j] >> 16;
+                if (firstL[tl] == k && firstR[tr] == k) { st[j] = 1; atomicOr(&takenL[tl >> 5], 1u << (tl & 31)); atomicOr(&takenR[tr >> 5], 1u << (tr & 31)); }
+            }
+        __syncthreads();
+        bool und = false;
+#pragma unroll
+        for (int j = 0; j < TF_ITEMS; j++)
+            if (j < n_items && st[j] == 2) {
+                const unsigned tl = tlr[j] & 0xFFFFu, tr = tlr[j] >> 16;
+                if (((takenL[tl >> 5] >> (tl & 31)) & 1u) || ((takenR[tr >> 5] >> (tr & 31)) & 1u)) st[j] = 0; else und = true;
+            }
+        if (und) s_und = 1;
+        __syncthreads();
+        const int again = s_und;
+        __syncthreads();
+        if (!again) break;
+    }
+    // kept entries in ascending k: k = tid + 256 j is j-major, so one block scan per j
     const svo_dmatch* pm = c.matches + match_base(c, vl, prev), *cm = c.matches + match_base(c, vl, cur);
     const svo_keypoint* pkl = c.kps + feat_base(c, vl, prev, 0), *pkr = c.kps + feat_base(c, vl, prev, 1);
     const svo_keypoint* ckl = c.kps + feat_base(c, vl, cur, 0), *ckr = c.kps + feat_base(c, vl, cur, 1);
     int* kq = c.trk_kq + (long long)vl * c.max_kps;
     float* ptsL = c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4, *ptsR = c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4;
     int nk = 0;
-    for (int base = 0; base < npm; base += 64) {
-        const int k = base + lane;
-        int tl = -1 - lane, tr = -1 - lane;     // distinct dummies so that idle lanes never "conflict"
-        bool pass = false;
-        if (k < npm) {
-            const unsigned a = pL[k], b = pR[k];
-            tl = (int)(a & 0xFFFFu); tr = (int)(b & 0xFFFFu);
-            pass = !((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th);
-            if (pass && (((ltaken[tl >> 5] >> (tl & 31)) & 1u) || ((rtaken[tr >> 5] >> (tr & 31)) & 1u))) pass = false;
-        }
-        // conflicts with earlier lanes of the chunk.  This kernel runs ONE wave per lane, so every LDS or cross-lane
-        // permute round trip is fully exposed; v_readlane into SGPRs keeps the 63 comparisons pure ALU
-        unsigned long long conf = 0;
 #pragma unroll
-        for (int j = 0; j < 63; j++) {
-            const int ol = __builtin_amdgcn_readlane(tl, j), orr = __builtin_amdgcn_readlane(tr, j);
-            if (j < lane && (ol == tl || orr == tr)) conf |= 1ull << j;
+    for (int j = 0; j < TF_ITEMS; j++) {
+        if (j >= n_items) break;                                                    // block-uniform
+        const int keep = st[j] == 1 ? 1 : 0;
+        int tot;
+        const int off = block_exclusive_scan(keep, scan, &tot);
+        if (keep) {
+            const int o = nk + off, k = tid + 256 * j;
+            const int tl = (int)(tlr[j] & 0xFFFFu), tr = (int)(tlr[j] >> 16);
+            kq[o] = k;
+            const svo_dmatch mp = pm[k];
+            const svo_keypoint a = pkl[mp.queryIdx], b = ckl[cm[tl].queryIdx];
+            ptsL[o * 4] = a.x; ptsL[o * 4 + 1] = a.y; ptsL[o * 4 + 2] = b.x; ptsL[o * 4 + 3] = b.y;
+            const svo_keypoint e = pkr[mp.trainIdx], f = ckr[cm[tr].trainIdx];
+            ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
         }
-        bool undecided = pass;
-        unsigned long long acc_mask = 0;
-        for (;;) {
-            const unsigned long long und = __ballot(undecided);
-            if (!und) break;
-            bool acc_now = false;
-            if (undecided) {
-                if (conf & acc_mask) undecided = false;
-                else if (!(conf & und)) { acc_now = true; undecided = false; }
-            }
-            acc_mask |= __ballot(acc_now);
-        }
-        if ((acc_mask >> lane) & 1ull) {
-            atomicOr(&ltaken[tl >> 5], 1u << (tl & 31)); atomicOr(&rtaken[tr >> 5], 1u << (tr & 31));
-            kq_l[nk + __popcll(acc_mask & ((1ull << lane) - 1ull))] = k;
-        }
-        nk += __popcll(acc_mask);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        nk += tot;
+        __syncthreads();
     }
-    // the pixel pairs for the two RANSACs (S4:181-189, 216-224), gathered after the sequential walk so that the three
-    // levels of dependent global loads (match -> keypoint index -> keypoint) pipeline across all kept entries
-    __threadfence_block();
-    for (int o = lane; o < nk; o += 64) {
-        const int k = kq_l[o];
-        kq[o] = k;
-        const int tl = (int)(pL[k] & 0xFFFFu), tr = (int)(pR[k] & 0xFFFFu);
-        const svo_dmatch mp = pm[k];
-        const svo_keypoint a = pkl[mp.queryIdx], b = ckl[cm[tl].queryIdx];
-        ptsL[o * 4] = a.x; ptsL[o * 4 + 1] = a.y; ptsL[o * 4 + 2] = b.x; ptsL[o * 4 + 3] = b.y;
-        const svo_keypoint e = pkr[mp.trainIdx], f = ckr[cm[tr].trainIdx];
-        ptsR[o * 4] = e.x; ptsR[o * 4 + 1] = e.y; ptsR[o * 4 + 2] = f.x; ptsR[o * 4 + 3] = f.y;
-    }
-    if (lane == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; }
+    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -714,10 +725,12 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
     return e <= 1.0;
 }
 
-// inlier counts: 16 hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
+// inlier counts: RC_HB hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
 // a wave-uniform address (scalar loads into SGPRs: a VALU operand each, no LDS round trip per use).  The block's best
 // hypothesis then tightens rs_bound (see above), so that later blocks of the launch and the next chunk stop earlier.
-#define RC_HB 16
+// RC_HB hypotheses per block: 16 when many lanes fill the GPU anyway (one fetch of the points serves 16 matrices), 4 when a
+// few lanes leave it empty and the block's own latency is what a frame waits for
+template <int RC_HB>
 __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 {
     __shared__ int cnt_s[RC_HB];
@@ -997,7 +1010,7 @@ void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st)
 }
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes * c.oct_cap), dim3(64), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 3 * sizeof(unsigned), st, c);
+    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 2 * sizeof(unsigned), st, c);
 }
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
@@ -1007,7 +1020,8 @@ void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {
     const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
-    hipLaunchKernelGGL(k_ransac_count, dim3((nh + RC_HB - 1) / RC_HB, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    if (c.n_lanes * c.n_oct <= 8) hipLaunchKernelGGL(k_ransac_count<4>, dim3((nh + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else hipLaunchKernelGGL(k_ransac_count<16>, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {

@@ -51,10 +51,14 @@ struct svo_ctx {
     // svo_get_values: device packing buffer and its page-locked host mirror
     uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
     bool imported_pending;                             // svo_import_frame ran since the last svo_process
+    // svo_use_graphs: the kernel sequence of a frame captured once per (flags, ring slot, thresholds) and replayed
+    struct GraphEntry { uint32_t flags; int slot, fast_th, orb_th; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs; bool use_graphs;
     // every stream that has had work of this context enqueued since the last full synchronisation (svo_set_stream)
     std::vector<hipStream_t> used_streams;
 };
 
+static void drop_graphs(svo_ctx* ctx);
 static void note_stream(svo_ctx* ctx)
 {
     for (hipStream_t s : ctx->used_streams) if (s == ctx->stream) return;
@@ -166,7 +170,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
-    ctx->imported_pending = false;
+    ctx->imported_pending = false; ctx->use_graphs = false;
     ctx->cip_ready = false; ctx->d_vals = nullptr; ctx->h_vals = nullptr; ctx->vals_bytes = 0;
     ctx->up_ready = false; ctx->up_slot = 0; ctx->det_slot = -1; ctx->s_copy = nullptr; ctx->slot_bytes = 0;
     for (int i = 0; i < 2; i++) { ctx->d_img0_ring[i] = nullptr; ctx->h_stage[i] = nullptr; ctx->ev_det_valid[i] = ctx->ev_h2d_valid[i] = false; }
@@ -247,6 +251,7 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     if (!ctx) return;
     sync_all(ctx);                                        // work may still be running on a stream the caller switched away from
     for (void* p : ctx->allocs) hipFree(p);
+    for (auto& g : ctx->graphs) hipGraphExecDestroy(g.exec);
     if (ctx->h_vals) hipHostFree(ctx->h_vals);
     if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
     if (ctx->d_ham_q) hipFree(ctx->d_ham_q);
@@ -269,6 +274,7 @@ extern "C" int svo_set_params(svo_ctx* ctx, const svo_params* p)
     ctx->fast_th = p->initial_FAST_threshold;            // resetFASTThreshold (H:532, 661)
     ctx->orb_th = (int)p->orb_max_distance;              // resetORBThreshold (H:539, 662)
     ctx->geom_ready = false;
+    drop_graphs(ctx);
     return SVO_OK;
 }
 extern "C" int svo_get_params(const svo_ctx* ctx, svo_params* p) { if (!ctx || !p) return SVO_ERR_ARG; *p = ctx->params; return SVO_OK; }
@@ -390,6 +396,14 @@ static void resize_table(int src, int dst, int* idx, int* frac)
     }
 }
 
+static void drop_graphs(svo_ctx* ctx)
+{
+    if (ctx->graphs.empty()) return;
+    sync_all(ctx);
+    for (auto& g : ctx->graphs) hipGraphExecDestroy(g.exec);
+    ctx->graphs.clear();
+}
+
 static int ensure_geometry(svo_ctx* ctx, int w, int h)
 {
     const svo_params& p = ctx->params;
@@ -404,6 +418,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     if (nlev > SVO_MAX_LEVELS) return SVO_ERR_UNSUPPORTED;
     if (noct > ctx->dc.oct_cap) return SVO_ERR_CAPACITY;       // svo_config.max_octaves
     HIPCHECK(sync_all(ctx));
+    drop_graphs(ctx);
     DevCtx& d = ctx->dc;
     int lw[SVO_MAX_LEVELS], lh[SVO_MAX_LEVELS], quota[SVO_MAX_LEVELS]; float sc[SVO_MAX_LEVELS];
     d.fast_orb = fast_orb ? 1 : 0; d.n_oct = noct;
@@ -582,6 +597,14 @@ static int upload_frames(svo_ctx* ctx, const svo_frame* frames, int w, int h, bo
     return SVO_OK;
 }
 
+extern "C" int svo_use_graphs(svo_ctx* ctx, int enable)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    if (!enable) drop_graphs(ctx);
+    ctx->use_graphs = enable != 0;
+    return SVO_OK;
+}
+
 extern "C" int svo_wait_upload(svo_ctx* ctx)
 {
     if (!ctx) return SVO_ERR_ARG;
@@ -636,6 +659,18 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             }
             d.img0_pitch = (int)stride;
             if (prepare) { for (int i = 0; i < 2 * d.n_lanes; i++) prep.src[i] = ptrs[i]; prep.src_stride = stride; }
+            else if (ctx->use_graphs) {
+                // a captured frame reads fixed addresses: the images go to the ring slot first (device to device, same stream)
+                rc = ensure_upload(ctx); if (rc) return rc;
+                const int slot = ctx->up_slot; ctx->up_slot = slot ^ 1; ctx->det_slot = slot;
+                const size_t img_bytes = (size_t)ipitch * ctx->cfg.max_h;
+                for (int i = 0; i < 2 * d.n_lanes; i++) {
+                    uint8_t* dst = ctx->d_img0_ring[slot] + (size_t)i * img_bytes;
+                    HIPCHECK(hipMemcpy2DAsync(dst, ipitch, ptrs[i], (size_t)stride, (size_t)w, (size_t)h, hipMemcpyDeviceToDevice, st));
+                    ptrs[i] = dst;
+                }
+                d.img0_pitch = ipitch;
+            }
         } else if (!prepare) {
             rc = upload_frames(ctx, frames, w, h, (flags & SVO_FLAG_PINNED_IMAGES) != 0, st, ptrs); if (rc) return rc;
             d.img0_pitch = ipitch;
@@ -659,6 +694,24 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         }
     } else if (!ctx->geom_ready && (flags & (SVO_RUN_MATCH | SVO_RUN_OPTIMIZE))) return SVO_ERR_STATE;
     d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
+    // svo_use_graphs: the launches below are captured once into a hipGraph per (flags, ring slot, thresholds) and replayed:
+    // ~30 kernel launches of a frame become one graph launch (what bounds ONE stream is launch latency, not the kernels)
+    bool capturing = false;
+    const bool graph_ok = ctx->use_graphs && !prepare && !ctx->cfg.kernel_times && (!(flags & SVO_RUN_DETECT) || ctx->det_slot >= 0);
+    const uint32_t gflags = flags & ~(uint32_t)(SVO_FLAG_DEVICE_IMAGES | SVO_FLAG_PINNED_IMAGES);
+    const int gslot = (flags & SVO_RUN_DETECT) ? ctx->det_slot : -1;
+    if (graph_ok) {
+        const bool ids_first = p.vo_use_matches_ids && ctx->imported_pending;       // changes one kernel argument: not replayable
+        for (auto& g : ctx->graphs)
+            if (!ids_first && g.flags == gflags && g.slot == gslot && g.fast_th == ctx->fast_th && g.orb_th == ctx->orb_th) {
+                HIPCHECK(hipGraphLaunch(g.exec, st));
+                ctx->imported_pending = false;
+                if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) { HIPCHECK(hipEventRecord(ctx->ev_det[ctx->det_slot], st)); ctx->ev_det_valid[ctx->det_slot] = true; }
+                return SVO_OK;
+            }
+        if (!ids_first) { HIPCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); capturing = true; }
+    }
+    struct CaptureGuard { hipStream_t st; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; hipStreamEndCapture(st, &g); if (g) hipGraphDestroy(g); *on = false; } } } guard{ st, &capturing };
     { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); if (prepare) launch_prepare(prep, 2 * d.n_lanes, st); }
     if (flags & SVO_RUN_DETECT) {
         if (d.fast_orb) {       // stage2_detect.cpp:502-515 on the x1/2 octave pyramid
@@ -735,6 +788,17 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         g.kernel_param = p.kernel_param; g.min_mod_out_vector = p.min_mod_out_vector; g.residual_threshold = p.residual_threshold;
         if (p.use_custom_initial_pose) g.use_custom_initial_pose = 1;        // deltaPose = initial_estimation = zeros (S5:504-505, default argument H:1045)
         { Span s(ctx, KT_GN); launch_gauss_newton(d, g, st); }
+    }
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        capturing = false;
+        HIPCHECK(hipStreamEndCapture(st, &graph));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        HIPCHECK(e);
+        ctx->graphs.push_back({ gflags, gslot, ctx->fast_th, ctx->orb_th, exec });
+        HIPCHECK(hipGraphLaunch(exec, st));
     }
     // stage 2 is the only reader of the level-0 images: once it is through, the ring slot may take the next upload
     if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) {

@@ -29,7 +29,7 @@ EXPORTS = [
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
     "svo_get_values", "svo_put_features_oct", "svo_put_matches_oct", "svo_put_match_ids_oct",
     "svo_handover_bytes", "svo_export_frame", "svo_import_frame",
-    "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
+    "svo_use_graphs", "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
 ]
 
 
@@ -201,6 +201,10 @@ class Context:
 
     def import_frame(self, dev_ptr, nbytes):
         self._ck(self.L.svo_import_frame(self.h, C.c_void_p(dev_ptr), C.c_size_t(nbytes)), "svo_import_frame")
+
+    def use_graphs(self, enable=True):
+        """Capture each distinct svo_process call into a hipGraph and replay it (one launch per frame)."""
+        self._ck(self.L.svo_use_graphs(self.h, int(enable)), "svo_use_graphs")
 
     def wait_upload(self):
         self._ck(self.L.svo_wait_upload(self.h), "svo_wait_upload")

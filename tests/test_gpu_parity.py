@@ -773,3 +773,37 @@ def test_capacity_overflow_is_reported_in_the_result_record(golden_dir):
     ok.process_host([(g["L0"], g["R0"])])
     assert ok.result(0).status == 0
     ok.close()
+
+
+def test_graph_replay_matches_plain_launches(golden_dir):
+    """svo_use_graphs: a frame's kernel sequence captured into a hipGraph and replayed.  Host frames and device frames, the
+    repeat flag (a different flag word: its own graph), a threshold change (its own graph) and a parameter change (graphs
+    dropped) all give the oracle's lists."""
+    import torch
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    for device_images in (False, True):
+        ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+        ctx.set_params(p); ctx.set_camera(cam); ctx.use_graphs(True)
+        orc = O().Oracle(p)
+        seq = [(0, False, None), (1, False, None), (1, True, None), (2, False, None), (3, False, 50), (2, False, None), (1, False, None), (0, False, None)]
+        for i, (t, rep, orbth) in enumerate(seq):
+            L, R = g["L%d" % t], g["R%d" % t]
+            if orbth is not None:
+                ctx.set_orb_threshold(orbth); orc.set_orb_threshold(orbth)
+            flags = hip.RUN_ALL | (hip.FLAG_REPEAT if rep else 0)
+            if device_images:
+                dl, dr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+                torch.cuda.synchronize()
+                ctx.process_device([(dl.data_ptr(), dr.data_ptr())], W, H, W, flags)
+            else:
+                ctx.process_host([(L, R)], flags)
+            r = ctx.result(0)
+            ro = orc.process(L, R, cam, repeat=rep)
+            assert_same_frame(ctx, 0, orc, r, ro, "graph dev=%s i=%d" % (device_images, i))
+        q = p.copy(); q.orb_nfeats = 150
+        ctx.set_params(q); orc.set_params(q)
+        for t in (1, 2):
+            ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+            assert_same_frame(ctx, 0, orc, ctx.result(0), orc.process(g["L%d" % t], g["R%d" % t], cam), "graph after set_params t=%d" % t)
+        ctx.close()

@@ -1,30 +1,66 @@
 #!/usr/bin/env python3
-"""One stream, one context (the reference's own usage: one estimator per camera rig): frames/s and ms per frame."""
-import os, sys, time
+"""ONE stream (the reference's own usage: one estimator per camera rig, demo-main.cpp:210-220), 1280x960, ~2000 keypoints:
+ms per frame with plain launches, with the frame captured into a hipGraph (svo_use_graphs), and with consecutive frames
+dealt to two / three contexts (stereo_vo_amd.pipeline.FrameParallelStream).  Prints one JSON line."""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stereo_vo_amd import hip
 from stereo_vo_amd.abi import north_star_params
 from stereo_vo_amd.synth import SyntheticStereoWorld
-W, H = 1280, 960
-dev = torch.device("cuda", 0)
-w = SyntheticStereoWorld(W, H, 800.0, 0.12, seed=0, n_frames=6, device=dev)
-frames = [w.render(t) for t in range(6)]
-torch.cuda.synchronize()
-ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=4096, kernel_times=False, stream=torch.cuda.current_stream().cuda_stream)
-ctx.set_params(north_star_params(hip.default_params(), orb_nfeats=2000)); ctx.set_camera(w.camera())
-sched = [0, 1, 2, 3, 4, 5, 4, 3, 2, 1]
-def step(i):
-    L, R = frames[sched[i % 10]]
-    ctx.process_device([(L.data_ptr(), R.data_ptr())], W, H, W)
-for i in range(10): step(i)
-ctx.wait()
-N = 200
-t0 = time.perf_counter()
-for i in range(N): step(i)
-ctx.wait(); dt = time.perf_counter() - t0
-print("pipelined enqueue: %.3f ms/frame, %.0f pairs/s" % (1e3 * dt / N, N / dt))
-t0 = time.perf_counter()
-for i in range(N): step(i); r = ctx.result(0)
-dt = time.perf_counter() - t0
-print("result read back every frame: %.3f ms/frame, %.0f pairs/s (valid %d)" % (1e3 * dt / N, N / dt, r.valid))
+from stereo_vo_amd.pipeline import FrameParallelStream
+
+
+def measure(width=1280, height=960, orb_nfeats=2000, n=200, device=0, quiet=False):
+    W, H = width, height
+    dev = torch.device("cuda", device)
+    w = SyntheticStereoWorld(W, H, 800.0 * W / 1280.0, 0.12, seed=0, n_frames=6, device=dev)
+    frames = [w.render(t) for t in range(6)]
+    torch.cuda.synchronize()
+    p = north_star_params(hip.default_params(), orb_nfeats=orb_nfeats)
+    cam = w.camera()
+    sched = [0, 1, 2, 3, 4, 5, 4, 3, 2, 1]
+    out = {}
+
+    def run_ctx(graphs):
+        ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=4096, device=device)
+        ctx.set_params(p); ctx.set_camera(cam)
+        if graphs: ctx.use_graphs(True)
+        def step(i):
+            L, R = frames[sched[i % 10]]
+            ctx.process_device([(L.data_ptr(), R.data_ptr())], W, H, W)
+        for i in range(12): step(i)
+        ctx.wait()
+        t0 = time.perf_counter()
+        for i in range(n): step(12 + i)
+        ctx.wait(); dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for i in range(n // 2): step(i); r = ctx.result(0)
+        dl = time.perf_counter() - t1
+        poses = list(r.outPose); valid = int(r.valid)
+        ctx.close()
+        return 1e3 * dt / n, 1e3 * dl / (n // 2), valid, poses
+
+    out["plain_ms"], out["plain_result_every_frame_ms"], v0, p0 = run_ctx(False)
+    out["graph_ms"], out["graph_result_every_frame_ms"], v1, p1 = run_ctx(True)
+    out["graph_same_result"] = bool(v0 == v1 and p0 == p1)
+    for G in (2, 3):
+        fp = FrameParallelStream(p, cam, W, H, lanes=1, contexts=G)
+        def push(i):
+            L, R = frames[sched[i % 10]]
+            fp.push([(L.data_ptr(), R.data_ptr())])
+        for i in range(12): push(i)
+        fp.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n): push(12 + i)
+        fp.synchronize(); dt = time.perf_counter() - t0
+        out["frame_parallel_%dctx_ms" % G] = 1e3 * dt / n
+        fp.close()
+    out = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
+    out["frame_parallel_speedup_2ctx"] = round(out["plain_ms"] / out["frame_parallel_2ctx_ms"], 3)
+    out["workload"] = "one %dx%d stream, orb_nfeats %d, frames resident in HBM, %d frames enqueued back to back" % (W, H, orb_nfeats, n)
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps({"single_stream": measure()}))
