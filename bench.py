@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
     ap.add_argument("--det-priority", default="low", choices=["low", "high"])
+    ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
@@ -161,7 +162,7 @@ def main():
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
     NC = max(1, args.contexts)
     batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=bool(args.post_on_rest),
-                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves)
+                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams)
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
     ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
     gathered = torch.cuda.Event()

@@ -22,7 +22,7 @@ from .abi import Result
 
 class StreamBatch:
     def __init__(self, params, cam, width, height, lanes, contexts=1, device=0, schedule="pipelined", post_on_rest=False,
-                 det_priority="low", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None):
+                 det_priority="low", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1):
         assert contexts >= 1 and lanes % contexts == 0 and lanes // contexts <= hip.MAX_LANES, \
             "lanes must split evenly over the contexts, at most %d streams per context" % hip.MAX_LANES
         self.W, self.H, self.B, self.NC, self.Bc = width, height, lanes, contexts, lanes // contexts
@@ -39,7 +39,10 @@ class StreamBatch:
             c.set_params(params); c.set_camera(cam)
             self.ctxs.append(c)
         self.rec = torch.zeros((lanes, C.sizeof(Result)), dtype=torch.uint8, device=self.dev)
-        self.s_det = torch.cuda.Stream(self.dev, priority=-1 if det_priority == "high" else 0)
+        # det_streams > 1: the detect phases of consecutive contexts go to different streams, so that the latency-bound tail of
+        # one context's stage 2 (small pyramid levels, selection, NMS) overlaps the throughput kernels of the next one's
+        self.s_dets = [torch.cuda.Stream(self.dev, priority=-1 if det_priority == "high" else 0) for _ in range(max(1, det_streams))]
+        self.s_det = self.s_dets[0]
         self.s_rest = torch.cuda.Stream(self.dev, priority=0 if det_priority == "high" else -1)
         self.det_done = [torch.cuda.Event() for _ in range(contexts)]
         self.rest_done = [torch.cuda.Event() for _ in range(contexts)]
@@ -59,11 +62,12 @@ class StreamBatch:
             pk = ptrs[k * Bc:(k + 1) * Bc]
             proc = c.process_pinned if pinned_host else c.process_device
             if self.pipelined:
+                s_det = self.s_dets[k % len(self.s_dets)]
                 if not self.first:
-                    self.s_det.wait_event(self.rest_done[k])
-                c.set_stream(self.s_det.cuda_stream)
+                    s_det.wait_event(self.rest_done[k])
+                c.set_stream(s_det.cuda_stream)
                 proc(pk, self.W, self.H, stride, hip.RUN_DETECT | (hip.FLAG_DETECT_NO_POST if self.post_on_rest else 0))
-                self.det_done[k].record(self.s_det)
+                self.det_done[k].record(s_det)
                 self.s_rest.wait_event(self.det_done[k])
                 c.set_stream(self.s_rest.cuda_stream)
                 c.run_stages(self.REST)
