@@ -695,31 +695,11 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
             M[r][2] = (fv[3 * r] * t1x + fv[3 * r + 1] * t1y) + fv[3 * r + 2];
         }
         double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
-        double Fv[9];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
-            Fv[cc] = s2 * M[0][cc]; Fv[3 + cc] = s2 * M[1][cc];
-            Fv[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+            F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
+            F[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
         }
-#pragma unroll
-        for (int j = 0; j < 9; j++) F[j] = Fv[j];
-        // single-precision copy for k_ransac_count's screening pass, with the guards that make its verdicts safe (see there)
-        float* G = c.rs_F32 + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 12;
-        const double X = (double)c.W, Y = (double)c.H, u = 5.0 * 5.9604644775390625e-08;          // 5 roundings of 2^-24 per line coefficient
-        double aF[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) { G[j] = (float)Fv[j]; aF[j] = fabs(Fv[j]); }
-        // l = F x1 (rows of F), l' = F^T x2 (columns of F): absolute error bounds of the coefficients and of the distance numerator
-        const double eBa = u * (aF[0] * X + aF[1] * Y + aF[2]), eBb = u * (aF[3] * X + aF[4] * Y + aF[5]), eBc = u * (aF[6] * X + aF[7] * Y + aF[8]);
-        const double eAa = u * (aF[0] * X + aF[3] * Y + aF[6]), eAb = u * (aF[1] * X + aF[4] * Y + aF[7]), eAc = u * (aF[2] * X + aF[5] * Y + aF[8]);
-        const double EB = 2.0 * (X * eBa + Y * eBb + eBc), EA = 2.0 * (X * eAa + Y * eAb + eAc);
-        const double gB = fmax(1024.0 * EB, 4096.0 * fmax(eBa, eBb)), gA = fmax(1024.0 * EA, 4096.0 * fmax(eAa, eAb));
-        // the screening pass trusts a side only when |l|^2 >= guard^2 (then both error terms stay below 2^-10 |l|); a guard that
-        // does not fit a float, or is not finite, disables the screening for this hypothesis
-        const double dA = 1.02 * gA * gA, dB = 1.02 * gB * gB;
-        G[9] = (dA < 1e37 && dA == dA) ? (float)dA + 1e-37f : __builtin_inff();
-        G[10] = (dB < 1e37 && dB == dB) ? (float)dB + 1e-37f : __builtin_inff();
-        G[11] = 0.0f;
     }
 }
 
@@ -745,29 +725,6 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
     return e <= 1.0;
 }
 
-// Screening pass of the epipolar test in SINGLE precision: 1 = certainly an inlier, 0 = certainly an outlier, 2 = undecided
-// (the caller then runs fm_inlier, the oracle's double-precision arithmetic).  G = the hypothesis' matrix rounded to float,
-// then the two guards G[9], G[10] computed by k_ransac_hyp.  Why the verdicts are safe: the points are floats already; a
-// line coefficient a = F0 x + F1 y + F2 evaluated in float is off by at most u (|F0| X + |F1| Y + |F2|) =: e_a with
-// u = 5 * 2^-24 (matrix rounding + four operations), the numerator d = x' a + y' b + c by at most E = 2 (X e_a + Y e_b + e_c),
-// and |l|^2 = a^2 + b^2 relatively by 2^-10 once |l| >= 4096 max(e_a, e_b).  The guard demands |l| >= max(1024 E, 4096
-// max(e_a, e_b)) (squared, with 2 % slack), so that |d| is known to 2^-10 |l| and |l|^2 to 2^-10: a verdict is given only
-// when d^2 and |l|^2 differ by more than 2^-8 relatively, four times what those errors can move the ratio; a NaN or a
-// failed guard compares false everywhere and comes out undecided.  About one point in a few thousand is undecided.
-__device__ __forceinline__ int fm_screen(const float* G, float x1, float y1, float x2, float y2)
-{
-    const float aB = fmaf(G[0], x1, fmaf(G[1], y1, G[2])), bB = fmaf(G[3], x1, fmaf(G[4], y1, G[5])), cB = fmaf(G[6], x1, fmaf(G[7], y1, G[8]));
-    const float aA = fmaf(G[0], x2, fmaf(G[3], y2, G[6])), bA = fmaf(G[1], x2, fmaf(G[4], y2, G[7])), cA = fmaf(G[2], x2, fmaf(G[5], y2, G[8]));
-    const float denB = fmaf(aB, aB, bB * bB), denA = fmaf(aA, aA, bA * bA);
-    const float dB = fmaf(x2, aB, fmaf(y2, bB, cB)), dA = fmaf(x1, aA, fmaf(y1, bA, cA));
-    const float ddB = dB * dB, ddA = dA * dA;
-    const float lo = 1.0f - 0.00390625f, hi = 1.0f + 0.00390625f;
-    const bool okA = denA >= G[9], okB = denB >= G[10];
-    const bool inA = okA & (ddA <= denA * lo), inB = okB & (ddB <= denB * lo);
-    const bool outA = okA & (ddA >= denA * hi), outB = okB & (ddB >= denB * hi);
-    return (inA & inB) ? 1 : ((outA | outB) ? 0 : 2);
-}
-
 // inlier counts: RC_HB hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
 // a wave-uniform address (scalar loads into SGPRs: a VALU operand each, no LDS round trip per use).  The block's best
 // hypothesis then tightens rs_bound (see above), so that later blocks of the launch and the next chunk stop earlier.
@@ -785,10 +742,8 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
     if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 9;
-    const float* G = c.rs_F32 + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 12;
     if (tid < RC_HB) cnt_s[tid] = 0;
     __syncthreads();
-    const bool screen_off = c.debug_mode == 13;                             // ablation / cross-check: every test in double precision
     int cnt[RC_HB];
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) cnt[h] = 0;
@@ -799,28 +754,13 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int i = base + q * 256 + tid; p[q] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
         const int live = min(4, (n - base - tid + 255) / 256);            // this thread's points of the tile
-        const unsigned livem = (1u << max(live, 0)) - 1u;
-        unsigned long long undecided = 0;                                   // bit 4 h + q: hypothesis h, point q of this thread
 #pragma unroll
         for (int h = 0; h < RC_HB; h++) {
-            const float* Gh = G + 12 * h;
+            const double* Fh = F + 9 * h;
             int a = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {                                   // branch-free: dead points are masked by `livem`
-                const int s = screen_off ? 2 : fm_screen(Gh, p[q].x, p[q].y, p[q].z, p[q].w);
-                const unsigned lq = (livem >> q) & 1u;
-                a += (int)((unsigned)s & lq);
-                undecided |= (unsigned long long)(((unsigned)s >> 1) & lq) << (4 * h + q);
-            }
+            for (int q = 0; q < 4; q++) { const int v = fm_inlier(Fh, p[q].x, p[q].y, p[q].z, p[q].w); a += q < live ? v : 0; }
             cnt[h] += a;
-        }
-        // the few undecided tests go through the oracle's double-precision arithmetic, ONE copy of it (unrolled into the loops
-        // above it would be 64 copies: more code than the instruction cache holds); their verdicts go straight to the LDS counts
-        while (undecided) {
-            const int bit = __ffsll((long long)undecided) - 1, h = bit >> 2, q = bit & 3;
-            undecided &= undecided - 1;
-            const float4 pp = q == 0 ? p[0] : (q == 1 ? p[1] : (q == 2 ? p[2] : p[3]));
-            if (fm_inlier(F + 9 * h, pp.x, pp.y, pp.z, pp.w)) atomicAdd(&cnt_s[h], 1);
         }
     }
 #pragma unroll
