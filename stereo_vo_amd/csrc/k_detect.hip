@@ -1498,6 +1498,154 @@ __global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance
     if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = nacc;
 }
 
+// FAST+ORB with nmsmAdaptive (stage2_detect.cpp:599-606 applies m_adaptive_non_max_sup, S2:141-215, to whatever the
+// detector produced -- here ALL FAST corners of an octave, tens of thousands).  One 1024-thread block per (octave, image).
+// Reference: sort by (response desc, index asc); radius^2 of rank k1 = min over rank 0 and over the ranks k2 in [1, k1) with
+// resp_k1 < 0.9 resp_k2 of the float squared distance; sort by (radius desc, index asc); keep the first min(num_out, N).
+// No rank order is needed for the radii: 0.9 resp_k2 > resp_k1 already implies resp_k2 > resp_k1, i.e. k2 < k1, so the set
+// is "rank 0, plus every corner whose score passes the 0.9 test" -- and FAST responses are small integers, so a counting
+// sort by score lines those corners up as a PREFIX whose length depends on the score alone.  Squared pixel distances stay
+// below 2^24: the float arithmetic of the reference is exact integer arithmetic.  The first min(num_out, N) of the radius
+// order come from a radix select on the radius (ties at the cut-off by position), then one LDS sort of <= max_kps keys.
+// Scratch (global, per image): by_score[cand_total] (key of every corner, score-descending buckets), xy (their x | y << 16),
+// radius[cand_total].
+__global__ void __launch_bounds__(1024) k_fastorb_anms(DevCtx c, uint32_t* by_score_all, uint32_t* radius_all, uint32_t* xy_all, int KMAX)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = (unsigned long long*)smem;                  // KMAX (power of two >= cap)
+    __shared__ unsigned hist[256], start[256], prefix_len[256];
+    __shared__ int scan[40];
+    __shared__ unsigned sh[8];
+    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& g = c.lv[level];
+    unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
+    if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
+    const int cap = min(min(c.kps_to_detect[level], g.quota), c.max_kps);
+    const int actual = min((int)nc, cap);                                  // S2:151
+    if (actual <= 0) { if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = 0; return; }
+    const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
+    uint32_t* bs = by_score_all + (long long)img * c.cand_total + g.cand_off;
+    uint32_t* rad = radius_all + (long long)img * c.cand_total + g.cand_off;
+    uint32_t* xy = xy_all + (long long)img * c.cand_total + g.cand_off;
+    const uint32_t gw = (uint32_t)g.w;
+    // ---- counting sort by score, descending buckets; the strongest corner (largest key) found on the way ----
+    for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+    if (tid == 0) sh[0] = 0;
+    __syncthreads();
+    uint32_t kmax = 0;
+    for (unsigned i = tid; i < nc; i += 1024) { const uint32_t k = ck[i]; atomicAdd(&hist[k >> 24], 1u); kmax = max(kmax, k); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+    if ((tid & 63) == 0) atomicMax(&sh[0], kmax);
+    __syncthreads();
+    {
+        const int mine = tid < 256 ? (int)hist[255 - tid] : 0;            // thread t owns score 255 - t
+        int tot;
+        const int before = block_exclusive_scan(mine, scan, &tot);
+        if (tid < 256) start[255 - tid] = (unsigned)before;
+    }
+    __syncthreads();
+    // prefix_len[s] = number of corners b with (double)s < 0.9 * (double)score_b (S2:183): whole buckets, from the top
+    if (tid < 256) {
+        unsigned len = 0;
+        for (int sb = 255; sb >= 0; sb--) if ((double)(float)tid < 0.9 * (double)(float)sb) len = start[sb] + hist[sb]; else break;
+        prefix_len[tid] = len;
+    }
+    __syncthreads();
+    for (int i = tid; i < 256; i += 1024) hist[i] = 0;                     // reused as the buckets' fill counters
+    __syncthreads();
+    for (unsigned i = tid; i < nc; i += 1024) {
+        const uint32_t k = ck[i], pos = 0xFFFFFFu - (k & 0xFFFFFFu);
+        const unsigned sl = start[k >> 24] + atomicAdd(&hist[k >> 24], 1u);
+        bs[sl] = k; xy[sl] = (pos % gw) | ((pos / gw) << 16);              // the divisions once per corner, not once per distance
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t top = sh[0], tpos = 0xFFFFFFu - (top & 0xFFFFFFu);
+    const int tx = (int)(tpos % gw), ty = (int)(tpos / gw);
+    // ---- radius^2 of every corner (index = position in by_score) ----
+    for (unsigned i = tid; i < nc; i += 1024) {
+        const uint32_t k = bs[i];
+        uint32_t r = 0xFFFFFFFFu;                                          // the strongest corner: infinite radius (S2:167)
+        if (k != top) {
+            const uint32_t me = xy[i];
+            const int x = (int)(me & 0xFFFFu), y = (int)(me >> 16);
+            int best = (x - tx) * (x - tx) + (y - ty) * (y - ty);           // S2:176
+            const unsigned len = prefix_len[k >> 24];
+            for (unsigned j = 0; j < len; j++) {                           // every lane of a wave reads the same entry: broadcast loads
+                const uint32_t pj = xy[j];
+                const int dx = x - (int)(pj & 0xFFFFu), dy = y - (int)(pj >> 16);
+                best = min(best, dx * dx + dy * dy);                       // S2:185 (the strongest corner may be among them: same minimum)
+            }
+            r = (uint32_t)best;
+        }
+        rad[i] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the first `actual` of the (radius desc, position asc) order: radix select on the radius ----
+    unsigned prefix = 0, mask = 0, need = (unsigned)actual;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < nc; i += 1024) { const uint32_t r = rad[i]; if ((r & mask) == prefix) atomicAdd(&hist[(r >> shift) & 255u], 1u); }
+        __syncthreads();
+        const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+        int tot;
+        const int before = block_exclusive_scan(mine, scan, &tot);
+        if (tid < 256 && (unsigned)before < need && need <= (unsigned)(before + mine)) { sh[1] = prefix | ((unsigned)(255 - tid) << shift); sh[2] = need - (unsigned)before; }
+        __syncthreads();
+        prefix = sh[1]; need = sh[2]; mask |= 255u << shift;
+        __syncthreads();
+    }
+    const uint32_t rcut = prefix;          // radii > rcut are all in; `need` of the corners with radius == rcut, smallest positions first
+    // among the ties, the `need` smallest positions = the `need` LARGEST inverted positions (key & 0xFFFFFF): radix select again
+    unsigned p2 = 0, m2 = 0, need2 = need;
+    for (int shift = 16; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < nc; i += 1024) if (rad[i] == rcut) { const uint32_t ip = bs[i] & 0xFFFFFFu; if ((ip & m2) == p2) atomicAdd(&hist[(ip >> shift) & 255u], 1u); }
+        __syncthreads();
+        const int mine = tid < 256 ? (int)hist[255 - tid] : 0;
+        int tot;
+        const int before = block_exclusive_scan(mine, scan, &tot);
+        if (tid < 256 && (unsigned)before < need2 && need2 <= (unsigned)(before + mine)) { sh[3] = p2 | ((unsigned)(255 - tid) << shift); sh[4] = need2 - (unsigned)before; }
+        __syncthreads();
+        p2 = sh[3]; need2 = sh[4]; m2 |= 255u << shift;
+        __syncthreads();
+    }
+    const uint32_t ipcut = p2;             // ties with inverted position >= ipcut are in (positions are unique)
+    for (int i = tid; i < KMAX; i += 1024) keys[i] = 0;
+    if (tid == 0) sh[5] = 0;
+    __syncthreads();
+    for (unsigned i = tid; i < nc; i += 1024) {
+        const uint32_t r = rad[i], k = bs[i];
+        if (r > rcut || (r == rcut && (k & 0xFFFFFFu) >= ipcut)) {
+            const unsigned sl = atomicAdd(&sh[5], 1u);
+            // (radius desc, position asc): position asc == inverted position desc; the score rides along in the low byte
+            if (sl < (unsigned)KMAX) keys[sl] = ((unsigned long long)r << 32) | ((unsigned long long)(k & 0xFFFFFFu) << 8) | (k >> 24);
+        }
+    }
+    __syncthreads();
+    int P = 64; while (P < actual) P <<= 1;
+    bitonic_sort_lds<true>(keys, P);
+    for (int i = tid; i < actual; i += 1024) {
+        const unsigned long long e = keys[i];
+        const uint32_t pos = 0xFFFFFFu - (uint32_t)((e >> 8) & 0xFFFFFFu);
+        const long long o = (long long)img * c.raw_cap + g.slot_off + i;
+        c.lvl_pos[o] = (pos % gw) | ((pos / gw) << 16);
+        c.lvl_resp[o] = (float)(uint32_t)(e & 0xFFu);                      // cv::FAST response = score
+    }
+    if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = actual;
+}
+
+void launch_fastorb_anms(const DevCtx& c, uint32_t* scratch3, hipStream_t st)
+{
+    int kmax = 64; while (kmax < c.max_kps) kmax <<= 1;
+    const size_t one = (size_t)c.n_img * c.cand_total;
+    hipLaunchKernelGGL(k_fastorb_anms, dim3(c.n_levels, c.n_img), dim3(1024), (size_t)kmax * 8, st, c, scratch3, scratch3 + one, scratch3 + 2 * one, kmax);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------

@@ -50,6 +50,7 @@ struct svo_ctx {
     DevCtx cip; bool cip_ready;
     // svo_get_values: device packing buffer and its page-locked host mirror
     uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
+    uint32_t* d_anms;                                  // scratch of k_fastorb_anms (3 x n_img x cand_total), allocated on first use
     bool imported_pending;                             // svo_import_frame ran since the last svo_process
     // svo_use_graphs: the kernel sequence of a frame captured once per (flags, ring slot, thresholds) and replayed
     struct GraphEntry { uint32_t flags; int slot, fast_th, orb_th; hipGraphExec_t exec; };
@@ -170,7 +171,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
-    ctx->imported_pending = false; ctx->use_graphs = false;
+    ctx->imported_pending = false; ctx->use_graphs = false; ctx->d_anms = nullptr;
     ctx->cip_ready = false; ctx->d_vals = nullptr; ctx->h_vals = nullptr; ctx->vals_bytes = 0;
     ctx->up_ready = false; ctx->up_slot = 0; ctx->det_slot = -1; ctx->s_copy = nullptr; ctx->slot_bytes = 0;
     for (int i = 0; i < 2; i++) { ctx->d_img0_ring[i] = nullptr; ctx->h_stage[i] = nullptr; ctx->ev_det_valid[i] = ctx->ev_h2d_valid[i] = false; }
@@ -632,7 +633,6 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if ((flags & SVO_RUN_MATCH) && p.match_method != SVO_SM_DESC_BF && p.match_method != SVO_SM_DESC_RBR) return SVO_ERR_UNSUPPORTED;   // smSAD: out of scope
     if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF && p.ifm_method != SVO_IFM_DESC_WIN) return SVO_ERR_UNSUPPORTED;      // ifmSAD / optical flow: out of scope
     if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD && p.nmsMethod != SVO_NMS_ADAPTIVE) return SVO_ERR_ARG;          // S2:608
-    if (p.non_maximal_suppression && p.nmsMethod == SVO_NMS_ADAPTIVE && p.detect_method != SVO_DM_ORB) return SVO_ERR_UNSUPPORTED;  // adaptive NMS: ORB detector only
     if (p.min_distance < 2) return SVO_ERR_ARG;            // cell size 0 divides by zero in the reference (S2:331-332)
     DevCtx& d = ctx->dc;
     const hipStream_t st = ctx->stream;
@@ -717,7 +717,10 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         if (d.fast_orb) {       // stage2_detect.cpp:502-515 on the x1/2 octave pyramid
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
-            { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
+            if (p.non_maximal_suppression && p.nmsMethod == SVO_NMS_ADAPTIVE) {      // S2:599-606 on the FAST detector's output
+                if (!ctx->d_anms) HIPCHECK(dev_alloc(ctx, &ctx->d_anms, (size_t)3 * d.n_img * ctx->cand_total_alloc));
+                Span s(ctx, KT_SELECT); launch_fastorb_anms(d, ctx->d_anms, st);
+            } else { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, 0, st); }
             if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, 0, st); }
         } else {                // stage2_detect.cpp:458-497

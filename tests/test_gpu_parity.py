@@ -807,3 +807,37 @@ def test_graph_replay_matches_plain_launches(golden_dir):
             ctx.process_host([(g["L%d" % t], g["R%d" % t])])
             assert_same_frame(ctx, 0, orc, ctx.result(0), orc.process(g["L%d" % t], g["R%d" % t], cam), "graph after set_params t=%d" % t)
         ctx.close()
+
+
+def test_adaptive_nms_after_fast_orb_matches_oracle():
+    """stage2_detect.cpp:599-606 applies m_adaptive_non_max_sup to whatever detector ran: nmsmAdaptive on the FAST+ORB
+    detector's output (every FAST corner of every x1/2 octave), two octaves, three frames, two lanes."""
+    from stereo_vo_amd.abi import DM_FAST_ORB
+    W, H = 640, 480
+    w = SyntheticStereoWorld(W, H, 400.0, 0.12, seed=12, n_frames=3)
+    cam = w.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=400)
+    p.detect_method = DM_FAST_ORB; p.nOctaves = 2; p.nmsMethod = 1
+    ctx = hip.Context(n_lanes=2, max_w=W, max_h=H, max_kps=2048, max_cand=1 << 16, max_octaves=2)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orcs = [O().Oracle(p), O().Oracle(p)]
+    for t in range(3):
+        L, R = [x.numpy() for x in w.render(t)]
+        frames = [(L, R), (R[:, ::-1].copy(), L[:, ::-1].copy())]
+        ctx.process_host(frames)
+        for lane in range(2):
+            ro = orcs[lane].process(frames[lane][0], frames[lane][1], cam)
+            r = ctx.result(lane)
+            for o in range(2):
+                for side in (0, 1):
+                    k, d = ctx.keypoints(lane, 0, side, o)
+                    ko, do = orcs[lane].keypoints(0, side, o)
+                    assert len(k) == len(ko) and k.tobytes() == ko.tobytes() and (d == do).all(), (t, lane, o, side, len(k), len(ko))
+                assert ctx.matches(lane, 0, o).tobytes() == orcs[lane].matches(0, o).tobytes()
+                assert ctx.tracked(lane, o).tobytes() == orcs[lane].tracked(o).tobytes()
+            assert (r.valid, r.error_code) == (ro.valid, ro.error_code)
+            if ro.valid:
+                dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
+                assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD
+            assert ctx.status_word(lane) == 0 and r.detected_left[0] > 100
+    ctx.close()
