@@ -695,11 +695,25 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
             M[r][2] = (fv[3 * r] * t1x + fv[3 * r + 1] * t1y) + fv[3 * r + 2];
         }
         double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
+        double Fv[9];
 #pragma unroll
         for (int cc = 0; cc < 3; cc++) {
-            F[cc] = s2 * M[0][cc]; F[3 + cc] = s2 * M[1][cc];
-            F[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+            Fv[cc] = s2 * M[0][cc]; Fv[3 + cc] = s2 * M[1][cc];
+            Fv[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
         }
+#pragma unroll
+        for (int j = 0; j < 9; j++) F[j] = Fv[j];
+        // guards of the matrix-core line evaluation in k_ransac_count (see there): E bounds how far its numerators can be from
+        // the oracle's operation order, given coordinates inside the image; a side is trusted when |l| >= 2^28 E
+        double aF[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) aF[j] = fabs(Fv[j]);
+        const double X = (double)c.W, Y = (double)c.H, u = 1.7763568394002505e-15;          // 2^-49
+        const double EB = u * (X * (aF[0] * X + aF[1] * Y + aF[2]) + Y * (aF[3] * X + aF[4] * Y + aF[5]) + (aF[6] * X + aF[7] * Y + aF[8]));
+        const double EA = u * (X * (aF[0] * X + aF[3] * Y + aF[6]) + Y * (aF[1] * X + aF[4] * Y + aF[7]) + (aF[2] * X + aF[5] * Y + aF[8]));
+        double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 2;
+        const double gA = 268435456.0 * EA, gB = 268435456.0 * EB;
+        Gd[0] = gA * gA; Gd[1] = gB * gB;            // an overflow or a NaN here makes every comparison against it false: the side is never trusted
     }
 }
 
@@ -723,6 +737,82 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
     const double eA = ddA * sA, eB = ddB * sB;
     const double e = eA > eB ? eA : eB;
     return e <= 1.0;
+}
+
+// Inlier counts on the MATRIX CORES: the two epipolar lines of every (hypothesis, pair), l = F x1 and l' = F^T x2, are small
+// dense products -- [16 rows = 4 hypotheses x (a, b, c, -)] x [4 = (x, y, 1, 0)] x [16 pairs] -- i.e. one
+// v_mfma_f64_16x16x4_f64 each per wave and tile of 16 pairs, after which lane (g, j) holds (a, b, c) of hypothesis g for pair j
+// in its own registers (result layout, pinned on the hardware: row i of the 16x16 tile sits in register i / 4 of lane
+// j + 16 (i % 4); operands: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k).  What is left per test on the VALU is the two
+// norms, the two numerators and the comparisons: about 45 instructions against 78.
+// The matrix core sums its four products in an order of its own, so a, b, c can differ from the oracle's ((F0 x + F1 y) + F2)
+// in the last bits.  E (k_ransac_hyp, per hypothesis and side) bounds the resulting shift of a numerator for coordinates
+// inside the image; a side is trusted only when |l| >= 2^28 E, which keeps d to 2^-28 |l| and |l|^2 to 2^-28 relatively, and a
+// verdict is given only when d^2 and |l|^2 differ by more than 2^-26: anything closer, and any failed guard or NaN, replays the
+// oracle's own expression (fm_inlier).  In practice nothing is ever that close; the replay is there so that the counts are
+// the oracle's by construction.
+typedef double rc_d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
+{
+    __shared__ int cnt_s[16];
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int n = c.trk_nk[vl];
+    if (n < 8) return;
+    int* bound = c.rs_bound + vl * 2 + side;
+    if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
+    const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 9;
+    const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 2;
+    const int w = tid >> 6, l = tid & 63, k = l >> 4, j = l & 15;
+    // operand A of the two products: lane l holds row i = l % 16 = 4 r + g (component r of hypothesis g of this wave), column k
+    const int ga = l & 3, ra = (l & 15) >> 2;
+    const double* Fa = F + 9 * (4 * w + ga);
+    const bool liveA = ra < 3 && k < 3;
+    const double a1 = liveA ? Fa[3 * ra + k] : 0.0;            // F[r][k]:   l  = F   (x1 y1 1)
+    const double a2 = liveA ? Fa[3 * k + ra] : 0.0;            // F[k][r]:   l' = F^T (x2 y2 1)
+    // the hypothesis this lane evaluates: g = l / 16
+    const double* Fe = F + 9 * (4 * w + k);
+    const double dminA = Gd[2 * (4 * w + k)], dminB = Gd[2 * (4 * w + k) + 1];
+    const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
+    int cnt = 0;
+    for (int base = 0; base < n; base += 16) {
+        const int pi = base + j;
+        const float4 p = pts[min(pi, n - 1)];
+        const double x1 = (double)p.x, y1 = (double)p.y, x2 = (double)p.z, y2 = (double)p.w;
+        const double b1 = k == 0 ? x1 : (k == 1 ? y1 : (k == 2 ? 1.0 : 0.0));
+        const double b2 = k == 0 ? x2 : (k == 1 ? y2 : (k == 2 ? 1.0 : 0.0));
+        rc_d4 z = { 0.0, 0.0, 0.0, 0.0 };
+        const rc_d4 LB = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, z, 0, 0, 0);
+        const rc_d4 LA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, z, 0, 0, 0);
+        const double denB = LB[0] * LB[0] + LB[1] * LB[1], dB = (x2 * LB[0] + y2 * LB[1]) + LB[2];
+        const double denA = LA[0] * LA[0] + LA[1] * LA[1], dA = (x1 * LA[0] + y1 * LA[1]) + LA[2];
+        const double ddA = dA * dA, ddB = dB * dB;
+        const bool okA = denA >= dminA, okB = denB >= dminB;
+        const bool inA = okA & (ddA <= denA * lo), inB = okB & (ddB <= denB * lo);
+        const bool outA = okA & (ddA >= denA * hi), outB = okB & (ddB >= denB * hi);
+        int v = (inA & inB) ? 1 : 0;
+        if (__builtin_expect(!((inA & inB) | outA | outB) || c.debug_mode == 13, 0)) v = fm_inlier(Fe, p.x, p.y, p.z, p.w);
+        cnt += pi < n ? v : 0;
+    }
+    // the 16 lanes of a group hold the partial counts of one hypothesis
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xF, 0xF, false);
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xF, 0xF, false);
+    cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xF, 0xF, false);
+    if (j == 0) { cnt_s[4 * w + k] = cnt; c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0 + 4 * w + k] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        // only hypotheses this chunk really generated count: beyond rs_gen the F matrices are leftovers of an earlier frame
+        const int gen = c.rs_gen[vl * 2 + side];
+        int best = 0, best_h = 0;
+        for (int h = 0; h < 16; h++) if (cnt_s[h] > best && h0 + h < gen) { best = cnt_s[h]; best_h = h0 + h; }
+        const int cur = *(volatile int*)bound;
+        if (best > 8 && best_h + 1 < cur) {
+            const int K = ransac_niters(best - 1, n, cur);
+            if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
+        }
+    }
 }
 
 // inlier counts: RC_HB hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
@@ -1021,7 +1111,8 @@ void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {
     const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
     if (c.n_lanes * c.n_oct <= 8) hipLaunchKernelGGL(k_ransac_count<4>, dim3((nh + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
-    else hipLaunchKernelGGL(k_ransac_count<16>, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else if (c.debug_mode == 14) hipLaunchKernelGGL(k_ransac_count<16>, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else hipLaunchKernelGGL(k_ransac_count_mfma, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {

@@ -228,6 +228,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.trk_pts, (size_t)NV * 2 * MK * 4));
     HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)NV * 2 * SVO_RANSAC_PAD * 9));
+    HIPCHECK(dev_alloc(ctx, &d.rs_guard, (size_t)NV * 2 * SVO_RANSAC_PAD * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)NV * 2 * SVO_RANSAC_PAD));
     HIPCHECK(dev_alloc(ctx, &d.rs_bound, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_gen, (size_t)NV * 2));

@@ -131,6 +131,7 @@ struct DevCtx {
     int* trk_nk;              // [n_lanes]
     float* trk_pts;           // [n_lanes][2 sides][max_kps][4]  (x1,y1,x2,y2) for the F-matrix RANSAC
     double* rs_F;             // [n_lanes][2][PAD][9]
+    double* rs_guard;         // [n_lanes][2][PAD][2]  per hypothesis: the |l'|^2 and |l|^2 below which the matrix-core lines are not trusted
     int* rs_cnt;              // [n_lanes][2][PAD]
     int* rs_bound;            // [n_lanes][2]  upper limit of the hypotheses the sequential stop can still reach
     int* rs_gen;              // [n_lanes][2]  end of the hypotheses the current chunk generated

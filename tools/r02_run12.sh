@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 echo "tests rc=$?" >> gpurun_out/r02_tests.log
 tail -4 gpurun_out/r02_tests.log
 grep -E "^E  |Error" gpurun_out/r02_tests.log | head -20
-run() { name=$1; shift; ( timeout 900 python bench.py --cpu-frames 0 --host-fed-steps 0 --single-stream 0 "$@" ) > gpurun_out/r02_bench_$name.json 2>> gpurun_out/r02_bench_e.err
+run() { name=$1; shift; ( timeout 900 python bench.py --cpu-frames 0 --host-fed-steps 0 --single-stream 0 "$@" ) > gpurun_out/r02_bench_$name.json 2>> gpurun_out/r02_bench_f.err
 python - $name <<'PY'
 import json, sys
 f = "gpurun_out/r02_bench_%s.json" % sys.argv[1]
@@ -17,8 +17,6 @@ except Exception as e:
     print(f, "FAILED", e)
 PY
 }
-run e_3ctx
-run e_1ctx --contexts 1 --lanes 64
-SVO_DEBUG_MODE=13 run e_1ctx_noscreen --contexts 1 --lanes 64
-run e_3ctx_det2 --det-streams 2
-run e_4ctx_det2 --det-streams 2 --contexts 4 --lanes 256
+run f_1ctx --contexts 1 --lanes 64
+SVO_DEBUG_MODE=14 run f_1ctx_valu --contexts 1 --lanes 64
+run f_3ctx
