@@ -381,7 +381,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     // ---- (1) packed cardinal test: 30 rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + 15, gq) ----
     const uint32_t* T32 = (const uint32_t*)tile;
     const uint32_t th = (uint32_t)th_fast;
-    const u16x2 t2 = { (unsigned short)th, (unsigned short)th }, t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
+    const u16x2 t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
     const int r0 = tid / FT_NG, gq = tid - r0 * FT_NG;
     uint32_t pe[2] = { 0, 0 }, po[2] = { 0, 0 };                        // nonzero halves = passing positions
     if (tid < 15 * FT_NG) {
@@ -389,10 +389,15 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
         for (int k = 0; k < 2; k++) {
             const uint32_t* row = T32 + (r0 + 15 * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
             const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
-            const uint32_t E = __builtin_amdgcn_alignbyte(Cn, C, 3), W = __builtin_amdgcn_alignbyte(C, Cp, 1);
-            const uint32_t m8 = 0x00FF00FFu, m8h = 0xFF00FF00u;
-            pe[k] = quick_half(C & m8, N & m8, E & m8, S & m8, W & m8, t2);               // positions 0 (low half), 2 (high half)
-            po[k] = quick_half(C & m8h, N & m8h, E & m8h, S & m8h, W & m8h, t2h);         // positions 1, 3, values << 8
+            // The test compares 16-bit halves whose HIGH byte is the pixel of interest; the low byte is whatever sits next to it
+            // and only matters when the high bytes tie at exactly the threshold, where it can let a position through that the
+            // exact score then zeroes again (a false alarm, never a miss: 16-bit max / min order by the high byte first).  So no
+            // masking: positions 1, 3 are the high bytes of the registers as loaded, positions 0, 2 those of the same registers
+            // one byte further left -- E / W come out of the funnel shifter in that alignment directly (W is simply Cp).
+            const uint32_t Eo = __builtin_amdgcn_alignbyte(Cn, C, 3), Wo = __builtin_amdgcn_alignbyte(C, Cp, 1);
+            const uint32_t Ee = __builtin_amdgcn_alignbyte(Cn, C, 2);
+            pe[k] = quick_half(C << 8, N << 8, Ee, S << 8, Cp, t2h);                      // positions 0 (low half), 2 (high half)
+            po[k] = quick_half(C, N, Eo, S, Wo, t2h);                                     // positions 1, 3
         }
     }
     {   // compaction by ballots: eight 64-lane masks (two tasks x four positions), counts and prefixes on the scalar
