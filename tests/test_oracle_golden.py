@@ -77,11 +77,14 @@ def test_config1_plumbing_sequence_tracks_ground_truth():
             est = pose6_to_matrix(np.array(r.outPose))
             errs.append(pose_error(est, w.gt_delta(t)))
             pose = pose @ est
-    assert n_valid >= 18
+    assert n_valid == 19
     errs = np.array(errs)
-    assert np.median(errs[:, 0]) < 3e-3 and np.median(errs[:, 1]) < 0.03
+    # observed on this sequence (steps of 0.05-0.3 m, ~120 tracked pairs per frame): per-frame rotation error median 0.7 mrad /
+    # max 2.2 mrad, translation error median 5 mm / max 16 mm; after 19 chained steps 6 mrad and 52 mm.  Bounds = observed x 1.5
+    assert np.median(errs[:, 0]) < 1.1e-3 and errs[:, 0].max() < 3.3e-3
+    assert np.median(errs[:, 1]) < 7.7e-3 and errs[:, 1].max() < 0.025
     er, et = pose_error(pose, w.poses[19])
-    assert er < 0.03 and et < 0.35
+    assert er < 9e-3 and et < 0.078
 
 
 def test_oracle_extras_against_frozen_vectors(golden_dir):
