@@ -61,7 +61,8 @@ typedef struct svo_config {
     int32_t device;         /* HIP device ordinal */
     int32_t n_lanes;        /* 1..SVO_MAX_LANES independent estimator streams per launch */
     int32_t max_w, max_h;   /* largest image the context will see */
-    int32_t max_kps;        /* capacity of every keypoint / pairing list (power of two, <= 4096) */
+    int32_t max_kps;        /* capacity of every keypoint / pairing list per octave (power of two, <= 8192; above 4096 the NMS and
+                               Gauss-Newton kernels keep their sort / hash arrays in global memory instead of LDS: slower per lane) */
     int32_t max_cand;       /* capacity of the per-level FAST candidate list at level 0 (scaled by area above) */
     int32_t kernel_times;   /* 1: bracket every kernel with HIP events (svo_kernel_times) */
     int32_t max_octaves;    /* 1..4: octave lists per lane (params_rectify.nOctaves of the FAST+ORB mode); 1 suffices for ORB */

@@ -524,8 +524,8 @@ __global__ void __launch_bounds__(256) k_fast_redo(DevCtx c)
 // select on the unique 32-bit keys, compute the Harris response of each, sort by (response desc, position asc)
 // and keep the best quota.  One 512-thread block per (image, level).
 // ------------------------------------------------------------------------------------------------------------
-#define SEL_MAX SVO_SEL_MAX
-#define SEL_TIE_MAX (2 * SEL_MAX)      // LDS tie list: u32 entries aliasing the u64 key array
+// SEL_MAX = capacity of the 2 * quota list of a level (template parameter: 2048 in the usual configurations, 4096 for contexts
+// with max_kps > 4096); the LDS tie list holds 2 * SEL_MAX u32 entries aliasing the u64 key array
 
 __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x, int y)
 {
@@ -596,8 +596,10 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
 // the score that 1.5 x (2 * quota) + 32 of this frame's candidates reach, and when a frame's th' turns out too high
 // (fewer than 2 * quota found) it discards the list and queues the pair for k_fast_redo at the caller's threshold,
 // after which pass 1 of this kernel selects from the complete list.  Same lists as the oracle, bit for bit, either way.
+template <int SEL_MAX>
 __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
 {
+    constexpr int SEL_TIE_MAX = 2 * SEL_MAX;
     __shared__ unsigned long long keys[SEL_MAX];
     __shared__ uint32_t sel[SEL_MAX];
     __shared__ unsigned hist[256];
@@ -711,7 +713,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
     }
     // hand the K winners to k_harris: one CU gathering 868 x 9 scattered rows was bound by its own outstanding-request
     // budget (55 us of this kernel's 108), the whole GPU does it in a few
-    uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX;
+    uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
     for (unsigned i = tid; i < K; i += blockDim.x) gsel[i] = sel[i];
     if (tid == 0) c.sel_n[il] = (int)K;
 }
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(256) k_harris(DevCtx c)
     const int K = g.quota > 0 ? c.sel_n[img * SVO_MAX_LEVELS + level] : 0;
     if ((int)(blockIdx.y * 256) >= K) return;
     if (i >= K) return;
-    const long long o = ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX + i;
+    const long long o = ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max + i;
     const uint32_t pos = 0xFFFFFFu - (c.sel_keys[o] & 0xFFFFFFu);
     const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
@@ -739,9 +741,11 @@ __global__ void __launch_bounds__(256) k_harris(DevCtx c)
 // spaced, which suits the heavy-tailed Harris response), bucket sizes by LDS atomics, scan, scatter, and each key ranks
 // itself inside its bucket by full 64-bit compares.  Any bucket function monotone in the key gives the exact order.
 #define SS_NB 1024
+template <int SEL_MAX>
 __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
 {
-    __shared__ unsigned long long keys[SEL_MAX], tmp[SEL_MAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];          // keys[SEL_MAX] | tmp[SEL_MAX] (72 KB of LDS in all at SEL_MAX = 4096)
+    unsigned long long* keys = (unsigned long long*)ss_smem, *tmp = keys + SEL_MAX;
     __shared__ int cnt[SS_NB], off[SS_NB], scan_s[32];
     __shared__ unsigned s_mn, s_mx, s_mnp; __shared__ int s_np;
     const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
@@ -749,7 +753,7 @@ __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
     if (g.quota <= 0) return;
     const int K = c.sel_n[img * SVO_MAX_LEVELS + level];
     if (K <= 0) return;                                      // lvl_n was zeroed by k_select
-    const unsigned long long* gk = c.sel_resp + ((long long)img * SVO_MAX_LEVELS + level) * SEL_MAX;
+    const unsigned long long* gk = c.sel_resp + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
     if (tid == 0) { s_mn = 0xFFFFFFFFu; s_mx = 0u; s_mnp = 0xFFFFFFFFu; s_np = 0; }
     for (int i = tid; i < SS_NB; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
@@ -1020,20 +1024,26 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
 //   m_update_indexes(order=true) (stage2_detect.cpp:65-130): re-sort by (pt.y asc, rank asc).
 // Writes the final keypoints + descriptors of the lane's current slot.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX, int pre)
+// NI = keys per thread: 4 (lists up to 4096) or 8 (up to 8192)
+template <int NI>
+__global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX, int pre, uint8_t* big)
 {
     // dynamic LDS only (G17): keys[NS_MAX] u64 | hkey[2*NS_MAX] | hval[2*NS_MAX] | cellxy[NS_MAX] | acc_idx[NS_MAX] u16 | state[NS_MAX] u8 | scan[32] | flag
+    // Above 4096 keys that is more LDS than a CU has: the first four arrays (24 of the 27 bytes per key) then live in a global
+    // scratch region of this (image, octave) -- `big` -- and only the small ones stay in LDS.  Same code either way: barriers
+    // order a workgroup's global accesses as they order its LDS accesses, the atomics work on both.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NS_HASH = 2 * NS_MAX;
-    unsigned long long* keys = (unsigned long long*)smem;
+    const int img = blockIdx.x, oct = blockIdx.y, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
+    unsigned char* wide = big ? big + ((size_t)img * c.oct_cap + oct) * ((size_t)NS_MAX * 28) : smem;
+    unsigned long long* keys = (unsigned long long*)wide;
     uint32_t* hkey = (uint32_t*)(keys + NS_MAX);
     uint32_t* hval = hkey + NS_HASH;
     uint32_t* cellxy = hval + NS_HASH;
-    unsigned short* acc_idx = (unsigned short*)(cellxy + NS_MAX);          // raw index of the i-th survivor
+    unsigned short* acc_idx = (unsigned short*)(big ? smem : (unsigned char*)(cellxy + NS_MAX));          // raw index of the i-th survivor
     unsigned char* state = (unsigned char*)(acc_idx + NS_MAX);
-    int* scan = (int*)(state + NS_MAX);
+    int* scan = (int*)(((uintptr_t)(state + NS_MAX) + 15) & ~(uintptr_t)15);
     int* flag = scan + 32;
-    const int img = blockIdx.x, oct = blockIdx.y, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
     const int vl = lane_id * c.oct_cap + oct;
     const svo_keypoint* rk = c.raw_kps + (long long)img * c.raw_cap;
     // pre != 0 (ORB mode): this kernel runs BEFORE the describe kernel -- the reference's NMS needs positions and
@@ -1090,10 +1100,10 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         if (tid == 0) { red[0] = 0xFFFFFFFFu; red[1] = 0u; red[2] = 0xFFFFFFFFu; red[3] = 0u; }
         for (int i = tid; i < NB; i += blockDim.x) bcnt[i] = 0;
         __syncthreads();
-        unsigned long long mykey[4]; int myb[4], mypos[4];
+        unsigned long long mykey[NI]; int myb[NI], mypos[NI];
         unsigned l0 = 0xFFFFFFFFu, l1 = 0u, l2 = 0xFFFFFFFFu, l3 = 0u;
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NI; it++) {
             const int i = tid + it * (int)blockDim.x;
             mykey[it] = i < n ? keys[i] : 0ull;
             if (i < n) {
@@ -1116,7 +1126,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         const float bscale = (float)(NB - 1) / range;
         __syncthreads();                                                  // red[] is scan[]: free it before the scans below
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NI; it++) {
             const int i = tid + it * (int)blockDim.x;
             if (i < n) {
                 const unsigned h = (unsigned)(mykey[it] >> 32);
@@ -1136,10 +1146,10 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
             __syncthreads();
         }
 #pragma unroll
-        for (int it = 0; it < 4; it++) { const int i = tid + it * (int)blockDim.x; if (i < n) tmp[boff[myb[it]] + mypos[it]] = mykey[it]; }
+        for (int it = 0; it < NI; it++) { const int i = tid + it * (int)blockDim.x; if (i < n) tmp[boff[myb[it]] + mypos[it]] = mykey[it]; }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NI; it++) {
             const int i = tid + it * (int)blockDim.x;
             if (i < n) {
                 const int b0 = boff[myb[it]], nb = bcnt[myb[it]];
@@ -1212,7 +1222,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         }
         __syncthreads();
         if (c.debug_mode == 26) return;
-        grid_nms_block<4>(n, gly, cellxy, hkey, hval, NS_HASH, state, flag);
+        grid_nms_block<NI>(n, gly, cellxy, hkey, hval, NS_HASH, state, flag);
         if (c.debug_mode == 23) return;
         // survivors in rank order, at most num_out_points of them (S2:342)
         for (int base = 0; base < n && nacc < num_out_points; base += blockDim.x) {
@@ -1246,9 +1256,9 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
         unsigned long long* tmp = (unsigned long long*)hval;
         for (int r = tid; r < H; r += blockDim.x) rcnt[r] = 0;
         __syncthreads();
-        int myrow[4], mypos[4];                                           // nacc <= 4096 keys, 1024 threads
+        int myrow[NI], mypos[NI];                                         // nacc <= NI * 1024 keys, 1024 threads
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NI; it++) {
             const int i = tid + it * (int)blockDim.x;
             myrow[it] = -1; mypos[it] = 0;
             if (i < nacc) { const int r = min(max((int)inv_ord32((uint32_t)(keys[i] >> 32)), 0), H - 1); myrow[it] = r; mypos[it] = atomicAdd(&rcnt[r], 1); }
@@ -1265,13 +1275,13 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
             __syncthreads();
         }
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NI; it++) {
             const int i = tid + it * (int)blockDim.x;
             if (i < nacc) tmp[roff[myrow[it]] + mypos[it]] = keys[i];
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4; it++) {
+        for (int it = 0; it < NI; it++) {
             const int i = tid + it * (int)blockDim.x;
             if (i < nacc) {
                 const int r = myrow[it], b0 = roff[r], n_r = rcnt[r];
@@ -1679,12 +1689,16 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 
 void launch_select(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
+    const bool big = c.sel_max > 2048;
+    if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
+    else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
     // the pairs whose speculated FAST threshold was too high (normally none: both launches retire at once)
     hipLaunchKernelGGL(k_fast_redo, dim3(4096), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_select, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
-    hipLaunchKernelGGL(k_harris, dim3(c.n_img, SEL_MAX / 256, c.n_levels), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_select_sort, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c);
+    if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
+    else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
+    hipLaunchKernelGGL(k_harris, dim3(c.n_img, c.sel_max / 256, c.n_levels), dim3(256), 0, st, c);
+    if (big) hipLaunchKernelGGL(k_select_sort<4096>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)4096 * 16, st, c);
+    else hipLaunchKernelGGL(k_select_sort<2048>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)2048 * 16, st, c);
 }
 
 void launch_describe(const DevCtx& c, int pre, hipStream_t st)
@@ -1702,20 +1716,36 @@ static int nms_pmax(const DevCtx& c)
     if (c.fast_orb) { for (int l = 0; l < c.n_levels; l++) if (c.lv[l].quota > n) n = c.lv[l].quota; } else n = c.n_slots;
     int p = 64; while (p < n) p <<= 1; return p;
 }
-static size_t nms_rowsort_smem(int pmax) { return (size_t)pmax * (8 + 8 + 8 + 4 + 2 + 1) + 4 * 40; }
+static size_t nms_rowsort_smem(int pmax) { return pmax > 4096 ? (size_t)pmax * 3 + 16 + 4 * 40 : (size_t)pmax * (8 + 8 + 8 + 4 + 2 + 1) + 16 + 4 * 40; }
 static size_t fastorb_nms_smem(int pmax, int accmax) { return (size_t)pmax * (8 + 16 + 16 + 4 + 1) + (size_t)accmax * 4 + 4 * (256 + 32 + 8) + 16; }
+
+size_t nms_rowsort_scratch_bytes(const DevCtx& c)          // global scratch of k_nms_rowsort for lists above 4096 keys (0: everything fits LDS)
+{
+    const int pmax = nms_pmax(c);
+    return pmax > 4096 ? (size_t)c.n_img * c.oct_cap * (size_t)pmax * 28 : 0;
+}
 
 hipError_t configure_nms_rowsort(const DevCtx& c)
 {
     hipError_t e = hipFuncSetAttribute((const void*)k_fastorb_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fastorb_nms_smem(FO_PMAX, c.max_kps));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_nms_rowsort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(nms_pmax(c)));
+    int kmax = 64; while (kmax < c.max_kps) kmax <<= 1;
+    e = hipFuncSetAttribute((const void*)k_fastorb_anms, hipFuncAttributeMaxDynamicSharedMemorySize, kmax * 8);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_select_sort<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16);
+    if (e != hipSuccess) return e;
+    const int pmax = nms_pmax(c);
+    if (pmax > 8192) return hipErrorInvalidValue;
+    e = hipFuncSetAttribute((const void*)k_nms_rowsort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(8192));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_nms_rowsort<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(pmax > 4096 ? 4096 : pmax));
 }
 
 void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st)
 {
     const int pmax = nms_pmax(c);
-    hipLaunchKernelGGL(k_nms_rowsort, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0);
+    if (pmax > 4096) hipLaunchKernelGGL(k_nms_rowsort<8>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, c.big_scratch);
+    else hipLaunchKernelGGL(k_nms_rowsort<4>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, (uint8_t*)nullptr);
 }
 
 void launch_half(const DevCtx& c, int level, hipStream_t st)

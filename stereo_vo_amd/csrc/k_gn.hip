@@ -306,22 +306,25 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
+__global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P, uint8_t* big)
 {
     // dynamic LDS: { keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] } U red[28][256] f64 | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
+    // `big` (lists above 4096 tracks): the sort / hash arrays of the stage-5 NMS mask move to a global scratch region of the lane,
+    // LDS keeps the reduction buffer and the byte arrays
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int PM = P.pmax;
-    unsigned long long* keys = (unsigned long long*)smem;
+    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    unsigned long long* keys = (unsigned long long*)(big ? big + (size_t)lane_id * ((size_t)PM * 28) : smem);
     uint32_t* hkey = (uint32_t*)(keys + PM);
     uint32_t* hval = hkey + 2 * PM;
     uint32_t* cellxy = hval + 2 * PM;
     // the sort/hash arrays are dead once the NMS mask exists; the same bytes then hold the 28 x 256 reduction buffer
-    const size_t region = (size_t)PM * 28 > GN_RED_BYTES ? (size_t)PM * 28 : GN_RED_BYTES;
+    const size_t region = (!big && (size_t)PM * 28 > GN_RED_BYTES) ? (size_t)PM * 28 : GN_RED_BYTES;
     unsigned char* state = smem + region;
     unsigned char* mask = state + PM;
-    int* scan = (int*)(mask + PM);
+    int* scan = (int*)(((uintptr_t)(mask + PM) + 15) & ~(uintptr_t)15);
     GnShared& sh = *(GnShared*)(scan + 40);
-    const int lane_id = blockIdx.x, tid = threadIdx.x;
+    double* redbuf = (double*)smem;
     LaneState& ls = c.lane[lane_id];
     svo_result& res = c.results[lane_id];
     if (!P.standalone && (!ls.has_prev || ls.m_error == SVO_VOEC_BAD_TRACKING)) return;      // P:305, P:332
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     while (num_it < P.initial_max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it >= 1)) {
         pCost = cCost;
         if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }                // S5:296
-        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, (double*)keys);
+        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
         err_code = SVO_VOEC_NONE;                                                                                    // S5:299
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:380-386, 569-573
@@ -457,7 +460,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     while (num_it_final < P.max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it_final >= 1)) {
         pCost = cCost;
         if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }
-        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, (double*)keys);
+        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:670-675 (result.error_code untouched)
             if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }
@@ -486,7 +489,11 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P)
     }
 }
 
-static size_t gn_smem(int pmax) { const size_t region = (size_t)pmax * 28 > GN_RED_BYTES ? (size_t)pmax * 28 : GN_RED_BYTES; return region + (size_t)pmax * 2 + sizeof(int) * 40 + sizeof(GnShared) + 16; }
+static size_t gn_smem(int pmax)
+{
+    const size_t region = (pmax <= 4096 && (size_t)pmax * 28 > GN_RED_BYTES) ? (size_t)pmax * 28 : GN_RED_BYTES;
+    return region + (size_t)pmax * 2 + 16 + sizeof(int) * 40 + sizeof(GnShared) + 16;
+}
 
 hipError_t configure_gauss_newton(int pmax)
 {
@@ -495,7 +502,7 @@ hipError_t configure_gauss_newton(int pmax)
 
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P);
+    hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
 // minima live in LDS.  (One wave walking 64 entries at a time took 70 us; the rounds take a few.)
 // Also gathers the pixel pairs for the two RANSACs (S4:181-189, 216-224).
 // ------------------------------------------------------------------------------------------------------------
-#define TF_ITEMS 16          // 256 threads x 16 >= max_kps (4096)
+// TF_ITEMS x 256 threads >= max_kps: 16 (lists up to 4096) or 32
+template <int TF_ITEMS>
 __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1073,6 +1074,16 @@ __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 // ------------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------------
+// contexts with max_kps > 4096 need more than the default 64 KB of dynamic LDS in some of the per-lane kernels
+hipError_t configure_match(int max_kps)
+{
+    if (max_kps <= 4096) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void*)k_track_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(max_kps / 32) * 8 + (size_t)max_kps * 8));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_match_lr_rbr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * 2 * max_kps + sizeof(int) * 32));
+    return e;
+}
+
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
@@ -1100,7 +1111,9 @@ void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st)
 }
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_filter, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 2 * sizeof(unsigned), st, c);
+    const size_t sm = (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 2 * sizeof(unsigned);
+    if (c.max_kps > 4096) hipLaunchKernelGGL(k_track_filter<32>, dim3(c.n_lanes * c.oct_cap), dim3(256), sm, st, c);
+    else hipLaunchKernelGGL(k_track_filter<16>, dim3(c.n_lanes * c.oct_cap), dim3(256), sm, st, c);
 }
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {

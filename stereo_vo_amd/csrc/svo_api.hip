@@ -160,7 +160,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     if (!cfg || !out) return SVO_ERR_ARG;
     *out = nullptr;
     if (cfg->n_lanes < 1 || cfg->n_lanes > SVO_MAX_LANES || cfg->max_w < 64 || cfg->max_h < 64) return SVO_ERR_ARG;
-    if (cfg->max_kps < 64 || cfg->max_kps > 4096 || (cfg->max_kps & (cfg->max_kps - 1))) return SVO_ERR_ARG;   // LDS budget of the NMS / GN kernels
+    if (cfg->max_kps < 64 || cfg->max_kps > 8192 || (cfg->max_kps & (cfg->max_kps - 1))) return SVO_ERR_ARG;   // above 4096 the NMS / GN kernels keep their sort and hash arrays in global scratch
     if ((long long)cfg->max_w * cfg->max_h >= (1 << 24)) return SVO_ERR_UNSUPPORTED;      // position packs into 24 bits
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return SVO_ERR_NO_DEVICE;
@@ -205,8 +205,14 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     d.redo_list = d.redo_flag + (size_t)NI * SVO_MAX_LEVELS; d.redo_n = d.redo_list + (size_t)NI * SVO_MAX_LEVELS;
     HIPCHECK(dev_alloc(ctx, &d.lvl_pos, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * ctx->raw_cap_alloc));
-    HIPCHECK(dev_alloc(ctx, &d.sel_keys, (size_t)NI * SVO_MAX_LEVELS * SVO_SEL_MAX));
-    HIPCHECK(dev_alloc(ctx, &d.sel_resp, (size_t)NI * SVO_MAX_LEVELS * SVO_SEL_MAX));
+    d.sel_max = MK > 4096 ? 2 * SVO_SEL_MAX : SVO_SEL_MAX;
+    HIPCHECK(dev_alloc(ctx, &d.sel_keys, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
+    HIPCHECK(dev_alloc(ctx, &d.sel_resp, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
+    d.big_scratch = nullptr; d.gn_scratch = nullptr;
+    if (MK > 4096) {
+        HIPCHECK(dev_alloc(ctx, &d.big_scratch, (size_t)NI * OC * (size_t)MK * 28));
+        HIPCHECK(dev_alloc(ctx, &d.gn_scratch, (size_t)L * (size_t)MK * 28));
+    }
     HIPCHECK(dev_alloc(ctx, &d.sel_n, (size_t)NI * SVO_MAX_LEVELS));
     HIPCHECK(dev_alloc(ctx, &d.lvl_n, (size_t)NI * SVO_MAX_LEVELS));
     HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * ctx->raw_cap_alloc));
@@ -245,6 +251,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     d.bf_dist = nullptr;
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
     HIPCHECK(configure_gauss_newton(MK));
+    HIPCHECK(configure_match(MK));
     return SVO_OK;
 }
 
@@ -460,7 +467,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
             rtab.insert(rtab.end(), yi.begin(), yi.end()); rtab.insert(rtab.end(), yf.begin(), yf.end());
             rt_off += 2 * (g.w + g.h);
         }
-        if (!fast_orb && 2 * g.quota > 2048) return SVO_ERR_UNSUPPORTED;           // k_select LDS budget (SEL_MAX)
+        if (!fast_orb && 2 * g.quota > d.sel_max) return SVO_ERR_CAPACITY;         // k_select's list capacity (2048, 4096 with max_kps > 4096)
         if (fast_orb && g.quota > d.max_kps) return SVO_ERR_CAPACITY;               // one octave's list must fit max_kps
     }
     for (int l = nlev; l < SVO_MAX_LEVELS; l++) { memset(&d.lv[l], 0, sizeof(LevelGeom)); d.lv[l].tile_off = tile_off; d.lv[l].slot_off = slot_off; }

@@ -86,6 +86,9 @@ struct DevCtx {
     int max_h;                // row-index table pitch
     int img0_pitch;
     int max_kps, raw_cap, cand_total, n_tiles, n_slots;
+    int sel_max;              // capacity of a level's 2 * quota list (2048, or 4096 when max_kps > 4096)
+    uint8_t* big_scratch;     // global stand-in for the large LDS arrays of k_nms_rowsort when lists exceed 4096 entries
+    uint8_t* gn_scratch;      // the same for k_gauss_newton
     FastDiv div_tiles;        // / n_tiles
     int fast_th, orb_th;
     int debug_mode;           // SVO_DEBUG_MODE env (kernel ablations while tuning; 0 in production)

@@ -33,6 +33,7 @@ void launch_fast(const DevCtx& c, hipStream_t st);
 void launch_select(const DevCtx& c, hipStream_t st);
 void launch_describe(const DevCtx& c, int pre, hipStream_t st);
 hipError_t configure_nms_rowsort(const DevCtx& c);
+size_t nms_rowsort_scratch_bytes(const DevCtx& c);
 void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st);
 void launch_half(const DevCtx& c, int level, hipStream_t st);
 void launch_fastorb_anms(const DevCtx& c, uint32_t* scratch3, hipStream_t st);     // scratch3: 3 x n_img x cand_total words
@@ -48,5 +49,6 @@ void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st);
 void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st);
 void launch_hamming_plain(const uint8_t* q, int nq, const uint8_t* t, int nt, unsigned* out, int nsplit, hipStream_t st);
 hipError_t configure_gauss_newton(int pmax);
+hipError_t configure_match(int max_kps);
 void launch_project_points(const float* uvu, int n, const svo_stereo_camera& cam, const double* delta6, float* pix, hipStream_t st);
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st);

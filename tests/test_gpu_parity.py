@@ -841,3 +841,30 @@ def test_adaptive_nms_after_fast_orb_matches_oracle():
                 assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD
             assert ctx.status_word(lane) == 0 and r.detected_left[0] > 100
     ctx.close()
+
+
+def test_five_thousand_keypoints_in_one_octave():
+    """The reference has no keypoint cap (stage2_detect.cpp:461-464: orb_nfeats is free).  A single-octave ORB run asking
+    for 5000 keypoints (7500 before the NMS) on 2048x1536 needs lists above 4096 entries: max_kps = 8192, where the NMS and
+    Gauss-Newton kernels keep their sort / hash arrays in global scratch.  Three frames against the oracle, every list."""
+    W, H = 2048, 1536
+    w = SyntheticStereoWorld(W, H, 1280.0, 0.12, seed=51, n_frames=3)
+    cam = w.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=5000)
+    ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=8192, max_cand=1 << 18)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        L, R = [x.numpy() for x in w.render(t)]
+        ctx.process_host([(L, R)])
+        r, ro = ctx.result(0), orc.process(L, R, cam)
+        assert_same_frame(ctx, 0, orc, r, ro, "5000 kps t=%d" % t)
+        assert r.status == 0 and r.detected_left[0] > 4096, (r.status, r.detected_left[0])
+    assert r.valid and r.tracked_feats_from_last_frame > 300
+    ctx.close()
+    # the same request against a 4096-entry context is refused outright (capacity), not cut silently
+    small = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=4096, max_cand=1 << 18)
+    small.set_params(p); small.set_camera(cam)
+    with pytest.raises(hip.SvoError, match="capacity"):
+        small.process_host([(L, R)])
+    small.close()
