@@ -100,6 +100,8 @@ int svo_get_orb_threshold(const svo_ctx* ctx);
  * this is what lets a caller run stage 2 of one context on a normal-priority stream and stages 3-5 of another on a
  * high-priority one (bench.py). */
 int svo_set_stream(svo_ctx* ctx, void* stream);
+/* the hipStream_t later calls enqueue on (so that a caller can order its own work -- an RCCL call, an event -- after a frame) */
+int svo_get_stream(svo_ctx* ctx, void** stream);
 /* request_data.stereo_cam (H:211), per lane; lane = -1 sets every lane */
 int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam);
 /* Stage 1 on the device (stage1_rectify.cpp:47-85).  Rectification maps of one camera of one lane (lane = -1: every

@@ -117,6 +117,13 @@ extern "C" const char* svo_strerror(int s)
         default: return "unknown status";
     }
 }
+// Every entry point runs on the context's GPU whatever device the calling thread had current (a host may own one
+// estimator per GPU and call them from one thread, or from one thread each: SURVEY.md 8b "Threading")
+static inline void use_device(const svo_ctx* ctx)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->cfg.device) (void)hipSetDevice(ctx->cfg.device);
+}
 extern "C" const char* svo_last_error(const svo_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 extern "C" void svo_abi_sizes(int32_t* out)
@@ -257,6 +264,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
 
 extern "C" void svo_destroy(svo_ctx* ctx)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return;
     sync_all(ctx);                                        // work may still be running on a stream the caller switched away from
     for (void* p : ctx->allocs) hipFree(p);
@@ -278,6 +286,7 @@ extern "C" void svo_destroy(svo_ctx* ctx)
 
 extern "C" int svo_set_params(svo_ctx* ctx, const svo_params* p)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !p) return SVO_ERR_ARG;
     ctx->params = *p;
     ctx->fast_th = p->initial_FAST_threshold;            // resetFASTThreshold (H:532, 661)
@@ -289,6 +298,7 @@ extern "C" int svo_set_params(svo_ctx* ctx, const svo_params* p)
 extern "C" int svo_get_params(const svo_ctx* ctx, svo_params* p) { if (!ctx || !p) return SVO_ERR_ARG; *p = ctx->params; return SVO_OK; }
 extern "C" int svo_set_fast_threshold(svo_ctx* ctx, int v)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     const int lo = ctx->params.fast_min_th, hi = ctx->params.fast_max_th, m = v > lo ? v : lo;
     ctx->fast_th = hi < m ? hi : m;
@@ -296,6 +306,7 @@ extern "C" int svo_set_fast_threshold(svo_ctx* ctx, int v)
 }
 extern "C" int svo_set_orb_threshold(svo_ctx* ctx, int v)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     const int lo = ctx->params.orb_min_th, hi = ctx->params.orb_max_th, m = v > lo ? v : lo;
     ctx->orb_th = hi < m ? hi : m;
@@ -306,14 +317,18 @@ extern "C" int svo_get_orb_threshold(const svo_ctx* ctx) { return ctx ? ctx->orb
 
 extern "C" int svo_set_stream(svo_ctx* ctx, void* stream)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     if (stream) ctx->stream = (hipStream_t)stream;
     else ctx->stream = ctx->stream0;
     return SVO_OK;
 }
 
+extern "C" int svo_get_stream(svo_ctx* ctx, void** stream) { if (!ctx || !stream) return SVO_ERR_ARG; *stream = (void*)ctx->stream; return SVO_OK; }
+
 extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !cam || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     HIPCHECK(sync_all(ctx));
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
@@ -323,6 +338,7 @@ extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* c
 
 extern "C" int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float* map_x, const float* map_y, int w, int h)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes || side < 0 || side > 1 || ((map_x == nullptr) != (map_y == nullptr))) return SVO_ERR_ARG;
     const int NI = 2 * ctx->cfg.n_lanes;
     if (map_x && (w <= 0 || h <= 0 || w > ctx->cfg.max_w || h > ctx->cfg.max_h || (ctx->n_maps > 0 && (w != ctx->map_w || h != ctx->map_h)))) return SVO_ERR_ARG;
@@ -366,6 +382,7 @@ extern "C" int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float
 
 extern "C" int svo_reset(svo_ctx* ctx, int lane)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     HIPCHECK(sync_all(ctx));
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
@@ -507,6 +524,7 @@ static void collect_spans(svo_ctx* ctx)
 
 extern "C" int svo_wait(svo_ctx* ctx)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     HIPCHECK(sync_all(ctx));
     collect_spans(ctx);
@@ -515,6 +533,7 @@ extern "C" int svo_wait(svo_ctx* ctx)
 
 extern "C" int svo_kernel_times(svo_ctx* ctx, const char** names, double* total_ms, int64_t* calls, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     for (int i = 0; i < KT_COUNT && i < cap; i++) { if (names) names[i] = kt_names[i]; if (total_ms) total_ms[i] = ctx->kt_total[i]; if (calls) calls[i] = ctx->kt_calls[i]; }
@@ -522,6 +541,7 @@ extern "C" int svo_kernel_times(svo_ctx* ctx, const char** names, double* total_
 }
 extern "C" int svo_kernel_times_select(svo_ctx* ctx, const char* name)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     if (!name || !*name) { ctx->kt_mask = 0xFFFFFFFFu; return SVO_OK; }
     for (int i = 0; i < KT_COUNT; i++) if (!strcmp(name, kt_names[i])) { ctx->kt_mask = 1u << i; return SVO_OK; }
@@ -530,6 +550,7 @@ extern "C" int svo_kernel_times_select(svo_ctx* ctx, const char* name)
 
 extern "C" int svo_kernel_times_reset(svo_ctx* ctx)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     for (int i = 0; i < KT_COUNT; i++) { ctx->kt_total[i] = 0; ctx->kt_calls[i] = 0; }
@@ -608,6 +629,7 @@ static int upload_frames(svo_ctx* ctx, const svo_frame* frames, int w, int h, bo
 
 extern "C" int svo_use_graphs(svo_ctx* ctx, int enable)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     if (!enable) drop_graphs(ctx);
     ctx->use_graphs = enable != 0;
@@ -616,6 +638,7 @@ extern "C" int svo_use_graphs(svo_ctx* ctx, int enable)
 
 extern "C" int svo_wait_upload(svo_ctx* ctx)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     if (ctx->up_ready) HIPCHECK(hipStreamSynchronize(ctx->s_copy));
     return SVO_OK;
@@ -633,6 +656,7 @@ extern "C" int svo_host_unregister(void* p) { return (p && hipHostUnregister(p) 
 // ---- processNewImagePair ---------------------------------------------------------------------------------
 extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags)
 {
+    if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
     const svo_params& p = ctx->params;
     // P:54-76: invalid selectors are hard errors; the variants outside the hot path are refused explicitly
@@ -830,6 +854,7 @@ static int slot_of(const LaneState& s, int which) { return which ? s.prev_slot :
 
 extern "C" int svo_get_results(svo_ctx* ctx, svo_result* res)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !res) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     HIPCHECK(hipMemcpy(res, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToHost));
@@ -837,6 +862,7 @@ extern "C" int svo_get_results(svo_ctx* ctx, svo_result* res)
 }
 extern "C" int svo_copy_results_async(svo_ctx* ctx, void* dst, size_t bytes)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !dst || bytes < sizeof(svo_result) * (size_t)ctx->cfg.n_lanes) return SVO_ERR_ARG;
     note_stream(ctx);
     HIPCHECK(hipMemcpyAsync(dst, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -844,6 +870,7 @@ extern "C" int svo_copy_results_async(svo_ctx* ctx, void* dst, size_t bytes)
 }
 extern "C" int svo_get_result(svo_ctx* ctx, int lane, svo_result* res)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !res || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     HIPCHECK(hipMemcpy(res, ctx->dc.results + lane, sizeof(svo_result), hipMemcpyDeviceToHost));
@@ -852,6 +879,7 @@ extern "C" int svo_get_result(svo_ctx* ctx, int lane, svo_result* res)
 
 extern "C" int svo_get_keypoints_oct(svo_ctx* ctx, int lane, int which, int side, int octave, svo_keypoint* kps, uint8_t* desc, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     if (which ? !s.has_prev : !s.has_cur) return 0;
@@ -866,11 +894,13 @@ extern "C" int svo_get_keypoints_oct(svo_ctx* ctx, int lane, int which, int side
 }
 extern "C" int svo_get_keypoints(svo_ctx* ctx, int lane, int which, int side, svo_keypoint* kps, uint8_t* desc, int cap)
 {
+    if (ctx) use_device(ctx);
     return svo_get_keypoints_oct(ctx, lane, which, side, 0, kps, desc, cap);
 }
 
 extern "C" int svo_get_row_index(svo_ctx* ctx, int lane, int which, int side, int octave, int32_t* idx, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave, H = ctx->dc.oh[octave];
@@ -881,6 +911,7 @@ extern "C" int svo_get_row_index(svo_ctx* ctx, int lane, int which, int side, in
 
 extern "C" int svo_get_matches_oct(svo_ctx* ctx, int lane, int which, int octave, svo_dmatch* mm, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     if (which ? !s.has_prev : !s.has_cur) return 0;
@@ -896,6 +927,7 @@ extern "C" int svo_get_matches(svo_ctx* ctx, int lane, int which, svo_dmatch* mm
 // ---- getValues in one synchronisation (H:704-724) ---------------------------------------------------------------
 extern "C" int svo_get_values(svo_ctx* ctx, int lane, int which, int octave, svo_values* v)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !v || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap || v->cap_kps < 0 || v->cap_matches < 0) return SVO_ERR_ARG;
     const int MK = ctx->dc.max_kps;
     if (!ctx->d_vals) {
@@ -929,6 +961,7 @@ extern "C" int svo_get_values(svo_ctx* ctx, int lane, int which, int octave, svo
 
 extern "C" int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int octave, int32_t* idx, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     const int slot = slot_of(s, which), vl = lane * ctx->dc.oct_cap + octave, H1 = ctx->dc.oh[octave] + 1;
@@ -939,6 +972,7 @@ extern "C" int svo_get_matches_row_index(svo_ctx* ctx, int lane, int which, int 
 
 extern "C" int svo_get_tracked_oct(svo_ctx* ctx, int lane, int octave, svo_index_pair* t, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     const int vl = lane * ctx->dc.oct_cap + octave;
@@ -952,6 +986,7 @@ extern "C" int svo_get_tracked(svo_ctx* ctx, int lane, svo_index_pair* t, int ca
 
 extern "C" int svo_get_match_ids(svo_ctx* ctx, int lane, int which, int octave, int32_t* ids, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     if (which ? !s.has_prev : !s.has_cur) return 0;
@@ -966,6 +1001,7 @@ extern "C" int svo_get_match_ids(svo_ctx* ctx, int lane, int which, int octave, 
 // resetIds (H:684): the next frame renumbers the previous IDs and becomes the key frame (P:254-267)
 extern "C" int svo_reset_ids(svo_ctx* ctx, int lane)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < -1 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     for (int l = 0; l < ctx->cfg.n_lanes; l++)
         if (lane < 0 || lane == l) { LaneState s; int rc = lane_state(ctx, l, &s); if (rc) return rc; s.reset_ids = 1; HIPCHECK(hipMemcpy(ctx->dc.lane + l, &s, sizeof(s), hipMemcpyHostToDevice)); }
@@ -975,6 +1011,7 @@ extern "C" int svo_reset_ids(svo_ctx* ctx, int lane)
 // setThisFrameAsKF (H:675-683): m_last_kf_max_id = max ID of the current frame's octave-0 pairings
 extern "C" int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
     if (!s.has_cur) return SVO_ERR_STATE;                 // ASSERTMSG_ "Current frame does not exist" (H:677)
@@ -992,6 +1029,7 @@ extern "C" int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane)
 
 extern "C" int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     svo_result res; int rc = svo_get_result(ctx, lane, &res); if (rc) return rc;
     const int n = res.n_residual, m = n < cap ? n : cap;
@@ -1001,6 +1039,7 @@ extern "C" int svo_get_residuals(svo_ctx* ctx, int lane, double* r, int cap)
 
 extern "C" int svo_get_outliers(svo_ctx* ctx, int lane, int32_t* idx, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     svo_result res; int rc = svo_get_result(ctx, lane, &res); if (rc) return rc;
     const int n = res.n_outliers, m = n < cap ? n : cap;
@@ -1019,6 +1058,7 @@ static int mark_present(svo_ctx* ctx, int lane, int which)
 
 extern "C" int svo_put_features_oct(svo_ctx* ctx, int lane, int which, int side, int octave, const svo_keypoint* kps, const uint8_t* desc, int n, int img_w, int img_h)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || (side | 1) != 1 || n < 0 || (n > 0 && !kps) || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     int rc = ensure_geometry(ctx, img_w, img_h); if (rc) return rc;
@@ -1037,11 +1077,13 @@ extern "C" int svo_put_features_oct(svo_ctx* ctx, int lane, int which, int side,
 }
 extern "C" int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keypoint* kps, const uint8_t* desc, int n, int img_w, int img_h)
 {
+    if (ctx) use_device(ctx);
     return svo_put_features_oct(ctx, lane, which, side, 0, kps, desc, n, img_w, img_h);
 }
 
 extern "C" int svo_put_matches_oct(svo_ctx* ctx, int lane, int which, int octave, const svo_dmatch* m, int n)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !m) || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
@@ -1055,6 +1097,7 @@ extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmat
 
 extern "C" int svo_put_match_ids_oct(svo_ctx* ctx, int lane, int which, int octave, const int32_t* ids, int n)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || (which | 1) != 1 || n < 0 || (n > 0 && !ids) || octave < 0 || octave >= ctx->dc.oct_cap) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     LaneState s; int rc = lane_state(ctx, lane, &s); if (rc) return rc;
@@ -1071,6 +1114,7 @@ extern "C" int svo_put_match_ids(svo_ctx* ctx, int lane, int which, const int32_
 
 extern "C" int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || lane < 0 || lane >= ctx->cfg.n_lanes || n < 0 || (n > 0 && !t)) return SVO_ERR_ARG;
     if (n > ctx->dc.max_kps) return SVO_ERR_CAPACITY;
     int rc = svo_wait(ctx); if (rc) return rc;
@@ -1110,6 +1154,7 @@ extern "C" int svo_projected_coords(svo_ctx* ctx, const svo_dmatch* pre_matches,
                                     const svo_keypoint* pre_right, int n_right, const int32_t* tracked_first,
                                     const svo_stereo_camera* cam, const double* change_pose6, float* pix, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || n_pre < 0 || (n_pre > 0 && (!pre_matches || !pre_left || !pre_right || !tracked_first)) || !cam || !change_pose6) return SVO_ERR_ARG;
     std::vector<float> uvu;
     for (int m = 0; m < n_pre; m++) {
@@ -1141,6 +1186,7 @@ extern "C" size_t svo_handover_bytes(const svo_ctx* ctx)
 }
 extern "C" int svo_export_frame(svo_ctx* ctx, void* dev_blob, size_t bytes)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !dev_blob || bytes < svo_handover_bytes(ctx)) return SVO_ERR_ARG;
     if (!ctx->geom_ready) return SVO_ERR_STATE;
     note_stream(ctx);
@@ -1150,6 +1196,7 @@ extern "C" int svo_export_frame(svo_ctx* ctx, void* dev_blob, size_t bytes)
 }
 extern "C" int svo_import_frame(svo_ctx* ctx, const void* dev_blob, size_t bytes)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !dev_blob || bytes < svo_handover_bytes(ctx)) return SVO_ERR_ARG;
     if (!ctx->geom_ready) return SVO_ERR_STATE;
     note_stream(ctx);
@@ -1217,6 +1264,7 @@ bool load_matches(FILE* f, std::vector<svo_dmatch>& m, std::vector<int32_t>& ids
 
 extern "C" int svo_save_state(svo_ctx* ctx, int lane, const char* path)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !path || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     if (ctx->dc.n_oct > 1) return SVO_ERR_UNSUPPORTED;                 // the reference's format holds one list per eye
     int rc = svo_wait(ctx); if (rc) return rc;
@@ -1251,6 +1299,7 @@ extern "C" int svo_save_state(svo_ctx* ctx, int lane, const char* path)
 
 extern "C" int svo_load_state(svo_ctx* ctx, int lane, const char* path)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !path || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     if (ctx->dc.oct_cap > 1 && ctx->dc.n_oct > 1) return SVO_ERR_UNSUPPORTED;
     FILE* f = fopen(path, "rb");
@@ -1324,6 +1373,7 @@ extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, i
                                   const svo_stereo_camera* cam, const double* init6,
                                   svo_result* res, double* residual, int32_t* outliers)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !cam || !res || n_tracked < 0 || n_pre < 0 || n_cur < 0 || n_pl < 0 || n_pr < 0 || n_cl < 0 || n_cr < 0) return SVO_ERR_ARG;
     if ((n_tracked > 0 && !tracked) || (n_pre > 0 && !pre_matches) || (n_cur > 0 && !cur_matches) || (n_pl > 0 && !pre_left) ||
         (n_pr > 0 && !pre_right) || (n_cl > 0 && !cur_left) || (n_cr > 0 && !cur_right)) return SVO_ERR_ARG;
@@ -1379,6 +1429,7 @@ extern "C" int svo_change_in_pose(svo_ctx* ctx, const svo_index_pair* tracked, i
 // ---- standalone brute-force matcher -------------------------------------------------------------------------
 extern "C" int svo_hamming_match(svo_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt, int32_t* idx, int32_t* dist)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!query || !idx || !dist)) || (nt > 0 && !train)) return SVO_ERR_ARG;
     if (nt > 65535) return SVO_ERR_UNSUPPORTED;            // train index packs into 16 bits
     if (nq == 0) return SVO_OK;
@@ -1410,6 +1461,7 @@ extern "C" int svo_hamming_match(svo_ctx* ctx, const uint8_t* query, int nq, con
 // ---- probes ------------------------------------------------------------------------------------------------
 extern "C" int svo_debug_get_level(svo_ctx* ctx, int lane, int side, int level, uint8_t* out, int cap, int* w, int* h)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes || level < 0 || level >= ctx->dc.n_levels) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     const LevelGeom& g = ctx->dc.lv[level];
@@ -1426,6 +1478,7 @@ extern "C" int svo_debug_get_level(svo_ctx* ctx, int lane, int side, int level, 
 
 extern "C" int svo_debug_get_raw_keypoints(svo_ctx* ctx, int lane, int side, svo_keypoint* kps, uint8_t* desc, int cap)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !ctx->geom_ready || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     const DevCtx& d = ctx->dc;
@@ -1446,6 +1499,7 @@ extern "C" int svo_debug_get_raw_keypoints(svo_ctx* ctx, int lane, int side, svo
 
 extern "C" int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w)
 {
+    if (ctx) use_device(ctx);
     if (!ctx || !w || lane < 0 || lane >= ctx->cfg.n_lanes) return SVO_ERR_ARG;
     int rc = svo_wait(ctx); if (rc) return rc;
     HIPCHECK(hipMemcpy(w, ctx->dc.status + lane, sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -20,6 +20,18 @@ def test_library_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_rccl_companion_exports_every_declared_symbol():
+    """include/svo_rccl.h: the exchange steps of the multi-GPU path; loading it needs no GPU, creating a group does"""
+    from stereo_vo_amd import rccl
+    L = rccl.lib()
+    hdr = open(os.path.join(ROOT, "include", "svo_rccl.h")).read()
+    declared = set(re.findall(r"\b(svo_group_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(rccl.EXPORTS), declared ^ set(rccl.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.svo_group_size(None) < 0 and L.svo_group_create_local(None, 0, None) < 0
+
+
 def test_abi_record_sizes():
     a = (C.c_int32 * 6)()
     hip.lib().svo_abi_sizes(a)
