@@ -340,20 +340,17 @@ struct FastSmem {
 };
 
 // one 64x28 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
-__device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, int t, int th_fast)
+// (src, pitch, gw, gh: the level's image; x0, y0: the tile's interior origin -- the caller has them from the tile table)
+__device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
 {
     uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = sm.out_keys;
     unsigned& s_count = sm.s_count; unsigned& s_nout = sm.s_nout;
     const int tid = threadIdx.x;
-    const LevelGeom& g = c.lv[level];
-    const int by = t / g.tiles_x, bx = t - by * g.tiles_x;
-    const int x0 = SVO_EDGE + bx * FT_W, y0 = SVO_EDGE + by * FT_H;      // interior origin
-    int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
     if (tid == 0) { s_nout = 0; s_count = 0; }
     // ---- stage the window [x0-7, x0+73) x [y0-4, y0+32): 36 rows x 10 chunks of 8 bytes, rows r and r+18 per thread ----
     if (tid < 180) {
         const int r = tid / 10, q = tid - r * 10;
-        const int ya = min(y0 - 4 + r, g.h - 1), yb = min(y0 - 4 + r + 18, g.h - 1);
+        const int ya = min(y0 - 4 + r, gh - 1), yb = min(y0 - 4 + r + 18, gh - 1);
         uint2 va, vb;
         if ((((uintptr_t)src | (uintptr_t)pitch) & 7) == 0) {
             const int xx = min(x0 - 7 + q * 8, pitch - 8);              // rows are readable up to the pitch
@@ -362,7 +359,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
         } else {
             // any pointer / stride: aligned-down dwords funnel-shifted into place.  Every dword read contains at least
             // one byte of the image (addresses are clamped to the dword of the last byte), so it cannot fault.
-            const uintptr_t last = ((uintptr_t)src + (uintptr_t)((long long)g.h * pitch) - 1) & ~(uintptr_t)3;
+            const uintptr_t last = ((uintptr_t)src + (uintptr_t)((long long)gh * pitch) - 1) & ~(uintptr_t)3;
             const uintptr_t aa = (uintptr_t)src + (uintptr_t)((long long)ya * pitch + x0 - 7 + q * 8);
             const uintptr_t ab = (uintptr_t)src + (uintptr_t)((long long)yb * pitch + x0 - 7 + q * 8);
             const uintptr_t a0 = aa & ~(uintptr_t)3, b0 = ab & ~(uintptr_t)3;
@@ -449,8 +446,8 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             const int n5 = score[nb + 2 * FT_SP], n6 = score[nbm + 2 * FT_SP + 1], n7 = score[nb + 2 * FT_SP + 2];
             const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
             const int x = x0 - 3 + q, y = y0 - 1 + r;
-            keep = (v > mx) & (r >= 1) & (r <= FT_H) & (q >= 3) & (q < 3 + FT_W) & (x < g.w - SVO_EDGE) & (y < g.h - SVO_EDGE);
-            key = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * g.w + x));
+            keep = (v > mx) & (r >= 1) & (r <= FT_H) & (q >= 3) & (q < 3 + FT_W) & (x < gw - SVO_EDGE) & (y < gh - SVO_EDGE);
+            key = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * gw + x));
         }
         const unsigned long long m = __ballot(keep);
         if (m) {
@@ -467,6 +464,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     if (tid < 64) {
         const unsigned nout = s_nout;
         if (nout != 0 && c.debug_mode != 4) {
+            const LevelGeom& g = c.lv[level];
             unsigned gbase = 0;
             if (tid == 0) gbase = atomicAdd(&c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE], nout);
             gbase = __shfl(gbase, 0, 64);
@@ -487,14 +485,27 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
     // goes to XCD k % 8, so the halo columns / rows that neighbouring tiles share are re-read from that XCD's L2 rather
     // than through another one.  (One contiguous eighth of every image per XCD shares more, but gives each XCD a
     // fixed set of pyramid levels -- their corner densities differ and the launch waits for the slowest XCD: measured.)
+    //
+    // A CU holds 8 of these workgroups and a workgroup lives ~3 us, so what a wave does BEFORE its loads are in flight is paid
+    // in throughput: working the tile's level, origin and source address out of the kernel arguments was a chain of
+    // six dependent scalar-load waits and a division.  The geometry of tile k is the same for every image and every frame:
+    // it comes from a table (svo_api.hip fills it with the level geometry), next to the image's eight thresholds and its
+    // level-0 pointer -- one round of scalar loads after the kernel arguments.
     const uint32_t slot = blockIdx.x >> 3;
     const uint32_t work = c.debug_mode == 8 ? blockIdx.x : (((slot / FT_CHUNK) * 8 + (blockIdx.x & 7)) * FT_CHUNK + slot % FT_CHUNK);
     const int img = (int)fastdiv(work, c.div_tiles), tile_id = (int)work - img * c.n_tiles;
     if (img >= c.n_img) return;
-    int level = 0;
+    const uint4 e = c.fast_tiles[tile_id];                  // x0 | y0 << 16, w | h << 16, level | pitch << 8, level offset in the pyramid
+    const uint4 tha = ((const uint4*)(c.fast_th_used + img * SVO_MAX_LEVELS))[0], thb = ((const uint4*)(c.fast_th_used + img * SVO_MAX_LEVELS))[1];
+    const uint8_t* base0 = c.img0[img];
+    const int level = (int)(e.z & 0xFFu);
+    const uint32_t thv[8] = { tha.x, tha.y, tha.z, tha.w, thb.x, thb.y, thb.z, thb.w };
+    uint32_t th = thv[0];
 #pragma unroll
-    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && tile_id >= c.lv[l].tile_off) level = l;
-    fast_tile(c, sm, img, level, tile_id - c.lv[level].tile_off, (int)c.fast_th_used[img * SVO_MAX_LEVELS + level]);
+    for (int l = 1; l < SVO_MAX_LEVELS; l++) th = level == l ? thv[l] : th;
+    const uint8_t* src = level == 0 ? base0 : c.pyr + (long long)img * c.pyr_bytes + e.w;
+    const int pitch = level == 0 ? c.img0_pitch : (int)(e.z >> 8);
+    fast_tile(c, sm, img, level, src, pitch, (int)(e.y & 0xFFFFu), (int)(e.y >> 16), (int)(e.x & 0xFFFFu), (int)(e.x >> 16), (int)th);
 }
 
 // The (image, level) pairs whose speculated threshold found fewer than 2 * quota corners (k_select) again, with the
@@ -511,8 +522,11 @@ __global__ void __launch_bounds__(256) k_fast_redo(DevCtx c)
         const int img = (int)(il / SVO_MAX_LEVELS), level = (int)(il % SVO_MAX_LEVELS);
         const int nt = c.lv[level].tiles_x * c.lv[level].tiles_y;
         int t = first;
+        int pitch; const uint8_t* src = level_ptr(c, img, level, pitch);
+        const int tx = c.lv[level].tiles_x, gw = c.lv[level].w, gh = c.lv[level].h;
         for (; t < nt; t += (int)gridDim.x) {
-            fast_tile(c, sm, img, level, t, c.fast_th);
+            const int by = t / tx, bx = t - by * tx;
+            fast_tile(c, sm, img, level, src, pitch, gw, gh, SVO_EDGE + bx * FT_W, SVO_EDGE + by * FT_H, c.fast_th);
             __syncthreads();                                                 // the tile's LDS is reused by the next one
         }
         first = t - nt;

@@ -35,7 +35,7 @@ struct svo_ctx {
     // filled by a dedicated copy stream, so that the upload of frame t+1 overlaps the kernels of frame t
     uint8_t* d_img0_ring[2]; uint8_t* h_stage[2]; size_t slot_bytes;
     hipStream_t s_copy; hipEvent_t ev_h2d[2], ev_det[2]; bool ev_det_valid[2], ev_h2d_valid[2], up_ready; int up_slot, det_slot;
-    long long pyr_bytes_alloc; int cand_total_alloc, rtab_alloc;
+    long long pyr_bytes_alloc; int cand_total_alloc, rtab_alloc, tile_tab_alloc;
     std::vector<void*> allocs;
     std::string last_error;
     std::vector<TimedSpan> spans; std::vector<hipEvent_t> free_events;
@@ -205,6 +205,9 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, (uint8_t***)&d.img0, (size_t)NI));
     HIPCHECK(dev_alloc(ctx, &d.pyr, (size_t)NI * ctx->pyr_bytes_alloc));
     HIPCHECK(dev_alloc(ctx, &d.rtab, (size_t)ctx->rtab_alloc));
+    // FAST tile table: the level tilings of an image of the largest size, all levels (scale 1.2: 3.3 x level 0; x1/2 octaves: 1.34 x)
+    ctx->tile_tab_alloc = 4 * ((cfg->max_w / SVO_FT_W + 2) * (cfg->max_h / SVO_FT_H + 2)) + 64;
+    HIPCHECK(dev_alloc(ctx, (uint4**)&d.fast_tiles, (size_t)ctx->tile_tab_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_keys, (size_t)NI * ctx->cand_total_alloc));
     HIPCHECK(dev_alloc(ctx, &d.cand_cnt, (size_t)NI * SVO_MAX_LEVELS * SVO_CNT_STRIDE));
     HIPCHECK(dev_alloc(ctx, &d.fast_th_dyn, (size_t)NI * SVO_MAX_LEVELS * 4 + 32));
@@ -495,6 +498,19 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     d.n_tiles = tile_off; d.n_slots = slot_off; d.cand_total = ctx->cand_total_alloc;
     d.div_tiles = make_fastdiv((uint32_t)(tile_off > 0 ? tile_off : 1));
     if (!rtab.empty()) HIPCHECK(hipMemcpy(d.rtab, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice));
+    {   // k_fast's tile table (same for every image and frame of this geometry)
+        if (tile_off > ctx->tile_tab_alloc) return SVO_ERR_CAPACITY;
+        std::vector<uint4> tt((size_t)tile_off);
+        for (int l = 0; l < nlev; l++) {
+            const LevelGeom& g = d.lv[l];
+            for (int t = 0; t < g.tiles_x * g.tiles_y; t++) {
+                const int by = t / g.tiles_x, bx = t - by * g.tiles_x;
+                tt[(size_t)g.tile_off + t] = make_uint4((uint32_t)(SVO_EDGE + bx * SVO_FT_W) | ((uint32_t)(SVO_EDGE + by * SVO_FT_H) << 16), (uint32_t)g.w | ((uint32_t)g.h << 16),
+                                                        (uint32_t)l | ((uint32_t)g.pitch << 8), (uint32_t)g.offset);
+            }
+        }
+        if (!tt.empty()) HIPCHECK(hipMemcpy((void*)d.fast_tiles, tt.data(), tt.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     HIPCHECK(configure_nms_rowsort(d));
     ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = fast_orb ? p.orb_nfeats : nfe; ctx->geom_nlevels = nlev;
     ctx->geom_method = p.detect_method; ctx->geom_noct = noct;

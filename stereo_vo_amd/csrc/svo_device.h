@@ -104,6 +104,7 @@ struct DevCtx {
     // this frame's k_fast ran with, redo_flag / redo_list / redo_n = the (image, level) pairs whose speculation failed
     uint32_t* fast_th_dyn;    // [n_img][SVO_MAX_LEVELS]   0 = no speculation (base threshold)
     uint32_t* fast_th_used;   // [n_img][SVO_MAX_LEVELS]
+    const uint4* fast_tiles;  // [n_tiles] geometry of FAST tile k of the concatenated level tilings: x0 | y0 << 16, w | h << 16, level | pitch << 8, pyramid offset
     uint32_t* redo_flag;      // [n_img][SVO_MAX_LEVELS]
     uint32_t* redo_list;      // [n_img * SVO_MAX_LEVELS]  img * SVO_MAX_LEVELS + level
     uint32_t* redo_n;         // [1]
