@@ -335,21 +335,27 @@ struct FastSmem {
     __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
     __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 16];
     unsigned short list[FT_SH * FT_SW];
-    uint32_t out_keys[FT_W * FT_H / 4 + 64];       // 3x3 NMS leaves at most one survivor per 2x2 block
     unsigned s_count, s_nout;
 };
+// the NMS survivors' keys (3x3 NMS leaves at most one per 2x2 block) go where the window was: it is dead once the scores exist,
+// and 2 KB less per tile is two more tiles per CU
+static_assert((FT_W * FT_H / 4 + 64) * 4 <= FT_LH * FT_LW, "out_keys aliases the window");
 
 // one 64x28 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
 // (src, pitch, gw, gh: the level's image; x0, y0: the tile's interior origin -- the caller has them from the tile table)
+// FT_NT threads per tile: the launch is latency-bound (T = 0.095 ms + 2.51 ms / tiles in flight per CU, measured by padding the
+// LDS allocation), and a CU's 32 wave slots hold 8 tiles with four waves each but 14 (the LDS limit) with two.
+#define FT_NT 128
 __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
 {
-    uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = sm.out_keys;
+    uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = (uint32_t*)sm.tile;
     unsigned& s_count = sm.s_count; unsigned& s_nout = sm.s_nout;
     const int tid = threadIdx.x;
     if (tid == 0) { s_nout = 0; s_count = 0; }
     // ---- stage the window [x0-7, x0+73) x [y0-4, y0+32): 36 rows x 10 chunks of 8 bytes, rows r and r+18 per thread ----
-    if (tid < 180) {
-        const int r = tid / 10, q = tid - r * 10;
+#pragma unroll
+    for (int task = tid; task < 180; task += FT_NT) {
+        const int r = task / 10, q = task - r * 10;
         const int ya = min(y0 - 4 + r, gh - 1), yb = min(y0 - 4 + r + 18, gh - 1);
         uint2 va, vb;
         if ((((uintptr_t)src | (uintptr_t)pitch) & 7) == 0) {
@@ -372,52 +378,57 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
         *(uint2*)&tile[r * FT_LW + q * 8] = va;
         *(uint2*)&tile[(r + 18) * FT_LW + q * 8] = vb;
     }
-    if (tid < (FT_SH * FT_SP + 15) / 16) ((uint4*)score)[tid] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (FT_SH * FT_SP + 15) / 16; i += FT_NT) ((uint4*)score)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (c.debug_mode == 1) return;
     // ---- (1) packed cardinal test: 30 rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + 15, gq) ----
     const uint32_t* T32 = (const uint32_t*)tile;
     const uint32_t th = (uint32_t)th_fast;
     const u16x2 t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
-    const int r0 = tid / FT_NG, gq = tid - r0 * FT_NG;
-    uint32_t pe[2] = { 0, 0 }, po[2] = { 0, 0 };                        // nonzero halves = passing positions
-    if (tid < 15 * FT_NG) {
+    constexpr int FT_TURNS = 256 / FT_NT;                               // 255 pair-tasks (r0, gq) + (r0 + 15, gq): FT_TURNS per thread
+    uint32_t pe[2 * FT_TURNS], po[2 * FT_TURNS];                        // nonzero halves = passing positions
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint32_t* row = T32 + (r0 + 15 * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
-            const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
-            // The test compares 16-bit halves whose HIGH byte is the pixel of interest; the low byte is whatever sits next to it
-            // and only matters when the high bytes tie at exactly the threshold, where it can let a position through that the
-            // exact score then zeroes again (a false alarm, never a miss: 16-bit max / min order by the high byte first).  So no
-            // masking: positions 1, 3 are the high bytes of the registers as loaded, positions 0, 2 those of the same registers
-            // one byte further left -- E / W come out of the funnel shifter in that alignment directly (W is simply Cp).
-            const uint32_t Eo = __builtin_amdgcn_alignbyte(Cn, C, 3), Wo = __builtin_amdgcn_alignbyte(C, Cp, 1);
-            const uint32_t Ee = __builtin_amdgcn_alignbyte(Cn, C, 2);
-            pe[k] = quick_half(C << 8, N << 8, Ee, S << 8, Cp, t2h);                      // positions 0 (low half), 2 (high half)
-            po[k] = quick_half(C, N, Eo, S, Wo, t2h);                                     // positions 1, 3
+    for (int u = 0; u < FT_TURNS; u++) {
+        const int pt = tid + u * FT_NT, r0 = pt / FT_NG, gq = pt - r0 * FT_NG;
+        pe[2 * u] = pe[2 * u + 1] = po[2 * u] = po[2 * u + 1] = 0;
+        if (pt < 15 * FT_NG) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t* row = T32 + (r0 + 15 * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
+                const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
+                // The test compares 16-bit halves whose HIGH byte is the pixel of interest; the low byte is whatever sits next to it
+                // and only matters when the high bytes tie at exactly the threshold, where it can let a position through that the
+                // exact score then zeroes again (a false alarm, never a miss: 16-bit max / min order by the high byte first).  So no
+                // masking: positions 1, 3 are the high bytes of the registers as loaded, positions 0, 2 those of the same registers
+                // one byte further left -- E / W come out of the funnel shifter in that alignment directly (W is simply Cp).
+                const uint32_t Eo = __builtin_amdgcn_alignbyte(Cn, C, 3), Wo = __builtin_amdgcn_alignbyte(C, Cp, 1);
+                const uint32_t Ee = __builtin_amdgcn_alignbyte(Cn, C, 2);
+                pe[2 * u + k] = quick_half(C << 8, N << 8, Ee, S << 8, Cp, t2h);              // positions 0 (low half), 2 (high half)
+                po[2 * u + k] = quick_half(C, N, Eo, S, Wo, t2h);                             // positions 1, 3
+            }
         }
     }
-    {   // compaction by ballots: eight 64-lane masks (two tasks x four positions), counts and prefixes on the scalar
-        // unit, one LDS atomic per wave (list order is irrelevant)
-        bool f[8];
-        unsigned long long bm[8];
+    {   // compaction by ballots: 8 * FT_TURNS 64-lane masks (tasks x four positions), counts and prefixes on the scalar
+        // unit, ONE LDS atomic per wave (list order is irrelevant)
+        bool f[8 * FT_TURNS];
+        unsigned long long bm[8 * FT_TURNS];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 2 * FT_TURNS; k++) {
             f[4 * k + 0] = (pe[k] & 0xFFFFu) != 0; f[4 * k + 1] = (po[k] & 0xFFFFu) != 0;
             f[4 * k + 2] = (pe[k] >> 16) != 0;     f[4 * k + 3] = (po[k] >> 16) != 0;
         }
         int total = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { bm[j] = __ballot(f[j]); total += __popcll(bm[j]); }
+        for (int j = 0; j < 8 * FT_TURNS; j++) { bm[j] = __ballot(f[j]); total += __popcll(bm[j]); }
         unsigned wbase = 0;
         if (total) {
             if ((tid & 63) == 0) wbase = atomicAdd(&s_count, (unsigned)total);
             wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
-            const int p0 = r0 * FT_SP + 4 * gq;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < 8 * FT_TURNS; j++) {
+                const int pt = tid + (j >> 3) * FT_NT, r0 = pt / FT_NG, gq = pt - r0 * FT_NG;
                 const unsigned idx = __builtin_amdgcn_mbcnt_hi((unsigned)(bm[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[j], wbase));
-                if (f[j]) list[idx] = (unsigned short)(p0 + (j >> 2) * 15 * FT_SP + (j & 3));
+                if (f[j]) list[idx] = (unsigned short)(r0 * FT_SP + 4 * gq + ((j >> 2) & 1) * 15 * FT_SP + (j & 3));
                 wbase += (unsigned)__popcll(bm[j]);
             }
         }
@@ -426,14 +437,14 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     const int ns = (int)s_count;
     if (c.debug_mode == 2) return;
     // ---- (2) score on the survivors only ----
-    for (int i = tid; i < ns; i += 256) {
+    for (int i = tid; i < ns; i += FT_NT) {
         const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
         score[pos] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
     }
     __syncthreads();
     if (c.debug_mode == 3) return;
     // ---- (3) 3x3 NMS on the listed interior positions; one global atomic per tile ----
-    for (int base = 0; base < ns; base += 256) {
+    for (int base = 0; base < ns; base += FT_NT) {
         const int i = base + tid;
         bool keep = false; uint32_t key = 0;
         if (i < ns) {
@@ -477,7 +488,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     }
 }
 
-__global__ void __launch_bounds__(256) k_fast(DevCtx c)
+__global__ void __launch_bounds__(FT_NT) k_fast(DevCtx c)
 {
     __shared__ FastSmem sm;
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The global work list
@@ -511,7 +522,7 @@ __global__ void __launch_bounds__(256) k_fast(DevCtx c)
 // The (image, level) pairs whose speculated threshold found fewer than 2 * quota corners (k_select) again, with the
 // caller's threshold.  Normally the list is empty and the launch retires at once; otherwise the workgroups stride over
 // the concatenated tile lists of the listed pairs.
-__global__ void __launch_bounds__(256) k_fast_redo(DevCtx c)
+__global__ void __launch_bounds__(FT_NT) k_fast_redo(DevCtx c)
 {
     __shared__ FastSmem sm;
     const unsigned n = *c.redo_n;
@@ -1698,7 +1709,7 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 {
     if (c.n_tiles <= 0) return;
     const long long total = (long long)c.n_tiles * c.n_img, unit = 8 * FT_CHUNK;
-    hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(FT_NT), 0, st, c);
 }
 
 void launch_select(const DevCtx& c, hipStream_t st)
@@ -1707,7 +1718,7 @@ void launch_select(const DevCtx& c, hipStream_t st)
     if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
     else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
     // the pairs whose speculated FAST threshold was too high (normally none: both launches retire at once)
-    hipLaunchKernelGGL(k_fast_redo, dim3(4096), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_fast_redo, dim3(4096), dim3(FT_NT), 0, st, c);
     if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
     else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
     hipLaunchKernelGGL(k_harris, dim3(c.n_img, c.sel_max / 256, c.n_levels), dim3(256), 0, st, c);
