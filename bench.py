@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
-    ap.add_argument("--det-priority", default="high", choices=["low", "high"], help="which of the two streams of the pipelined schedule gets the high HIP priority: the detect stream (default: the throughput kernels keep the CUs they ask for, the latency-bound stage 3-5 kernels fill in; 50.0 k vs 49.2 k pairs/s measured) or the stage 3-5 stream")
+    ap.add_argument("--det-priority", default="low", choices=["low", "high"], help="which of the two streams of the pipelined schedule gets the high HIP priority: the stage 3-5 stream (default 'low' = detect stream at normal priority: the latency-bound stage 3-5 kernels get their few workgroups placed at once and the detect kernels, which fill every wave slot they are given, take the rest; 53.3 k vs 47.1 k pairs/s measured with the two-wave k_fast) or the detect stream")
     ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")

@@ -911,23 +911,29 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     if (img >= c.n_img) return;
     // pre != 0: the NMS ran first (k_nms_rowsort, pre mode); work item = final keypoint fi of the image's current list,
     // final_slot names the detector slot it came from, and only the angle and the descriptor are left to fill in
-    int slot = bx * 4 + wid;             // position in the level-segmented arrays
+    // A wave lives ~5 us and a CU holds 32 of them, so dependent loads before the window is in flight cost throughput (see
+    // k_fast).  The work item of the describe-after-NMS path comes from ONE list the NMS kernel wrote for it (position, level)
+    // beside its length and the slot flag -- one round of loads; the detector-order path chains through slot -> level -> rank.
+    int slot = bx * 4 + wid;             // position in the level-segmented arrays / in the image's final list
     long long fo = 0;
+    int level = 0;
+    uint32_t pos;
     if (pre) {
         const int lane_id = img >> 1, vl0 = lane_id * c.oct_cap;
+        const int n_final = c.desc_n[img];
+        const uint2 w = c.desc_work[(long long)img * c.raw_cap + slot];
         const int cur = 1 - c.lane[lane_id].prev_slot;
-        if (slot >= c.n_kps[feat_cnt_idx(vl0, cur, img & 1)]) return;
+        if (slot >= n_final) return;
         fo = feat_base(c, vl0, cur, img & 1) + slot;
-        slot = __builtin_amdgcn_readfirstlane(c.final_slot[fo]);
-    }
-    if (slot >= c.n_slots) return;
-    int level = 0;
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.x); level = __builtin_amdgcn_readfirstlane((int)w.y);
+    } else {
+        if (slot >= c.n_slots) return;
 #pragma unroll
-    for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
+        for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
+        if (slot - c.lv[level].slot_off >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
+    }
     const LevelGeom& g = c.lv[level];
-    const int rank = slot - g.slot_off;
-    if (!pre && rank >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
-    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     uint32_t* R32 = raw32[wid];
@@ -1326,8 +1332,13 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     const long long ob = feat_base(c, vl, cur, side);
     for (int i = tid; i < nacc; i += blockDim.x) {
         const int s = slot_of(acc_idx[(int)(keys[i] & 0xFFFFFFFFull)]);
-        c.kps[ob + i] = kp_at(s);
-        if (pre) { c.final_slot[ob + i] = s; continue; }
+        const svo_keypoint kp = kp_at(s);
+        c.kps[ob + i] = kp;
+        if (pre) {      // k_describe's work item i of this image: everything it needs to start loading, in one place
+            c.final_slot[ob + i] = s;
+            c.desc_work[(long long)img * c.raw_cap + i] = make_uint2(lpos[s], (uint32_t)kp.octave);
+            continue;
+        }
         const uint4* sd = (const uint4*)(c.raw_desc + ((long long)img * c.raw_cap + s) * 32);
         uint4* dd = (uint4*)(c.desc + (ob + i) * 32);
         dd[0] = sd[0]; dd[1] = sd[1];
@@ -1351,6 +1362,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     if (tid == 0) {
         c.n_kps[feat_cnt_idx(vl, cur, side)] = nacc;
         c.raw_n[img] = n;
+        if (pre) c.desc_n[img] = nacc;
         if (side == 0) c.results[lane_id].detected_left[oct] = nacc; else c.results[lane_id].detected_right[oct] = nacc;
     }
 }

@@ -228,6 +228,8 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * ctx->raw_cap_alloc));
     HIPCHECK(dev_alloc(ctx, &d.raw_desc, (size_t)NI * ctx->raw_cap_alloc * 32));
     HIPCHECK(dev_alloc(ctx, &d.raw_n, (size_t)NI));
+    HIPCHECK(dev_alloc(ctx, &d.desc_work, (size_t)NI * ctx->raw_cap_alloc + 8));
+    HIPCHECK(dev_alloc(ctx, &d.desc_n, (size_t)NI));
     HIPCHECK(dev_alloc(ctx, &d.kps, (size_t)NV * 4 * MK));
     HIPCHECK(dev_alloc(ctx, &d.desc, (size_t)NV * 4 * MK * 32));
     HIPCHECK(dev_alloc(ctx, &d.mdesc, (size_t)NV * 4 * MK * 32));

@@ -117,6 +117,8 @@ struct DevCtx {
     svo_keypoint* raw_kps;
     uint8_t* raw_desc;
     int* raw_n;               // [n_img]
+    uint2* desc_work;         // [n_img][raw_cap] describe-after-NMS work list: (x | y << 16 at its level, level) of final keypoint i
+    int* desc_n;              // [n_img] its length
     svo_keypoint* kps;
     uint8_t* desc;
     int* final_slot;          // same index space as kps: detector slot of each final keypoint (describe-after-NMS path)

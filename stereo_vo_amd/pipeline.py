@@ -5,7 +5,7 @@ module runs `contexts` of them side by side so that the per-stream, latency-boun
 overlap the throughput kernels of stage 2 of the next:
 
   schedule "pipelined": ONE HIP stream carries the detect phases (stage 2) of all contexts back to back, ANOTHER carries
-      stages 3-5 of each frame; the detect stream has the higher priority by default (det_priority).  Events: stages 3-5 of context k wait for detect(k);
+      stages 3-5 of each frame; the stage 3-5 stream has the higher priority by default (det_priority = "low").  Events: stages 3-5 of context k wait for detect(k);
       the next detect of context k waits for its stages 3-5 (stage 4 reads the feature slot detection overwrites next).
   schedule "free": every context runs its whole frame on its own stream, unsynchronised with the others.
 
@@ -22,7 +22,7 @@ from .abi import Result
 
 class StreamBatch:
     def __init__(self, params, cam, width, height, lanes, contexts=1, device=0, schedule="pipelined", post_on_rest=False,
-                 det_priority="high", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1):
+                 det_priority="low", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1):
         assert contexts >= 1 and lanes % contexts == 0 and lanes // contexts <= hip.MAX_LANES, \
             "lanes must split evenly over the contexts, at most %d streams per context" % hip.MAX_LANES
         self.W, self.H, self.B, self.NC, self.Bc = width, height, lanes, contexts, lanes // contexts
