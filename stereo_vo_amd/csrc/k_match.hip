@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
         np_total += tot;
         __syncthreads();
     }
-    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; }
+    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 7; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
         nk += tot;
         __syncthreads();
     }
-    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; }
+    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 7; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -776,8 +776,23 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
     const double* Fe = F + 9 * (4 * w + k);
     const double dminA = Gd[2 * (4 * w + k)], dminB = Gd[2 * (4 * w + k) + 1];
     const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
+    // A hypothesis matters only if it is a RECORD (its count exceeds that of every earlier hypothesis, k_track_finalize), and
+    // every hypothesis of chunks 1, 2 comes after all of chunk 0 (chunk 2: after all of chunk 1 as well), whose best count is
+    // known by now: once a hypothesis cannot exceed that floor even if every remaining pair were an inlier, its exact count is
+    // of no consequence -- the partial count it leaves is below the floor too, so it is no record, and as an under-estimate it
+    // only loosens the rs_bound it feeds.  A wave stops when all four of its hypotheses are there (a contaminated sample
+    // explains 10-20 % of the pairs against the floor's 50-60 %: about half way through the list).
+    const int floor_cnt = chunk ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
     int cnt = 0;
     for (int base = 0; base < n; base += 16) {
+        if (chunk && base && (base & 127) == 0) {
+            int gsum = cnt;                                              // the group's count so far, in all its 16 lanes
+            gsum += __builtin_amdgcn_update_dpp(0, gsum, 0xB1, 0xF, 0xF, false);
+            gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x4E, 0xF, 0xF, false);
+            gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x141, 0xF, 0xF, false);
+            gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x140, 0xF, 0xF, false);
+            if (__ballot(gsum + (n - base) <= floor_cnt) == ~0ull && c.debug_mode != 16) break;
+        }
         const int pi = base + j;
         const float4 p = pts[min(pi, n - 1)];
         const double x1 = (double)p.x, y1 = (double)p.y, x2 = (double)p.z, y2 = (double)p.w;
@@ -813,6 +828,9 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
             const int K = ransac_niters(best - 1, n, cur);
             if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
         }
+        // the floors of the later chunks: best count of chunk 0 (for chunk 1), of chunks 0 and 1 (for chunk 2)
+        if (chunk == 0 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2], best);
+        if (chunk <= 1 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2 + 1], best);
     }
 }
 

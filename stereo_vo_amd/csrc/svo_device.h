@@ -141,6 +141,7 @@ struct DevCtx {
     int* rs_cnt;              // [n_lanes][2][PAD]
     int* rs_bound;            // [n_lanes][2]  upper limit of the hypotheses the sequential stop can still reach
     int* rs_gen;              // [n_lanes][2]  end of the hypotheses the current chunk generated
+    int* rs_floor;            // [n_lanes][2][2] best inlier count of chunk 0 / of chunks 0-1: what a later hypothesis must exceed to matter
     svo_index_pair* tracked;  // [n_lanes][max_kps]
     int* n_tracked;           // [n_lanes]
     // stage 5
