@@ -628,11 +628,17 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
 #pragma unroll
     for (int i = 0; i < 8; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
     c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
+    // the sixteen square roots of the mean-distance normalisation: lane i < 8 of the group takes point i, the sums then run over
+    // the lanes' values in the oracle's order (a double-precision sqrt is ~30 instructions; sixteen per lane were a fifth of the kernel)
     double d1 = 0, d2 = 0;
+    {
+        float4 Pm = P[0];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const double ax = (double)P[i].x - c1x, ay = (double)P[i].y - c1y, bx = (double)P[i].z - c2x, by = (double)P[i].w - c2y;
-        d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
+        for (int i = 1; i < 8; i++) if ((gl & 7) == i) Pm = P[i];
+        const double ax = (double)Pm.x - c1x, ay = (double)Pm.y - c1y, bx = (double)Pm.z - c2x, by = (double)Pm.w - c2y;
+        const double r1 = sqrt(ax * ax + ay * ay), r2 = sqrt(bx * bx + by * by);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { d1 += group_bcast(r1, i); d2 += group_bcast(r2, i); }
     }
     const double s1 = 11.313708498984761 / d1, s2 = 11.313708498984761 / d2;
     // ---- column gl of the system: A[i][0..8] = x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1 ----
