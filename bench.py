@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--single-stream", type=int, default=1, help="1: also time ONE stream alone (plain launches, hipGraph replay, frames dealt to 2 / 3 contexts); N=1, config2 only")
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
-    ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5")
+    ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5; 2: on a third stream of its own")
     ap.add_argument("--det-priority", default="low", choices=["low", "high"], help="which of the two streams of the pipelined schedule gets the high HIP priority: the stage 3-5 stream (default 'low' = detect stream at normal priority: the latency-bound stage 3-5 kernels get their few workgroups placed at once and the detect kernels, which fill every wave slot they are given, take the rest; 53.3 k vs 47.1 k pairs/s measured with the two-wave k_fast) or the detect stream")
     ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
@@ -161,7 +161,7 @@ def main():
         from stereo_vo_amd.abi import DM_FAST_ORB
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
     NC = max(1, args.contexts)
-    batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=bool(args.post_on_rest),
+    batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else bool(args.post_on_rest)),
                         det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams)
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
     ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]

@@ -28,6 +28,9 @@ class StreamBatch:
         self.W, self.H, self.B, self.NC, self.Bc = width, height, lanes, contexts, lanes // contexts
         self.dev = torch.device("cuda", device)
         self.pipelined = contexts > 1 and schedule == "pipelined"
+        # post_on_rest: False = NMS + describe stay on the detect stream; True = they run on the stage 3-5 stream; "own" = on a
+        # third stream, so that the detect stream goes straight on to the next context's resize + FAST
+        self.post_own = post_on_rest == "own"
         self.post_on_rest = bool(post_on_rest)
         if max_cand is None:
             max_cand = (1 << 18) if width * height > 2000000 else (1 << 17)
@@ -48,7 +51,9 @@ class StreamBatch:
         self.rest_done = [torch.cuda.Event() for _ in range(contexts)]
         self.done = [torch.cuda.Event() for _ in range(contexts)]
         self.first = True
-        self.REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE | (hip.RUN_DETECT_POST if post_on_rest else 0)
+        self.REST = hip.RUN_MATCH | hip.RUN_TRACK | hip.RUN_OPTIMIZE | (hip.RUN_DETECT_POST if (post_on_rest and not self.post_own) else 0)
+        self.s_post = torch.cuda.Stream(self.dev, priority=0 if det_priority == "high" else -1) if self.post_own else None
+        self.pre_done = [torch.cuda.Event() for _ in range(contexts)]
 
     def step(self, ptrs, stride=None, pinned_host=False):
         """Enqueue one frame of every lane.  ptrs[lane] = (left, right) addresses of 8-bit grey images of the batch's
@@ -67,7 +72,14 @@ class StreamBatch:
                     s_det.wait_event(self.rest_done[k])
                 c.set_stream(s_det.cuda_stream)
                 proc(pk, self.W, self.H, stride, hip.RUN_DETECT | (hip.FLAG_DETECT_NO_POST if self.post_on_rest else 0))
-                self.det_done[k].record(s_det)
+                if self.post_own:
+                    self.pre_done[k].record(s_det)
+                    self.s_post.wait_event(self.pre_done[k])
+                    c.set_stream(self.s_post.cuda_stream)
+                    c.run_stages(hip.RUN_DETECT_POST)
+                    self.det_done[k].record(self.s_post)
+                else:
+                    self.det_done[k].record(s_det)
                 self.s_rest.wait_event(self.det_done[k])
                 c.set_stream(self.s_rest.cuda_stream)
                 c.run_stages(self.REST)
