@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P, uint
             if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { err_code = SVO_VOEC_INCR_FUNC_COST_STG1; abort_ = true; } }
         }
         num_it++;
-        __syncthreads();
+        // no barrier here: eval_rgn ends with one, and thread 0 rewrites sh.* only behind the next call's two barriers
     }
     // ---- keep only the inliers (S5:601-611); "outliers" receives the INLIER cur-match indices ----
     const int n_res = first ? 0 : T;
@@ -473,7 +473,6 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P, uint
             if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { abort_ = true; err_code = SVO_VOEC_INCR_FUNC_COST_STG2; } }
         }
         num_it_final++;
-        __syncthreads();
     }
     if (tid == 0) {
         double pose[6], delta[6];
