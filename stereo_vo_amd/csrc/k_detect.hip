@@ -1066,6 +1066,8 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NS_HASH = 2 * NS_MAX;
     const int img = blockIdx.x, oct = blockIdx.y, lane_id = img >> 1, side = img & 1, tid = threadIdx.x;
+    const bool raster = do_nms == 3;          // FAST + ORB with the NMS switched off: every corner, in cv::FAST's raster order
+    if (raster) do_nms = 0;
     unsigned char* wide = big ? big + ((size_t)img * c.oct_cap + oct) * ((size_t)NS_MAX * 28) : smem;
     unsigned long long* keys = (unsigned long long*)wide;
     uint32_t* hkey = (uint32_t*)(keys + NS_MAX);
@@ -1266,6 +1268,18 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
             __syncthreads();
         }
         if (nacc > num_out_points) nacc = num_out_points;
+    } else if (raster) {
+        // no NMS after FAST: the reference keeps cv::FAST's output as it comes, in raster order (S2:613-614), which is what the
+        // row sort below then keeps inside a row.  k_fastorb_nms delivered the corners by score: back to (y, x) order.
+        for (int i = tid; i < P; i += blockDim.x) {
+            unsigned long long k = ~0ull;
+            if (i < n) { const svo_keypoint kp = kp_at(slot_of(i)); k = ((unsigned long long)((uint32_t)kp.y * (uint32_t)W + (uint32_t)kp.x) << 32) | (unsigned)i; }
+            keys[i] = k;
+        }
+        bitonic_sort_lds<false>(keys, P);
+        for (int i = tid; i < n; i += blockDim.x) acc_idx[i] = (unsigned short)(keys[i] & 0xFFFFFFFFull);
+        nacc = n;
+        __syncthreads();
     } else {
         for (int i = tid; i < n; i += blockDim.x) acc_idx[i] = (unsigned short)i;
         nacc = n;
@@ -1413,7 +1427,9 @@ __global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance
     const LevelGeom& g = c.lv[level];
     unsigned nc = c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE];
     if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
-    const int cap = min(min(c.kps_to_detect[level], g.quota), ACC_MAX);    // quota = slots reserved for this octave
+    // quota = slots reserved for this octave; the reference's cap kps_to_detect belongs to its NMS (S2:342), without NMS every corner stays
+    const int cap = do_nms ? min(min(c.kps_to_detect[level], g.quota), ACC_MAX) : min(g.quota, ACC_MAX);
+    if (!do_nms && nc > (unsigned)cap && tid == 0) { atomicOr(&c.status[img >> 1], SVO_ST_KPS_OVERFLOW); atomicOr(&c.results[img >> 1].status, (int)SVO_ST_KPS_OVERFLOW); }
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
     const unsigned cell = (unsigned)((double)min_distance / 2.0);
     const float inv = 1.0f / (float)cell;
@@ -1781,8 +1797,8 @@ hipError_t configure_nms_rowsort(const DevCtx& c)
 void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st)
 {
     const int pmax = nms_pmax(c);
-    if (pmax > 4096) hipLaunchKernelGGL(k_nms_rowsort<8>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, c.big_scratch);
-    else hipLaunchKernelGGL(k_nms_rowsort<4>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? 0 : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, (uint8_t*)nullptr);
+    if (pmax > 4096) hipLaunchKernelGGL(k_nms_rowsort<8>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? (do_nms == 3 ? 3 : 0) : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, c.big_scratch);
+    else hipLaunchKernelGGL(k_nms_rowsort<4>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? (do_nms == 3 ? 3 : 0) : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, (uint8_t*)nullptr);
 }
 
 void launch_half(const DevCtx& c, int level, hipStream_t st)

@@ -444,7 +444,8 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     // stage1_rectify.cpp:80: one octave for dmORB (cv::ORB builds its own x1/1.2 pyramid), params_rectify.nOctaves otherwise
     const int noct = fast_orb ? (p.nOctaves < 1 ? 1 : p.nOctaves) : 1;
     int nlev = fast_orb ? noct : p.orb_nlevels; if (nlev < 1) nlev = 1;
-    if (ctx->geom_ready && ctx->geom_w == w && ctx->geom_h == h && ctx->geom_nfe == (fast_orb ? p.orb_nfeats : nfe) && ctx->geom_nlevels == nlev &&
+    const int nfe_key = fast_orb ? (p.non_maximal_suppression ? p.orb_nfeats : -1) : nfe;      // FAST + ORB without NMS keeps every corner: its own slot layout
+    if (ctx->geom_ready && ctx->geom_w == w && ctx->geom_h == h && ctx->geom_nfe == nfe_key && ctx->geom_nlevels == nlev &&
         ctx->geom_method == p.detect_method && ctx->geom_noct == noct) return SVO_OK;
     if (w > ctx->cfg.max_w || h > ctx->cfg.max_h || w < 64 || h < 64) return SVO_ERR_CAPACITY;
     if (nlev > SVO_MAX_LEVELS) return SVO_ERR_UNSUPPORTED;
@@ -460,7 +461,13 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
         for (int o = 0; o < SVO_MAX_OCTAVES; o++) d.kps_to_detect[o] = o == 0 ? (int)k0 : (o < noct ? (int)(size_t)round((double)k0 / pow(2, o)) : 0);
     }
     if (fast_orb) {
-        for (int l = 0; l < nlev; l++) { lw[l] = l ? lw[l - 1] / 2 : w; lh[l] = l ? lh[l - 1] / 2 : h; sc[l] = 1.0f; quota[l] = d.kps_to_detect[l]; }   // mrpt x1/2 octaves (S1:82-83)
+        // mrpt x1/2 octaves (S1:82-83).  Slots per octave: what the NMS may keep (kps_to_detect); without NMS the reference keeps EVERY
+        // FAST corner (S2:613-614: no cap at all) -- here as many as the context's lists hold, max_kps for octave 0 and half of the one
+        // before for the others (a quarter of the pixels each), beyond which SVO_ST_KPS_OVERFLOW is raised
+        for (int l = 0; l < nlev; l++) {
+            lw[l] = l ? lw[l - 1] / 2 : w; lh[l] = l ? lh[l - 1] / 2 : h; sc[l] = 1.0f;
+            quota[l] = p.non_maximal_suppression ? d.kps_to_detect[l] : std::max(64, d.max_kps >> l);
+        }
     } else {
         level_sizes(w, h, nlev, lw, lh, sc);
         level_quota(nfe, nlev, quota);
@@ -515,7 +522,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
         if (!tt.empty()) HIPCHECK(hipMemcpy((void*)d.fast_tiles, tt.data(), tt.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
     HIPCHECK(configure_nms_rowsort(d));
-    ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = fast_orb ? p.orb_nfeats : nfe; ctx->geom_nlevels = nlev;
+    ctx->geom_ready = true; ctx->geom_w = w; ctx->geom_h = h; ctx->geom_nfe = nfe_key; ctx->geom_nlevels = nlev;
     ctx->geom_method = p.detect_method; ctx->geom_noct = noct;
     return SVO_OK;
 }
@@ -773,7 +780,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
                 Span s(ctx, KT_SELECT); launch_fastorb_anms(d, ctx->d_anms, st);
             } else { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, 0, st); }
-            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, 0, p.min_distance, 0, st); }
+            if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression ? 0 : 3, p.min_distance, 0, st); }   // 0: the NMS ran above; 3: none, raster order
         } else {                // stage2_detect.cpp:458-497
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
@@ -793,7 +800,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     } else if (flags & SVO_RUN_DETECT_POST) {       // the post-processing a SVO_FLAG_DETECT_NO_POST call left out
         if (!ctx->geom_ready) return SVO_ERR_STATE;
         const int nms_mode = p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0;
-        if (d.fast_orb || d.debug_mode == 9) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, d.fast_orb ? 0 : nms_mode, p.min_distance, 0, st); }
+        if (d.fast_orb || d.debug_mode == 9) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, d.fast_orb ? (p.non_maximal_suppression ? 0 : 3) : nms_mode, p.min_distance, 0, st); }
         else {
             { Span s(ctx, KT_NMS); launch_nms_rowsort(d, nms_mode, p.min_distance, 1, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, 1, st); }

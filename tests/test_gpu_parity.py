@@ -868,3 +868,108 @@ def test_five_thousand_keypoints_in_one_octave():
     with pytest.raises(hip.SvoError, match="capacity"):
         small.process_host([(L, R)])
     small.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SVO_FUZZ_SEEDS", "24")))))
+def test_random_parameter_sets_match_oracle(seed):
+    """Parameter combinations nobody wrote a dedicated test for: every documented key of the path (SURVEY.md 8b "Config keys")
+    drawn at random in ORB mode -- pyramid depth, feature count, NMS on / off / adaptive and its cell size, FAST threshold,
+    response floor, both stereo matchers with and without the 1-to-1 rule, both trackers, RANSAC on / off, robust kernel on /
+    off, iteration limits, warm start, match IDs -- four frames each, every list bit-exact, poses within tolerance."""
+    rng = np.random.RandomState(1000 + seed)
+    w, h = [(640, 480), (512, 384), (800, 600), (417, 311)][seed % 4]
+    world = SyntheticStereoWorld(w + (-w) % 8, h + (-h) % 8, 400.0 * w / 640.0, 0.12, seed=100 + seed, n_frames=4)
+    cam = StereoCamera.simple(400.0 * w / 640.0, w / 2.0, h / 2.0, 0.12, w, h)
+    p = north_star_params(hip.default_params(), orb_nfeats=int(rng.choice([60, 200, 500, 900])))
+    p.orb_nlevels = int(rng.choice([1, 2, 3, 5, 8]))
+    p.non_maximal_suppression = int(rng.rand() < 0.75)
+    p.nmsMethod = int(rng.rand() < 0.3)
+    p.min_distance = int(rng.choice([2, 3, 4, 7, 10]))
+    p.initial_FAST_threshold = int(rng.choice([5, 12, 20, 35]))
+    p.minimum_ORB_response = float(rng.choice([0.0, 0.0, 1e-4]))
+    p.match_method = int(rng.rand() < 0.4)
+    p.enable_robust_1to1_match = int(rng.rand() < 0.6)
+    p.max_y_diff = float(rng.choice([0.0, 1.0, 2.0, 3.5]))
+    p.orb_max_distance = float(rng.choice([30.0, 60.0, 90.0]))
+    p.ifm_method = int(rng.rand() < 0.4)
+    p.ifm_win_w = int(rng.choice([5, 15, 40])); p.ifm_win_h = int(rng.choice([5, 15, 40]))
+    p.filter_fund_matrix = int(rng.rand() < 0.8)
+    p.use_robust_kernel = int(rng.rand() < 0.6)
+    p.kernel_param = float(rng.choice([1.0, 3.0, 10.0]))
+    p.initial_max_iters = int(rng.choice([1, 3, 10])); p.max_iters = int(rng.choice([1, 20, 100]))
+    p.max_incr_cost = int(rng.choice([0, 3]))
+    p.residual_threshold = float(rng.choice([2.0, 10.0, 50.0]))
+    p.bad_tracking_th = int(rng.choice([5, 30]))
+    p.use_previous_pose_as_initial = int(rng.rand() < 0.5)
+    p.vo_use_matches_ids = int(rng.rand() < 0.5)
+    tag = "seed %d: %dx%d levels %d nfeats %d nms %d/%d md %d th %d match %d/%d ydiff %.1f ifm %d F %d robust %d" % (
+        seed, w, h, p.orb_nlevels, p.orb_nfeats, p.non_maximal_suppression, p.nmsMethod, p.min_distance, p.initial_FAST_threshold,
+        p.match_method, p.enable_robust_1to1_match, p.max_y_diff, p.ifm_method, p.filter_fund_matrix, p.use_robust_kernel)
+    # a level's 2 x quota list must fit the selection kernels (2048 entries; 4096 for contexts with max_kps > 4096): few levels x many features
+    max_kps = 8192 if (p.orb_nlevels <= 2 and p.orb_nfeats >= 500) else 2048
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=max_kps, max_cand=1 << 16)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(4):
+        L, R = [np.ascontiguousarray(x.numpy()[:h, :w]) for x in world.render(t)]
+        ctx.process_host([(L, R)])
+        r, ro = ctx.result(0), orc.process(L, R, cam)
+        assert_same_frame(ctx, 0, orc, r, ro, "%s t=%d" % (tag, t))
+        if p.vo_use_matches_ids:
+            assert (ctx.match_ids(0, 0) == orc.match_ids(0)).all(), (tag, t, "match ids")
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SVO_FUZZ_SEEDS", "16")))))
+def test_random_parameter_sets_fast_orb_match_oracle(seed):
+    """The same for detect_method = FAST + ORB on the x1/2 octave pyramid (stage2_detect.cpp:502-515): 1-3 octaves, the
+    threshold limits that drive the reference's FAST-threshold adaptation, both NMS methods or none, both matchers / trackers."""
+    from stereo_vo_amd.abi import DM_FAST_ORB
+    rng = np.random.RandomState(2000 + seed)
+    w, h = [(640, 480), (800, 600), (512, 384)][seed % 3]
+    world = SyntheticStereoWorld(w, h, 400.0 * w / 640.0, 0.12, seed=200 + seed, n_frames=4)
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=int(rng.choice([150, 400, 900])))
+    p.detect_method = DM_FAST_ORB
+    p.nOctaves = int(rng.choice([1, 2, 3]))
+    p.non_maximal_suppression = int(rng.rand() < 0.75)
+    p.nmsMethod = int(rng.rand() < 0.3)
+    p.min_distance = int(rng.choice([2, 3, 5, 8]))
+    p.initial_FAST_threshold = int(rng.choice([8, 20, 40]))
+    p.fast_min_th = int(rng.choice([3, 5])); p.fast_max_th = int(rng.choice([30, 60]))
+    p.match_method = int(rng.rand() < 0.4)
+    p.enable_robust_1to1_match = int(rng.rand() < 0.6)
+    p.max_y_diff = float(rng.choice([1.0, 2.0]))
+    p.orb_min_th = int(rng.choice([20, 30])); p.orb_max_th = int(rng.choice([60, 100]))
+    p.ifm_method = int(rng.rand() < 0.4)
+    p.use_robust_kernel = int(rng.rand() < 0.6)
+    p.vo_use_matches_ids = int(rng.rand() < 0.5)
+    tag = "seed %d: %dx%d octaves %d nfeats %d nms %d/%d md %d th %d match %d ifm %d" % (
+        seed, w, h, p.nOctaves, p.orb_nfeats, p.non_maximal_suppression, p.nmsMethod, p.min_distance, p.initial_FAST_threshold, p.match_method, p.ifm_method)
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=4096, max_cand=1 << 17, max_octaves=3)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(4):
+        L, R = [x.numpy() for x in world.render(t)]
+        ctx.process_host([(L, R)])
+        r, ro = ctx.result(0), orc.process(L, R, cam)
+        # without NMS the reference keeps every FAST corner (S2:613-614), the context as many as its lists hold (max_kps >> octave):
+        # a frame that exceeds them must say so in the result record, and is then no parity case
+        if not p.non_maximal_suppression and any(max(ro.detected_left[o], ro.detected_right[o]) > max(64, 4096 >> o) for o in range(p.nOctaves)):
+            assert r.status & 2, (tag, t, "list capacity exceeded without SVO_ST_KPS_OVERFLOW")
+            ctx.close()
+            return
+        assert r.status == 0, (tag, t, r.status)
+        assert (r.valid, r.error_code, r.n_octaves) == (ro.valid, ro.error_code, ro.n_octaves), (tag, t)
+        for o in range(p.nOctaves):
+            for side in (0, 1):
+                k, d = ctx.keypoints(0, 0, side, octave=o)
+                ko, do = orc.keypoints(0, side, octave=o)
+                assert k.tobytes() == ko.tobytes() and (d == do).all(), (tag, t, "keypoints", o, side)
+            assert ctx.matches(0, 0, octave=o).tobytes() == orc.matches(0, octave=o).tobytes(), (tag, t, "pairings", o)
+            assert ctx.tracked(0, octave=o).tobytes() == orc.tracked(octave=o).tobytes(), (tag, t, "tracked", o)
+        assert ctx.fast_threshold() == orc.fast_threshold(), (tag, t, "FAST threshold")
+        if ro.valid:
+            dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
+            assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD, (tag, t, dp)
+    ctx.close()
