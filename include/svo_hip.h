@@ -111,7 +111,8 @@ int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam);
  * camera's images (bilinear, constant-0 border, S1:70-72) before detection.  map_x = map_y = NULL clears the map
  * (areImagesRectified(), S1:61-65). */
 int svo_set_rectify_map(svo_ctx* ctx, int lane, int side, const float* map_x, const float* map_y, int w, int h);
-/* forget both frames and the warm start of one lane (a freshly constructed estimator, C:28-50); -1 = all */
+/* forget both frames, the warm start and the match-ID counters of one lane (a freshly constructed estimator, C:28-50); -1 = all.
+ * The FAST / ORB thresholds belong to the context (all its lanes share svo_params) and stay as they are: svo_set_*_threshold. */
 int svo_reset(svo_ctx* ctx, int lane);
 
 /* processNewImagePair for every lane (P:41-385): ENQUEUES the whole frame on the context's stream and
@@ -173,7 +174,7 @@ typedef struct svo_values {
 } svo_values;
 int svo_get_values(svo_ctx* ctx, int lane, int which, int octave, svo_values* v);
 int svo_reset_ids(svo_ctx* ctx, int lane);
-int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane);
+int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane);   /* H:675-683; SVO_ERR_STATE while the lane has no current frame with pairings */
 
 /* the precomputed-data bypass (request_data.use_precomputed_data, H:214-218, P:131-162, P:219-251):
  * load caller-supplied features / pairings into a lane's current (which=0) or previous (which=1) frame. */

@@ -870,7 +870,7 @@ def test_five_thousand_keypoints_in_one_octave():
     small.close()
 
 
-@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SVO_FUZZ_SEEDS", "24")))))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SVO_FUZZ_SEEDS", "16")))))
 def test_random_parameter_sets_match_oracle(seed):
     """Parameter combinations nobody wrote a dedicated test for: every documented key of the path (SURVEY.md 8b "Config keys")
     drawn at random in ORB mode -- pyramid depth, feature count, NMS on / off / adaptive and its cell size, FAST threshold,
@@ -972,4 +972,57 @@ def test_random_parameter_sets_fast_orb_match_oracle(seed):
         if ro.valid:
             dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
             assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD, (tag, t, dp)
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SVO_FUZZ_SEEDS", "8")))))
+def test_random_call_sequences_match_oracle(seed):
+    """What a caller may do BETWEEN frames, in random order, mirrored on the oracle: the next frame, the same frame again with
+    request.repeat (P:86-89), a featureless frame (voecBadTracking -> the recovery rule keeps the older frame, P:326-330), new
+    FAST / ORB thresholds (H:531, 538), resetIds (H:684), setThisFrameAsKF (H:675-683), a fresh estimator (svo_reset).  Every
+    list, the match IDs of both slots, the key-frame counter and both thresholds after every call."""
+    rng = np.random.RandomState(3000 + seed)
+    w, h = 640, 480
+    world = SyntheticStereoWorld(w, h, 400.0, 0.12, seed=300 + seed, n_frames=16)
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=int(rng.choice([300, 600])))
+    p.vo_use_matches_ids = 1
+    p.ifm_method = int(rng.rand() < 0.3); p.match_method = int(rng.rand() < 0.3)
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=2048, max_cand=1 << 16)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    blank = np.full((h, w), 90, np.uint8)
+    t = 0; last = None; log = []; have_pairings = False
+    for step in range(14):
+        op = rng.choice(["next", "next", "next", "repeat", "blank", "fast_th", "orb_th", "reset_ids", "kf", "reset"])
+        log.append(op)
+        if op in ("fast_th", "orb_th"):
+            v = int(rng.choice([2, 10, 25, 45, 80, 200]))
+            if op == "fast_th": ctx.set_fast_threshold(v); orc.set_fast_threshold(v)
+            else: ctx.set_orb_threshold(v); orc.set_orb_threshold(v)
+            assert (ctx.fast_threshold(), ctx.orb_threshold()) == (orc.fast_threshold(), orc.orb_threshold()), (seed, log)
+            continue
+        if op == "reset_ids": ctx.reset_ids(0); orc.L.svo_oracle_reset_ids(orc.h); continue
+        if op == "kf":
+            if have_pairings: ctx.set_this_frame_as_kf(0); orc.L.svo_oracle_set_this_frame_as_kf(orc.h)
+            else:
+                with pytest.raises(hip.SvoError): ctx.set_this_frame_as_kf(0)          # nothing to make a key frame of
+            continue
+        if op == "reset":                       # the thresholds are the context's, not the lane's: carried over by hand
+            ctx.reset(0); orc = O().Oracle(p); last = None; have_pairings = False
+            orc.set_fast_threshold(ctx.fast_threshold()); orc.set_orb_threshold(ctx.orb_threshold())
+            continue
+        repeat = op == "repeat" and last is not None
+        if op == "blank": L = R = blank
+        elif repeat: L, R = last
+        else:
+            L, R = [x.numpy() for x in world.render(t)]; t += 1
+        last = (L, R)
+        ctx.process_host([(L, R)], hip.RUN_ALL | (hip.FLAG_REPEAT if repeat else 0))
+        r, ro = ctx.result(0), orc.process(L, R, cam, repeat=repeat)
+        assert_same_frame(ctx, 0, orc, r, ro, "seed %d %s" % (seed, log))
+        have_pairings = ro.stereo_matches[0] > 0
+        assert (ctx.match_ids(0, 0) == orc.match_ids(0)).all(), (seed, log, "ids cur")
+        assert r.tracked_feats_from_last_KF == ro.tracked_feats_from_last_KF, (seed, log)
+        assert (ctx.fast_threshold(), ctx.orb_threshold()) == (orc.fast_threshold(), orc.orb_threshold()), (seed, log)
     ctx.close()
