@@ -246,15 +246,18 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
 
 // ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
-// Integer VALU issue is what bounds this kernel (measured ~90 % VALU-busy), so the design minimises instructions:
+// Two things bound this kernel: integer VALU issue (the dense test of step 1 is its throughput floor, ~0.1 ms at 64 lanes) and
+// how many tiles a CU keeps in flight -- a tile lives a few microseconds of dependent loads, barriers and LDS round trips, and
+// the launch time falls as 1 / tiles-in-flight (fast_tile below: two waves per tile, 9 KB of LDS, geometry from a table).
+// So the design minimises instructions AND a tile's footprint in wave slots and LDS:
 // Tile = 64x28 interior pixels.  The 80x36 source window (3 px circle radius + 1 px NMS halo, start aligned to
-// 8 bytes) is staged in LDS with two 8-byte loads per thread.  A three-step cascade keeps the expensive work dense:
+// 8 bytes) is staged in LDS with 8-byte loads (360 of them over 128 threads).  A three-step cascade keeps the expensive work dense:
 //   (1) every position of the 68x30 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
 //       contains two ADJACENT compass points, so a corner needs two adjacent compass pixels both brighter than
 //       c+t or both darker than c-t.  It runs on FOUR positions per lane-op: the centre row / N / S come in as
 //       aligned LDS dwords, E / W by v_alignbyte, and the comparisons are saturating packed-16-bit subtractions
-//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  30 rows x 17 groups = 2 x 255 tasks: two per thread,
-//       15 rows apart, so the index arithmetic is done once.  Survivors are compacted into an LDS list by one scan;
+//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  30 rows x 17 groups = 2 x 255 tasks in pairs 15 rows apart
+//       (the index arithmetic is shared), two pairs per thread.  Survivors are compacted into an LDS list by one scan;
 //   (2) only the listed positions compute the arc-min score (both polarities through one packed min network);
 //   (3) the 3x3 NMS also walks the list; survivors are appended to the level's candidate list with one global
 //       atomic per tile, issued by a single wave.
