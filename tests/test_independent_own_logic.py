@@ -1,0 +1,278 @@
+"""A SECOND READING of the reference's OWN bookkeeping at realistic sizes (TEST INFRASTRUCTURE, CPU only).
+
+tests/test_oracle_units.py pins these pieces of oracle/svo_oracle.c with hand-built toy cases; here each is written again in
+plain Python as a literal walk through the reference's loops (file:line in every docstring) -- vectors, `erase`, `fill`,
+pre-increments and all -- and run against the oracle on thousands of random inputs.  Where the reference leaves the order of
+equal keys to an unstable std::sort the oracle's documented choice (input index ascending) is used on both sides.
+float means IEEE binary32 arithmetic, one rounding per operation, as the reference's C++ evaluates cv::Point2f expressions."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stereo_vo_amd.abi import keypoint_dtype, north_star_params
+
+f32 = np.float32
+
+
+def random_kps(rng, n, w, h, integer=False, resp_levels=None):
+    k = np.zeros(n, keypoint_dtype)
+    x = rng.uniform(0, w - 1, n); y = rng.uniform(0, h - 1, n)
+    if integer:
+        x, y = np.floor(x), np.floor(y)
+    k["x"], k["y"] = x.astype(np.float32), y.astype(np.float32)
+    k["response"] = (rng.randint(0, resp_levels, n) if resp_levels else rng.uniform(1e-6, 1e-2, n)).astype(np.float32)
+    k["size"] = 31.0; k["class_id"] = -1
+    return k
+
+
+def ref_nms_walk(kps, min_distance, W, H, num_out):
+    """m_non_max_sup, copying overload (stage2_detect.cpp:322-369)"""
+    n = len(kps)
+    order = sorted(range(n), key=lambda i: (-float(kps["response"][i]), i))            # S2:322-324 (ties: input order)
+    cell = int(min_distance / 2.0)                                                       # S2:331 (unsigned <- double)
+    inv = f32(1.0) / f32(cell)                                                           # S2:332
+    glx = int(f32(1) + f32(W) * inv); gly = int(f32(1) + f32(H) * inv)                   # S2:334-335
+    occ = np.zeros((glx, gly), bool)                                                     # S2:337-338
+    out = []; k = 0
+    while len(out) < num_out and k < n:                                                  # S2:342
+        idx = order[k]; k += 1
+        sx = int(f32(kps["x"][idx]) * inv); sy = int(f32(kps["y"][idx]) * inv)           # S2:348-349
+        if sx >= glx or sy >= gly:
+            continue                              # outside the matrix: undefined in the reference, skipped by the oracle
+        if occ[sx, sy]:
+            continue                                                                     # S2:351-352
+        occ[sx, sy] = True                                                               # S2:355-359
+        if sx > 0: occ[sx - 1, sy] = True
+        if sy > 0: occ[sx, sy - 1] = True
+        if sx < glx - 1: occ[sx + 1, sy] = True
+        if sy < gly - 1: occ[sx, sy + 1] = True
+        out.append(idx)                                                                  # S2:362
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_grid_nms_walk(seed):
+    rng = np.random.RandomState(seed)
+    w, h = [(640, 480), (1280, 960), (417, 311)][seed % 3]
+    n = [300, 3000, 1500][seed % 3]
+    kps = random_kps(rng, n, w, h, integer=seed % 2 == 0, resp_levels=50 if seed < 3 else None)   # many equal responses / none
+    for md in (2, 3, 4, 7, 10):
+        for cap in (n, n // 3, 17):
+            assert list(O.nms_copy(kps, md, w, h, cap)) == ref_nms_walk(kps, md, w, h, cap), (seed, md, cap)
+
+
+def ref_row_sort_index(kps, H):
+    """m_update_indexes(order = true) (stage2_detect.cpp:65-130)"""
+    n = len(kps)
+    order = sorted(range(n), key=lambda i: (float(kps["y"][i]), i))                      # S2:87-90 (ties: input order)
+    ys = [f32(kps["y"][i]) for i in order]
+    idx = [0] * H                                                                        # S2:74 (a fresh vector)
+    from_row = 0; feats_till_now = 0; current_row = 0
+    for i, y in enumerate(ys):                                                           # S2:108
+        if i == 0:                                                                       # S2:111-117
+            current_row = int(y)
+            to_row = current_row
+            for r in range(from_row, to_row): idx[r] = 0
+            from_row = to_row
+            continue
+        if y == f32(int(current_row)):                                                   # S2:119 (float against int(current_row))
+            feats_till_now += 1
+            continue
+        current_row = int(y)                                                             # S2:124
+        to_row = current_row
+        feats_till_now += 1                                                              # S2:127: fill(.., ++feats_till_now)
+        for r in range(from_row, to_row): idx[r] = feats_till_now
+        from_row = to_row
+    return order, idx
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_row_sort_and_row_index(seed):
+    rng = np.random.RandomState(10 + seed)
+    H = [480, 960, 311][seed % 3]
+    n = [0, 1, 5, 800, 2500, 2500][seed]
+    kps = random_kps(rng, n, 640, H, integer=seed % 2 == 1)           # scaled (non-integer) rows of levels > 0, and integer ones
+    order, idx = O.row_sort_index(kps, H)
+    want_order, want_idx = ref_row_sort_index(kps, H)
+    assert list(order) == want_order and list(idx) == want_idx, seed
+
+
+def ref_anms(kps, num_out, min_radius_th=0.0):
+    """m_adaptive_non_max_sup (stage2_detect.cpp:141-215)"""
+    N = len(kps)
+    actual = min(num_out, N)                                                             # S2:151
+    if actual == 0:
+        return []
+    order = sorted(range(N), key=lambda i: (-float(kps["response"][i]), i))              # S2:158-160
+    x = kps["x"].astype(np.float32); y = kps["y"].astype(np.float32); resp = kps["response"].astype(np.float64)
+    radius = [0.0] * N
+    s0 = order[0]
+    radius[s0] = float("inf")                                                            # S2:167
+    for k1 in range(1, N):                                                               # S2:171
+        a = order[k1]
+        dx = f32(x[a] - x[s0]); dy = f32(y[a] - y[s0])
+        min_ri = float(abs(f32(f32(dx * dx) + f32(dy * dy))))                            # S2:176
+        for k2 in range(k1 - 1, 0, -1):                                                  # S2:179 (rank 0 is never compared by response)
+            b = order[k2]
+            if resp[a] < 0.9 * resp[b]:                                                  # S2:183 (double)
+                dx = f32(x[a] - x[b]); dy = f32(y[a] - y[b])
+                this_ri = float(abs(f32(f32(dx * dx) + f32(dy * dy))))
+                if this_ri < min_ri: min_ri = this_ri
+        radius[a] = min_ri
+    by_radius = sorted(range(N), key=lambda i: (-radius[i], i))                          # S2:194-196 (ties: input order)
+    th2 = min_radius_th * min_radius_th
+    return [i for i in by_radius[:actual] if radius[i] > th2]                            # S2:207-214
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_adaptive_nms(seed):
+    rng = np.random.RandomState(20 + seed)
+    n = [40, 300, 700, 700][seed]
+    kps = random_kps(rng, n, 640, 480, integer=seed % 2 == 0, resp_levels=30 if seed == 3 else None)
+    for cap in (n, n // 2, 11):
+        assert list(O.anms_copy(kps, cap)) == ref_anms(kps, cap), (seed, cap)
+
+
+def hamming(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def ref_match_lr_bf(kl, dl, kr, dr, one2one, max_y_diff, orb_th, width):
+    """smDescBF (stage3_match_left_right.cpp:83-178): BFMatcher(NORM_HAMMING).match = first minimum over the train set"""
+    matches = []
+    for q in range(len(kl)):                                                             # S3:91-94
+        best, bd = -1, 1 << 30
+        for t in range(len(kr)):
+            d = hamming(dl[q], dr[t])
+            if d < bd: best, bd = t, d
+        if best >= 0: matches.append([q, best, float(bd)])
+    if one2one:                                                                          # S3:124-147
+        cand = [[-1.0, 0] for _ in range(len(kr))]
+        for q, t, d in matches:
+            if cand[t][0] < 0 or cand[t][0] > d: cand[t] = [d, q]
+        matches = [m for m in matches if m[0] == cand[m[1]][1]]
+    out = []
+    for q, t, d in matches:                                                              # S3:155-168
+        diff = int(f32(kl["y"][q]) - f32(kr["y"][t])); disp = int(f32(kl["x"][q]) - f32(kr["x"][t]))
+        if abs(diff) > max_y_diff or d > orb_th or disp < 1 or disp > width: continue
+        out.append((q, t, d))
+    return out
+
+
+def ref_pairings_row_index(kl, matches, H):
+    """matches_lr_row_index (stage3_match_left_right.cpp:425-445); the last entry is the documented deviation: the number of
+    PAIRINGS where the reference stores the number of left keypoints (S3:443), SURVEY.md 8a a8"""
+    ri = [0] * (H + 1); idx = 0; n = len(matches)
+    for y in range(H):                                                                   # S3:437-442
+        ri[y] = idx
+        while idx < n and f32(kl["y"][matches[idx][0]]) <= y: idx += 1
+    ri[H] = n
+    return ri
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_stereo_brute_force_pairing(seed):
+    rng = np.random.RandomState(30 + seed)
+    n = [60, 250, 250, 400][seed]
+    W, H = 640, 480
+    # right = left shifted by a disparity, descriptors of true partners a few bits apart, plus distractors and exact duplicates (ties)
+    kl = random_kps(rng, n, W, H)
+    order = np.argsort(kl["y"], kind="stable"); kl = kl[order]
+    kr = kl.copy(); kr["x"] -= rng.uniform(-3, 60, n).astype(np.float32); kr["y"] += rng.uniform(-2.5, 2.5, n).astype(np.float32)
+    dl = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    dr = dl.copy()
+    for i in range(n):
+        for b in rng.randint(0, 256, rng.randint(0, 40)): dr[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    dup = rng.randint(0, n, n // 6); dr[dup] = dr[(dup + 1) % n]                        # equal train rows: first minimum decides
+    perm = np.argsort(kr["y"], kind="stable"); kr, dr = kr[perm], dr[perm]
+    idxl = np.zeros(H, np.int64); idxr = np.zeros(H, np.int64)
+    for one2one in (0, 1):
+        for ydiff, th in ((1.0, 60), (0.0, 30), (2.0, 255)):
+            p = north_star_params(O.default_params())
+            p.enable_robust_1to1_match = one2one; p.max_y_diff = ydiff
+            m, ri = O.match_lr(p, th, kl, dl, idxl, kr, dr, idxr, W, H)
+            got = [(int(a), int(b), float(c)) for a, b, c in zip(m["queryIdx"], m["trainIdx"], m["distance"])]
+            assert got == ref_match_lr_bf(kl, dl, kr, dr, one2one, ydiff, th, W), (seed, one2one, ydiff, th)
+            assert list(ri) == ref_pairings_row_index(kl, got, H), (seed, one2one, ydiff, th, "row index")
+
+
+def bf_first_min(Q, T):
+    out = []
+    for q in range(len(Q)):
+        best, bd = -1, 1 << 30
+        for t in range(len(T)):
+            d = hamming(Q[q], T[t])
+            if d < bd: best, bd = t, d
+        out.append([q, best, bd])
+    return out
+
+
+def ref_track_bf(pkl, pdl, pkr, pdr, pm, ckl, cdl, ckr, cdr, cm, orb_th):
+    """ifmDescBF (stage4_match_consecutive.cpp:100-305).  The two cv::findFundamentalMat calls (S4:202, 237) are third-party: their
+    inlier masks come from the oracle's frozen RANSAC (O.ransac_fundamental); everything the reference itself does around them --
+    descriptor gathering, the two brute-force matches, the sequential joint collision filter, the both-must-be-good rule, the
+    erase-by-mask walk, the consistency check -- is walked here."""
+    preL = [pdl[m["queryIdx"]] for m in pm]; preR = [pdr[m["trainIdx"]] for m in pm]      # S4:105-113
+    curL = [cdl[m["queryIdx"]] for m in cm]; curR = [cdr[m["trainIdx"]] for m in cm]      # S4:125-131
+    matL = bf_first_min(preL, curL); matR = bf_first_min(preR, curR)                      # S4:141-142
+    if len(cm) == 0:
+        return []
+    ltm = [False] * len(cm); rtm = [False] * len(cm)                                     # S4:145
+    i = 0
+    while i < len(matL):                                                                 # S4:147-160
+        if matL[i][2] > orb_th or matR[i][2] > orb_th or ltm[matL[i][1]] or rtm[matR[i][1]]:
+            del matL[i]; del matR[i]
+        else:
+            ltm[matL[i][1]] = rtm[matR[i][1]] = True
+            i += 1
+    p1 = np.array([[pkl["x"][pm["queryIdx"][q]], pkl["y"][pm["queryIdx"][q]]] for q, t, d in matL], np.float32).reshape(-1, 2)   # S4:187-196
+    p2 = np.array([[ckl["x"][cm["queryIdx"][t]], ckl["y"][cm["queryIdx"][t]]] for q, t, d in matL], np.float32).reshape(-1, 2)
+    nL, maskL = O.ransac_fundamental(p1, p2)[:2]                                         # S4:201-205
+    p1 = np.array([[pkr["x"][pm["trainIdx"][q]], pkr["y"][pm["trainIdx"][q]]] for q, t, d in matR], np.float32).reshape(-1, 2)    # S4:216-224
+    p2 = np.array([[ckr["x"][cm["trainIdx"][t]], ckr["y"][cm["trainIdx"][t]]] for q, t, d in matR], np.float32).reshape(-1, 2)
+    nR, maskR = O.ransac_fundamental(p1, p2)[:2]                                         # S4:236-240
+    if nL >= 8 and nR >= 8:                                                              # S4:243-255
+        k = 0; i = 0
+        while i < len(matL) and i < len(matR):
+            if maskL[k] == 0 or maskR[k] == 0: del matL[i]; del matR[i]
+            else: i += 1
+            k += 1
+    return [(a[0], a[1]) for a, b in zip(matL, matR) if a[0] == b[0] and a[1] == b[1]]   # S4:276-287
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_inter_frame_tracking_around_the_ransac(seed):
+    from stereo_vo_amd.abi import dmatch_dtype
+    rng = np.random.RandomState(40 + seed)
+    W, H = 640, 480
+    nk, nm = 260, [6, 90, 180, 180][seed]                  # keypoints per image, stereo pairings per frame (6: too few for the F filter)
+    def frame(shift):
+        kl = random_kps(rng, nk, W, H); kr = kl.copy(); kr["x"] -= 20.0
+        kl["x"] += shift; kr["x"] += shift
+        return kl, kr
+    pkl, pkr = frame(0.0)
+    ckl, ckr = pkl.copy(), pkr.copy()
+    move = (np.array([3.0, 1.0]) + rng.normal(0, 0.2, (nk, 2))).astype(np.float32)      # one rigid image motion + pixel noise
+    ckl["x"] += move[:, 0]; ckl["y"] += move[:, 1]; ckr["x"] += move[:, 0]; ckr["y"] += move[:, 1]
+    bad = rng.rand(nk) < 0.25                              # a quarter of the features jump: outliers of the epipolar geometry
+    ckl["x"][bad] += rng.uniform(-80, 80, bad.sum()).astype(np.float32); ckr["y"][bad] += rng.uniform(-60, 60, bad.sum()).astype(np.float32)
+    pdl = rng.randint(0, 256, (nk, 32)).astype(np.uint8); pdr = rng.randint(0, 256, (nk, 32)).astype(np.uint8)
+    def noisy(d, nbits):
+        d = d.copy()
+        for i in range(len(d)):
+            for b in rng.randint(0, 256, rng.randint(0, nbits)): d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        return d
+    cdl, cdr = noisy(pdl, 50), noisy(pdr, 50)
+    dup = rng.randint(0, nk, nk // 8); cdl[dup] = cdl[(dup + 3) % nk]          # collisions: two queries with the same best train
+    def pairing(n):
+        q = np.sort(rng.choice(nk, n, replace=False))
+        m = np.zeros(n, dmatch_dtype); m["queryIdx"] = q; m["trainIdx"] = q; m["distance"] = 10.0
+        return m
+    pm = pairing(nm); cm = pm.copy() if seed % 2 else pairing(nm)                    # the same features paired again / another subset
+    ri = np.zeros(H + 1, np.int64)
+    p = north_star_params(O.default_params())
+    for th in (40, 70, 255):
+        got = O.track(p, th, pkl, pdl, pkr, pdr, pm, ri, ckl, cdl, ckr, cdr, cm, ri, W, H)
+        want = ref_track_bf(pkl, pdl, pkr, pdr, pm, ckl, cdl, ckr, cdr, cm, th)
+        assert [(int(a), int(b)) for a, b in zip(got["first"], got["second"])] == want, (seed, th)
+    assert len(want) > 0 or seed % 2 == 0
