@@ -410,3 +410,79 @@ def test_stage5_control_flow(seed):
             last = want["delta"]
         else:
             last = None
+
+
+class RefEstimator:
+    """processNewImagePair (process_new_image_pair.cpp:41-385) composed in Python from the stage functions walked above: the
+    prev / cur shift with the recovery rule (P:86-95), stage 2 = detector -> NMS (cap kps_to_detect, S2:404-407, 583-597) -> row
+    sort + index (S2:618), stage 3, first-iteration / bad-tracking rules (P:305-330), stage 5 through getChangeInPose's estimator
+    (its m_last_computed_pose is the warm start of the next call, S5:720-721).  Third-party pieces (detector, RANSAC, projection)
+    are the oracle's stage functions; the driver logic is what is walked."""
+
+    def __init__(self, p, cam, W, H):
+        self.p, self.cam, self.W, self.H = p, cam, W, H
+        self.prev = self.cur = None
+        self.m_error = 0
+        self.fast_th = p.initial_FAST_threshold; self.orb_th = int(p.orb_max_distance)           # H:661-662
+        self.solver = O.Oracle(p)                                                                # holds m_last_computed_pose
+
+    def _detect(self, img):
+        p = self.p
+        nfe = int(1.5 * p.orb_nfeats) if p.non_maximal_suppression else p.orb_nfeats              # S2:461-464
+        k, d = O.orb_detect(img, nfe, p.orb_nlevels, self.fast_th)                                # S2:482-493 (cv::ORB stand-in)
+        if p.non_maximal_suppression:
+            k0 = int(float(p.orb_nfeats) * 2.0 / (2 ** 1 - 1))                                    # S2:405 with nOctaves = 1 (S1:80)
+            order = ref_nms_walk(k, p.min_distance, self.W, self.H, k0)                           # S2:585-597
+            k, d = k[order], d[order]
+        order, idx = ref_row_sort_index(k, self.H)                                                # S2:618
+        return k[order], d[order], np.array(idx, np.int64)
+
+    def process(self, L, R, repeat=False):
+        p = self.p
+        if not repeat and self.m_error not in (5, 1): self.prev = self.cur                        # P:86-89
+        self.m_error = 0                                                                          # P:94-95
+        kl, dl, il = self._detect(L); kr, dr, ir = self._detect(R)
+        m, ri = O.match_lr(p, self.orb_th, kl, dl, il, kr, dr, ir, self.W, self.H)
+        self.cur = dict(kl=kl, dl=dl, kr=kr, dr=dr, m=m, ri=ri)
+        out = dict(valid=False, error_code=0, tracked=None)
+        if self.prev is None:                                                                     # P:347-351
+            out["error_code"] = 4; return out
+        pv, cu = self.prev, self.cur
+        t = O.track(p, self.orb_th, pv["kl"], pv["dl"], pv["kr"], pv["dr"], pv["m"], pv["ri"], cu["kl"], cu["dl"], cu["kr"], cu["dr"], cu["m"], cu["ri"], self.W, self.H)
+        out["tracked"] = t
+        if len(t) < p.bad_tracking_th:                                                            # P:321-325
+            self.m_error = out["error_code"] = 5; return out
+        valid, r, resid, outl = self.solver.change_in_pose(t, pv["m"], cu["m"], pv["kl"], pv["kr"], cu["kl"], cu["kr"], self.cam)
+        if r.error_code == 1: self.m_error = 1                                                    # S5:381 sets m_error too
+        out.update(valid=valid, error_code=r.error_code, pose=np.array(r.outPose), outliers=outl)
+        return out
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_driver_rules_and_stage_composition(seed):
+    from stereo_vo_amd.synth import SyntheticStereoWorld
+    rng = np.random.RandomState(60 + seed)
+    W, H = 320, 240
+    world = SyntheticStereoWorld(W, H, 200.0, 0.12, seed=60 + seed, n_frames=8)
+    cam = world.camera()
+    p = north_star_params(O.default_params(), orb_nfeats=[150, 250, 150][seed])
+    p.non_maximal_suppression = int(seed != 2); p.orb_nlevels = [8, 4, 8][seed]
+    ref = RefEstimator(p, cam, W, H); orc = O.Oracle(p)
+    blank = np.full((H, W), 70, np.uint8)
+    ops = ["next", "next", "blank", "next", "repeat", "next", "blank", "blank", "next", "next"]
+    t = 0; last = None
+    for op in ops:
+        if op == "blank": L = R = blank
+        elif op == "repeat": L, R = last
+        else: L, R = [x.numpy() for x in world.render(t)]; t += 1
+        last = (L, R)
+        got = orc.process(L, R, cam, repeat=(op == "repeat")); want = ref.process(L, R, repeat=(op == "repeat"))
+        for side, (k, d) in enumerate(((ref.cur["kl"], ref.cur["dl"]), (ref.cur["kr"], ref.cur["dr"]))):
+            ko, do = orc.keypoints(0, side)
+            assert ko.tobytes() == k.tobytes() and (do == d).all(), (seed, op, "keypoints", side)
+        assert orc.matches(0).tobytes() == ref.cur["m"].tobytes(), (seed, op, "pairings")
+        assert (bool(got.valid), got.error_code) == (bool(want["valid"]), want["error_code"]), (seed, op, got.error_code, want["error_code"])
+        if want["tracked"] is not None:
+            assert orc.tracked().tobytes() == want["tracked"].tobytes(), (seed, op, "tracked")
+        if want["valid"]:
+            assert np.abs(np.array(got.outPose) - want["pose"]).max() < 1e-12 and (orc.outliers() == want["outliers"]).all(), (seed, op)
