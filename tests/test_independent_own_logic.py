@@ -636,3 +636,71 @@ def test_inter_frame_windowed_tracking(seed):
         want = ref_track_win(pkl, pdl, pkr, pm, pri, ckl, cdl, ckr, cm, cri, win_w, win_h, W, H)
         assert [(int(a), int(b)) for a, b in zip(got["first"], got["second"])] == [(int(a), int(b)) for a, b in want], (seed, win_w, win_h)
     assert len(want) > 0
+
+
+def ref_projection(lmks, cam, delta):
+    """m_pinhole_stereo_projection (stage5_optimization.cpp:35-257) derived in matrix form instead of entry by entry:
+    R = I + v W - u W^2 with W = [w]x, v = sin(t)/t, u = (cos(t) - 1)/t^2 (S5:100-118), so
+    dR/dw_k = v_k W + v G_k - u_k W^2 - u (G_k W + W G_k) with G_k the generators -- which is what the reference's 27 formulas
+    spell out (S5:119-161), all but ONE: its dr22/dw3 reads (w2^2 + w3^2) du/dw3 where the derivative is (w1^2 + w2^2) du/dw3
+    (S5:162).  The oracle and the kernels keep the reference's entry; so does this reading, as an explicit patch.
+    Below 1e-5 rad: R = I + W and the generators (S5:65-97).  Pixels are stored as float (TPixelCoordf, S5:188-195)."""
+    w = np.array(delta[:3], float); t = np.array(delta[3:], float)
+    G = [np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], float), np.array([[0, 0, 1], [0, 0, 0], [-1, 0, 0]], float), np.array([[0, -1, 0], [1, 0, 0], [0, 0, 0]], float)]
+    Wm = w[0] * G[0] + w[1] * G[1] + w[2] * G[2]
+    th = np.sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2])
+    if th < 1e-5:
+        R = np.eye(3) + Wm; dR = G
+    else:
+        u = (np.cos(th) - 1) / th ** 2; v = np.sin(th) / th
+        du = [((-np.sin(th) * wk / th) * th ** 2 - (np.cos(th) - 1) * 2 * wk) / th ** 4 for wk in w]
+        dv = [wk * (th * np.cos(th) - np.sin(th)) / th ** 3 for wk in w]
+        W2 = Wm @ Wm
+        R = np.eye(3) + v * Wm - u * W2
+        dR = [dv[k] * Wm + v * G[k] - du[k] * W2 - u * (G[k] @ Wm + Wm @ G[k]) for k in range(3)]
+        dR[2][2, 2] = (w[1] ** 2 + w[2] ** 2) * du[2]                                     # S5:162, as the reference has it
+    X = lmks @ R.T + t
+    X2 = X[:, 0] - cam.baseline
+    Z = X[:, 2]
+    pix = np.stack([cam.l_fx * X[:, 0] / Z + cam.l_cx, cam.l_fy * X[:, 1] / Z + cam.l_cy, cam.r_fx * X2 / Z + cam.r_cx, cam.r_fy * X[:, 1] / Z + cam.r_cy], 1).astype(np.float32)
+    J = np.zeros((len(lmks), 4, 6))
+    for j in range(6):
+        Xd = lmks @ dR[j].T if j < 3 else np.tile(np.eye(3)[j - 3], (len(lmks), 1))
+        J[:, 0, j] = cam.l_fx * (Xd[:, 0] * Z - X[:, 0] * Xd[:, 2]) / (Z * Z)
+        J[:, 1, j] = cam.l_fy * (Xd[:, 1] * Z - X[:, 1] * Xd[:, 2]) / (Z * Z)
+        J[:, 2, j] = cam.r_fx * (Xd[:, 0] * Z - X2 * Xd[:, 2]) / (Z * Z)
+        J[:, 3, j] = cam.r_fy * (Xd[:, 1] * Z - X[:, 1] * Xd[:, 2]) / (Z * Z)
+    return pix, J
+
+
+def test_projection_and_jacobian_in_matrix_form():
+    from stereo_vo_amd.abi import StereoCamera
+    rng = np.random.RandomState(90)
+    cam = StereoCamera.simple(718.856, 607.19, 185.22, 0.537, 1241, 376)
+    Z = rng.uniform(3, 40, 200)
+    X = np.c_[rng.uniform(-0.6, 0.6, 200) * Z, rng.uniform(-0.2, 0.2, 200) * Z, Z]
+    deltas = [np.zeros(6), np.array([3e-6, -2e-6, 1e-6, 0.1, 0.0, -0.3]), np.array([0.01, -0.02, 0.005, 0.05, -0.02, -0.4]),
+              np.array([0.3, 0.2, -0.4, 1.0, -0.5, 0.7]), np.array([0, 0, 0.02, 0, 0, 0.0]), rng.normal(0, 0.05, 6)]
+    worst = 0.0
+    for d in deltas:
+        pix, J = O.project(X, cam, d)
+        wp, wJ = ref_projection(X, cam, d)
+        assert (pix == wp).mean() > 0.99 and np.abs(pix - wp).max() < 1e-4          # float32 pixels: a last-bit tie at worst
+        scale = np.abs(wJ).max(axis=(0, 1), keepdims=True) + 1e-30
+        assert (np.abs(J - wJ) / scale).max() < 1e-12, d
+        worst = max(worst, float((np.abs(J - wJ) / scale).max()))
+    # and the patched entry is the only place where the reference departs from the derivative of its own R
+    d = deltas[3]; eps = 1e-6
+    _, Jr = ref_projection(X, cam, d)
+    num = np.zeros_like(Jr)
+    for j in range(6):
+        dp = d.copy(); dm = d.copy(); dp[j] += eps; dm[j] -= eps
+        w = np.array(d[:3]); th = np.linalg.norm(w)
+        def exact_pixels(dd):
+            from scipy.spatial.transform import Rotation
+            Rm = Rotation.from_rotvec(dd[:3]).as_matrix(); Xc = X @ Rm.T + dd[3:]
+            return np.stack([cam.l_fx * Xc[:, 0] / Xc[:, 2] + cam.l_cx, cam.l_fy * Xc[:, 1] / Xc[:, 2] + cam.l_cy,
+                             cam.r_fx * (Xc[:, 0] - cam.baseline) / Xc[:, 2] + cam.r_cx, cam.r_fy * Xc[:, 1] / Xc[:, 2] + cam.r_cy], 1)
+        num[:, :, j] = (exact_pixels(dp) - exact_pixels(dm)) / (2 * eps)
+    err = np.abs(Jr - num).max(axis=(0, 1))
+    assert err[[0, 1, 3, 4, 5]].max() < 1e-4 and err[2] > 10 * err[[0, 1]].max()       # only the w3 column carries the S5:162 entry
