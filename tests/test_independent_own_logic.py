@@ -753,3 +753,69 @@ def test_match_id_bookkeeping(seed):
             assert list(orc.match_ids(1)) == list(ref.prev["ids"]), (seed, op, "previous ids")
         if want["valid"]:
             assert got.tracked_feats_from_last_KF == want["from_kf"], (seed, op)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_fast_orb_octaves_composition(seed):
+    """detect_method = FAST + ORB on the x1/2 octave pyramid, composed in Python: scaleHalfSmooth octaves (S1:82-83), FAST + ORB
+    describe per octave (S2:502-515), the per-octave NMS quota k0 = size_t(nfeats * 2 nOct / (2^nOct - 1)), k_o = round(k0 / 2^o)
+    (S2:404-407), pairing and tracking per octave, and stage 5 on the tracked pairs of ALL octaves with the coordinates multiplied
+    by 2^octave (S5:408-461) -- whose `outliers` hold per-octave current-pairing indices (S5:603-610)."""
+    from stereo_vo_amd.synth import SyntheticStereoWorld
+    from stereo_vo_amd.abi import DM_FAST_ORB, dmatch_dtype, index_pair_dtype
+    W, H = 320, 240
+    nOct = [2, 3][seed]
+    world = SyntheticStereoWorld(W, H, 200.0, 0.12, seed=90 + seed, n_frames=4)
+    cam = world.camera()
+    p = north_star_params(O.default_params(), orb_nfeats=[120, 200][seed])
+    p.detect_method = DM_FAST_ORB; p.nOctaves = nOct; p.ifm_method = seed
+    orc = O.Oracle(p); solver = O.Oracle(p)
+    k0 = int(float(p.orb_nfeats) * float(2 * nOct) / (2 ** nOct - 1))
+    quota = [k0] + [int(np.floor(k0 / 2.0 ** o + 0.5)) for o in range(1, nOct)]
+    prev = None
+    for t in range(4):
+        L, R = [x.numpy() for x in world.render(t)]
+        got = orc.process(L, R, cam)
+        cur = []
+        imgs = [L, R]
+        for o in range(nOct):
+            if o: imgs = [O.half_smooth(im) for im in imgs]
+            h, w = imgs[0].shape
+            sides = []
+            for im in imgs:
+                k, d = O.fast_orb_detect(im, p.initial_FAST_threshold)
+                order = ref_nms_walk(k, p.min_distance, w, h, quota[o]); k, d = k[order], d[order]
+                order, idx = ref_row_sort_index(k, h); sides.append((k[order], d[order], np.array(idx, np.int64)))
+            (kl, dl, il), (kr, dr, ir) = sides
+            m, ri = O.match_lr(p, int(p.orb_max_distance), kl, dl, il, kr, dr, ir, w, h)
+            cur.append(dict(kl=kl, dl=dl, kr=kr, dr=dr, m=m, ri=ri, w=w, h=h))
+            for side, (k, d) in enumerate(((kl, dl), (kr, dr))):
+                ko, do = orc.keypoints(0, side, o)
+                assert ko.tobytes() == k.tobytes() and (do == d).all(), (seed, t, o, side)
+            assert orc.matches(0, o).tobytes() == m.tobytes(), (seed, t, o)
+        if prev is not None:
+            l1l, l1r, l2l, l2r, back = [], [], [], [], []
+            for o in range(nOct):
+                pv, cu = prev[o], cur[o]
+                tr = O.track(p, int(p.orb_max_distance), pv["kl"], pv["dl"], pv["kr"], pv["dr"], pv["m"], pv["ri"], cu["kl"], cu["dl"], cu["kr"], cu["dr"], cu["m"], cu["ri"], cu["w"], cu["h"])
+                assert orc.tracked(o).tobytes() == tr.tobytes(), (seed, t, o)
+                for a, b in zip(tr["first"], tr["second"]):
+                    for lst, src, idx in ((l1l, pv["kl"], pv["m"]["queryIdx"][a]), (l1r, pv["kr"], pv["m"]["trainIdx"][a]),
+                                          (l2l, cu["kl"], cu["m"]["queryIdx"][b]), (l2r, cu["kr"], cu["m"]["trainIdx"][b])):
+                        kp = src[idx].copy(); kp["x"] = f32(kp["x"]) * f32(2 ** o); kp["y"] = f32(kp["y"]) * f32(2 ** o)
+                        lst.append(kp)
+                    back.append(int(b))
+            T = len(back)
+            if T >= p.bad_tracking_th:
+                ident = np.zeros(T, dmatch_dtype); ident["queryIdx"] = ident["trainIdx"] = np.arange(T)
+                pairs = np.zeros(T, index_pair_dtype); pairs["first"] = pairs["second"] = np.arange(T)
+                arr = lambda lst: np.array(lst, dtype=keypoint_dtype)
+                valid, r, resid, outl = solver.change_in_pose(pairs, ident, ident, arr(l1l), arr(l1r), arr(l2l), arr(l2r), cam)
+                assert (bool(got.valid), got.error_code) == (bool(valid), r.error_code), (seed, t)
+                if valid:
+                    assert np.abs(np.array(got.outPose) - np.array(r.outPose)).max() < 1e-12, (seed, t)
+                    assert list(orc.outliers()) == [back[i] for i in outl], (seed, t)
+            else:
+                assert got.error_code == 5
+        prev = cur
+    assert got.valid
