@@ -386,9 +386,15 @@ int svo_oracle_orb_detect(const uint8_t* img, int w, int h, int stride, int nfea
         uint32_t* keys = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)ccap);
         int nc = fast_nms_candidates(score, W, H, keys, ccap);
         free(score);
-        /* keep the best 2*quota by (FAST score desc, position asc) */
+        /* KeyPointsFilter::retainBest(2 * quota) by FAST score: the best 2*quota AND everything that ties with the last of them
+         * ("the boundary response ... in the case of FAST may be ambiguous": integer scores tie routinely) */
         qsort(keys, (size_t)nc, sizeof(uint32_t), cmp_u32_desc);
-        if (nc > 2 * quota[l]) nc = 2 * quota[l];
+        if (nc > 2 * quota[l]) {
+            int cut = 2 * quota[l];
+            const uint32_t boundary = keys[cut - 1] >> 24;
+            while (cut < nc && (keys[cut] >> 24) == boundary) cut++;
+            nc = cut;
+        }
         /* Harris response, keep the best quota by (response desc, position asc) */
         uint64_t* hk = (uint64_t*)xmalloc(sizeof(uint64_t) * (size_t)(nc ? nc : 1));
         for (int i = 0; i < nc; i++) {

@@ -692,6 +692,26 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
     }
     const unsigned n_tie = s_ntie;
     uint32_t cutoff;
+    // cv::KeyPointsFilter::retainBest keeps EVERY candidate that ties with the K-th by response, and FAST scores are integers:
+    // the whole score bin of the K-th key goes to the Harris ranking (K - need keys above the bin + all n_tie of it), as long as
+    // the list holds them; a bin too large for it is cut at exactly K (position order) and reported in the result's status word
+    const unsigned K_ties = (K - need) + n_tie;
+    if (K_ties <= (unsigned)SEL_MAX) {
+        cutoff = prefix;                                                   // score byte of the K-th key, low bits zero: the whole bin
+        for (unsigned base = tid; base < nc; base += 8 * 512) {
+            uint32_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const unsigned i = base + u * 512; k[u] = i < nc ? ck[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (base + u * 512 < nc && k[u] >= cutoff) sel[atomicAdd(&s_sel, 1u)] = k[u];
+        }
+        __syncthreads();
+        uint32_t* gsel_t = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
+        for (unsigned i = tid; i < K_ties; i += blockDim.x) gsel_t[i] = sel[i];
+        if (tid == 0) c.sel_n[il] = (int)K_ties;
+        return;
+    }
+    if (tid == 0) { atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW); atomicOr(&c.results[img >> 1].status, (int)SVO_ST_CAND_OVERFLOW); }
     if (n_tie <= SEL_TIE_MAX) {
         for (unsigned base = tid; base < nc; base += 8 * 512) {
             uint32_t k[8];
