@@ -146,3 +146,21 @@ def test_pose_conventions_against_scipy():
             # keeps it, hence the looser bound on the w3 column
             tol = 5e-3 if j == 2 else 2e-4
             assert np.abs(jac[:, :, j] - num).max() < tol * max(1.0, np.abs(num).max()), (j, np.abs(jac[:, :, j] - num).max())
+
+
+def test_per_level_feature_split(scene):
+    """cv::ORB hands level l about nfeatures (1 - f) / (1 - f^L) f^l keypoints, f = 1 / 1.2, rounded level by level in single
+    precision, the last level taking the remainder (Rublee et al. 2011, sec. 6.1 "scale pyramid"; OpenCV's computeKeyPoints).
+    On an image with corners to spare the detector's per-level counts ARE that split."""
+    rng = np.random.RandomState(3)
+    img = (rng.rand(480, 640) * 255).astype(np.uint8)              # white noise: thousands of FAST corners on every level
+    for nfeatures, nlevels in ((500, 8), (1000, 5), (300, 3), (77, 2), (50, 1)):
+        k, _ = O.orb_detect(img, nfeatures, nlevels, 20)
+        got = [int((k["octave"] == l).sum()) for l in range(nlevels)]
+        f = np.float32(1.0 / 1.2)
+        nd = np.float32(nfeatures) * (np.float32(1) - f) / (np.float32(1) - np.float32(float(f) ** nlevels))
+        want, total = [], 0
+        for l in range(nlevels - 1):
+            n = int(np.rint(nd)); want.append(n); total += n; nd = np.float32(nd * f)
+        want.append(max(nfeatures - total, 0))
+        assert got == want and sum(got) == nfeatures, (nfeatures, nlevels, got, want)
