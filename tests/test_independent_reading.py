@@ -164,3 +164,13 @@ def test_per_level_feature_split(scene):
             n = int(np.rint(nd)); want.append(n); total += n; nd = np.float32(nd * f)
         want.append(max(nfeatures - total, 0))
         assert got == want and sum(got) == nfeatures, (nfeatures, nlevels, got, want)
+
+
+def test_pyramid_level_sizes():
+    """level l of cv::ORB's pyramid: scale = (float) 1.2^l, size = round(dimension / scale) (OpenCV's getScale / cvRound)"""
+    for w, h in ((1280, 960), (1241, 376), (640, 480), (2048, 1536), (417, 311)):
+        lw, lh, sc = O.pyramid_sizes(w, h, 8)
+        for l in range(8):
+            s = np.float32(1.2 ** l)
+            assert sc[l] == float(s), (w, h, l)
+            assert (lw[l], lh[l]) == (int(np.rint(np.float32(w) / s)), int(np.rint(np.float32(h) / s))), (w, h, l, lw[l], lh[l])
