@@ -36,6 +36,7 @@ from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 import ctypes as C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+PMC_PROFILES = ("r03_pmc.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")    # newest first; tools/pmc_passes.py writes them
 
 
 def lane_seeds(rank, world_size, lanes):
@@ -109,6 +110,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=64, help="upper bound on the frames per probe stream replayed on the CPU oracle (baseline timing + parity probe; 0 = skip)")
     ap.add_argument("--host-fed-steps", type=int, default=16, help="steps of the host-fed leg (page-locked host frames uploaded per step on the contexts' copy streams; 0 = skip); N=1 only")
     ap.add_argument("--single-stream", type=int, default=1, help="1: also time ONE stream alone (plain launches, hipGraph replay, frames dealt to 2 / 3 contexts); N=1, config2 only")
+    ap.add_argument("--exclusive", type=int, default=1, help="1: after the timed region, time the roofline kernel again with one context alone on the GPU (roofline.exclusive); 0 = skip (profiling runs)")
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5; 2: on a third stream of its own")
@@ -243,21 +245,34 @@ def main():
         # L2 memory-side read / write requests counted by size in separate rocprofv3 --pmc runs of this same command),
         # scaled from the profiled lane count to this run's; None when the profile does not cover this workload.
         # `traffic_source` names the file so that a reader can tell a carried-over constant from a live counter.
-        traffic, traffic_source = None, None
-        for prof in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic, traffic_source, valu_frac, valu_table = None, None, None, None
+        kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
+        for prof in PMC_PROFILES:
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
-                kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
-                if pm.get("workload") == args.workload and kk in pm["read_bytes"]:
+                if pm.get("workload") != args.workload:
+                    continue
+                if "kernels" in pm:            # tools/pmc_passes.py (round 3 on): traffic and issue counters of every kernel, steady state
+                    e = pm["kernels"].get(kk)
+                    if e is None:
+                        continue
+                    traffic = int((e.get("read_bytes", 0) + e.get("write_bytes", 0)) * Bc / pm["lanes"])
+                    valu_frac = e.get("valu_issue_frac")
+                    valu_table = {k: v["valu_issue_frac"] for k, v in pm["kernels"].items() if "valu_issue_frac" in v}
+                elif kk in pm["read_bytes"]:
                     traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * Bc / pm["lanes"])
-                    traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)" % prof
-                    break
+                else:
+                    continue
+                traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)" % prof
+                break
             except Exception:
                 pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4),
                     "streams_per_launch": Bc,
+                    "valu_issue_frac": valu_frac, "valu_issue_frac_by_kernel": valu_table,
+                    "valu_issue_note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of a launch with one context alone, from the same committed PMC passes as `traffic`: the share of the VALU issue slots the kernel fills -- the bound that binds here when it is near 1 and `frac` is not",
                     "note": ("dominant kernel of the detect stream; stage 3-5 kernels run on the overlap stream and their spans are time-shared, not exclusive" if pipelined else "single stream: every span is an exclusive duration")}
         # end-to-end algorithmic traffic of the whole path (SURVEY.md 8d formula), for the DESIGN.md table
         P = sum(a * b for a, b in lv) / float(W * H)
@@ -279,6 +294,8 @@ def main():
         # the roofline kernel once more with the GPU to itself (one context, nothing on the overlap stream): in the pipelined
         # schedule its spans are time-shared with the stage 3-5 kernels of the other contexts
         try:
+            if not args.exclusive:
+                raise RuntimeError("skipped (--exclusive 0)")
             batch.reset()
             c0 = batch.ctxs[0]
             c0.kernel_times_select(dom)

@@ -98,8 +98,11 @@ int svo_get_orb_threshold(const svo_ctx* ctx);
 /* Switch the HIP stream that later svo_process / svo_copy_results_async calls enqueue on (NULL: the context's own).
  * Ordering between work already enqueued on the old stream and work on the new one is the caller's business (events):
  * this is what lets a caller run stage 2 of one context on a normal-priority stream and stages 3-5 of another on a
- * high-priority one (bench.py). */
+ * high-priority one (bench.py).  Stream lifetime: a stream must stay alive while calls that enqueue on it are being made; once
+ * the caller has switched away it may synchronise and destroy the stream -- later svo_wait / svo_get_* / svo_destroy wait on
+ * context-owned events recorded behind the work, never on the stream handle. */
 int svo_set_stream(svo_ctx* ctx, void* stream);
+int svo_get_device(const svo_ctx* ctx);           /* HIP device ordinal of the context (svo_config.device); < 0 on error */
 /* the hipStream_t later calls enqueue on (so that a caller can order its own work -- an RCCL call, an event -- after a frame) */
 int svo_get_stream(svo_ctx* ctx, void** stream);
 /* request_data.stereo_cam (H:211), per lane; lane = -1 sets every lane */

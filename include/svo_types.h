@@ -106,8 +106,23 @@ typedef struct svo_result {
     int32_t n_outliers;      /* size of result.outliers (which holds INLIER cur-match indices, S5:603-610) */
     int32_t n_residual;      /* size of result.out_residual */
     int32_t status;          /* 0, or capacity bits: 1 = a level's FAST candidate list overflowed svo_config.max_cand, 2 = a keypoint /
-                                track list was cut at svo_config.max_kps (the reference has no such limits: stage2_detect.cpp:461-464) */
+                                track list was cut at svo_config.max_kps (the reference has no such limits: stage2_detect.cpp:461-464),
+                                4 = svo_import_frame was handed a hand-over record of another layout */
+    int32_t track_stats[8];  /* where stage 4's candidates go, summed over the octaves (SVO_TS_*): no reference counterpart -- the
+                                reference prints some of them at verbose level 2 (stage4_match_consecutive.cpp:205, 240) */
 } svo_result;
+
+/* indices of svo_result.track_stats: previous-frame pairings that ...                                      (ifmDescBF | ifmDescWin) */
+enum {
+    SVO_TS_THRESHOLD = 0,    /* pass the descriptor-distance threshold on both sides (S4:149)               | = SVO_TS_COLLISION */
+    SVO_TS_COLLISION = 1,    /* survive the joint collision filter (S4:145-160): the RANSAC's input         | survivors of S4:640-679 */
+    SVO_TS_INLIERS_L = 2,    /* inliers of the left-left fundamental matrix (S4:202-205); 0 = no model */
+    SVO_TS_INLIERS_R = 3,    /* inliers of the right-right one (S4:237-240) */
+    SVO_TS_HYP_L = 4,        /* hypotheses the left RANSAC visited before its confidence stop */
+    SVO_TS_HYP_R = 5,        /* the same, right */
+    SVO_TS_BOTH_MASKS = 6,   /* are inliers of both models (S4:243-255; = SVO_TS_COLLISION when a model was not found) */
+    SVO_TS_TRACKED = 7       /* also pass the left/right consistency check (S4:282): tracked_pairs */
+};
 
 #define SVO_MAX_OCTAVES 4
 #define SVO_DESC_BYTES 32

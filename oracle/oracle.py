@@ -45,6 +45,11 @@ def lib(native=False):
     return _LIB[native]
 
 
+def version() -> int:
+    """SVO_ORACLE_VERSION: the version of the frozen definitions (oracle/svo_oracle.h); stored in the golden files and the bench line"""
+    return int(lib().svo_oracle_version())
+
+
 def default_params() -> Params:
     p = Params()
     lib().svo_oracle_params_defaults(C.byref(p))

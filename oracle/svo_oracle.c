@@ -38,6 +38,8 @@ static int cmp_u64_desc(const void* a, const void* b) { uint64_t x = *(const uin
 static int cmp_u64_asc(const void* a, const void* b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : (x > y ? 1 : 0); }
 static int cmp_u32_desc(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? 1 : (x > y ? -1 : 0); }
 
+int svo_oracle_version(void) { return SVO_ORACLE_VERSION; }
+
 void svo_oracle_params_defaults(svo_params* p)
 {
     memset(p, 0, sizeof(*p));
@@ -745,8 +747,46 @@ static void ransac_sample(int h, int n, int* idx)
     }
 }
 
+/* Rank-2 enforcement of a (normalised) 3x3 fundamental matrix f, row-major [frozen]: cv::findFundamentalMat returns rank-2
+ * models (its 7-point solver by construction, its 8-point solver by zeroing the smallest singular value, S4:202, 237).  Zeroing
+ * the smallest singular value is f <- f (I - v v^T) with v the right singular vector of the smallest singular value, i.e. the
+ * eigenvector of S = f^T f for its smallest eigenvalue.  That eigenvalue is the smallest root of the characteristic cubic
+ * q(t) = t^3 - c2 t^2 + c1 t - c0; S is positive semi-definite, so q is increasing and concave left of it and Newton's
+ * iteration from t = 0 climbs to it monotonically (eight fixed steps; quadratic convergence).  v is the cross product of two
+ * rows of S - t I, the pair with the largest norm (first maximum).  +, -, *, / only, one IEEE operation per operator: the HIP
+ * kernel repeats the expressions verbatim and both sides get the same bits.  A degenerate f (double smallest root, zero
+ * matrix) yields 0 / 0 = NaN entries; fm_inlier then counts no inliers for that hypothesis, on both sides alike. */
+static void rank2_enforce(double* f)
+{
+    const double s00 = (f[0] * f[0] + f[3] * f[3]) + f[6] * f[6], s01 = (f[0] * f[1] + f[3] * f[4]) + f[6] * f[7], s02 = (f[0] * f[2] + f[3] * f[5]) + f[6] * f[8];
+    const double s11 = (f[1] * f[1] + f[4] * f[4]) + f[7] * f[7], s12 = (f[1] * f[2] + f[4] * f[5]) + f[7] * f[8], s22 = (f[2] * f[2] + f[5] * f[5]) + f[8] * f[8];
+    const double c2 = (s00 + s11) + s22;
+    const double m00 = s11 * s22 - s12 * s12, m11 = s00 * s22 - s02 * s02, m22 = s00 * s11 - s01 * s01;
+    const double c1 = (m00 + m11) + m22;
+    const double c0 = (s00 * m00 - s01 * (s01 * s22 - s12 * s02)) + s02 * (s01 * s12 - s11 * s02);
+    double t = 0.0;
+    for (int it = 0; it < 8; it++) {
+        const double q = ((t - c2) * t + c1) * t - c0, dq = (3.0 * t - 2.0 * c2) * t + c1;
+        if (!(dq > 0.0)) break;
+        t = t - q / dq;
+    }
+    const double a00 = s00 - t, a11 = s11 - t, a22 = s22 - t;
+    /* rows r0 = (a00 s01 s02), r1 = (s01 a11 s12), r2 = (s02 s12 a22) */
+    const double x0 = s01 * s12 - s02 * a11, y0 = s02 * s01 - a00 * s12, z0 = a00 * a11 - s01 * s01;       /* r0 x r1 */
+    const double x1 = s01 * a22 - s02 * s12, y1 = s02 * s02 - a00 * a22, z1 = a00 * s12 - s01 * s02;       /* r0 x r2 */
+    const double x2 = a11 * a22 - s12 * s12, y2 = s12 * s02 - s01 * a22, z2 = s01 * s12 - a11 * s02;       /* r1 x r2 */
+    const double n0 = (x0 * x0 + y0 * y0) + z0 * z0, n1 = (x1 * x1 + y1 * y1) + z1 * z1, n2 = (x2 * x2 + y2 * y2) + z2 * z2;
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+    for (int r = 0; r < 3; r++) {
+        const double w = ((f[3 * r] * vx + f[3 * r + 1] * vy) + f[3 * r + 2] * vz) / nn;
+        f[3 * r] = f[3 * r] - w * vx; f[3 * r + 1] = f[3 * r + 1] - w * vy; f[3 * r + 2] = f[3 * r + 2] - w * vz;
+    }
+}
+
 /* normalised linear 8-point solution (Hartley) through the null vector of the 8x9 system, found by
- * Gauss-Jordan elimination with full pivoting.  No rank-2 enforcement (hypothesis scoring only). */
+ * Gauss-Jordan elimination with full pivoting, then made rank 2 (rank2_enforce) before it is denormalised. */
 static void eight_point(const float* p1, const float* p2, const int* s, double* F)
 {
     double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
@@ -779,6 +819,7 @@ static void eight_point(const float* p1, const float* p2, const int* s, double* 
     double f[9];
     f[perm[8]] = 1.0;
     for (int i = 0; i < 8; i++) f[perm[i]] = -A[i][8];
+    rank2_enforce(f);
     /* F = T2^T * F0 * T1 */
     const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
     double M[3][3];
@@ -875,6 +916,9 @@ int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8
 /* ------------------------------------------------------------------------------------------------ */
 /* stage 4: inter-frame tracking  (S4:71-801)                                                       */
 /* ------------------------------------------------------------------------------------------------ */
+/* svo_result.track_stats of the call under way (SVO_TS_*): filled by track_bf / track_win, summed over the octaves by
+ * svo_oracle_process.  Thread-local: bench.py replays several oracle instances on several threads. */
+static __thread int g_ts[8];
 static int track_bf(int orb_th,
                     const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr, const svo_dmatch* pm, int npm,
                     const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr, const svo_dmatch* cm, int ncm,
@@ -895,10 +939,12 @@ static int track_bf(int orb_th,
     int* kq = (int*)xmalloc(sizeof(int) * (size_t)npm);
     int nk = 0;
     for (int k = 0; k < npm; k++) {
+        if (!((float)dL[k] > (float)orb_th || (float)dR[k] > (float)orb_th)) g_ts[SVO_TS_THRESHOLD]++;
         if ((float)dL[k] > (float)orb_th || (float)dR[k] > (float)orb_th || ltm[tL[k]] || rtm[tR[k]]) continue;
         ltm[tL[k]] = rtm[tR[k]] = 1;
         kq[nk++] = k;
     }
+    g_ts[SVO_TS_COLLISION] += nk;
     /* S4:171-241 fundamental matrix on left-left, then right-right pixel pairs */
     float* p1 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(nk ? nk : 1)), *p2 = (float*)xmalloc(sizeof(float) * 2 * (size_t)(nk ? nk : 1));
     uint8_t* inL = (uint8_t*)xmalloc((size_t)(nk ? nk : 1)), *inR = (uint8_t*)xmalloc((size_t)(nk ? nk : 1));
@@ -907,22 +953,26 @@ static int track_bf(int orb_th,
         const svo_keypoint* a = &pkl[pm[k].queryIdx], *b = &ckl[cm[tL[k]].queryIdx];   /* S4:183-189 */
         p1[2 * i] = a->x; p1[2 * i + 1] = a->y; p2[2 * i] = b->x; p2[2 * i + 1] = b->y;
     }
-    const int numInL = svo_oracle_ransac_fundamental(p1, p2, nk, inL, NULL, NULL, NULL);   /* S4:202-205 */
+    int hypL = 0, hypR = 0;
+    const int numInL = svo_oracle_ransac_fundamental(p1, p2, nk, inL, NULL, NULL, &hypL);  /* S4:202-205 */
     for (int i = 0; i < nk; i++) {
         int k = kq[i];
         const svo_keypoint* a = &pkr[pm[k].trainIdx], *b = &ckr[cm[tR[k]].trainIdx];   /* S4:218-224 */
         p1[2 * i] = a->x; p1[2 * i + 1] = a->y; p2[2 * i] = b->x; p2[2 * i + 1] = b->y;
     }
-    const int numInR = svo_oracle_ransac_fundamental(p1, p2, nk, inR, NULL, NULL, NULL);   /* S4:237-240 */
+    const int numInR = svo_oracle_ransac_fundamental(p1, p2, nk, inR, NULL, NULL, &hypR);  /* S4:237-240 */
     const int goodFL = numInL >= 8, goodFR = numInR >= 8;
+    g_ts[SVO_TS_INLIERS_L] += numInL; g_ts[SVO_TS_INLIERS_R] += numInR; g_ts[SVO_TS_HYP_L] += hypL; g_ts[SVO_TS_HYP_R] += hypR;
     int t = 0;
     for (int i = 0; i < nk; i++) {
         int k = kq[i];
         if (goodFL && goodFR && (inL[i] == 0 || inR[i] == 0)) continue;             /* S4:243-255 */
+        g_ts[SVO_TS_BOTH_MASKS]++;
         if (tL[k] != tR[k]) continue;                                               /* S4:282 consistency */
         if (t < cap) { out[t].first = k; out[t].second = tL[k]; }                   /* S4:285 */
         t++;
     }
+    g_ts[SVO_TS_TRACKED] += t < cap ? t : cap;
     free(preL); free(preR); free(curL); free(curR); free(tL); free(dL); free(tR); free(dR);
     free(ltm); free(rtm); free(kq); free(p1); free(p2); free(inL); free(inR);
     return t < cap ? t : cap;
@@ -987,14 +1037,21 @@ static int track_win(const svo_params* p,
         pot[j].first = pi; pot[j].second = i; j++;
     }
     uint8_t* inL = (uint8_t*)xmalloc((size_t)(np ? np : 1)), *inR = (uint8_t*)xmalloc((size_t)(np ? np : 1));
-    int use_f = svo_oracle_ransac_fundamental(l1, l2, np, inL, NULL, NULL, NULL) >= 8;   /* S4:684-687 */
-    if (use_f) use_f = svo_oracle_ransac_fundamental(r1, r2, np, inR, NULL, NULL, NULL) >= 8;   /* S4:696-699 */
+    /* (the HIP path evaluates both models unconditionally; the counters follow that: the right RANSAC's figures are reported
+     * even when the left one found no model and the reference would not have run it -- the tracked pairs are the same) */
+    int hypL = 0, hypR = 0;
+    const int numInL = svo_oracle_ransac_fundamental(l1, l2, np, inL, NULL, NULL, &hypL);   /* S4:684-687 */
+    const int numInR = svo_oracle_ransac_fundamental(r1, r2, np, inR, NULL, NULL, &hypR);   /* S4:696-699 */
+    const int use_f = numInL >= 8 && numInR >= 8;
+    g_ts[SVO_TS_THRESHOLD] += np; g_ts[SVO_TS_COLLISION] += np;
+    g_ts[SVO_TS_INLIERS_L] += numInL; g_ts[SVO_TS_INLIERS_R] += numInR; g_ts[SVO_TS_HYP_L] += hypL; g_ts[SVO_TS_HYP_R] += hypR;
     int t = 0;
     for (int i = 0; i < np; i++) {                                                  /* S4:708-714 */
         if (use_f && (!inL[i] || !inR[i])) continue;
         if (t < cap) out[t] = pot[i];
         t++;
     }
+    g_ts[SVO_TS_BOTH_MASKS] += t; g_ts[SVO_TS_TRACKED] += t < cap ? t : cap;
     free(cmf); free(cms); free(l1); free(l2); free(r1); free(r2); free(pot); free(inL); free(inR);
     return t < cap ? t : cap;
 }
@@ -1572,6 +1629,7 @@ int svo_oracle_process(svo_oracle* o, const uint8_t* left, const uint8_t* right,
     if (o->prev && o->prev->present) {                                              /* P:305 */
         pair_data* prev = o->prev;
         o->m_num_tracked_last_frame = 0; o->m_num_tracked_last_kf = 0;              /* S4:743 */
+        memset(g_ts, 0, sizeof(g_ts));
         for (int oc = 0; oc < nOct; oc++) {                                         /* P:314 stage4_track */
             pairing_t* pp = &prev->pr[oc], *cp = &cur->pr[oc];
             int cap = pp->n > 0 ? pp->n : 1;
@@ -1596,6 +1654,7 @@ int svo_oracle_process(svo_oracle* o, const uint8_t* left, const uint8_t* right,
             o->m_num_tracked_last_frame += t;                                       /* S4:746 */
             for (int k = 0; k < cp->n_ids; k++) if (cp->ids[k] <= o->m_last_kf_max_id) o->m_num_tracked_last_kf++;   /* S4:747-751 */
         }
+        for (int k = 0; k < 8; k++) result->track_stats[k] = g_ts[k];
         if (o->m_num_tracked_last_frame < p->bad_tracking_th) {                     /* P:326-330 */
             o->m_error = result->error_code = SVO_VOEC_BAD_TRACKING;
         }

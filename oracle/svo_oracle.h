@@ -20,6 +20,14 @@
 extern "C" {
 #endif
 
+/* Version of the FROZEN definitions (everything the reference delegates to third-party code and this file therefore pins by
+ * itself).  Bumped whenever one of them changes, stored in every tests/golden/oracle_*.npz and printed in the bench line, so
+ * that a change of the yardstick is visible in the record:
+ *   1  round 1;  2  round 2 (RANSAC schedule 256 -> 1000 with cv::RANSACUpdateNumIters, retainBest keeps ties);
+ *   3  round 3 (rank-2 enforcement of the 8-point fundamental matrix, as cv::findFundamentalMat returns rank-2 models) */
+#define SVO_ORACLE_VERSION 3
+int svo_oracle_version(void);
+
 typedef struct svo_oracle svo_oracle;
 
 void svo_oracle_params_defaults(svo_params* p);

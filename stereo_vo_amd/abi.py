@@ -62,7 +62,11 @@ class Result(C.Structure):
         ("tracked_feats_from_last_KF", C.c_int32), ("tracked_feats_from_last_frame", C.c_int32),
         ("detected_left", C.c_int32 * 4), ("detected_right", C.c_int32 * 4), ("stereo_matches", C.c_int32 * 4),
         ("n_octaves", C.c_int32), ("n_outliers", C.c_int32), ("n_residual", C.c_int32), ("status", C.c_int32),
+        ("track_stats", C.c_int32 * 8),
     ]
+
+# indices of Result.track_stats (include/svo_types.h SVO_TS_*)
+TS_NAMES = ("threshold", "collision", "inliers_left", "inliers_right", "hyp_left", "hyp_right", "both_masks", "tracked")
 
 
 def north_star_params(base: Params, orb_nfeats=1350) -> Params:

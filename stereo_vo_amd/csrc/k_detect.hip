@@ -97,6 +97,7 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
         r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = c.n_oct;
         if (detect) r.status = 0;
         r.tracked_feats_from_last_frame = 0; r.tracked_feats_from_last_KF = 0;
+        if (flags & SVO_RUN_TRACK) for (int k = 0; k < 8; k++) r.track_stats[k] = 0;
         for (int k = 0; k < 6; k++) { r.outPose[k] = 0; r.delta[k] = 0; }
     }
 }
@@ -136,8 +137,8 @@ void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_
 // K1: one pyramid level from the previous one, bilinear with the frozen 11-bit integer tables.
 // HBM-bound on paper (~1.44 source bytes read + 1 written per output pixel), VALU-issue-bound in practice, so the
 // blend is written for instruction count.  A 256-thread block produces a 128x32 destination tile: the <= 160x41
-// source window is staged in LDS by aligned dwords (240 threads x 7 passes of 6 rows), the tile's slice of the
-// x / y tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
+// source window is staged in LDS by LDS-DMA (global_load_lds_dwordx4: 42 rows x 11 chunks of 16 bytes, two wave-instructions
+// per wave, no VGPR round trip), the tile's slice of the x / y tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
 // Per pixel: the two taps of each source row come out of two aligned LDS dwords as a u16 pair by one v_perm (the
 // selector is a per-column constant), v_dot2_u32_u16 applies (2048 - ax, ax), two 24-bit multiply-adds apply the
 // row weights pre-scaled by 4 so that the rounded result lands in byte 3, and three v_perm pack four results.
@@ -145,7 +146,7 @@ void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_
 // ------------------------------------------------------------------------------------------------------------
 #define RZ_W 128
 #define RZ_H 32
-#define RZ_SP 160     // LDS window pitch in bytes (40 dwords >= 128 * 1.2 + 2 + 3)
+#define RZ_SP 176     // LDS window pitch in bytes: 11 DMA chunks of 16 (>= 128 * 1.2 + 2 + 15, the window origin is 16-byte aligned in x)
 #define RZ_SH 41      // >= 32 * 1.2 + 2
 #define RZ_CHUNK 16   // consecutive tiles per XCD turn
 
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
     int spitch; const uint8_t* src = level_ptr(c, img, level - 1, spitch);
     uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
     const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
-    const int sx0 = xi[dx0] & ~3, sy0 = yi[dy0];                       // window origin (block-uniform)
+    const int sx0 = xi[dx0] & ~15, sy0 = yi[dy0];                      // window origin (block-uniform)
     if (tid < RZ_W) {
         const int x = min(dx0 + tid, d.w - 1), rx = xi[x] - sx0, ax = xf[x];
         xw[tid] = (uint32_t)(2048 - ax) | ((uint32_t)ax << 16);                                    // dot2 weights
@@ -182,19 +183,23 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
         yr[tid - RZ_W] = (uint32_t)(yi[y] - sy0);
     }
     if (c.debug_mode == 5) { /* ablation: no staging */ }
-    else if ((((uintptr_t)src | (uintptr_t)spitch) & 3) == 0) {
-        if (tid < 240) {
-            const int r = tid / 40, q = tid - r * 40;
-            const uint32_t xx = (uint32_t)min(sx0 + 4 * q, spitch - 4);
-            uint32_t v[7];
-#pragma unroll
-            for (int p = 0; p < 7; p++) {
-                const uint32_t yy = (uint32_t)min(sy0 + r + 6 * p, s.h - 1);
-                v[p] = *(const uint32_t*)(src + (__umul24(yy, (uint32_t)spitch) + xx));          // 32-bit offset from a uniform base
-            }
-#pragma unroll
-            for (int p = 0; p < 7; p++) win[tid + 240 * p] = v[p];                                 // rows 0..41 (pitch 40 dwords)
-        }
+    else if ((spitch & 15) == 0) {
+        // LDS-DMA: chunk i = (row i / 11, piece i % 11) lands at LDS byte 16 i.  The source base may sit at any byte alignment
+        // (tools/ubench/glds_align.hip); with the origin 16-aligned in x and a pitch that is a multiple of 16 no chunk
+        // straddles the end of a row, so the clamp to the last chunk of the row only ever moves chunks that lie wholly
+        // beyond it (never read: the taps stop at column s.w - 1).
+        typedef const void __attribute__((address_space(1)))* gptr_t;
+        typedef void __attribute__((address_space(3)))* lptr_t;
+        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+        auto chunk_src = [&](int i) -> const uint8_t* {
+            const int r = (i * 745) >> 13, q = i - 11 * r;                  // i / 11, i % 11 for i < 512
+            const int yy = min(sy0 + r, s.h - 1), xx = min(sx0 + 16 * q, spitch - 16);
+            return src + (uint32_t)(yy * spitch + xx);
+        };
+        uint8_t* wb = (uint8_t*)win;
+        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(tid), (lptr_t)(wb + wid * 1024), 16, 0, 0);
+        if (tid + 256 < (RZ_SH + 1) * (RZ_SP / 16)) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(tid + 256), (lptr_t)(wb + 4096 + wid * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         uint8_t* wb = (uint8_t*)win;
         for (int i = tid; i < RZ_SH * RZ_SP; i += 256) {
@@ -355,33 +360,33 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     unsigned& s_count = sm.s_count; unsigned& s_nout = sm.s_nout;
     const int tid = threadIdx.x;
     if (tid == 0) { s_nout = 0; s_count = 0; }
-    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+32): 36 rows x 10 chunks of 8 bytes, rows r and r+18 per thread ----
-#pragma unroll
-    for (int task = tid; task < 180; task += FT_NT) {
-        const int r = task / 10, q = task - r * 10;
-        const int ya = min(y0 - 4 + r, gh - 1), yb = min(y0 - 4 + r + 18, gh - 1);
-        uint2 va, vb;
-        if ((((uintptr_t)src | (uintptr_t)pitch) & 7) == 0) {
-            const int xx = min(x0 - 7 + q * 8, pitch - 8);              // rows are readable up to the pitch
-            va = *(const uint2*)(src + (long long)ya * pitch + xx);
-            vb = *(const uint2*)(src + (long long)yb * pitch + xx);
-        } else {
-            // any pointer / stride: aligned-down dwords funnel-shifted into place.  Every dword read contains at least
-            // one byte of the image (addresses are clamped to the dword of the last byte), so it cannot fault.
-            const uintptr_t last = ((uintptr_t)src + (uintptr_t)((long long)gh * pitch) - 1) & ~(uintptr_t)3;
-            const uintptr_t aa = (uintptr_t)src + (uintptr_t)((long long)ya * pitch + x0 - 7 + q * 8);
-            const uintptr_t ab = (uintptr_t)src + (uintptr_t)((long long)yb * pitch + x0 - 7 + q * 8);
-            const uintptr_t a0 = aa & ~(uintptr_t)3, b0 = ab & ~(uintptr_t)3;
-            const uint32_t a_0 = *(const uint32_t*)min(a0, last), a_1 = *(const uint32_t*)min(a0 + 4, last), a_2 = *(const uint32_t*)min(a0 + 8, last);
-            const uint32_t b_0 = *(const uint32_t*)min(b0, last), b_1 = *(const uint32_t*)min(b0 + 4, last), b_2 = *(const uint32_t*)min(b0 + 8, last);
-            const uint32_t sa = (uint32_t)(aa & 3) * 8u, sb = (uint32_t)(ab & 3) * 8u;
-            va.x = __builtin_amdgcn_alignbit(a_1, a_0, sa); va.y = __builtin_amdgcn_alignbit(a_2, a_1, sa);
-            vb.x = __builtin_amdgcn_alignbit(b_1, b_0, sb); vb.y = __builtin_amdgcn_alignbit(b_2, b_1, sb);
-        }
-        *(uint2*)&tile[r * FT_LW + q * 8] = va;
-        *(uint2*)&tile[(r + 18) * FT_LW + q * 8] = vb;
+    // the score map is cleared BEFORE the DMA is issued: the compiler orders every LDS store behind an outstanding LDS-DMA
+    // (s_waitcnt vmcnt(0)), so a store placed after it would wait out the whole fetch
+    static_assert((FT_SH * FT_SP + 15) / 16 <= FT_NT + 8, "score-map clear: one 16-byte store per thread + 8");
+    ((uint4*)score)[tid] = make_uint4(0, 0, 0, 0);
+    if (tid < (FT_SH * FT_SP + 15) / 16 - FT_NT) ((uint4*)score)[FT_NT + tid] = make_uint4(0, 0, 0, 0);
+    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+32) with the LDS-DMA path (global_load_lds_dwordx4): a wave-instruction
+    //      lands 64 x 16 bytes at LDS base + lane * 16 straight from the lanes' global addresses, no VGPR round trip and no
+    //      ds_write.  The window is 36 rows x 5 chunks of 16 bytes = 180 chunks, chunk i at LDS byte 16 i (pitch 80): three
+    //      wave-instructions per tile (chunks 0..63 by wave 0, 64..127 by wave 1, 128..179 by wave 0 again) where the
+    //      register path spent ~50 VALU instructions per wave on address arithmetic, clamps and 8-byte ds_writes.
+    //      The source may sit at ANY byte alignment and the destination base at any dword (tools/ubench/glds_align.hip pins
+    //      both on the hardware), so one path serves every pointer / stride.  Chunks are clamped to the image proper
+    //      (x <= gw - 16, y <= gh - 1): a clamped chunk holds shifted bytes, but only columns >= gw - 16 can be affected and
+    //      nothing right of column gw - 28 is ever read by an interior position (EDGE 31 - radius 3 - NMS halo 1).
+    {
+        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+        auto chunk_src = [&](int i) -> const uint8_t* {
+            const int r = (i * 205) >> 10, q = i - 5 * r;                   // i / 5, i % 5 for i < 1024
+            const int yy = min(y0 - 4 + r, gh - 1), xx = min(x0 - 7 + 16 * q, gw - 16);
+            return src + (uint32_t)(yy * pitch + xx);                       // 32-bit offset from the level's uniform base
+        };
+        typedef const void __attribute__((address_space(1)))* gptr_t;
+        typedef void __attribute__((address_space(3)))* lptr_t;
+        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(tid), (lptr_t)(tile + wid * 1024), 16, 0, 0);
+        if (tid < 180 - FT_NT) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(FT_NT + tid), (lptr_t)(tile + 2048), 16, 0, 0);
     }
-    for (int i = tid; i < (FT_SH * FT_SP + 15) / 16; i += FT_NT) ((uint4*)score)[i] = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's DMA chunks have landed; the barrier covers the other wave's
     __syncthreads();
     if (c.debug_mode == 1) return;
     // ---- (1) packed cardinal test: 30 rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + 15, gq) ----
@@ -411,28 +416,32 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             }
         }
     }
-    {   // compaction by ballots: 8 * FT_TURNS 64-lane masks (tasks x four positions), counts and prefixes on the scalar
-        // unit, ONE LDS atomic per wave (list order is irrelevant)
-        bool f[8 * FT_TURNS];
-        unsigned long long bm[8 * FT_TURNS];
+    {   // compaction: the thread's 16 verdicts become one bit mask (bit 8 p + g: position p of group g = 2 u + k), a DPP scan of
+        // the popcounts gives every lane its first list slot, ONE LDS atomic per wave reserves the wave's range, and each lane
+        // writes its own survivors.  (Sixteen ballots with their mbcnt pairs and conditional stores cost ~100 VALU instructions
+        // per wave whether the tile held one candidate or fifty; this costs ~25 plus ~12 per survivor of the busiest lane, and
+        // at the speculated thresholds 2 % of the positions survive.)  List order is irrelevant.  Entry = r << 8 | q.
+        const u16x2 one2 = { 1, 1 };
+        uint32_t m = 0;
 #pragma unroll
-        for (int k = 0; k < 2 * FT_TURNS; k++) {
-            f[4 * k + 0] = (pe[k] & 0xFFFFu) != 0; f[4 * k + 1] = (po[k] & 0xFFFFu) != 0;
-            f[4 * k + 2] = (pe[k] >> 16) != 0;     f[4 * k + 3] = (po[k] >> 16) != 0;
+        for (int g = 0; g < 2 * FT_TURNS; g++) {
+            const uint32_t fe = as_u32(__builtin_elementwise_min(as_u16x2(pe[g]), one2)), fo = as_u32(__builtin_elementwise_min(as_u16x2(po[g]), one2));
+            m |= (fe | (fo << 8)) << g;                                    // positions 0, 2 from pe's halves; 1, 3 from po's
         }
-        int total = 0;
-#pragma unroll
-        for (int j = 0; j < 8 * FT_TURNS; j++) { bm[j] = __ballot(f[j]); total += __popcll(bm[j]); }
-        unsigned wbase = 0;
+        const int cnt = __popc(m), inc = wave_inclusive_scan(cnt);
+        const int total = __builtin_amdgcn_readlane(inc, 63);
         if (total) {
+            unsigned wbase = 0;
             if ((tid & 63) == 0) wbase = atomicAdd(&s_count, (unsigned)total);
-            wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase);
+            unsigned idx = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase) + (unsigned)(inc - cnt);
+            int eb[FT_TURNS];
 #pragma unroll
-            for (int j = 0; j < 8 * FT_TURNS; j++) {
-                const int pt = tid + (j >> 3) * FT_NT, r0 = pt / FT_NG, gq = pt - r0 * FT_NG;
-                const unsigned idx = __builtin_amdgcn_mbcnt_hi((unsigned)(bm[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[j], wbase));
-                if (f[j]) list[idx] = (unsigned short)(r0 * FT_SP + 4 * gq + ((j >> 2) & 1) * 15 * FT_SP + (j & 3));
-                wbase += (unsigned)__popcll(bm[j]);
+            for (int u = 0; u < FT_TURNS; u++) { const int pt = tid + u * FT_NT, r0 = pt / FT_NG, gq = pt - r0 * FT_NG; eb[u] = (r0 << 8) | (4 * gq); }
+            static_assert(FT_TURNS == 2, "the decode below selects between two turns");
+            while (m) {
+                const int b = __builtin_ctz(m); m &= m - 1;
+                const int g = b & 7;
+                list[idx++] = (unsigned short)(((g & 2) ? eb[1] : eb[0]) + (g & 1) * (15 << 8) + (b >> 3));
             }
         }
     }
@@ -441,8 +450,8 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     if (c.debug_mode == 2) return;
     // ---- (2) score on the survivors only ----
     for (int i = tid; i < ns; i += FT_NT) {
-        const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
-        score[pos] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
+        const int e = list[i], r = e >> 8, q = e & 0xFF;
+        score[r * FT_SP + q] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
     }
     __syncthreads();
     if (c.debug_mode == 3) return;
@@ -451,7 +460,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
         const int i = base + tid;
         bool keep = false; uint32_t key = 0;
         if (i < ns) {
-            const int pos = list[i], r = pos / FT_SP, q = pos - r * FT_SP;
+            const int e = list[i], r = e >> 8, q = e & 0xFF, pos = r * FT_SP + q;
             // nine byte reads at immediate offsets, issued together; the middle column goes through an opaque copy of
             // the base so that no two fuse into a misaligned ds_read_u16.  (r = 0 reads below the map: rejected below.)
             const int nb = pos - FT_SP - 1; int nbm = nb; asm volatile("" : "+v"(nbm));
@@ -882,18 +891,22 @@ __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
 // K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x40 window.
 // One wave per keypoint slot, 4 independent waves per block (no block barriers: every wave owns its LDS region).
 // VALU issue bounds this kernel (PMC: ~85 % busy), so every phase is written for instruction count:
-//   A  window rows y-18..y+18, columns x-19..x+20 fetched as aligned dwords, byte-aligned with v_alignbyte on the
-//      way into LDS; lane = (row mod 6, dword), seven steps of 6 rows with one 64-bit add each;
+//   A  window rows y-18..y+18, columns x-19..x+28 by LDS-DMA (global_load_lds_dwordx4): 37 rows x 3 chunks of 16 bytes land
+//      at LDS pitch 48 straight from their (byte-unaligned) global addresses -- two wave-instructions per keypoint where
+//      the register path spent 14 loads, 7 funnel shifts and 7 ds_writes; columns beyond x+20 are padding;
 //   B  moments by v_dot4_u32_u8: the disc starts on a dword boundary (column x-15 = byte 4), one lane = one
 //      (row, dword) with a 0/1 weight dword (row sums -> m01) and a (u+15) weight dword (-> m10 + 15 * sum);
 //      248 lane-tasks, 4 per lane; wave sums by DPP + readlane;
 //   C  horizontal 7-tap pass by two v_dot4_u32_u8 per output (taps 18,33,49,56 | 49,33,18,0 on bytes funnel-shifted
 //      into place), 4 outputs per lane-task, 4 x u16 out as one b64;
-//   D  vertical 7-tap pass over the whole 31x32 patch, lane = (column pair, 8-row segment), 14 row reads in order,
-//      blurred BYTES written over the raw window;
+//   D  vertical 7-tap pass over the whole 31x32 patch, lane = (column pair, 8-row segment), 14 row reads in order, the rows
+//      re-paired per column by v_perm so that v_dot2_u32_u16 applies two taps at once (4 dot ops per output instead of
+//      7 multiply-adds), blurred BYTES written over the raw window; the horizontal pass's rows sit at a pitch of 18 dwords
+//      so that the four row segments of a wave read disjoint LDS banks (at 16 they were a 2-way conflict on every read);
 //   E  256 tests: one byte gather per sample point (LDS byte offsets from a per-bin table), four wave ballots.
 // ------------------------------------------------------------------------------------------------------------
-#define DP_P 40      // LDS row pitch of the raw window (10 dwords)
+#define DP_PW 12     // LDS row pitch of the raw window in dwords (3 DMA chunks of 16 bytes; 10 dwords are used)
+#define DP_HP 36     // row pitch of the horizontal pass in u16 (18 dwords: see D)
 
 __device__ __forceinline__ float atan2_deg(float y, float x)
 {
@@ -918,8 +931,8 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
 
 __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int pre)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * 10 + 6];
-    __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * 32];    // horizontal pass, 32 columns (31 used)
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * DP_PW + 4];
+    __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * DP_HP]; // horizontal pass, 32 columns (31 used) at pitch 36
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -960,30 +973,18 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     uint32_t* R32 = raw32[wid];
-    // ---- A: window rows y-18..y+18, columns x-19..x+20 ----
-    if ((((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0) {
-        const int xa = (x - 19) & ~3, sh = (x - 19) & 3;
-        if (lane < 60) {
-            const int r0 = lane / 10, k = lane - r0 * 10;
-            const uint32_t* p = (const uint32_t*)(lim + (long long)(y - 18 + r0) * pitch + xa) + k;
-            const long long step = (long long)6 * pitch;
-            uint32_t* dst = R32 + lane;                                         // (r0 + 6 i) * 10 + k = lane + 60 i
-            uint32_t lo[7], hi[7];
-#pragma unroll
-            for (int i = 0; i < 7; i++) {
-                if (i < 6 || r0 == 0) { lo[i] = p[0]; hi[i] = p[1]; }          // rows 36 + r0 exist for r0 = 0 only
-                p = (const uint32_t*)((const uint8_t*)p + step);
-            }
-#pragma unroll
-            for (int i = 0; i < 7; i++) if (i < 6 || r0 == 0) dst[60 * i] = __builtin_amdgcn_alignbyte(hi[i], lo[i], sh);
-        }
-    } else {
-        const uint8_t* Rb = (const uint8_t*)R32; (void)Rb;
-        for (int t = lane; t < 370; t += 64) {
-            const int r = t / 10, k = t - r * 10;
-            const uint8_t* p = lim + (long long)(y - 18 + r) * pitch + (x - 19 + 4 * k);
-            R32[t] = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
-        }
+    // ---- A: window rows y-18..y+18, columns x-19..x+28 (x+20 needed), LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) ----
+    //      every byte read lies inside the image: keypoints keep EDGE = 31 pixels from every border
+    {
+        typedef const void __attribute__((address_space(1)))* gptr_t;
+        typedef void __attribute__((address_space(3)))* lptr_t;
+        auto chunk_src = [&](int i) -> const uint8_t* {
+            const int r = (i * 171) >> 9, q = i - 3 * r;                    // i / 3, i % 3 for i < 128
+            return lim + (uint32_t)((y - 18 + r) * pitch + (x - 19) + 16 * q);
+        };
+        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(lane), (lptr_t)R32, 16, 0, 0);
+        if (lane < 37 * 3 - 64) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(64 + lane), (lptr_t)(R32 + 256), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     wave_lds_sync();
     // ---- B: moments over the disc: 31 rows x 8 dwords = 248 lane-tasks ----
@@ -992,7 +993,7 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     for (int i = 0; i < 4; i++) {
         const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read rows that exist
         const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 3 (vr = 31: row 34)
-        const uint32_t px = R32[(vr + 3) * 10 + 1 + d];
+        const uint32_t px = R32[(vr + 3) * DP_PW + 1 + d];
         const uint32_t s = udot4(px, g_disc_m[en], 0u);
         m10u = udot4(px, g_disc_x[en], m10u);
         msum += (int)s;
@@ -1009,13 +1010,13 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     unsigned short* Hb = hb[wid];
     for (int t = lane; t < 37 * 8; t += 64) {
         const int r = t >> 3, gq = t & 7;
-        const uint32_t w0 = R32[r * 10 + gq], w1 = R32[r * 10 + gq + 1], w2 = R32[r * 10 + gq + 2];
+        const uint32_t w0 = R32[r * DP_PW + gq], w1 = R32[r * DP_PW + gq + 1], w2 = R32[r * DP_PW + gq + 2];
         const uint32_t o0 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), GA, 0u));
         const uint32_t o1 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), GA, 0u));
         const uint32_t o2 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), GA, 0u));
         const uint32_t o3 = udot4(w2, GB, udot4(w1, GA, 0u));
         uint2 pk; pk.x = o0 | (o1 << 16); pk.y = o2 | (o3 << 16);
-        *(uint2*)&Hb[r * 32 + gq * 4] = pk;
+        *(uint2*)&Hb[r * DP_HP + gq * 4] = pk;
     }
     wave_lds_sync();
     // ---- D: vertical 7-tap pass over the whole 31 x 32 patch -> blurred bytes Bl (aliases the raw window, no longer
@@ -1023,23 +1024,31 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     //      conflicts, when the vertical pass was evaluated at the 512 sample points only: 56 scattered ds_read_u16 per
     //      lane); the full pass reads each lane's 14 input rows once, in order, and leaves ONE byte gather per sample.
     //      Exact: sum_r g[r] * Hb is the same integer whichever pass runs first; one rounding, (s + 32768) >> 16.
-    const int G0 = c_gauss7[0], G1 = c_gauss7[1], G2 = c_gauss7[2], G3 = c_gauss7[3];
+    const uint32_t G0 = (uint32_t)c_gauss7[0], G1 = (uint32_t)c_gauss7[1], G2 = (uint32_t)c_gauss7[2], G3 = (uint32_t)c_gauss7[3];
+    const rz_u16x2 T01 = __builtin_bit_cast(rz_u16x2, G0 | (G1 << 16)), T23 = __builtin_bit_cast(rz_u16x2, G2 | (G3 << 16));
+    const rz_u16x2 T21 = __builtin_bit_cast(rz_u16x2, G2 | (G1 << 16)), T0x = __builtin_bit_cast(rz_u16x2, G0);
     uint8_t* Bl = (uint8_t*)R32;
     {
         const int cp = lane & 15, sg = lane >> 4;                          // column pair 2cp, 2cp+1; output rows 8 sg .. 8 sg + 7
         const uint32_t* H32 = (const uint32_t*)Hb;
-        int lo[14], hi[14];
+        uint32_t w[15];
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
-            const uint32_t w = H32[min(8 * sg + i, 36) * 16 + cp];
-            lo[i] = (int)(w & 0xFFFFu); hi[i] = (int)(w >> 16);
-        }
+        for (int i = 0; i < 14; i++) w[i] = H32[min(8 * sg + i, 36) * (DP_HP / 2) + cp];
+        w[14] = 0;                                                         // partner of row 13 in its pair: weight 0
         wave_lds_sync();                                                   // every lane has read: the raw window may be overwritten
+        // pa[j] = rows (j, j + 1) of column 2cp, pb[j] = the same of column 2cp + 1: out(o) = (G0 G1).P[o] + (G2 G3).P[o+2] + (G2 G1).P[o+4] + (G0 0).P[o+6]
+        rz_u16x2 pa[14], pb[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            pa[j] = __builtin_bit_cast(rz_u16x2, __builtin_amdgcn_perm(w[j + 1], w[j], 0x05040100u));
+            pb[j] = __builtin_bit_cast(rz_u16x2, __builtin_amdgcn_perm(w[j + 1], w[j], 0x07060302u));
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int sa = __mul24(G0, lo[i] + lo[i + 6]) + __mul24(G1, lo[i + 1] + lo[i + 5]) + __mul24(G2, lo[i + 2] + lo[i + 4]) + __mul24(G3, lo[i + 3]);
-            const int sb = __mul24(G0, hi[i] + hi[i + 6]) + __mul24(G1, hi[i + 1] + hi[i + 5]) + __mul24(G2, hi[i + 2] + hi[i + 4]) + __mul24(G3, hi[i + 3]);
-            const uint32_t v = (uint32_t)((sa + 32768) >> 16) | ((uint32_t)((sb + 32768) >> 16) << 8);
+            // same integer sum as g0 (r0 + r6) + g1 (r1 + r5) + g2 (r2 + r4) + g3 r3, + 32768 for the one rounding; < 2^24, so the result is byte 2
+            const uint32_t sa = __builtin_amdgcn_udot2(pa[i + 6], T0x, __builtin_amdgcn_udot2(pa[i + 4], T21, __builtin_amdgcn_udot2(pa[i + 2], T23, __builtin_amdgcn_udot2(pa[i], T01, 32768u, false), false), false), false);
+            const uint32_t sb = __builtin_amdgcn_udot2(pb[i + 6], T0x, __builtin_amdgcn_udot2(pb[i + 4], T21, __builtin_amdgcn_udot2(pb[i + 2], T23, __builtin_amdgcn_udot2(pb[i], T01, 32768u, false), false), false), false);
+            const uint32_t v = __builtin_amdgcn_perm(sb, sa, 0x0c0c0602u);
             if (8 * sg + i < 31) *(unsigned short*)&Bl[(8 * sg + i) * 32 + 2 * cp] = (unsigned short)v;
         }
     }

@@ -16,9 +16,13 @@
 #include "svo_kernels.h"
 
 // byte layout of one lane-octave's record (all offsets multiples of 16):
-//   header (256 B): int32 n_kps[2], n_matches, n_ids, present, pad[3]; LaneState (lane-level, octave 0 only carries it)
+//   header (256 B): magic, version and the geometry the layout depends on (max_kps, max_h, oct_cap, n_lanes) -- a record from a
+//       differently configured context (another rank's, say) has other offsets: the importer checks them and refuses;
+//       int32 n_kps[2], n_matches, n_ids, present; LaneState (lane-level, octave 0 only carries it)
 //   kps[2][max_kps] | desc[2][max_kps][32] | matches[max_kps] | ids[max_kps] | row_index[2][max_h] | mrow_index[max_h + 1]
-struct HandoverHeader { int32_t n_kps[2], n_matches, n_ids, present, pad[3]; LaneState ls; };
+#define SVO_HANDOVER_MAGIC 0x53564F48      // "SVOH"
+#define SVO_HANDOVER_VERSION 2
+struct HandoverHeader { int32_t magic, version, max_kps, max_h, oct_cap, n_lanes; int32_t n_kps[2], n_matches, n_ids, present, pad; LaneState ls; };
 static_assert(sizeof(HandoverHeader) <= 256, "header slot");
 
 static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -43,6 +47,12 @@ __host__ __device__ static inline HandoverOffsets handover_offsets(int max_kps, 
     return o;
 }
 
+__device__ __forceinline__ bool handover_header_ok(const DevCtx& c, const HandoverHeader* h)
+{
+    return h->magic == SVO_HANDOVER_MAGIC && h->version == SVO_HANDOVER_VERSION && h->max_kps == c.max_kps && h->max_h == c.max_h &&
+           h->oct_cap == c.oct_cap && h->n_lanes == c.n_lanes;
+}
+
 __device__ __forceinline__ void copy_words(const void* src, void* dst, size_t nbytes, int t, int nt)
 {
     const uint32_t* sp = (const uint32_t*)src; uint32_t* dp = (uint32_t*)dst;
@@ -65,6 +75,7 @@ __global__ void __launch_bounds__(256) k_export_frame(DevCtx c, uint8_t* blob)
     const int t = blockIdx.y * blockDim.x + threadIdx.x, nt = gridDim.y * blockDim.x;
     if (t == 0) {
         HandoverHeader* h = (HandoverHeader*)rec;
+        h->magic = SVO_HANDOVER_MAGIC; h->version = SVO_HANDOVER_VERSION; h->max_kps = c.max_kps; h->max_h = c.max_h; h->oct_cap = c.oct_cap; h->n_lanes = c.n_lanes;
         h->n_kps[0] = nl; h->n_kps[1] = nr; h->n_matches = nm; h->n_ids = ni; h->present = present ? 1 : 0;
         h->ls = s;
     }
@@ -89,8 +100,14 @@ __global__ void __launch_bounds__(256) k_import_frame(DevCtx c, const uint8_t* b
     const uint8_t* rec = blob + (size_t)vl * o.total;
     const HandoverHeader* h = (const HandoverHeader*)rec;
     const int slot = c.lane[lane].prev_slot;                 // not modified below
-    const int nl = h->n_kps[0], nr = h->n_kps[1], nm = h->n_matches, ni = h->n_ids;
     const int t = blockIdx.y * blockDim.x + threadIdx.x, nt = gridDim.y * blockDim.x;
+    if (!handover_header_ok(c, h)) {                          // another layout (or not a record at all): nothing is copied, the lane is flagged
+        if (t == 0) { atomicOr(&c.status[lane], SVO_ST_HANDOVER_MISMATCH); atomicOr(&c.results[lane].status, (int)SVO_ST_HANDOVER_MISMATCH); }
+        return;
+    }
+    // counts are clamped to the lists' capacity: a damaged record must not write past the lane's lists
+    const int nl = min(max(h->n_kps[0], 0), c.max_kps), nr = min(max(h->n_kps[1], 0), c.max_kps);
+    const int nm = min(max(h->n_matches, 0), c.max_kps), ni = min(max(h->n_ids, 0), c.max_kps);
     const size_t MK = (size_t)c.max_kps, H = (size_t)c.max_h;
     copy_words(rec + o.kps, c.kps + feat_base(c, vl, slot, 0), (size_t)nl * sizeof(svo_keypoint), t, nt);
     copy_words(rec + o.kps + MK * sizeof(svo_keypoint), c.kps + feat_base(c, vl, slot, 1), (size_t)nr * sizeof(svo_keypoint), t, nt);
@@ -114,6 +131,7 @@ __global__ void k_import_state(DevCtx c, const uint8_t* blob)
     if (lane >= c.n_lanes) return;
     const HandoverOffsets o = handover_offsets(c.max_kps, c.max_h);
     const HandoverHeader* h = (const HandoverHeader*)(blob + (size_t)lane * c.oct_cap * o.total);
+    if (!handover_header_ok(c, h)) return;                  // flagged by k_import_frame; the lane keeps what it had
     LaneState& s = c.lane[lane];
     const LaneState& e = h->ls;
     s.has_prev = h->present;

@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
         np_total += tot;
         __syncthreads();
     }
+    if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], np_total); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], np_total); }
     if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 7; }
 }
 
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
     unsigned* takenL = firstR + c.max_kps;                 // max_kps / 32 bits
     unsigned* takenR = takenL + c.max_kps / 32;
     __shared__ int scan[40];
-    __shared__ int s_und;
+    __shared__ int s_und, s_th;
     const int vl = blockIdx.x, lane_id = vl / c.oct_cap, tid = threadIdx.x;
     if (vl % c.oct_cap >= c.n_oct) return;
     const LaneState& ls = c.lane[lane_id];
@@ -437,6 +438,15 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
             tlr[j] = (a & 0xFFFFu) | (b << 16);                                   // tl | tr << 16
             st[j] = ((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th) ? 0 : 2;      // S4:149
         }
+    }
+    {   // svo_result.track_stats[SVO_TS_THRESHOLD]: candidates that pass the distance threshold on both sides
+        int nth = 0;
+#pragma unroll
+        for (int j = 0; j < TF_ITEMS; j++) nth += st[j] == 2 ? 1 : 0;
+        if (tid == 0) s_th = 0;
+        __syncthreads();
+        nth = wave_sum_uniform(nth);
+        if ((tid & 63) == 0) atomicAdd(&s_th, nth);
     }
     for (int i = tid; i < c.max_kps / 32; i += 256) { takenL[i] = 0; takenR[i] = 0; }
     const int n_items = (npm + 255) / 256;
@@ -494,6 +504,7 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
         nk += tot;
         __syncthreads();
     }
+    if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], s_th); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], nk); }
     if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 7; }
 }
 
@@ -545,6 +556,40 @@ __device__ __forceinline__ int ransac_niters(int cnt, int n, int max_iters)
     const double d = svo_ln(denom);
     if (d >= 0.0 || -num >= (double)max_iters * (-d)) return max_iters;
     return (int)rint(num / d);
+}
+
+// Rank-2 enforcement of the normalised 8-point solution (oracle: rank2_enforce, operation for operation): f <- f (I - v v^T / v.v)
+// with v the eigenvector of f^T f for its smallest eigenvalue -- the smallest root of the characteristic cubic by eight Newton
+// steps from 0 (monotone: f^T f is positive semi-definite), v = the largest of the three row cross products of f^T f - t I.
+__device__ __forceinline__ void rank2_enforce(double* f)
+{
+    const double s00 = (f[0] * f[0] + f[3] * f[3]) + f[6] * f[6], s01 = (f[0] * f[1] + f[3] * f[4]) + f[6] * f[7], s02 = (f[0] * f[2] + f[3] * f[5]) + f[6] * f[8];
+    const double s11 = (f[1] * f[1] + f[4] * f[4]) + f[7] * f[7], s12 = (f[1] * f[2] + f[4] * f[5]) + f[7] * f[8], s22 = (f[2] * f[2] + f[5] * f[5]) + f[8] * f[8];
+    const double c2 = (s00 + s11) + s22;
+    const double m00 = s11 * s22 - s12 * s12, m11 = s00 * s22 - s02 * s02, m22 = s00 * s11 - s01 * s01;
+    const double c1 = (m00 + m11) + m22;
+    const double c0 = (s00 * m00 - s01 * (s01 * s22 - s12 * s02)) + s02 * (s01 * s12 - s11 * s02);
+    double t = 0.0;
+    bool go = true;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const double q = ((t - c2) * t + c1) * t - c0, dq = (3.0 * t - 2.0 * c2) * t + c1;
+        go = go && dq > 0.0;                                               // the oracle's `break`: once stopped, t stays
+        if (go) t = t - q / dq;
+    }
+    const double a00 = s00 - t, a11 = s11 - t, a22 = s22 - t;
+    const double x0 = s01 * s12 - s02 * a11, y0 = s02 * s01 - a00 * s12, z0 = a00 * a11 - s01 * s01;
+    const double x1 = s01 * a22 - s02 * s12, y1 = s02 * s02 - a00 * a22, z1 = a00 * s12 - s01 * s02;
+    const double x2 = a11 * a22 - s12 * s12, y2 = s12 * s02 - s01 * a22, z2 = s01 * s12 - a11 * s02;
+    const double n0 = (x0 * x0 + y0 * y0) + z0 * z0, n1 = (x1 * x1 + y1 * y1) + z1 * z1, n2 = (x2 * x2 + y2 * y2) + z2 * z2;
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double w = ((f[3 * r] * vx + f[3 * r + 1] * vy) + f[3 * r + 2] * vz) / nn;
+        f[3 * r] = f[3 * r] - w * vx; f[3 * r + 1] = f[3 * r + 1] - w * vy; f[3 * r + 2] = f[3 * r + 2] - w * vz;
+    }
 }
 
 // Evaluating hypotheses OUT OF ORDER still bounds what the sequential scan visits.  The scan visits [0, E), E = the first k
@@ -694,6 +739,7 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
 #pragma unroll
     for (int j = 0; j < 9; j++) fv[j] = group_bcast(fmine, j);
     if (gl == 0 && h < gen) {
+        rank2_enforce(fv);
         const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
         double M[3][3];
 #pragma unroll
@@ -904,7 +950,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
     unsigned char* in_l = smem;                         // max_kps
     unsigned char* in_r = in_l + c.max_kps;             // max_kps
     int* scan = (int*)(in_r + c.max_kps);               // 32
-    __shared__ int s_best[2], s_cnt[2];
+    __shared__ int s_best[2], s_cnt[2], s_vis[2], s_both;
     const int vl = blockIdx.x, lane_id = vl / c.oct_cap, oct = vl % c.oct_cap, tid = threadIdx.x;
     if (oct >= c.n_oct) return;
     LaneState& ls = c.lane[lane_id];
@@ -920,6 +966,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
         const int side = tid >> 7, t = tid & 127, wv = (tid >> 6) & 1, ln = tid & 63;
         __shared__ int run_max[2], wave_max[2][2];
         if (tid < 2) { rec_n[tid] = 0; run_max[tid] = 7; }
+        if (tid == 0) s_both = 0;
         __syncthreads();
         const int lim = n >= 8 ? min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP) : 0;
         const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_PAD;
@@ -951,6 +998,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
                 if (cnt > (best_cnt > 7 ? best_cnt : 7)) { best_cnt = cnt; best_k = k; niters = ransac_niters(cnt, n, niters); }
             }
             s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
+            s_vis[side] = n >= 8 ? max(best_k + 1, niters) : 0;
         } else if (t == 0) {
             int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1;
             for (int r = 0; r < nr; r++) {                                   // next record in index order = smallest index above `last`
@@ -961,6 +1009,9 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
                 niters = min(niters, rec_K[side][sel]);
             }
             s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
+            // hypotheses the sequential loop visits: it leaves at the first k that is no longer below the budget, and a record may
+            // cut the budget below its own index (oracle: svo_oracle_ransac_fundamental's n_hyp_used)
+            s_vis[side] = n >= 8 ? max(last + 1, niters) : 0;
         }
         __syncthreads();
     }
@@ -994,6 +1045,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
             k = kq[i];
             keep = 1;
             if (use_f && (in_l[i] == 0 || in_r[i] == 0)) keep = 0;
+            if (keep) atomicAdd(&s_both, 1);                          // svo_result.track_stats[SVO_TS_BOTH_MASKS]
             if (win_mode) tl = (int)pL[i];                            // survivor list of k_track_win: (previous, current) pairing (S4:708-714)
             else {
                 tl = (int)(pL[k] & 0xFFFFu);
@@ -1007,7 +1059,13 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
         t_total += tot;
         __syncthreads();
     }
-    if (tid == 0) c.n_tracked[vl] = t_total;
+    if (tid == 0) {
+        c.n_tracked[vl] = t_total;
+        int* ts = c.results[lane_id].track_stats;                    // summed over the octaves (k_begin_frame zeroed them)
+        atomicAdd(&ts[SVO_TS_INLIERS_L], s_cnt[0]); atomicAdd(&ts[SVO_TS_INLIERS_R], s_cnt[1]);
+        atomicAdd(&ts[SVO_TS_HYP_L], s_vis[0]); atomicAdd(&ts[SVO_TS_HYP_R], s_vis[1]);
+        atomicAdd(&ts[SVO_TS_BOTH_MASKS], s_both); atomicAdd(&ts[SVO_TS_TRACKED], t_total);
+    }
 }
 
 // m_num_tracked_pairs_from_last_frame = sum over octaves (S4:743-752), then the bad-tracking gate (P:326-330) and the

@@ -55,26 +55,49 @@ struct svo_ctx {
     // svo_use_graphs: the kernel sequence of a frame captured once per (flags, ring slot, thresholds) and replayed
     struct GraphEntry { uint32_t flags; int slot, fast_th, orb_th; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs; bool use_graphs;
-    // every stream that has had work of this context enqueued since the last full synchronisation (svo_set_stream)
-    std::vector<hipStream_t> used_streams;
+    // every stream that has had work of this context enqueued since the last full synchronisation (svo_set_stream), each with
+    // a context-owned event recorded behind the last work enqueued on it.  Synchronising waits on the EVENTS, never on the
+    // foreign stream handles: a caller may synchronise and destroy its own stream and switch back with svo_set_stream(NULL);
+    // an event recorded on a stream that has since been destroyed is simply complete.
+    struct UsedStream { hipStream_t s; hipEvent_t ev; bool dirty; };
+    std::vector<UsedStream> used_streams;
 };
 
 static void drop_graphs(svo_ctx* ctx);
 static void note_stream(svo_ctx* ctx)
 {
-    for (hipStream_t s : ctx->used_streams) if (s == ctx->stream) return;
-    ctx->used_streams.push_back(ctx->stream);
+    for (auto& u : ctx->used_streams) if (u.s == ctx->stream) { u.dirty = true; return; }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    ctx->used_streams.push_back({ ctx->stream, ev, true });
+}
+// record "everything enqueued so far" on the current stream (after the last launch of an entry point; never while capturing)
+static void mark_stream(svo_ctx* ctx)
+{
+    if (ctx->stream == ctx->stream0 && ctx->own_stream) return;  // the context's own stream is synchronised by handle
+    for (auto& u : ctx->used_streams) if (u.s == ctx->stream && u.ev) { (void)hipEventRecord(u.ev, ctx->stream); return; }
+}
+// wait for what this context left on streams other than the current one
+static hipError_t sync_foreign(svo_ctx* ctx)
+{
+    hipError_t first = hipSuccess;
+    for (auto& u : ctx->used_streams) {
+        if (!u.dirty || u.s == ctx->stream) continue;
+        const hipError_t e = ((u.s == ctx->stream0 && ctx->own_stream) || !u.ev) ? hipStreamSynchronize(u.s) : hipEventSynchronize(u.ev);
+        if (first == hipSuccess) first = e;
+        u.dirty = false;
+    }
+    return first;
 }
 // wait for everything this context has enqueued, on whichever stream (a caller that switched streams with
 // svo_set_stream may have left work on the earlier ones)
 static hipError_t sync_all(svo_ctx* ctx)
 {
-    hipError_t first = hipSuccess;
-    for (hipStream_t s : ctx->used_streams) { if (s == ctx->stream) continue; const hipError_t e = hipStreamSynchronize(s); if (first == hipSuccess) first = e; }
+    hipError_t first = sync_foreign(ctx);
     if (ctx->up_ready) { const hipError_t e2 = hipStreamSynchronize(ctx->s_copy); if (first == hipSuccess) first = e2; }
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (first == hipSuccess) first = e;
-    ctx->used_streams.clear();
+    for (auto& u : ctx->used_streams) u.dirty = false;
     return first;
 }
 
@@ -284,6 +307,7 @@ extern "C" void svo_destroy(svo_ctx* ctx)
         for (int i = 0; i < 2; i++) { hipEventDestroy(ctx->ev_h2d[i]); hipEventDestroy(ctx->ev_det[i]); if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]); }
         hipStreamDestroy(ctx->s_copy);
     }
+    for (auto& u : ctx->used_streams) if (u.ev) hipEventDestroy(u.ev);
     for (auto& s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream0);
@@ -330,6 +354,7 @@ extern "C" int svo_set_stream(svo_ctx* ctx, void* stream)
     return SVO_OK;
 }
 
+extern "C" int svo_get_device(const svo_ctx* ctx) { return ctx ? ctx->cfg.device : SVO_ERR_ARG; }
 extern "C" int svo_get_stream(svo_ctx* ctx, void** stream) { if (!ctx || !stream) return SVO_ERR_ARG; *stream = (void*)ctx->stream; return SVO_OK; }
 
 extern "C" int svo_set_camera(svo_ctx* ctx, int lane, const svo_stereo_camera* cam)
@@ -754,6 +779,10 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
     // svo_use_graphs: the launches below are captured once into a hipGraph per (flags, ring slot, thresholds) and replayed:
     // ~30 kernel launches of a frame become one graph launch (what bounds ONE stream is launch latency, not the kernels)
+    // every lazily allocated buffer a frame may need exists BEFORE a capture begins: hipMalloc / hipMemset are refused on a
+    // capturing thread and would invalidate the capture (the adaptive NMS after the FAST+ORB detector has such a buffer)
+    if ((flags & SVO_RUN_DETECT) && d.fast_orb && p.non_maximal_suppression && p.nmsMethod == SVO_NMS_ADAPTIVE && !ctx->d_anms)
+        HIPCHECK(dev_alloc(ctx, &ctx->d_anms, (size_t)3 * d.n_img * ctx->cand_total_alloc));
     bool capturing = false;
     const bool graph_ok = ctx->use_graphs && !prepare && !ctx->cfg.kernel_times && (!(flags & SVO_RUN_DETECT) || ctx->det_slot >= 0);
     const uint32_t gflags = flags & ~(uint32_t)(SVO_FLAG_DEVICE_IMAGES | SVO_FLAG_PINNED_IMAGES);
@@ -765,6 +794,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
                 HIPCHECK(hipGraphLaunch(g.exec, st));
                 ctx->imported_pending = false;
                 if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) { HIPCHECK(hipEventRecord(ctx->ev_det[ctx->det_slot], st)); ctx->ev_det_valid[ctx->det_slot] = true; }
+                mark_stream(ctx);
                 return SVO_OK;
             }
         if (!ids_first) { HIPCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); capturing = true; }
@@ -776,7 +806,6 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             if (p.non_maximal_suppression && p.nmsMethod == SVO_NMS_ADAPTIVE) {      // S2:599-606 on the FAST detector's output
-                if (!ctx->d_anms) HIPCHECK(dev_alloc(ctx, &ctx->d_anms, (size_t)3 * d.n_img * ctx->cand_total_alloc));
                 Span s(ctx, KT_SELECT); launch_fastorb_anms(d, ctx->d_anms, st);
             } else { Span s(ctx, KT_SELECT); launch_fastorb_nms(d, p.non_maximal_suppression, p.min_distance, st); }
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, 0, st); }
@@ -865,6 +894,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) {
         HIPCHECK(hipEventRecord(ctx->ev_det[ctx->det_slot], st)); ctx->ev_det_valid[ctx->det_slot] = true;
     }
+    mark_stream(ctx);
     HIPCHECK(hipGetLastError());
     return SVO_OK;
 }
@@ -892,6 +922,7 @@ extern "C" int svo_copy_results_async(svo_ctx* ctx, void* dst, size_t bytes)
     if (!ctx || !dst || bytes < sizeof(svo_result) * (size_t)ctx->cfg.n_lanes) return SVO_ERR_ARG;
     note_stream(ctx);
     HIPCHECK(hipMemcpyAsync(dst, ctx->dc.results, sizeof(svo_result) * ctx->cfg.n_lanes, hipMemcpyDeviceToDevice, ctx->stream));
+    mark_stream(ctx);
     return SVO_OK;
 }
 extern "C" int svo_get_result(svo_ctx* ctx, int lane, svo_result* res)
@@ -963,7 +994,7 @@ extern "C" int svo_get_values(svo_ctx* ctx, int lane, int which, int octave, svo
     }
     // whatever the context still has in flight on other streams must be done; the pack + copy below then run on the
     // current stream and the single synchronisation of this call waits for them
-    for (hipStream_t st : ctx->used_streams) if (st != ctx->stream) HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(sync_foreign(ctx));
     note_stream(ctx);
     launch_pack_values(ctx->dc, lane, which, octave, ctx->d_vals, ctx->stream);
     HIPCHECK(hipMemcpyAsync(ctx->h_vals, ctx->d_vals, ctx->vals_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1217,6 +1248,7 @@ extern "C" int svo_export_frame(svo_ctx* ctx, void* dev_blob, size_t bytes)
     if (!ctx->geom_ready) return SVO_ERR_STATE;
     note_stream(ctx);
     launch_export_frame(ctx->dc, (uint8_t*)dev_blob, ctx->stream);
+    mark_stream(ctx);
     HIPCHECK(hipGetLastError());
     return SVO_OK;
 }
@@ -1228,6 +1260,7 @@ extern "C" int svo_import_frame(svo_ctx* ctx, const void* dev_blob, size_t bytes
     note_stream(ctx);
     launch_import_frame(ctx->dc, (const uint8_t*)dev_blob, ctx->stream);
     ctx->imported_pending = true;
+    mark_stream(ctx);
     HIPCHECK(hipGetLastError());
     return SVO_OK;
 }

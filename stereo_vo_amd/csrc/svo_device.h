@@ -28,6 +28,7 @@
 // status-word bits (svo_debug_get_status_word)
 #define SVO_ST_CAND_OVERFLOW 1u
 #define SVO_ST_KPS_OVERFLOW 2u
+#define SVO_ST_HANDOVER_MISMATCH 4u  // svo_import_frame was handed a record of another layout (magic / version / max_kps / max_h / octaves / lanes)
 
 // division of a 32-bit unsigned by a launch-time constant (Granlund-Montgomery round-up): exact for every x, and on a
 // wave-uniform x it compiles to s_mul_hi_u32 + three scalar ops -- the hardware has no integer divide, and the

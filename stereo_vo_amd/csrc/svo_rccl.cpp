@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,10 +18,17 @@ struct svo_group {
     std::vector<ncclComm_t> comm;
     std::vector<int> device;
     std::vector<hipEvent_t> ev;            // orders the gather after the context's stream when another stream carries it
+    // a local group is driven by one host thread per GPU and ranks tend to fail together: the text of the last failure is kept
+    // under a lock (svo_group_last_error hands out a per-thread copy)
+    std::mutex err_lock;
     std::string last_error;
 };
 
-static int fail(svo_group* g, const char* what, const char* text) { if (g) g->last_error = std::string(what) + ": " + text; return SVO_ERR_HIP; }
+static int fail(svo_group* g, const char* what, const char* text)
+{
+    if (g) { std::lock_guard<std::mutex> lk(g->err_lock); g->last_error = std::string(what) + ": " + text; }
+    return SVO_ERR_HIP;
+}
 #define NCCLCHECK(g, expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return fail(g, #expr, ncclGetErrorString(_r)); } while (0)
 #define HIPCHK(g, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(g, #expr, hipGetErrorString(_e)); } while (0)
 
@@ -72,7 +80,13 @@ extern "C" void svo_group_destroy(svo_group* g)
 }
 
 extern "C" int svo_group_size(const svo_group* g) { return g ? g->n_ranks : SVO_ERR_ARG; }
-extern "C" const char* svo_group_last_error(const svo_group* g) { return g ? g->last_error.c_str() : ""; }
+extern "C" const char* svo_group_last_error(const svo_group* g)
+{
+    static thread_local std::string copy;
+    if (!g) return "";
+    { std::lock_guard<std::mutex> lk(const_cast<svo_group*>(g)->err_lock); copy = g->last_error; }
+    return copy.c_str();
+}
 
 extern "C" int svo_group_allgather_results(svo_group* g, int rank, svo_ctx* ctx, void* stream, void* dev_records, size_t bytes)
 {
@@ -81,9 +95,11 @@ extern "C" int svo_group_allgather_results(svo_group* g, int rank, svo_ctx* ctx,
     if (rank < 0 || rank >= g->n_ranks || bytes % ((size_t)g->n_ranks * sizeof(svo_result)) != 0) return SVO_ERR_ARG;
     const int s = slot_of(g, rank);
     const size_t chunk = bytes / (size_t)g->n_ranks;
+    // the context must live on this rank's GPU: the communicator, the event and the receive buffer do
+    if (svo_get_device(ctx) != g->device[s]) { fail(g, "svo_group_allgather_results", "the context's device is not this rank's"); return SVO_ERR_ARG; }
     // in place: this rank's records go straight into their slot of the receive buffer, on the context's stream
     const int rc = svo_copy_results_async(ctx, (char*)dev_records + (size_t)rank * chunk, chunk);
-    if (rc != SVO_OK) { g->last_error = std::string("svo_copy_results_async: ") + svo_last_error(ctx); return rc; }
+    if (rc != SVO_OK) { fail(g, "svo_copy_results_async", svo_last_error(ctx)); return rc; }
     void* cs = nullptr;
     if (svo_get_stream(ctx, &cs) != SVO_OK) return SVO_ERR_ARG;
     hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)cs;

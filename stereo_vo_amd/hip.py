@@ -21,7 +21,7 @@ FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES, FLAG_DETECT_NO_
 EXPORTS = [
     "svo_config_defaults", "svo_params_defaults", "svo_create", "svo_destroy", "svo_strerror", "svo_last_error",
     "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
-    "svo_get_orb_threshold", "svo_set_stream", "svo_get_stream", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
+    "svo_get_orb_threshold", "svo_set_stream", "svo_get_stream", "svo_get_device", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",

@@ -41,6 +41,7 @@ def outputs(bgr, mx, my, k, kl, kr, m, tracked, pose):
 
 if __name__ == "__main__":
     out = outputs(*inputs())
+    out["oracle_version"] = np.array(O.version())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_extras.npz")
     np.savez_compressed(path, **out)
-    print("wrote", path, {k: v.shape for k, v in out.items()})
+    print("wrote", path, {k: np.shape(v) for k, v in out.items()})

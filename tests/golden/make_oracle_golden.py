@@ -16,7 +16,7 @@ w = SyntheticStereoWorld(W, H, F, 0.12, seed=7, n_frames=NF, noise_sigma=1.5)
 p = north_star_params(O.default_params(), orb_nfeats=220)
 o = O.Oracle(p)
 cam = w.camera()
-out = {"W": W, "H": H, "F": F, "baseline": 0.12, "cx": w.cx, "cy": w.cy, "orb_nfeats": 220}
+out = {"W": W, "H": H, "F": F, "baseline": 0.12, "cx": w.cx, "cy": w.cy, "orb_nfeats": 220, "oracle_version": O.version()}
 for t in range(NF):
     L, R = [x.numpy() for x in w.render(t)]
     r = o.process(L, R, cam)
@@ -34,5 +34,6 @@ for t in range(NF):
     out["delta%d" % t] = np.array(r.delta)
     out["scalars%d" % t] = np.array([r.num_it, r.num_it_final, r.valid, r.error_code, r.tracked_feats_from_last_frame,
                                      r.detected_left[0], r.detected_right[0], r.stereo_matches[0], r.n_outliers, r.n_residual])
-    print(t, out["scalars%d" % t])
+    out["track_stats%d" % t] = np.array(list(r.track_stats))
+    print(t, out["scalars%d" % t], out["track_stats%d" % t])
 np.savez_compressed(os.path.join(os.path.dirname(__file__), "oracle_small_seq.npz"), **out)

@@ -124,8 +124,9 @@ def steered_brief(img, x, y, angle_deg, pairs):
     return np.packbits(bits.reshape(32, 8), axis=1, bitorder="little").reshape(32), margin
 
 
-def eight_point(p1, p2):
-    """Hartley's normalised 8-point algorithm (no rank-2 projection): F with x2^T F x1 = 0, unit Frobenius norm"""
+def eight_point(p1, p2, rank2=True):
+    """Hartley's normalised 8-point algorithm: F with x2^T F x1 = 0, unit Frobenius norm; rank2: the smallest singular value of
+    the normalised solution is zeroed before denormalising (Hartley 1997 section 3.2; what cv::findFundamentalMat's models are)"""
     def norm(p):
         c = p.mean(0)
         s = np.sqrt(2.0) / np.mean(np.linalg.norm(p - c, axis=1))
@@ -134,6 +135,9 @@ def eight_point(p1, p2):
     h1 = (np.c_[p1, np.ones(len(p1))] @ T1.T); h2 = (np.c_[p2, np.ones(len(p2))] @ T2.T)
     A = np.stack([np.kron(b, a) for a, b in zip(h1, h2)])
     F0 = np.linalg.svd(A)[2][-1].reshape(3, 3)
+    if rank2:
+        U, S, Vt = np.linalg.svd(F0)
+        F0 = U @ np.diag([S[0], S[1], 0.0]) @ Vt
     F = T2.T @ F0 @ T1
     return F / np.linalg.norm(F)
 

@@ -112,7 +112,21 @@ def test_eight_point_and_epipolar_distance():
     Fo = F / np.linalg.norm(F)
     if np.sum(Fo * Fm) < 0: Fm = -Fm
     assert np.abs(Fo - Fm).max() < 1e-6
+    sv = np.linalg.svd(Fo, compute_uv=False)
+    assert sv[2] < 1e-12 * sv[0]                                  # the oracle's model has rank 2 (SVO_ORACLE_VERSION 3)
     assert IR.symmetric_epipolar_sq(Fo, x1[:8].astype(np.float64), x2[:8].astype(np.float64)).max() < 1e-6
+    # eight NOISY correspondences: the plain 8-point solution has full rank, and the oracle's Newton / cross-product projection
+    # must agree with the SVD truncation of the independent reading
+    xn1 = (x1[8:16] + rng.normal(0, 0.7, (8, 2))).astype(np.float32); xn2 = (x2[8:16] + rng.normal(0, 0.7, (8, 2))).astype(np.float32)
+    cnt, mask, F, bh, nu = O.ransac_fundamental(xn1, xn2)
+    if cnt >= 8:
+        Fm = IR.eight_point(xn1.astype(np.float64), xn2.astype(np.float64)); Fo = F / np.linalg.norm(F)
+        if np.sum(Fo * Fm) < 0: Fm = -Fm
+        assert np.abs(Fo - Fm).max() < 1e-6
+        sv = np.linalg.svd(Fo, compute_uv=False)
+        assert sv[2] < 1e-10 * sv[0]
+        full = IR.eight_point(xn1.astype(np.float64), xn2.astype(np.float64), rank2=False)
+        assert np.linalg.svd(full, compute_uv=False)[2] > 1e-7     # the un-projected solution of noisy points is NOT rank 2
     # RANSAC on 400 points with 30 % gross outliers: the inlier mask is exactly "symmetric epipolar distance <= 1 px"
     # under the returned model, and the true correspondences are found
     bad = rng.choice(400, 120, replace=False)

@@ -17,9 +17,11 @@ def load_small_seq(golden_dir):
 
 def test_small_sequence_matches_frozen_vectors(golden_dir):
     g, cam, p = load_small_seq(golden_dir)
+    assert int(g["oracle_version"]) == O.version(), "golden vectors minted by another version of the frozen definitions: re-mint them"
     o = O.Oracle(p)
     for t in range(4):
         r = o.process(g["L%d" % t], g["R%d" % t], cam)
+        assert list(r.track_stats) == g["track_stats%d" % t].tolist()
         for side in (0, 1):
             k, d = o.keypoints(0, side)
             assert k.tobytes() == g["kps%d_%d" % (side, t)].tobytes()
@@ -95,7 +97,8 @@ def test_oracle_extras_against_frozen_vectors(golden_dir):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     g = np.load(os.path.join(golden_dir, "oracle_extras.npz"))
     out = mod.outputs(*mod.inputs())
-    assert set(out) == set(g.files)
+    assert int(g["oracle_version"]) == O.version(), "golden vectors minted by another version of the frozen definitions: re-mint them"
+    assert set(out) | {"oracle_version"} == set(g.files)
     for name, v in out.items():
         assert v.shape == g[name].shape and v.tobytes() == g[name].tobytes(), name
     assert len(out["anms_all"]) > len(out["anms_r3"]) >= 1 and len(out["anms_100"]) <= 100

@@ -11,7 +11,7 @@ from stereo_vo_amd.synth import SyntheticStereoWorld
 from stereo_vo_amd.pipeline import FrameParallelStream
 
 
-def measure(width=1280, height=960, orb_nfeats=2000, n=200, device=0, quiet=False):
+def measure(width=1280, height=960, orb_nfeats=2000, n=200, device=0, quiet=False, only_plain=False):
     W, H = width, height
     dev = torch.device("cuda", device)
     w = SyntheticStereoWorld(W, H, 800.0 * W / 1280.0, 0.12, seed=0, n_frames=6, device=dev)
@@ -42,6 +42,8 @@ def measure(width=1280, height=960, orb_nfeats=2000, n=200, device=0, quiet=Fals
         return 1e3 * dt / n, 1e3 * dl / (n // 2), valid, poses
 
     out["plain_ms"], out["plain_result_every_frame_ms"], v0, p0 = run_ctx(False)
+    if only_plain:          # profiling runs: one variant, so that the kernel statistics are those of plain launches alone
+        return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
     out["graph_ms"], out["graph_result_every_frame_ms"], v1, p1 = run_ctx(True)
     out["graph_same_result"] = bool(v0 == v1 and p0 == p1)
     for G in (2, 3):
@@ -63,4 +65,4 @@ def measure(width=1280, height=960, orb_nfeats=2000, n=200, device=0, quiet=Fals
 
 
 if __name__ == "__main__":
-    print(json.dumps({"single_stream": measure()}))
+    print(json.dumps({"single_stream": measure(only_plain="--only-plain" in sys.argv)}))

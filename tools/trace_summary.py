@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Per-launch durations of the svo kernels from a rocprofv3 kernel_trace.csv, grouped by (kernel, grid size)."""
-import csv, sys, collections
+import csv, sys, collections, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _kname import kname
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.OrderedDict()
 for r in rows:
-    n = r["Kernel_Name"].split("(")[0]
-    if not n.startswith("k_"): continue
+    n = kname(r["Kernel_Name"])
+    if n is None: continue
     key = (n, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     acc.setdefault(key, []).append(d)
