@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from stereo_vo_amd import hip  # noqa: E402
-from stereo_vo_amd.abi import Result, north_star_params  # noqa: E402
+from stereo_vo_amd.abi import Result, TS_NAMES, north_star_params  # noqa: E402
 from stereo_vo_amd.synth import SyntheticStereoWorld  # noqa: E402
 from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 
@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5; 2: on a third stream of its own")
     ap.add_argument("--det-priority", default="low", choices=["low", "high"], help="which of the two streams of the pipelined schedule gets the high HIP priority: the stage 3-5 stream (default 'low' = detect stream at normal priority: the latency-bound stage 3-5 kernels get their few workgroups placed at once and the detect kernels, which fill every wave slot they are given, take the rest; 53.3 k vs 47.1 k pairs/s measured with the two-wave k_fast) or the detect stream")
     ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
+    ap.add_argument("--scene", default="planes", choices=["planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): planes = wall + ground + facades (every earlier round's numbers), relief = the same plus 28 billboards at 4..22 m (non-planar depth)")
+    ap.add_argument("--relief-lanes", type=int, default=16, help="N=1, config2: streams of the extra leg on the OTHER scene type (reported as `other_scene`: pass-through counters and pose error against ground truth beside the timed scene's); 0 = skip")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
@@ -153,7 +155,7 @@ def main():
     cxy = dict(cx=607.19, cy=185.22) if kitti else {}
     seeds = lane_seeds(rank, world, B)
     # four scenes shared by the streams (textures are the slow part to mint), one trajectory per stream
-    worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=s, n_frames=F, device=dev, scene_seed=s % 4, **cxy) for s in seeds]
+    worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=s, n_frames=F, device=dev, scene_seed=s % 4, scene=args.scene, **cxy) for s in seeds]
     frames = [[w.render(t) for t in range(F)] for w in worlds]          # [lane][t] -> (L, R) uint8 on device
     cam = worlds[0].camera()
     torch.cuda.synchronize()
@@ -215,6 +217,8 @@ def main():
     mean_kps = float(np.mean([r.detected_left[0] for r in results]))
     mean_match = float(np.mean([r.stereo_matches[0] for r in results]))
     mean_track = float(np.mean([r.tracked_feats_from_last_frame for r in results]))
+    ts_mean = {k: round(float(np.mean([r.track_stats[i] for r in results])), 1) for i, k in enumerate(TS_NAMES)}
+    dist_info = dist_audit(allrec, batch.rec, world, rank, local_rank, dev)
     assert allrec is not None and allrec.shape[0] == world * B
     if args.dump_records:      # tests/test_gpu_parity.py: every rank's own records and what the all-gather handed it
         np.savez(args.dump_records + ".rank%d.npz" % rank, local=batch.rec.cpu().numpy(), gathered=allrec.cpu().numpy(), rank=rank, world=world,
@@ -282,6 +286,13 @@ def main():
             cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
         if world == 1 and args.host_fed_steps > 0:
             host_fed = host_fed_leg(args, batch, frames, dev)
+        other_scene = None
+        if world == 1 and args.relief_lanes > 0 and args.workload == "config2":
+            batch.synchronize()
+            try:
+                other_scene = other_scene_leg(args, p, dev, local_rank, focal, baseline)
+            except Exception as e:
+                other_scene = {"error": str(e)}
         single_stream = None
         if world == 1 and args.single_stream and args.workload == "config2":
             batch.synchronize()
@@ -328,6 +339,11 @@ def main():
             "algorithmic_bytes_per_pair": int(pair_bytes),
             "valid_last_step": "%d/%d" % (n_valid, B),
             "mean_kps": round(mean_kps, 1), "mean_matches": round(mean_match, 1), "mean_tracked": round(mean_track, 1),
+            "scene": args.scene,
+            "track_funnel_mean": ts_mean,
+            "track_funnel_note": "svo_result.track_stats of the last timed step, mean over this rank's streams: previous-frame pairings that pass the descriptor threshold on both sides -> survive the joint collision filter (S4:145-160) -> are inliers of the left / right F-matrix RANSAC (1.0 px, S4:202, 237; hyp_* = hypotheses visited before the 0.99-confidence stop) -> of both -> pass the L/R consistency check (S4:282) = tracked",
+            "other_scene": other_scene,
+            "dist": dist_info,
             "kernels_ms_per_context_step": {k: round(v["ms_per_step"], 4) for k, v in per_kernel_warm.items()},
             "kernels_ms_note": "all kernels: HIP-event spans of the %d warm-up steps; roofline kernel: spans of the timed region" % args.warmup,
         }
@@ -336,6 +352,66 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def dist_audit(allrec, local_rec, world, rank, local_rank, dev):
+    """What lets the first real N > 1 run be audited from its JSON line: the backend, how many distinct
+    (host, device) pairs the ranks sit on, the RCCL version, and whether every rank's gathered record table is rank 0's --
+    with rank r's own records at slot r.  None at N = 1."""
+    if world == 1:
+        return None
+    import hashlib, socket
+    import torch.distributed as dist
+    own = local_rec.cpu().numpy().tobytes()
+    table = allrec.cpu().numpy()
+    per = table.shape[0] // world
+    me = {"rank": rank, "host": socket.gethostname(), "device": int(local_rank), "device_name": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu",
+          "table": hashlib.blake2b(table.tobytes(), digest_size=16).hexdigest(),
+          "own_slot_ok": table[rank * per:(rank + 1) * per].tobytes() == own}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return {"backend": dist.get_backend(), "world_size": world, "ranks_seen": len({(e["host"], e["device"]) for e in everyone}),
+            "hosts": sorted({e["host"] for e in everyone}), "rccl_version": ver,
+            "gathered_tables_equal": all(e["table"] == everyone[0]["table"] for e in everyone),
+            "own_records_at_own_slot": all(e["own_slot_ok"] for e in everyone),
+            "note": "ranks_seen = distinct (hostname, device) pairs over the ranks (== world_size on a real multi-GPU run; 1 when a test puts every rank on one GPU)"}
+
+
+def other_scene_leg(args, p, dev, device_index, focal, baseline):
+    """The scene type the timed region did NOT use, on a small batch: where stage 4's candidates go and how far the poses are
+    from the renderer's ground truth, beside the timed scene's figures.  Untimed; HIP poses against ground truth directly."""
+    from stereo_vo_amd.synth import pose6_to_matrix, pose_error
+    scene = "relief" if args.scene == "planes" else "planes"
+    W, H, F, B = args.width, args.height, args.frames, args.relief_lanes
+    worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=1000 + s, n_frames=F, device=dev, scene_seed=s % 4, scene=scene) for s in range(B)]
+    frames = [[w.render(t) for t in range(F)] for w in worlds]
+    torch.cuda.synchronize()
+    ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=4096, device=device_index)
+    ctx.set_params(p); ctx.set_camera(worlds[0].camera())
+    acc = {k: [] for k in TS_NAMES}
+    et, er, n_valid, n_frames = [], [], 0, 0
+    for t in range(F):
+        ctx.process_device([(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)], W, H, W)
+        res = ctx.results()
+        if t == 0:
+            continue
+        for l, r in enumerate(res):
+            n_frames += 1
+            for i, k in enumerate(TS_NAMES):
+                acc[k].append(r.track_stats[i])
+            if r.valid:
+                n_valid += 1
+                e_r, e_t = pose_error(pose6_to_matrix(np.array(r.outPose)), worlds[l].gt_delta(t))
+                et.append(e_t); er.append(e_r)
+    ctx.close()
+    return {"scene": scene, "streams": B, "frames_per_stream": F - 1, "valid": "%d/%d" % (n_valid, n_frames),
+            "track_funnel_mean": {k: round(float(np.mean(v)), 1) for k, v in acc.items()},
+            "pose_vs_ground_truth": {"translation_rmse_m": float(np.sqrt(np.mean(np.square(et)))) if et else None,
+                                     "rotation_rmse_rad": float(np.sqrt(np.mean(np.square(er)))) if er else None, "frames": len(et)}}
 
 
 def host_fed_leg(args, batch, frames, dev):
@@ -433,7 +509,7 @@ def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
     for t_ in ts: t_.start()
     for t_ in ts: t_.join()
     dtm = time.perf_counter() - c0
-    cpu_baseline = {"value": round(n / dt1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+    cpu_baseline = {"value": round(n / dt1, 3), "unit": "stereo pairs/s", "cores": 1, "kind": "port", "oracle_version": O.version(),
                     "sample": "first %d frames of stream 0's schedule (%dx%d, orb_nfeats=%d) on ONE thread of the C oracle (%s build); host has %d cores"
                               % (n, args.width, args.height, args.orb_nfeats, "-O3 -march=native, made on this host" if native else "-O3 -msse4.2 portable", os.cpu_count() or 0),
                     "multi_thread": {"value": round(len(others) * n / dtm, 3) if others else None, "unit": "stereo pairs/s", "cores": threads, "streams": len(others),

@@ -1,0 +1,87 @@
+/* svo_batch.h -- the batched / pipelined schedules of the MI355X stereo-VO hot path behind the C-ABI (libsvo_hip.so).
+ *
+ * The reference's caller is a C++ loop around one estimator (demo-stereo-odometry/demo-main.cpp:210-220); all of an
+ * estimator's state is per instance (libstereo-odometry/include/libstereo-odometry.h:732-831), so any number of them run
+ * side by side.  A context (svo_hip.h) drives up to SVO_MAX_LANES of them through every kernel launch; what fills an
+ * MI355X is SEVERAL such contexts whose latency-bound stages 3-5 overlap the throughput kernels of stage 2 of the next
+ * one.  That choreography -- two HIP streams with priorities, the events between them, the reuse hold-off of the result
+ * buffer -- lives here, in the library, so that a C / C++ host gets the benchmarked schedule with one call per step:
+ *
+ *   svo_batch       n_contexts x lanes independent streams, one frame of every stream per svo_batch_step
+ *   svo_fpstream    ONE stream (or lanes streams advancing together) whose consecutive frames are dealt round-robin to
+ *                   several contexts: stages 2-3 of frame t overlap stages 4-5 of frame t-1 (SURVEY.md 8e "within one
+ *                   stream"); results equal the sequential run list for list
+ *
+ * Conventions as in svo_hip.h: plain pointers and sizes, int status (0 ok, < 0 error), nothing throws, no CPU fallback.
+ * Neither object is thread-safe; one host thread drives one batch (one batch per GPU and thread on a multi-GPU node).
+ */
+#ifndef SVO_BATCH_H
+#define SVO_BATCH_H
+#include "svo_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SVO_SCHED_PIPELINED = 0,   /* ONE stream carries stage 2 of the contexts back to back, ANOTHER stages 3-5 of each frame */
+       SVO_SCHED_FREE = 1 };      /* every context runs its whole frame on its own stream, unsynchronised with the others */
+
+typedef struct svo_batch svo_batch;
+
+typedef struct svo_batch_config {
+    svo_config ctx;           /* per CONTEXT: n_lanes = streams per context (<= SVO_MAX_LANES); .stream is ignored */
+    int32_t n_contexts;       /* contexts side by side on ctx.device (total streams = n_contexts * ctx.n_lanes) */
+    int32_t schedule;         /* SVO_SCHED_*; a single context always runs SVO_SCHED_FREE */
+    int32_t det_priority_high;/* 0 (default, measured best): the stage 3-5 stream gets the high HIP priority -- its few workgroups are
+                                 placed at once and the detect kernels take every remaining wave slot; 1: the detect stream does */
+    int32_t post_mode;        /* where the reference's own post-processing of the detector output (NMS + row sort + describe) runs:
+                                 0 on the detect stream (default), 1 on the stage 3-5 stream, 2 on a third stream of its own */
+    int32_t det_streams;      /* >= 1: detect phases of consecutive contexts alternate over this many streams (default 1) */
+    int32_t _pad;
+} svo_batch_config;
+
+void svo_batch_config_defaults(svo_batch_config* c);
+int  svo_batch_create(const svo_batch_config* cfg, svo_batch** out);
+void svo_batch_destroy(svo_batch* b);
+const char* svo_batch_last_error(const svo_batch* b);
+int  svo_batch_lanes(const svo_batch* b);                       /* n_contexts * lanes per context */
+int  svo_batch_contexts(const svo_batch* b);
+/* context k (borrowed: per-context calls of svo_hip.h -- getters, thresholds, kernel times -- go through it; do not destroy it,
+ * and do not call svo_set_stream on it between steps) */
+svo_ctx* svo_batch_context(svo_batch* b, int k);
+int  svo_batch_set_params(svo_batch* b, const svo_params* p);   /* every context (loadParamsFromConfigFile, H:554-663) */
+int  svo_batch_set_camera(svo_batch* b, int lane, const svo_stereo_camera* cam);   /* global lane index, -1 = every stream */
+/* Where every step leaves the result records: caller-owned DEVICE memory of svo_batch_lanes() * sizeof(svo_result) bytes, in
+ * lane order (lane = context * lanes_per_context + lane_in_context) -- e.g. this rank's slot of an all-gather buffer.
+ * NULL: a buffer of the batch's own (svo_batch_results reads it). */
+int  svo_batch_set_results_buffer(svo_batch* b, void* dev_records, size_t bytes);
+/* processNewImagePair for every stream: frames[lane], lane in [0, svo_batch_lanes).  `flags`: SVO_FLAG_DEVICE_IMAGES,
+ * SVO_FLAG_PINNED_IMAGES or neither (pageable host images), | SVO_FLAG_BGR_IMAGES.  ENQUEUES and returns. */
+int  svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags);
+/* make the caller's hipStream_t wait for the last step's work of every context (e.g. before an all-gather of the records) */
+int  svo_batch_wait_on_stream(svo_batch* b, void* stream);
+/* the NEXT step's result copies wait for this hipEvent_t (e.g. the all-gather that still reads the records buffer) */
+int  svo_batch_hold_for_event(svo_batch* b, void* event);
+int  svo_batch_synchronize(svo_batch* b);
+int  svo_batch_results(svo_batch* b, svo_result* res /* svo_batch_lanes() entries */);    /* implies svo_batch_synchronize */
+int  svo_batch_reset(svo_batch* b);                             /* every stream a freshly constructed estimator again (C:28-50) */
+
+typedef struct svo_fpstream svo_fpstream;
+/* cfg as for one context (n_lanes streams advancing together; .stream ignored); n_contexts >= 1 contexts take the frames in turn */
+int  svo_fpstream_create(const svo_config* cfg, int n_contexts, svo_fpstream** out);
+void svo_fpstream_destroy(svo_fpstream* f);
+const char* svo_fpstream_last_error(const svo_fpstream* f);
+int  svo_fpstream_contexts(const svo_fpstream* f);
+svo_ctx* svo_fpstream_context(svo_fpstream* f, int k);          /* borrowed */
+svo_ctx* svo_fpstream_last_owner(svo_fpstream* f);              /* the context that ran the frame pushed last (NULL before the first) */
+int  svo_fpstream_set_params(svo_fpstream* f, const svo_params* p);
+int  svo_fpstream_set_camera(svo_fpstream* f, int lane, const svo_stereo_camera* cam);
+/* the next frame of the stream(s): frames[lane]; flags as for svo_batch_step.  Enqueues and returns; the frame's result records
+ * (n_lanes of them) land in the owner context -- svo_get_result(s) on svo_fpstream_last_owner waits for them. */
+int  svo_fpstream_push(svo_fpstream* f, const svo_frame* frames, uint32_t flags);
+int  svo_fpstream_synchronize(svo_fpstream* f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -88,7 +88,10 @@ void svo_destroy(svo_ctx* ctx);
 const char* svo_strerror(int status);
 const char* svo_last_error(const svo_ctx* ctx);   /* text of the last HIP failure */
 
-/* loadParamsFromConfigFile (H:554-663): stores the record, then resetFASTThreshold / resetORBThreshold */
+/* loadParamsFromConfigFile (H:554-663): stores the record, then resetFASTThreshold / resetORBThreshold.  The reference has no
+ * keypoint cap (stage2_detect.cpp:461-464); a request that this context's lists cannot hold (orb_nfeats against
+ * svo_config.max_kps, nOctaves against max_octaves) is refused here with SVO_ERR_CAPACITY -- the numbers are in svo_last_error --
+ * and the parameters in force stay as they were. */
 int svo_set_params(svo_ctx* ctx, const svo_params* p);
 int svo_get_params(const svo_ctx* ctx, svo_params* p);
 int svo_set_fast_threshold(svo_ctx* ctx, int v);  /* setFASTThreshold, clamped (H:531) */

@@ -39,6 +39,15 @@ const char* svo_group_last_error(const svo_group* g);
  *     Enqueued on `stream` (NULL: the context's own) after the frame's kernels, so it overlaps the host's next call. */
 int svo_group_allgather_results(svo_group* g, int rank, svo_ctx* ctx, void* stream, void* dev_records, size_t bytes);
 
+/* the same exchange for records that are already in place: `dev_table` holds n_ranks equal slots (bytes in all), this rank's
+ * slot was written on this GPU by work that `stream` already waits for (e.g. svo_batch_set_results_buffer pointed a batch at
+ * it and svo_batch_wait_on_stream ordered `stream` behind the step); in-place ncclAllGather on `stream`. */
+int svo_group_allgather_inplace(svo_group* g, int rank, void* dev_table, size_t bytes, void* stream);
+/* what the communicator itself says about the group (ncclCommCount / ncclCommUserRank / ncclCommCuDevice of `rank`'s
+ * communicator): lets a host print, next to its numbers, how many ranks RCCL really connected */
+int svo_group_comm_count(const svo_group* g, int rank);
+int svo_group_comm_device(const svo_group* g, int rank);
+
 /* (2) hand-over record of svo_export_frame / svo_import_frame between two ranks; bytes = svo_handover_bytes(ctx) */
 int svo_group_send_frame(svo_group* g, int rank, int to_rank, const void* dev_blob, size_t bytes, void* stream);
 int svo_group_recv_frame(svo_group* g, int rank, int from_rank, void* dev_blob, size_t bytes, void* stream);

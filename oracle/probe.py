@@ -40,7 +40,7 @@ def digest_of(src, lane, res):
     d.valid, d.error_code = int(res.valid), int(res.error_code)
     d.outliers = _h(src.outliers() if is_orc else src.outliers(lane)) if res.valid else ""
     d.pose = np.array(res.outPose, np.float64)
-    d.n = (len(kl[0]), len(kr[0]), int(res.stereo_matches[0]), int(res.tracked_feats_from_last_frame), int(res.n_outliers), int(res.n_residual))
+    d.n = (len(kl[0]), len(kr[0]), int(res.stereo_matches[0]), int(res.tracked_feats_from_last_frame), int(res.n_outliers), int(res.n_residual)) + tuple(res.track_stats)
     d.residual = (src.residuals() if is_orc else src.residuals(lane)) if res.valid else None
     return d
 

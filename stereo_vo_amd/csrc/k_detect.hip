@@ -97,7 +97,7 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
         r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = c.n_oct;
         if (detect) r.status = 0;
         r.tracked_feats_from_last_frame = 0; r.tracked_feats_from_last_KF = 0;
-        if (flags & SVO_RUN_TRACK) for (int k = 0; k < 8; k++) r.track_stats[k] = 0;
+        for (int k = 0; k < 8; k++) r.track_stats[k] = 0;
         for (int k = 0; k < 6; k++) { r.outPose[k] = 0; r.delta[k] = 0; }
     }
 }

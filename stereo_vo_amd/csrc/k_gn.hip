@@ -1,4 +1,4 @@
-// k_gn.hip -- stage 5 on the device: one persistent 256-thread workgroup per lane runs the whole optimiser
+// k_gn.hip -- stage 5 on the device: one persistent 512-thread workgroup per lane runs the whole optimiser
 // (gather, grid-NMS mask, triangulation, both Gauss-Newton phases, residual gating, pose inverse) in ONE launch
 // with no host round trip.
 //
@@ -149,7 +149,8 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 }
 
 #define GN_NSUM 28
-#define GN_RED_BYTES ((size_t)GN_NSUM * 256 * sizeof(double))
+#define GN_NT 512            // threads of the lane's workgroup: one pass over up to 512 tracks per iteration
+#define GN_RED_BYTES ((size_t)GN_NSUM * GN_NT * sizeof(double))
 struct GnShared {
     double part[4][GN_NSUM];
     double tot[GN_NSUM];
@@ -262,18 +263,18 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
             for (int b = a; b < 6; b++) { acc[h] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b] + J[3][a] * J[3][b]; h++; }   // ... Hessian NOT (S5:364-369)
         }
     }
-    // block reduction of the 28 sums through LDS: red[i][tid], then 8 threads per sum add 32 entries each and finish
-    // with three shuffles (28 shuffle trees of 6 steps each cost ~5x more on this latency-bound kernel)
+    // block reduction of the 28 sums through LDS: red[i][tid], then 16 threads per sum add 32 entries each and finish
+    // with four shuffles (28 shuffle trees of 6 steps each cost ~5x more on this latency-bound kernel)
 #pragma unroll
-    for (int i = 0; i < GN_NSUM; i++) red[i * 256 + tid] = acc[i];
+    for (int i = 0; i < GN_NSUM; i++) red[i * GN_NT + tid] = acc[i];
     __syncthreads();
-    if (tid < GN_NSUM * 8) {
-        const int sidx = tid >> 3, part = tid & 7;
-        const double* rp = red + sidx * 256 + part;
+    if (tid < GN_NSUM * 16) {
+        const int sidx = tid >> 4, part = tid & 15;
+        const double* rp = red + sidx * GN_NT + part;
         double sum = 0;
 #pragma unroll
-        for (int k = 0; k < 32; k++) sum += rp[8 * k];
-        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+        for (int k = 0; k < GN_NT / 16; k++) sum += rp[16 * k];
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
         if (part == 0) sh.tot[sidx] = sum;
     }
     __syncthreads();
@@ -306,9 +307,9 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P, uint8_t* big)
+__global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, uint8_t* big)
 {
-    // dynamic LDS: { keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] } U red[28][256] f64 | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
+    // dynamic LDS: { keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] } U red[28][GN_NT] f64 | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
     // `big` (lists above 4096 tracks): the sort / hash arrays of the stage-5 NMS mask move to a global scratch region of the lane,
     // LDS keeps the reduction buffer and the byte arrays
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P, uint
     uint32_t* hkey = (uint32_t*)(keys + PM);
     uint32_t* hval = hkey + 2 * PM;
     uint32_t* cellxy = hval + 2 * PM;
-    // the sort/hash arrays are dead once the NMS mask exists; the same bytes then hold the 28 x 256 reduction buffer
+    // the sort/hash arrays are dead once the NMS mask exists; the same bytes then hold the 28 x GN_NT reduction buffer
     const size_t region = (!big && (size_t)PM * 28 > GN_RED_BYTES) ? (size_t)PM * 28 : GN_RED_BYTES;
     unsigned char* state = smem + region;
     unsigned char* mask = state + PM;
@@ -363,7 +364,22 @@ __global__ void __launch_bounds__(256) k_gauss_newton(DevCtx c, GNParams P, uint
     }
     __threadfence_block();
     // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283); cap = T ----
-    bitonic_sort_lds<true>(keys, Pn);
+    if (T <= 2 * GN_NT && !big) {
+        // a few hundred keys: every key counts the keys above it (the keys are unique, so the counts are the descending ranks).
+        // All lanes read the same LDS word at a time (a broadcast): T reads per key and two barriers, where the bitonic network
+        // needs 45 compare-exchange stages at 512 keys (~10 us of the ~25 us this kernel spends before its first iteration).
+        unsigned long long* sorted = (unsigned long long*)hkey;             // 2 PM u32 = PM u64, free until the NMS builds its hash
+        __syncthreads();
+        for (int i = tid; i < T; i += blockDim.x) {
+            const unsigned long long k = keys[i];
+            int above = 0;
+            for (int j = 0; j < T; j++) above += keys[j] > k ? 1 : 0;
+            sorted[above] = k;
+        }
+        __syncthreads();
+        for (int i = tid; i < T; i += blockDim.x) keys[i] = sorted[i];
+        __syncthreads();
+    } else bitonic_sort_lds<true>(keys, Pn);
     {
         const unsigned cell = (unsigned)((double)P.min_distance / 2.0);
         const float inv = 1.0f / (float)cell;
@@ -501,7 +517,7 @@ hipError_t configure_gauss_newton(int pmax)
 
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(GN_NT), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------

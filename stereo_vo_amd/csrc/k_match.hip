@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
             const unsigned a = gL[k], b = gR[k];
             tlr[j] = (a & 0xFFFFu) | (b << 16);                                   // tl | tr << 16
             st[j] = ((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th) ? 0 : 2;      // S4:149
+            if ((int)(a & 0xFFFFu) >= ncm || (int)(b & 0xFFFFu) >= ncm) { st[j] = 0; atomicOr(&c.status[lane_id], SVO_ST_INTERNAL); }   // no match was written for k: never the case on a sound frame
         }
     }
     {   // svo_result.track_stats[SVO_TS_THRESHOLD]: candidates that pass the distance threshold on both sides
@@ -450,7 +451,11 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
     }
     for (int i = tid; i < c.max_kps / 32; i += 256) { takenL[i] = 0; takenR[i] = 0; }
     const int n_items = (npm + 255) / 256;
-    for (;;) {
+    // every round decides at least the smallest undecided candidate, so npm rounds always suffice: the bound only matters if the
+    // lists handed to this kernel are corrupt (a train index outside [0, ncm) would walk out of the LDS tables) -- then the lane is
+    // flagged (SVO_ST_INTERNAL) and the loop left instead of spinning for ever
+    for (int round = 0;; round++) {
+        if (round > npm) { if (tid == 0) { atomicOr(&c.status[lane_id], SVO_ST_INTERNAL); atomicOr(&c.results[lane_id].status, (int)SVO_ST_INTERNAL); } break; }
         for (int i = tid; i < ncm; i += 256) { firstL[i] = 0xFFFFFFFFu; firstR[i] = 0xFFFFFFFFu; }
         if (tid == 0) s_und = 0;
         __syncthreads();

@@ -314,10 +314,43 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     delete ctx;
 }
 
+void level_quota(int nfeatures, int nlevels, int* q);
+
+// The reference has no keypoint cap (stage2_detect.cpp:461-464: orb_nfeats is free); a context has one (svo_config.max_kps).
+// A request that cannot fit whatever the image size is refused HERE, when the parameters are loaded, with SVO_ERR_CAPACITY and
+// the numbers in svo_last_error -- not at the first frame, and never by cutting a list silently.  (What depends on the image
+// size -- pyramid and candidate buffers -- is still checked by the first svo_process.)
+static int params_fit(svo_ctx* ctx, const svo_params& p)
+{
+    const bool fast_orb = p.detect_method == SVO_DM_FAST_ORB;
+    if (p.detect_method != SVO_DM_ORB && !fast_orb) return SVO_OK;          // refused as unsupported by svo_process
+    char msg[256];
+    const int MK = ctx->dc.max_kps;
+    if (fast_orb) {
+        const int noct = p.nOctaves < 1 ? 1 : p.nOctaves;
+        if (noct > ctx->dc.oct_cap) { snprintf(msg, sizeof(msg), "nOctaves %d exceeds svo_config.max_octaves %d", noct, ctx->dc.oct_cap); ctx->last_error = msg; return SVO_ERR_CAPACITY; }
+        if (p.non_maximal_suppression) {
+            const size_t k0 = (size_t)((double)(size_t)p.orb_nfeats * (double)(2 * noct) / (pow(2, noct) - 1));            // S2:404-407
+            if ((long long)k0 > MK) { snprintf(msg, sizeof(msg), "orb_nfeats %d keeps up to %zu keypoints in octave 0, svo_config.max_kps is %d", p.orb_nfeats, k0, MK); ctx->last_error = msg; return SVO_ERR_CAPACITY; }
+        }
+        return SVO_OK;
+    }
+    const int nfe = p.non_maximal_suppression ? (int)(size_t)(1.5 * (double)(size_t)p.orb_nfeats) : p.orb_nfeats;       // S2:461-464
+    int nlev = p.orb_nlevels < 1 ? 1 : p.orb_nlevels;
+    if (nlev > SVO_MAX_LEVELS) return SVO_OK;                                  // refused as unsupported by the first frame
+    if (nfe > MK) { snprintf(msg, sizeof(msg), "orb_nfeats %d asks the detector for %d keypoints, svo_config.max_kps is %d (largest supported: 8192)", p.orb_nfeats, nfe, MK); ctx->last_error = msg; return SVO_ERR_CAPACITY; }
+    int quota[SVO_MAX_LEVELS];
+    level_quota(nfe, nlev, quota);
+    for (int l = 0; l < nlev; l++)
+        if (2 * quota[l] > ctx->dc.sel_max) { snprintf(msg, sizeof(msg), "level %d ranks 2 x %d corners, the selection list of this context holds %d (max_kps > 4096 doubles it)", l, quota[l], ctx->dc.sel_max); ctx->last_error = msg; return SVO_ERR_CAPACITY; }
+    return SVO_OK;
+}
+
 extern "C" int svo_set_params(svo_ctx* ctx, const svo_params* p)
 {
     if (ctx) use_device(ctx);
     if (!ctx || !p) return SVO_ERR_ARG;
+    { const int rc = params_fit(ctx, *p); if (rc) return rc; }
     ctx->params = *p;
     ctx->fast_th = p->initial_FAST_threshold;            // resetFASTThreshold (H:532, 661)
     ctx->orb_th = (int)p->orb_max_distance;              // resetORBThreshold (H:539, 662)
@@ -431,7 +464,7 @@ extern "C" int svo_reset(svo_ctx* ctx, int lane)
 }
 
 // cv::ORB per-level feature budget (oracle: orb_level_quota)
-static void level_quota(int nfeatures, int nlevels, int* q)
+void level_quota(int nfeatures, int nlevels, int* q)
 {
     const float factor = (float)(1.0 / 1.2);
     float nd = (float)nfeatures * (1.0f - factor) / (1.0f - (float)pow((double)factor, (double)nlevels));

@@ -1,0 +1,309 @@
+// svo_batch.cpp -- include/svo_batch.h: the batched / pipelined and the frame-parallel schedules, on HIP streams and events,
+// over the public C-ABI of svo_hip.h only (svo_set_stream, svo_process, svo_copy_results_async, svo_export / import_frame).
+//
+// No reference counterpart: the reference runs one estimator on one thread (demo-main.cpp:210-220).  What makes the lanes and
+// contexts independent is that all estimator state is per instance (libstereo-odometry.h:732-831).
+//
+// Pipelined schedule, per step and context k:
+//     detect stream:      [wait rest_done[k] of the previous step]  stage 2 of context k                  -> det_done[k]
+//     stage 3-5 stream:   [wait det_done[k]]  stages 3-5 of context k, result records -> records buffer  -> rest_done[k]
+// so stages 3-5 of context k overlap stage 2 of context k + 1.  Stage 4 reads the feature slot that the NEXT detect of the
+// same context overwrites, hence the wait on rest_done[k].
+#include "../../include/svo_batch.h"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace {
+struct Err { std::string text; };
+int hip_fail(std::string& dst, const char* what, hipError_t e) { dst = std::string(what) + ": " + hipGetErrorString(e); return SVO_ERR_HIP; }
+}
+#define BHIP(obj, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return hip_fail((obj)->last_error, #expr, _e); } while (0)
+#define BSVO(obj, c, expr) do { int _rc = (expr); if (_rc < 0) { (obj)->last_error = std::string(#expr) + ": " + svo_strerror(_rc) + " [" + svo_last_error(c) + "]"; return _rc; } } while (0)
+
+static const uint32_t IMG_FLAGS = SVO_FLAG_DEVICE_IMAGES | SVO_FLAG_PINNED_IMAGES | SVO_FLAG_BGR_IMAGES;
+
+struct svo_batch {
+    svo_batch_config cfg;
+    int NC = 0, Bc = 0, B = 0;
+    bool pipelined = false, first = true;
+    std::vector<svo_ctx*> ctx;
+    std::vector<hipStream_t> own;                    // one per context: the stream it was created with (free schedule)
+    std::vector<hipStream_t> s_dets; hipStream_t s_rest = nullptr, s_post = nullptr;
+    std::vector<hipEvent_t> det_done, rest_done, done, pre_done;
+    uint8_t* rec = nullptr; uint8_t* own_rec = nullptr;
+    std::string last_error;
+};
+
+extern "C" void svo_batch_config_defaults(svo_batch_config* c)
+{
+    if (!c) return;
+    svo_config_defaults(&c->ctx);
+    c->ctx.n_lanes = SVO_MAX_LANES;
+    c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 0; c->post_mode = 0; c->det_streams = 1; c->_pad = 0;
+}
+
+extern "C" const char* svo_batch_last_error(const svo_batch* b) { return b ? b->last_error.c_str() : ""; }
+extern "C" int svo_batch_lanes(const svo_batch* b) { return b ? b->B : SVO_ERR_ARG; }
+extern "C" int svo_batch_contexts(const svo_batch* b) { return b ? b->NC : SVO_ERR_ARG; }
+extern "C" svo_ctx* svo_batch_context(svo_batch* b, int k) { return (b && k >= 0 && k < b->NC) ? b->ctx[(size_t)k] : nullptr; }
+
+static int make_stream(std::string& err, hipStream_t* s, bool high)
+{
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);                    // numerically lower = higher priority
+    const hipError_t e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, high ? greatest : 0);
+    return e == hipSuccess ? SVO_OK : hip_fail(err, "hipStreamCreateWithPriority", e);
+}
+
+extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
+{
+    if (!cfg || !out) return SVO_ERR_ARG;
+    *out = nullptr;
+    if (cfg->n_contexts < 1 || cfg->ctx.n_lanes < 1 || cfg->ctx.n_lanes > SVO_MAX_LANES || cfg->post_mode < 0 || cfg->post_mode > 2) return SVO_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->ctx.device >= ndev) return SVO_ERR_NO_DEVICE;
+    svo_batch* b = new svo_batch();
+    *out = b;                                                                    // so that the caller can read last_error and destroy
+    b->cfg = *cfg; b->NC = cfg->n_contexts; b->Bc = cfg->ctx.n_lanes; b->B = b->NC * b->Bc;
+    b->pipelined = b->NC > 1 && cfg->schedule == SVO_SCHED_PIPELINED;
+    BHIP(b, hipSetDevice(cfg->ctx.device));
+    for (int k = 0; k < b->NC; k++) {
+        hipStream_t s = nullptr;
+        BHIP(b, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        b->own.push_back(s);
+        svo_config c = cfg->ctx; c.stream = s;
+        svo_ctx* x = nullptr;
+        const int rc = svo_create(&c, &x);
+        if (rc != SVO_OK) { b->last_error = std::string("svo_create: ") + svo_strerror(rc) + (x ? std::string(" [") + svo_last_error(x) + "]" : std::string()); if (x) svo_destroy(x); return rc; }
+        b->ctx.push_back(x);
+        hipEvent_t e[4];
+        for (int i = 0; i < 4; i++) BHIP(b, hipEventCreateWithFlags(&e[i], hipEventDisableTiming));
+        b->det_done.push_back(e[0]); b->rest_done.push_back(e[1]); b->done.push_back(e[2]); b->pre_done.push_back(e[3]);
+    }
+    const int nd = cfg->det_streams > 1 ? cfg->det_streams : 1;
+    for (int i = 0; i < nd; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high != 0); if (rc) return rc; b->s_dets.push_back(s); }
+    { int rc = make_stream(b->last_error, &b->s_rest, cfg->det_priority_high == 0); if (rc) return rc; }
+    if (cfg->post_mode == 2) { int rc = make_stream(b->last_error, &b->s_post, cfg->det_priority_high == 0); if (rc) return rc; }
+    BHIP(b, hipMalloc((void**)&b->own_rec, (size_t)b->B * sizeof(svo_result)));
+    BHIP(b, hipMemset(b->own_rec, 0, (size_t)b->B * sizeof(svo_result)));
+    b->rec = b->own_rec;
+    return SVO_OK;
+}
+
+extern "C" void svo_batch_destroy(svo_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->cfg.ctx.device);
+    (void)hipDeviceSynchronize();
+    for (svo_ctx* c : b->ctx) { (void)svo_set_stream(c, nullptr); svo_destroy(c); }
+    for (hipStream_t s : b->s_dets) (void)hipStreamDestroy(s);
+    if (b->s_rest) (void)hipStreamDestroy(b->s_rest);
+    if (b->s_post) (void)hipStreamDestroy(b->s_post);
+    for (hipStream_t s : b->own) (void)hipStreamDestroy(s);
+    for (auto* v : { &b->det_done, &b->rest_done, &b->done, &b->pre_done }) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    if (b->own_rec) (void)hipFree(b->own_rec);
+    delete b;
+}
+
+extern "C" int svo_batch_set_params(svo_batch* b, const svo_params* p)
+{
+    if (!b || !p) return SVO_ERR_ARG;
+    for (svo_ctx* c : b->ctx) BSVO(b, c, svo_set_params(c, p));
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_set_camera(svo_batch* b, int lane, const svo_stereo_camera* cam)
+{
+    if (!b || !cam || lane < -1 || lane >= b->B) return SVO_ERR_ARG;
+    if (lane < 0) { for (svo_ctx* c : b->ctx) BSVO(b, c, svo_set_camera(c, -1, cam)); return SVO_OK; }
+    svo_ctx* c = b->ctx[(size_t)(lane / b->Bc)];
+    BSVO(b, c, svo_set_camera(c, lane % b->Bc, cam));
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_set_results_buffer(svo_batch* b, void* dev_records, size_t bytes)
+{
+    if (!b || (dev_records && bytes < (size_t)b->B * sizeof(svo_result))) return SVO_ERR_ARG;
+    int rc = svo_batch_synchronize(b); if (rc) return rc;
+    b->rec = dev_records ? (uint8_t*)dev_records : b->own_rec;
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags)
+{
+    if (!b || !frames || (flags & ~IMG_FLAGS)) return SVO_ERR_ARG;
+    BHIP(b, hipSetDevice(b->cfg.ctx.device));
+    const size_t rsz = sizeof(svo_result);
+    const uint32_t REST = SVO_RUN_MATCH | SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_FLAG_NO_SHIFT | (b->cfg.post_mode == 1 ? (uint32_t)SVO_RUN_DETECT_POST : 0u);
+    for (int k = 0; k < b->NC; k++) {
+        svo_ctx* c = b->ctx[(size_t)k];
+        const svo_frame* pk = frames + (size_t)k * b->Bc;
+        uint8_t* dst = b->rec + (size_t)k * b->Bc * rsz;
+        if (b->pipelined) {
+            hipStream_t s_det = b->s_dets[(size_t)k % b->s_dets.size()];
+            if (!b->first) BHIP(b, hipStreamWaitEvent(s_det, b->rest_done[(size_t)k], 0));
+            BSVO(b, c, svo_set_stream(c, s_det));
+            BSVO(b, c, svo_process(c, pk, SVO_RUN_DETECT | (b->cfg.post_mode ? (uint32_t)SVO_FLAG_DETECT_NO_POST : 0u) | flags));
+            if (b->cfg.post_mode == 2) {
+                BHIP(b, hipEventRecord(b->pre_done[(size_t)k], s_det));
+                BHIP(b, hipStreamWaitEvent(b->s_post, b->pre_done[(size_t)k], 0));
+                BSVO(b, c, svo_set_stream(c, b->s_post));
+                BSVO(b, c, svo_process(c, nullptr, SVO_RUN_DETECT_POST | SVO_FLAG_NO_SHIFT));
+                BHIP(b, hipEventRecord(b->det_done[(size_t)k], b->s_post));
+            } else BHIP(b, hipEventRecord(b->det_done[(size_t)k], s_det));
+            BHIP(b, hipStreamWaitEvent(b->s_rest, b->det_done[(size_t)k], 0));
+            BSVO(b, c, svo_set_stream(c, b->s_rest));
+            BSVO(b, c, svo_process(c, nullptr, REST));
+            BSVO(b, c, svo_copy_results_async(c, dst, (size_t)b->Bc * rsz));
+            BHIP(b, hipEventRecord(b->rest_done[(size_t)k], b->s_rest));
+        } else {
+            BSVO(b, c, svo_set_stream(c, nullptr));
+            BSVO(b, c, svo_process(c, pk, SVO_RUN_ALL | flags));
+            BSVO(b, c, svo_copy_results_async(c, dst, (size_t)b->Bc * rsz));
+            BHIP(b, hipEventRecord(b->done[(size_t)k], b->own[(size_t)k]));
+        }
+    }
+    b->first = false;
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_wait_on_stream(svo_batch* b, void* stream)
+{
+    if (!b) return SVO_ERR_ARG;
+    if (b->first) return SVO_OK;                                                 // nothing enqueued yet
+    for (int k = 0; k < b->NC; k++) BHIP(b, hipStreamWaitEvent((hipStream_t)stream, b->pipelined ? b->rest_done[(size_t)k] : b->done[(size_t)k], 0));
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_hold_for_event(svo_batch* b, void* event)
+{
+    if (!b || !event) return SVO_ERR_ARG;
+    if (b->pipelined) BHIP(b, hipStreamWaitEvent(b->s_rest, (hipEvent_t)event, 0));
+    else for (hipStream_t s : b->own) BHIP(b, hipStreamWaitEvent(s, (hipEvent_t)event, 0));
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_synchronize(svo_batch* b)
+{
+    if (!b) return SVO_ERR_ARG;
+    BHIP(b, hipSetDevice(b->cfg.ctx.device));
+    for (hipStream_t s : b->s_dets) BHIP(b, hipStreamSynchronize(s));
+    if (b->s_post) BHIP(b, hipStreamSynchronize(b->s_post));
+    if (b->s_rest) BHIP(b, hipStreamSynchronize(b->s_rest));
+    for (svo_ctx* c : b->ctx) BSVO(b, c, svo_wait(c));
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_results(svo_batch* b, svo_result* res)
+{
+    if (!b || !res) return SVO_ERR_ARG;
+    int rc = svo_batch_synchronize(b); if (rc) return rc;
+    for (int k = 0; k < b->NC; k++) BSVO(b, b->ctx[(size_t)k], svo_get_results(b->ctx[(size_t)k], res + (size_t)k * b->Bc));
+    return SVO_OK;
+}
+
+extern "C" int svo_batch_reset(svo_batch* b)
+{
+    if (!b) return SVO_ERR_ARG;
+    int rc = svo_batch_synchronize(b); if (rc) return rc;
+    for (svo_ctx* c : b->ctx) { BSVO(b, c, svo_set_stream(c, nullptr)); BSVO(b, c, svo_reset(c, -1)); }
+    b->first = true;
+    return SVO_OK;
+}
+
+// ---- frame-parallelism within one stream ---------------------------------------------------------------------------------
+// Context g = t % G runs stages 2-3 of frame t on its own stream as soon as it is free -- overlapping stages 4-5 of frame t - 1
+// on the context before it -- then imports the previous owner's hand-over record (svo_export_frame / svo_import_frame), runs
+// stages 4-5 and exports its own.  Same results as one context fed sequentially; frames per second are bounded by
+// max(stages 4-5 of one frame, a whole frame / G) instead of a whole frame.
+struct svo_fpstream {
+    svo_config cfg; int G = 0; long long t = 0;
+    std::vector<svo_ctx*> ctx; std::vector<hipStream_t> st; std::vector<hipEvent_t> exported; std::vector<uint8_t*> blob;
+    size_t nbytes = 0;
+    std::string last_error;
+};
+
+extern "C" const char* svo_fpstream_last_error(const svo_fpstream* f) { return f ? f->last_error.c_str() : ""; }
+extern "C" int svo_fpstream_contexts(const svo_fpstream* f) { return f ? f->G : SVO_ERR_ARG; }
+extern "C" svo_ctx* svo_fpstream_context(svo_fpstream* f, int k) { return (f && k >= 0 && k < f->G) ? f->ctx[(size_t)k] : nullptr; }
+extern "C" svo_ctx* svo_fpstream_last_owner(svo_fpstream* f) { return (f && f->t > 0) ? f->ctx[(size_t)((f->t - 1) % f->G)] : nullptr; }
+
+extern "C" int svo_fpstream_create(const svo_config* cfg, int n_contexts, svo_fpstream** out)
+{
+    if (!cfg || !out || n_contexts < 1) return SVO_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) return SVO_ERR_NO_DEVICE;
+    svo_fpstream* f = new svo_fpstream();
+    *out = f;
+    f->cfg = *cfg; f->G = n_contexts;
+    BHIP(f, hipSetDevice(cfg->device));
+    for (int g = 0; g < f->G; g++) {
+        hipStream_t s = nullptr;
+        BHIP(f, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        f->st.push_back(s);
+        svo_config c = *cfg; c.stream = s;
+        svo_ctx* x = nullptr;
+        const int rc = svo_create(&c, &x);
+        if (rc != SVO_OK) { f->last_error = std::string("svo_create: ") + svo_strerror(rc) + (x ? std::string(" [") + svo_last_error(x) + "]" : std::string()); if (x) svo_destroy(x); return rc; }
+        f->ctx.push_back(x);
+        hipEvent_t e; BHIP(f, hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->exported.push_back(e);
+    }
+    f->nbytes = svo_handover_bytes(f->ctx[0]);
+    for (int g = 0; g < f->G; g++) { uint8_t* p = nullptr; BHIP(f, hipMalloc((void**)&p, f->nbytes)); BHIP(f, hipMemset(p, 0, f->nbytes)); f->blob.push_back(p); }
+    return SVO_OK;
+}
+
+extern "C" void svo_fpstream_destroy(svo_fpstream* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (svo_ctx* c : f->ctx) svo_destroy(c);
+    for (hipStream_t s : f->st) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : f->exported) (void)hipEventDestroy(e);
+    for (uint8_t* p : f->blob) (void)hipFree(p);
+    delete f;
+}
+
+extern "C" int svo_fpstream_set_params(svo_fpstream* f, const svo_params* p)
+{
+    if (!f || !p) return SVO_ERR_ARG;
+    for (svo_ctx* c : f->ctx) BSVO(f, c, svo_set_params(c, p));
+    return SVO_OK;
+}
+
+extern "C" int svo_fpstream_set_camera(svo_fpstream* f, int lane, const svo_stereo_camera* cam)
+{
+    if (!f || !cam) return SVO_ERR_ARG;
+    for (svo_ctx* c : f->ctx) BSVO(f, c, svo_set_camera(c, lane, cam));
+    return SVO_OK;
+}
+
+extern "C" int svo_fpstream_push(svo_fpstream* f, const svo_frame* frames, uint32_t flags)
+{
+    if (!f || !frames || (flags & ~IMG_FLAGS)) return SVO_ERR_ARG;
+    BHIP(f, hipSetDevice(f->cfg.device));
+    const int g = (int)(f->t % f->G);
+    svo_ctx* c = f->ctx[(size_t)g]; hipStream_t s = f->st[(size_t)g];
+    BSVO(f, c, svo_process(c, frames, SVO_RUN_DETECT | SVO_RUN_MATCH | flags));             // stages 2-3: independent of every other frame
+    if (f->t > 0) {
+        const int gp = (int)((f->t - 1) % f->G);
+        BHIP(f, hipStreamWaitEvent(s, f->exported[(size_t)gp], 0));
+        BSVO(f, c, svo_import_frame(c, f->blob[(size_t)gp], f->nbytes));
+    }
+    BSVO(f, c, svo_process(c, nullptr, SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_FLAG_NO_SHIFT));
+    BSVO(f, c, svo_export_frame(c, f->blob[(size_t)g], f->nbytes));
+    BHIP(f, hipEventRecord(f->exported[(size_t)g], s));
+    f->t++;
+    return SVO_OK;
+}
+
+extern "C" int svo_fpstream_synchronize(svo_fpstream* f)
+{
+    if (!f) return SVO_ERR_ARG;
+    BHIP(f, hipSetDevice(f->cfg.device));
+    for (svo_ctx* c : f->ctx) BSVO(f, c, svo_wait(c));
+    return SVO_OK;
+}

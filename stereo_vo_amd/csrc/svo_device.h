@@ -28,6 +28,7 @@
 // status-word bits (svo_debug_get_status_word)
 #define SVO_ST_CAND_OVERFLOW 1u
 #define SVO_ST_KPS_OVERFLOW 2u
+#define SVO_ST_INTERNAL 8u            // an internal consistency bound was hit (a loop that must terminate did not, an index left its list): a bug, reported instead of a hang
 #define SVO_ST_HANDOVER_MISMATCH 4u  // svo_import_frame was handed a record of another layout (magic / version / max_kps / max_h / octaves / lanes)
 
 // division of a 32-bit unsigned by a launch-time constant (Granlund-Montgomery round-up): exact for every x, and on a
@@ -330,7 +331,7 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
     }
     __syncthreads();
     if constexpr (ITEMS == 0) {
-        for (;;) {
+        for (int round = 0; round <= n; round++) {                     // every round decides the lowest-rank undecided representative: n rounds always suffice
             if (tid == 0) *flag = 0;
             __syncthreads();
             bool pending = false;
@@ -379,7 +380,7 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
             }
         }
     }
-    for (;;) {
+    for (int round = 0; round <= n; round++) {
         if (tid == 0) *flag = 0;
         __syncthreads();
         bool pending = false;

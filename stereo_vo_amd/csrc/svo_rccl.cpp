@@ -109,6 +109,36 @@ extern "C" int svo_group_allgather_results(svo_group* g, int rank, svo_ctx* ctx,
     return SVO_OK;
 }
 
+extern "C" int svo_group_allgather_inplace(svo_group* g, int rank, void* dev_table, size_t bytes, void* stream)
+{
+    if (!g || !dev_table) return SVO_ERR_ARG;
+    if (!g->local) rank = g->my_rank;
+    if (rank < 0 || rank >= g->n_ranks || bytes == 0 || bytes % (size_t)g->n_ranks != 0) return SVO_ERR_ARG;
+    const int s = slot_of(g, rank);
+    const size_t chunk = bytes / (size_t)g->n_ranks;
+    HIPCHK(g, hipSetDevice(g->device[s]));
+    NCCLCHECK(g, ncclAllGather((const char*)dev_table + (size_t)rank * chunk, dev_table, chunk, ncclChar, g->comm[s], (hipStream_t)stream));
+    return SVO_OK;
+}
+
+extern "C" int svo_group_comm_count(const svo_group* g, int rank)
+{
+    if (!g) return SVO_ERR_ARG;
+    if (!g->local) rank = g->my_rank;
+    if (rank < 0 || rank >= g->n_ranks) return SVO_ERR_ARG;
+    int n = 0;
+    return ncclCommCount(g->comm[slot_of(g, rank)], &n) == ncclSuccess ? n : SVO_ERR_HIP;
+}
+
+extern "C" int svo_group_comm_device(const svo_group* g, int rank)
+{
+    if (!g) return SVO_ERR_ARG;
+    if (!g->local) rank = g->my_rank;
+    if (rank < 0 || rank >= g->n_ranks) return SVO_ERR_ARG;
+    int d = -1;
+    return ncclCommCuDevice(g->comm[slot_of(g, rank)], &d) == ncclSuccess ? d : SVO_ERR_HIP;
+}
+
 extern "C" int svo_group_send_frame(svo_group* g, int rank, int to_rank, const void* dev_blob, size_t bytes, void* stream)
 {
     if (!g || !dev_blob) return SVO_ERR_ARG;

@@ -33,10 +33,25 @@ EXPORTS = [
 ]
 
 
+BATCH_EXPORTS = [
+    "svo_batch_config_defaults", "svo_batch_create", "svo_batch_destroy", "svo_batch_last_error", "svo_batch_lanes", "svo_batch_contexts",
+    "svo_batch_context", "svo_batch_set_params", "svo_batch_set_camera", "svo_batch_set_results_buffer", "svo_batch_step",
+    "svo_batch_wait_on_stream", "svo_batch_hold_for_event", "svo_batch_synchronize", "svo_batch_results", "svo_batch_reset",
+    "svo_fpstream_create", "svo_fpstream_destroy", "svo_fpstream_last_error", "svo_fpstream_contexts", "svo_fpstream_context",
+    "svo_fpstream_last_owner", "svo_fpstream_set_params", "svo_fpstream_set_camera", "svo_fpstream_push", "svo_fpstream_synchronize",
+]
+
+
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("n_lanes", C.c_int32), ("max_w", C.c_int32), ("max_h", C.c_int32),
                 ("max_kps", C.c_int32), ("max_cand", C.c_int32), ("kernel_times", C.c_int32), ("max_octaves", C.c_int32),
                 ("stream", C.c_void_p)]
+
+
+class BatchConfig(C.Structure):
+    """svo_batch_config (include/svo_batch.h)"""
+    _fields_ = [("ctx", Config), ("n_contexts", C.c_int32), ("schedule", C.c_int32), ("det_priority_high", C.c_int32),
+                ("post_mode", C.c_int32), ("det_streams", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Image(C.Structure):
@@ -70,6 +85,13 @@ def lib():
         for n in ("svo_destroy", "svo_config_defaults", "svo_params_defaults", "svo_abi_sizes"):
             getattr(L, n).restype = None
         L.svo_destroy.argtypes = [C.c_void_p]
+        for n in ("svo_batch_last_error", "svo_fpstream_last_error"):
+            getattr(L, n).restype = C.c_char_p; getattr(L, n).argtypes = [C.c_void_p]
+        for n in ("svo_batch_context", "svo_fpstream_context", "svo_fpstream_last_owner"):
+            getattr(L, n).restype = C.c_void_p
+        for n in ("svo_batch_destroy", "svo_fpstream_destroy", "svo_batch_config_defaults"):
+            getattr(L, n).restype = None
+        L.svo_batch_destroy.argtypes = [C.c_void_p]; L.svo_fpstream_destroy.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -106,6 +128,18 @@ class Context:
             self.h = None
             raise SvoError("svo_create failed: " + msg)
         self._keep = None
+        self._owned = True
+
+    @classmethod
+    def from_handle(cls, handle, n_lanes, max_kps):
+        """A view of a context that something else owns (svo_batch_context / svo_fpstream_context): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.h = C.c_void_p(handle)
+        self.n_lanes, self.max_kps = n_lanes, max_kps
+        self._keep = None
+        self._owned = False
+        return self
 
     def _err(self, rc):
         s = self.L.svo_strerror(rc).decode()
@@ -122,7 +156,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.svo_destroy(self.h)
+            if getattr(self, "_owned", True):
+                self.L.svo_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -10,7 +10,8 @@ from . import hip
 from .abi import Result
 
 EXPORTS = ["svo_group_create_local", "svo_group_unique_id", "svo_group_create_rank", "svo_group_destroy", "svo_group_size",
-           "svo_group_last_error", "svo_group_allgather_results", "svo_group_send_frame", "svo_group_recv_frame"]
+           "svo_group_last_error", "svo_group_allgather_results", "svo_group_send_frame", "svo_group_recv_frame",
+           "svo_group_allgather_inplace", "svo_group_comm_count", "svo_group_comm_device"]
 ID_BYTES = 128
 _lib = None
 

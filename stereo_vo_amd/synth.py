@@ -1,5 +1,9 @@
 """Deterministic synthetic stereo sequences: textured planes seen by a rectified pinhole pair.
 
+Two scene types: "planes" (a far wall, the ground and three or four facades: the default, and what every committed number before
+round 3 was measured on) and "relief" (the same plus a few dozen small billboards at depths of 4 .. 22 m: depth discontinuities
+everywhere in the image, so that the scene is not a handful of planes -- a near-degenerate configuration for a fundamental matrix).
+
 Plays the role of the image source of the reference's demo (demo-stereo-odometry/demo-main.cpp:200-220,
 mrpt CCameraSensor) on inputs that can be generated on the GPU box from this repository alone.
 Rendering uses torch so that it runs on the CPU here and on cuda:0 in bench.py; every random quantity comes
@@ -67,7 +71,9 @@ class SyntheticStereoWorld:
     _scene_cache = {}
 
     def __init__(self, width, height, focal, baseline=0.12, seed=0, n_frames=20, device="cpu",
-                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048, scene_seed=None):
+                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048, scene_seed=None, scene="planes"):
+        assert scene in ("planes", "relief")
+        self.scene = scene
         self.w, self.h, self.f, self.B = int(width), int(height), float(focal), float(baseline)
         self.cx = (self.w - 1) / 2.0 if cx is None else float(cx)
         self.cy = (self.h - 1) / 2.0 if cy is None else float(cy)
@@ -85,7 +91,7 @@ class SyntheticStereoWorld:
         self._ray = torch.stack([(xs - self.cx) / self.f, (ys - self.cy) / self.f, torch.ones_like(xs)], dim=-1)  # h,w,3
 
     def _build_scene(self, tex_size):
-        key = (self.scene_seed, tex_size)
+        key = (self.scene_seed, tex_size, self.scene)
         if key in SyntheticStereoWorld._scene_cache:
             self.planes, texs = SyntheticStereoWorld._scene_cache[key]
             self.textures = [torch.from_numpy(t).to(self.device).float() for t in texs]
@@ -109,8 +115,25 @@ class SyntheticStereoWorld:
             eu = np.array([math.cos(tilt), 0, math.sin(tilt)])
             ev = np.array([0, 1.0, 0])
             planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), 0.012 + 0.002 * k))
+        n_tex = len(planes)
+        if self.scene == "relief":
+            # billboards: small, nearly fronto-parallel textured rectangles scattered through the viewing volume (the camera
+            # advances ~1 m over a sequence).  They share the base planes' textures at random offsets (entries 6, 7 of the tuple)
+            # with a texel size that grows with depth, so that every one shows corners at the scale the detector looks at.
+            half_fov = 0.5 * self.w / self.f
+            for k in range(28):
+                z = rng.uniform(4.0, 22.0)
+                xc = rng.uniform(-0.9 * half_fov * z, 0.9 * half_fov * z)
+                yc = rng.uniform(-0.35 * z, 1.0)
+                hw, hh = rng.uniform(0.25, 0.9) * (0.5 + z / 12.0), rng.uniform(0.25, 0.9) * (0.5 + z / 12.0)
+                tilt = rng.uniform(-0.25, 0.25)
+                n = np.array([math.sin(tilt), 0, -math.cos(tilt)])
+                eu = np.array([math.cos(tilt), 0, math.sin(tilt)])
+                ev = np.array([0, 1.0, 0])
+                planes.append((np.array([xc, yc, z]), n, eu, ev, (-hw, hw, -hh, hh), 0.004 + 0.0009 * z,
+                               rng.randint(0, n_tex - 1), (rng.uniform(0, tex_size), rng.uniform(0, tex_size))))
         self.planes = planes
-        texs = [_manhattan_texture(rng, tex_size, 5000) for _ in planes]
+        texs = [_manhattan_texture(rng, tex_size, 5000) for _ in range(n_tex)]
         SyntheticStereoWorld._scene_cache[key] = (planes, texs)
         self.textures = [torch.from_numpy(t).to(self.device).float() for t in texs]
         self.tex_size = tex_size
@@ -151,7 +174,10 @@ class SyntheticStereoWorld:
         d = self._ray @ R.T                                        # h,w,3 world directions
         best_s = torch.full((self.h, self.w), float("inf"), device=dev)
         img = torch.full((self.h, self.w), 90.0, device=dev)
-        for (P, n, eu, ev, ext, mpt), tex in zip(self.planes, self.textures):
+        for pi, pl in enumerate(self.planes):
+            P, n, eu, ev, ext, mpt = pl[:6]
+            tex = self.textures[pl[6] if len(pl) > 6 else pi]
+            tu0, tv0 = pl[7] if len(pl) > 7 else (0.0, 0.0)
             Pt = torch.tensor(P, dtype=torch.float32, device=dev)
             nt = torch.tensor(n, dtype=torch.float32, device=dev)
             eut = torch.tensor(eu, dtype=torch.float32, device=dev)
@@ -161,8 +187,8 @@ class SyntheticStereoWorld:
             X = o + s.unsqueeze(-1) * d - Pt
             a, b = X @ eut, X @ evt
             ok = (s > 0.05) & (s < best_s) & (a >= ext[0]) & (a <= ext[1]) & (b >= ext[2]) & (b <= ext[3]) & torch.isfinite(s)
-            tu = a / mpt + self.tex_size / 2.0
-            tv = b / mpt + self.tex_size / 2.0
+            tu = a / mpt + (self.tex_size / 2.0 + tu0)
+            tv = b / mpt + (self.tex_size / 2.0 + tv0)
             # wrap the texture so that large planes stay textured everywhere
             tu = torch.remainder(tu, self.tex_size - 1.0)
             tv = torch.remainder(tv, self.tex_size - 1.0)

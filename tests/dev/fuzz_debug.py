@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: FAST+ORB fuzz seeds of tests/test_gpu_parity.py, first differences printed (debug aid)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from stereo_vo_amd import hip
 from stereo_vo_amd.abi import north_star_params, DM_FAST_ORB

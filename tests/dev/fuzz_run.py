@@ -2,7 +2,7 @@
 """GPU box: the randomized-parameter parity tests of tests/test_gpu_parity.py for a range of seeds, one line per seed, flushed
 BEFORE the seed runs (so that a hang names its seed).  usage: fuzz_run.py orb|fast_orb|calls first last"""
 import os, sys, time, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as T
 fn = {"orb": T.test_random_parameter_sets_match_oracle, "fast_orb": T.test_random_parameter_sets_fast_orb_match_oracle, "calls": T.test_random_call_sequences_match_oracle}[sys.argv[1]]

@@ -5,7 +5,7 @@ import os
 os.environ.setdefault("SVO_DEBUG_MODE", "9")    # raw (pre-NMS) keypoints carry angles / descriptors only in this mode
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from stereo_vo_amd import hip
 from stereo_vo_amd.abi import StereoCamera, north_star_params

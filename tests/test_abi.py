@@ -20,6 +20,17 @@ def test_library_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_batch_scheduler_exports_every_declared_symbol():
+    """include/svo_batch.h: the batched / pipelined and frame-parallel schedulers live in libsvo_hip.so, behind the C-ABI"""
+    L = hip.lib()
+    hdr = open(os.path.join(ROOT, "include", "svo_batch.h")).read()
+    declared = set(re.findall(r"\b(svo_(?:batch|fpstream)_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hip.BATCH_EXPORTS), declared ^ set(hip.BATCH_EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.svo_batch_lanes(None) < 0 and L.svo_batch_create(None, None) < 0 and L.svo_fpstream_push(None, None, 0) < 0
+
+
 def test_rccl_companion_exports_every_declared_symbol():
     """include/svo_rccl.h: the exchange steps of the multi-GPU path; loading it needs no GPU, creating a group does"""
     from stereo_vo_amd import rccl

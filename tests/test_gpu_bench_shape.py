@@ -101,6 +101,11 @@ def test_bench_two_ranks_on_one_gpu_gather_real_records(tmp_path):
     line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["lanes_per_gpu"] == 8
+    # the audit block of an N > 1 run: both ranks were forced onto the box's one GPU, so ONE (host, device) pair is seen --
+    # on a real multi-GPU node ranks_seen must equal world_size
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_seen"] == 1 and d["gathered_tables_equal"] and d["own_records_at_own_slot"]
+    assert set(line["track_funnel_mean"]) == {"threshold", "collision", "inliers_left", "inliers_right", "hyp_left", "hyp_right", "both_masks", "tracked"}
     r0, r1 = np.load(dump + ".rank0.npz"), np.load(dump + ".rank1.npz")
     # every rank holds the same gathered array = rank 0's records followed by rank 1's (stream s -> rank s // lanes)
     assert r0["gathered"].tobytes() == r1["gathered"].tobytes()

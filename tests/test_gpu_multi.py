@@ -47,7 +47,7 @@ def test_cpp_host_one_rank_rccl_gather_equals_the_demo(tmp_path):
     want = _demo_trace(tmp_path, seq, "a")
     out = subprocess.check_output([exe, "--gpus", "1", "--gather", "rccl", "--nfeats", "500", "--out", str(tmp_path / "mg"), seq], timeout=600)
     line = json.loads(out.decode().strip().splitlines()[-1])
-    assert line["ranks"] == 1 and line["gather"] == "rccl" and line["frames"] == 8
+    assert line["ranks"] == 1 and line["gather"] == "rccl" and line["frames"] == 8 and line["rccl_comm_count"] == 1 and line["tables_equal"]
     assert open(str(tmp_path / "mg_stream0.txt")).read() == want
 
 

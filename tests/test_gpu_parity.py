@@ -2,6 +2,7 @@
 
 Bar (BASELINE.json north_star): keypoints, descriptors, pairings and tracked pairs bit-exact; poses within
 1e-4 rad / 1e-3 m.  Every test here needs a real MI355X: run with `pytest -m gpu`."""
+import ctypes as C
 import os
 import numpy as np
 import pytest
@@ -32,6 +33,7 @@ def assert_same_frame(ctx, lane, orc, r, ro, tag):
     assert (r.valid, r.error_code) == (ro.valid, ro.error_code), (tag, r.valid, r.error_code, ro.valid, ro.error_code)
     assert (r.detected_left[0], r.detected_right[0], r.stereo_matches[0]) == (ro.detected_left[0], ro.detected_right[0], ro.stereo_matches[0])
     assert (r.n_residual, r.n_outliers) == (ro.n_residual, ro.n_outliers), tag
+    assert list(r.track_stats) == list(ro.track_stats), (tag, "stage-4 pass-through counters", list(r.track_stats), list(ro.track_stats))
     if ro.valid:
         dp = np.abs(np.array(r.outPose) - np.array(ro.outPose))
         assert dp[:3].max() < POSE_TOL_M and dp[3:].max() < POSE_TOL_RAD, (tag, dp)
@@ -760,8 +762,9 @@ def test_capacity_overflow_is_reported_in_the_result_record(golden_dir):
     g, cam, p = load_small(golden_dir)
     q = p.copy(); q.orb_nfeats = 220
     ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=64, max_cand=1 << 15)
-    ctx.set_params(q); ctx.set_camera(cam)
+    ctx.set_camera(cam)
     try:
+        ctx.set_params(q)                # 330 keypoints asked of the detector, 64 slots: refused when the parameters are loaded
         ctx.process_host([(g["L0"], g["R0"])])
         r = ctx.result(0)
         assert r.status & 2 and ctx.status_word(0) & 2
@@ -809,9 +812,11 @@ def test_graph_replay_matches_plain_launches(golden_dir):
         ctx.close()
 
 
-def test_adaptive_nms_after_fast_orb_matches_oracle():
+@pytest.mark.parametrize("graphs", [False, True])
+def test_adaptive_nms_after_fast_orb_matches_oracle(graphs):
     """stage2_detect.cpp:599-606 applies m_adaptive_non_max_sup to whatever detector ran: nmsmAdaptive on the FAST+ORB
-    detector's output (every FAST corner of every x1/2 octave), two octaves, three frames, two lanes."""
+    detector's output (every FAST corner of every x1/2 octave), two octaves, three frames, two lanes.  With graphs: the first
+    frame of this mode needs a lazily allocated scratch buffer, which must exist before the capture begins."""
     from stereo_vo_amd.abi import DM_FAST_ORB
     W, H = 640, 480
     w = SyntheticStereoWorld(W, H, 400.0, 0.12, seed=12, n_frames=3)
@@ -820,8 +825,10 @@ def test_adaptive_nms_after_fast_orb_matches_oracle():
     p.detect_method = DM_FAST_ORB; p.nOctaves = 2; p.nmsMethod = 1
     ctx = hip.Context(n_lanes=2, max_w=W, max_h=H, max_kps=2048, max_cand=1 << 16, max_octaves=2)
     ctx.set_params(p); ctx.set_camera(cam)
+    if graphs:
+        ctx.use_graphs(True)
     orcs = [O().Oracle(p), O().Oracle(p)]
-    for t in range(3):
+    for t in (0, 1, 2, 1, 0) if graphs else range(3):          # with graphs: both ring slots captured, then replayed
         L, R = [x.numpy() for x in w.render(t)]
         frames = [(L, R), (R[:, ::-1].copy(), L[:, ::-1].copy())]
         ctx.process_host(frames)
@@ -864,9 +871,9 @@ def test_five_thousand_keypoints_in_one_octave():
     ctx.close()
     # the same request against a 4096-entry context is refused outright (capacity), not cut silently
     small = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=4096, max_cand=1 << 18)
-    small.set_params(p); small.set_camera(cam)
-    with pytest.raises(hip.SvoError, match="capacity"):
-        small.process_host([(L, R)])
+    small.set_camera(cam)
+    with pytest.raises(hip.SvoError, match="capacity.*max_kps is 4096"):
+        small.set_params(p)              # svo_set_params itself says so (SVO_ERR_CAPACITY + the numbers), before any frame
     small.close()
 
 
@@ -1026,3 +1033,60 @@ def test_random_call_sequences_match_oracle(seed):
         assert r.tracked_feats_from_last_KF == ro.tracked_feats_from_last_KF, (seed, log)
         assert (ctx.fast_threshold(), ctx.orb_threshold()) == (orc.fast_threshold(), orc.orb_threshold()), (seed, log)
     ctx.close()
+
+
+def test_foreign_stream_may_be_destroyed_after_the_caller_switched_away(golden_dir):
+    """svo_set_stream takes raw hipStream_t handles.  A C caller may enqueue frames on its own stream, synchronise it, DESTROY
+    it and switch back to the context's stream: later waits / getters / svo_destroy must not touch the dead handle (they wait
+    on context-owned events recorded behind the work instead)."""
+    rt = C.CDLL("libamdhip64.so")
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(4):
+        st = C.c_void_p()
+        assert rt.hipStreamCreateWithFlags(C.byref(st), C.c_uint(1)) == 0             # hipStreamNonBlocking
+        ctx.set_stream(st.value)
+        ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+        assert rt.hipStreamSynchronize(st) == 0
+        ctx.set_stream(None)
+        assert rt.hipStreamDestroy(st) == 0
+        r = ctx.result(0)                                                             # svo_wait inside: must not synchronise `st`
+        ro = orc.process(g["L%d" % t], g["R%d" % t], cam)
+        assert_same_frame(ctx, 0, orc, r, ro, "destroyed stream t=%d" % t)
+    ctx.close()
+
+
+def test_hand_over_record_of_another_layout_is_refused(golden_dir):
+    """svo_import_frame checks the record's header (magic, version, max_kps, max_h, octaves, lanes): a record exported by a
+    differently configured context has other offsets; it is not unpacked, the lane's status word says so, and the importer's
+    own state stays usable."""
+    import torch
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    a = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    b = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=2048, max_cand=1 << 15)
+    for c in (a, b):
+        c.set_params(p); c.set_camera(cam)
+        c.process_host([(g["L0"], g["R0"])]); c.process_host([(g["L1"], g["R1"])])
+    nb = max(a.handover_bytes(), b.handover_bytes())
+    blob = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    a.export_frame(blob.data_ptr(), nb); a.wait()
+    before = b.keypoints(0, 1, 0)[0].tobytes()                                        # b's previous frame
+    b.import_frame(blob.data_ptr(), nb); b.wait()
+    assert b.status_word(0) & 4 and b.result(0).status & 4
+    assert b.keypoints(0, 1, 0)[0].tobytes() == before
+    # a matching record is taken, and garbage is refused as well
+    a.import_frame(blob.data_ptr(), nb); a.wait()
+    assert a.status_word(0) & 4 == 0
+    blob.fill_(0x5A)
+    a.import_frame(blob.data_ptr(), nb); a.wait()
+    assert a.status_word(0) & 4
+    # b carries on as if nothing had happened (the flag is per frame: cleared by the next detect)
+    orc = O().Oracle(p)
+    for t in (0, 1, 2):
+        ro = orc.process(g["L%d" % t], g["R%d" % t], cam)
+    b.process_host([(g["L2"], g["R2"])])
+    assert_same_frame(b, 0, orc, b.result(0), ro, "after a refused import")
+    a.close(); b.close()

@@ -31,7 +31,11 @@ def _worker(rank, world, port, lanes, q):
         rec[i] = torch.frombuffer(bytearray(bytes(r)), dtype=torch.uint8)
     allrec = bench.gather_records(rec, world)
     tmax = bench.reduce_max(0.5 + rank, torch.device("cpu"), world)
-    q.put((rank, seeds, allrec.numpy().tobytes(), tmax))
+    try:
+        audit = bench.dist_audit(allrec, rec, world, rank, rank, torch.device("cpu"))        # pretend rank r sits on device r
+    except Exception as e:                                                                 # (device name lookup needs a GPU)
+        audit = {"error": repr(e)}
+    q.put((rank, seeds, allrec.numpy().tobytes(), tmax, audit))
     dist.destroy_process_group()
 
 
@@ -53,6 +57,11 @@ def test_two_rank_sharding_and_gather():
     assert [r.outPose[0] for r in recs] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]  # ordered by stream id = rank-major
     assert [r.tracked_feats_from_last_frame for r in recs] == [100, 101, 102, 103, 104, 105]
     assert outs[0][3] == outs[1][3] == 1.5                               # MAX over ranks of the step time
+    # the audit block bench.py prints for N > 1: both ranks agree, two distinct (host, device) pairs, tables equal, own slot right
+    a0, a1 = outs[0][4], outs[1][4]
+    assert "error" not in a0, a0
+    assert a0 == a1 and a0["backend"] == "gloo" and a0["world_size"] == 2 and a0["ranks_seen"] == 2
+    assert a0["gathered_tables_equal"] and a0["own_records_at_own_slot"] and len(a0["hosts"]) == 1
 
 
 def test_frame_schedule_is_ping_pong():

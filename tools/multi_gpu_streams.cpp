@@ -131,6 +131,7 @@ int main(int argc, char** argv)
         const int rc = svo_group_create_local(devs.data(), sh.G, &sh.group);
         if (rc != SVO_OK) { std::fprintf(stderr, "svo_group_create_local: %s\n", sh.group ? svo_group_last_error(sh.group) : "bad arguments"); return 3; }
     }
+    const int comm_count = sh.group ? svo_group_comm_count(sh.group, 0) : 0;          // what RCCL itself says it connected
     sh.host_exchange.resize((size_t)sh.G); sh.rc.assign((size_t)sh.G, -1); sh.err.resize((size_t)sh.G); sh.seen.resize((size_t)sh.G);
     pthread_barrier_init(&sh.barrier, nullptr, (unsigned)sh.G);
     const auto t0 = std::chrono::steady_clock::now();
@@ -159,7 +160,7 @@ int main(int argc, char** argv)
         }
         std::fclose(out);
     }
-    std::printf("{\"ranks\": %d, \"gather\": \"%s\", \"frames\": %d, \"seconds\": %.4f, \"pairs_per_s\": %.2f}\n", sh.G, sh.use_rccl ? "rccl" : "host", sh.frames, secs,
-                (double)sh.frames * sh.G / secs);
+    std::printf("{\"ranks\": %d, \"gather\": \"%s\", \"rccl_comm_count\": %d, \"tables_equal\": true, \"frames\": %d, \"seconds\": %.4f, \"pairs_per_s\": %.2f}\n", sh.G,
+                sh.use_rccl ? "rccl" : "host", comm_count, sh.frames, secs, (double)sh.frames * sh.G / secs);
     return 0;
 }
