@@ -11,6 +11,7 @@
 #include "svo_device.h"
 #include "svo_kernels.h"
 #include <float.h>
+#include <stdlib.h>
 
 struct Rot { double r[9]; double dr[3][9]; int small_angle; };
 
@@ -149,8 +150,8 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 }
 
 #define GN_NSUM 28
-#define GN_NT 512            // threads of the lane's workgroup: one pass over up to 512 tracks per iteration
-#define GN_RED_BYTES ((size_t)GN_NSUM * GN_NT * sizeof(double))
+#define GN_NT_MAX 512        // the kernel is built for 256 and for 512 threads per lane (template parameter NT): SVO_GN_NT picks, see launch_gauss_newton
+#define GN_RED_BYTES ((size_t)GN_NSUM * GN_NT_MAX * sizeof(double))
 struct GnShared {
     double part[4][GN_NSUM];
     double tot[GN_NSUM];
@@ -162,26 +163,30 @@ struct GnShared {
     int n_non_masked;
 };
 
-// Cholesky solve of the 6x6 normal equations with every index static (registers, no scratch).  Returns false when a
-// pivot is not safely positive; the caller then takes the general path (solve_sym6).
+// Solve of the 6x6 normal equations by the square-root-free Cholesky form H = L D L^T (unit lower L), every index static
+// (registers, no scratch).  This runs on ONE thread between two barriers of every iteration, so what counts is the length of
+// its dependent chain: one division per column, where L L^T needs a square root and a division (~30 dependent instructions more
+// per column).  Same pivots as the L L^T form (d_j = l_jj^2), same positivity test; the solution agrees to rounding, which is
+// what stage 5's tolerance is stated in.  Returns false when a pivot is not safely positive; the caller then takes the general
+// path (solve_sym6).
 __device__ __forceinline__ bool chol6(const double* H, const double* g, double dmax, double* x)
 {
-    double L[6][6], inv[6];
+    double L[6][6], d[6], inv[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
+        double w[6];                                                        // w[k] = L[j][k] * d[k]
         double s = H[j * 6 + j];
 #pragma unroll
-        for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+        for (int k = 0; k < j; k++) { w[k] = L[j][k] * d[k]; s -= L[j][k] * w[k]; }
         ok = ok && (s > 1e-13 * dmax);
-        const double ljj = sqrt(s);
-        L[j][j] = ljj;
-        inv[j] = 1.0 / ljj;
+        d[j] = s;
+        inv[j] = 1.0 / s;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double t = H[i * 6 + j];
 #pragma unroll
-            for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+            for (int k = 0; k < j; k++) t -= L[i][k] * w[k];
             L[i][j] = t * inv[j];
         }
     }
@@ -190,17 +195,18 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
     for (int i = 0; i < 6; i++) { double t = g[i];
 #pragma unroll
         for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
-        y[i] = t * inv[i]; }
+        y[i] = t; }
 #pragma unroll
-    for (int i = 5; i >= 0; i--) { double t = y[i];
+    for (int i = 5; i >= 0; i--) { double t = y[i] * inv[i];
 #pragma unroll
         for (int k = i + 1; k < 6; k++) t -= L[k][i] * x[k];
-        x[i] = t * inv[i]; }
+        x[i] = t; }
     return ok;
 }
 
 // one m_evalRGN (S5:275-390) with the rotation taken from sh.R / sh.delta (prepared by thread 0).  On return every
 // thread sees sh.ok, sh.cost, sh.step, and sh.delta / sh.R already advanced by the step (S5:576-577).
+template <int GN_NT>
 __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
                          const double* lmk, const float* obs, double* residual, GnShared& sh, double* red)
 {
@@ -268,13 +274,15 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
 #pragma unroll
     for (int i = 0; i < GN_NSUM; i++) red[i * GN_NT + tid] = acc[i];
     __syncthreads();
-    if (tid < GN_NSUM * 16) {
-        const int sidx = tid >> 4, part = tid & 15;
+    constexpr int PER = GN_NT / 32;                                            // threads per sum: 8 (256 threads) or 16 (512)
+    if (tid < GN_NSUM * PER) {
+        const int sidx = tid / PER, part = tid % PER;
         const double* rp = red + sidx * GN_NT + part;
         double sum = 0;
 #pragma unroll
-        for (int k = 0; k < GN_NT / 16; k++) sum += rp[16 * k];
-        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
+        for (int k = 0; k < 32; k++) sum += rp[PER * k];
+#pragma unroll
+        for (int o = 1; o < PER; o <<= 1) sum += __shfl_xor(sum, o, 64);
         if (part == 0) sh.tot[sidx] = sum;
     }
     __syncthreads();
@@ -307,6 +315,7 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
     __syncthreads();
 }
 
+template <int GN_NT>
 __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, uint8_t* big)
 {
     // dynamic LDS: { keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] } U red[28][GN_NT] f64 | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
@@ -364,7 +373,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     }
     __threadfence_block();
     // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283); cap = T ----
-    if (T <= 2 * GN_NT && !big) {
+    if (T <= 1024 && !big) {
         // a few hundred keys: every key counts the keys above it (the keys are unique, so the counts are the descending ranks).
         // All lanes read the same LDS word at a time (a broadcast): T reads per key and two barriers, where the bitonic network
         // needs 45 compare-exchange stages at 512 keys (~10 us of the ~25 us this kernel spends before its first iteration).
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     while (num_it < P.initial_max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it >= 1)) {
         pCost = cCost;
         if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }                // S5:296
-        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
+        eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
         err_code = SVO_VOEC_NONE;                                                                                    // S5:299
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:380-386, 569-573
@@ -476,7 +485,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     while (num_it_final < P.max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it_final >= 1)) {
         pCost = cCost;
         if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }
-        eval_rgn(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
+        eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
         cCost = sh.cost;
         if (!sh.ok) {                                                                                                // S5:670-675 (result.error_code untouched)
             if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }
@@ -512,12 +521,17 @@ static size_t gn_smem(int pmax)
 
 hipError_t configure_gauss_newton(int pmax)
 {
-    return hipFuncSetAttribute((const void*)k_gauss_newton, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+    hipError_t e = hipFuncSetAttribute((const void*)k_gauss_newton<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_gauss_newton<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
 }
 
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_gauss_newton, dim3(c.n_lanes), dim3(GN_NT), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
+    static int nt = 0;
+    if (!nt) { const char* e = getenv("SVO_GN_NT"); nt = (e && atoi(e) == 512) ? 512 : 256; }
+    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
+    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1171,6 +1171,23 @@ hipError_t configure_match(int max_kps)
     return e;
 }
 
+// The brute-force results are atomicMin keys and start from all ones.  A kernel, not hipMemsetAsync: captured into a hipGraph
+// (svo_use_graphs) a byte memset of more than 64 KB came back incomplete on replay -- two lanes x two octaves x 2048 keypoints
+// was the first configuration to cross that size, its pairings went wrong and the stale indices walked k_track_filter out of
+// its tables (tests/test_gpu_parity.py::test_adaptive_nms_after_fast_orb_matches_oracle[True]).
+__global__ void __launch_bounds__(256) k_fill_ones(uint4* p, size_t n16, int* tail, int n_tail)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (i < (size_t)n_tail) tail[i] = -1;
+}
+void launch_fill_ones(int* p, size_t n_words, hipStream_t st)
+{
+    const size_t n16 = n_words / 4;
+    const size_t n = n16 > 4 ? n16 : 4;
+    hipLaunchKernelGGL(k_fill_ones, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint4*)p, n16, p + 4 * n16, (int)(n_words - 4 * n16));
+}
+
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);

@@ -870,7 +870,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     }
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {
-        HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
+        launch_fill_ones(d.bf_idx, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps, st);      // a kernel, not hipMemsetAsync: see launch_fill_ones
         if (p.match_method == SVO_SM_DESC_BF) {
             { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
             { Span s(ctx, KT_LR_FILTER); launch_match_lr_filter(d, p.enable_robust_1to1_match, p.max_y_diff, st); }
@@ -883,7 +883,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if (flags & SVO_RUN_TRACK) {
         const int win = p.ifm_method == SVO_IFM_DESC_WIN;
         if (!win) {
-            if (!(flags & SVO_RUN_MATCH) || p.match_method != SVO_SM_DESC_BF) HIPCHECK(hipMemsetAsync(d.bf_idx, 0xFF, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps * sizeof(int), st));
+            if (!(flags & SVO_RUN_MATCH) || p.match_method != SVO_SM_DESC_BF) launch_fill_ones(d.bf_idx, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps, st);
             { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
             { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
         } else {                                                // ifmDescWin (stage4_match_consecutive.cpp:435-738)

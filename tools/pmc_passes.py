@@ -25,7 +25,7 @@ extra = sys.argv[2:]
 STEPS, WARM, SKIP = 5, 3, 3          # 8 steps in all, the first 3 dropped
 LANES = 64
 cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARM), "--cpu-frames", "0", "--host-fed-steps", "0",
-       "--single-stream", "0", "--exclusive", "0", "--contexts", "1", "--lanes", str(LANES)] + extra
+       "--single-stream", "0", "--exclusive", "0", "--relief-lanes", "0", "--contexts", "1", "--lanes", str(LANES)] + extra
 env = dict(os.environ, TMPDIR="/tmp")
 PASSES = {
     "rd": ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
@@ -36,10 +36,17 @@ PASSES = {
 
 
 def run_pass(name, counters):
+    try:
+        return _run_pass(name, counters)
+    except subprocess.TimeoutExpired:
+        return {}, {}
+
+
+def _run_pass(name, counters):
     out = "/tmp/pmc_%s_%s" % (tag, name)
     subprocess.run(["rm", "-rf", out])
     subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--"] + cmd,
-                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=400)
     files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
     if not files:
         return {}, {}
