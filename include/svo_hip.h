@@ -94,6 +94,11 @@ const char* svo_last_error(const svo_ctx* ctx);   /* text of the last HIP failur
  * and the parameters in force stay as they were. */
 int svo_set_params(svo_ctx* ctx, const svo_params* p);
 int svo_get_params(const svo_ctx* ctx, svo_params* p);
+/* The file half of loadParamsFromConfigFile / loadParamsFromConfigFileName (H:551-672): reads the reference's INI keys from the
+ * seven sections {RECTIFY, DETECT, MATCH, IF-MATCH, LEAST_SQUARES, GUI, GENERAL} (an empty or NULL name skips the group) into
+ * *p, keeping the current value of every key that is absent (`if_match_method` falls back to 0 as at H:611).  Host only: needs
+ * no context and no GPU; follow it with svo_set_params.  SVO_ERR_ARG when the file cannot be opened (H:669 asserts it exists). */
+int svo_params_load_ini(const char* path, const char* const sections[7], svo_params* p);
 int svo_set_fast_threshold(svo_ctx* ctx, int v);  /* setFASTThreshold, clamped (H:531) */
 int svo_set_orb_threshold(svo_ctx* ctx, int v);   /* setORBThreshold, clamped (H:538) */
 int svo_get_fast_threshold(const svo_ctx* ctx);

@@ -107,6 +107,15 @@ public:
 
     /** loadParamsFromConfigFile's effect (H:554-663): push `params`, then reset both dynamic thresholds */
     void applyParams() { check(svo_set_params(m_ctx, &params), "svo_set_params"); }
+    /** Loads configuration from an INI file from its name (H:665-672); sections in the order RECTIFY, DETECT, MATCH, IF-MATCH,
+      * LEAST_SQUARES, GUI, GENERAL (H:551-553), an empty name skips the group */
+    void loadParamsFromConfigFileName(const std::string& fileName, const std::vector<std::string>& sections) {
+        if (sections.size() != 7) throw std::runtime_error("loadParamsFromConfigFile: seven section names expected");    // H:556
+        const char* names[7];
+        for (int i = 0; i < 7; i++) names[i] = sections[i].c_str();
+        check(svo_params_load_ini(fileName.c_str(), names, &params), "svo_params_load_ini");
+        applyParams();                                                                   // resetFASTThreshold / resetORBThreshold, H:662-663
+    }
     void setVerbosityLevel(int level) { m_verbose_level = level; }                       // H:527
     int getFASTThreshold() { return svo_get_fast_threshold(m_ctx); }                     // H:530
     void setFASTThreshold(int v) { check(svo_set_fast_threshold(m_ctx, v), "svo_set_fast_threshold"); }   // H:531

@@ -20,7 +20,7 @@ FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES, FLAG_DETECT_NO_
 # every entry point include/svo_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "svo_config_defaults", "svo_params_defaults", "svo_create", "svo_destroy", "svo_strerror", "svo_last_error",
-    "svo_set_params", "svo_get_params", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
+    "svo_set_params", "svo_get_params", "svo_params_load_ini", "svo_set_fast_threshold", "svo_set_orb_threshold", "svo_get_fast_threshold",
     "svo_get_orb_threshold", "svo_set_stream", "svo_get_stream", "svo_get_device", "svo_set_camera", "svo_set_rectify_map", "svo_reset", "svo_process", "svo_wait", "svo_get_result", "svo_get_results", "svo_copy_results_async",
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
@@ -99,6 +99,20 @@ def lib():
 def default_params() -> Params:
     p = Params()
     lib().svo_params_defaults(C.byref(p))
+    return p
+
+
+def load_params_ini(path, sections, p: Params = None) -> Params:
+    """loadParamsFromConfigFileName (H:665-672): the reference's INI keys from the seven sections
+    [rectify, detect, match, if-match, least_squares, gui, general] ('' skips a group) over `p` (defaults when None)."""
+    if len(sections) != 7:
+        raise ValueError("seven section names expected (H:556)")
+    if p is None:
+        p = default_params()
+    arr = (C.c_char_p * 7)(*[s.encode() if s else None for s in sections])
+    rc = lib().svo_params_load_ini(str(path).encode(), arr, C.byref(p))
+    if rc != 0:
+        raise SvoError("svo_params_load_ini(%s): %s" % (path, lib().svo_strerror(rc).decode()))
     return p
 
 
