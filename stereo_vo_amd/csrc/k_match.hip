@@ -597,6 +597,39 @@ __device__ __forceinline__ void rank2_enforce(double* f)
     }
 }
 
+// the tail of eight_point (oracle): rank-2 enforcement, F = T2^T f T1, and the guards of the matrix-core line evaluation
+__device__ __forceinline__ void store_hypothesis(const DevCtx& c, int vl, int side, int h, double* fv, double s1, double s2, double c1x, double c1y, double c2x, double c2y)
+{
+    rank2_enforce(fv);
+    const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
+    double M[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        M[r][0] = fv[3 * r] * s1; M[r][1] = fv[3 * r + 1] * s1;
+        M[r][2] = (fv[3 * r] * t1x + fv[3 * r + 1] * t1y) + fv[3 * r + 2];
+    }
+    double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
+    double Fv[9];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+        Fv[cc] = s2 * M[0][cc]; Fv[3 + cc] = s2 * M[1][cc];
+        Fv[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) F[j] = Fv[j];
+    // guards of the matrix-core line evaluation in k_ransac_count (see there): E bounds how far its numerators can be from
+    // the oracle's operation order, given coordinates inside the image; a side is trusted when |l| >= 2^28 E
+    double aF[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) aF[j] = fabs(Fv[j]);
+    const double X = (double)c.W, Y = (double)c.H, u = 1.7763568394002505e-15;          // 2^-49
+    const double EB = u * (X * (aF[0] * X + aF[1] * Y + aF[2]) + Y * (aF[3] * X + aF[4] * Y + aF[5]) + (aF[6] * X + aF[7] * Y + aF[8]));
+    const double EA = u * (X * (aF[0] * X + aF[3] * Y + aF[6]) + Y * (aF[1] * X + aF[4] * Y + aF[7]) + (aF[2] * X + aF[5] * Y + aF[8]));
+    double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 2;
+    const double gA = 268435456.0 * EA, gB = 268435456.0 * EB;
+    Gd[0] = gA * gA; Gd[1] = gB * gB;            // an overflow or a NaN here makes every comparison against it false: the side is never trusted
+}
+
 // Evaluating hypotheses OUT OF ORDER still bounds what the sequential scan visits.  The scan visits [0, E), E = the first k
 // that is no longer below the budget (a record at k may cut the budget below k itself: k is still visited, so E can exceed the
 // final budget).  A visited hypothesis h with count c > 7 leaves a budget <= K(c) whether it is a record or not (a record
@@ -743,36 +776,118 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
     double fv[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) fv[j] = group_bcast(fmine, j);
-    if (gl == 0 && h < gen) {
-        rank2_enforce(fv);
-        const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
-        double M[3][3];
+    if (gl == 0 && h < gen) store_hypothesis(c, vl, side, h, fv, s1, s2, c1x, c1y, c2x, c2y);
+}
+
+// step K of the oracle's Gauss-Jordan elimination with full pivoting (eight_point) on a thread's own registers
+template <int K>
+__device__ __forceinline__ void gj_step(double (&A)[8][9], int (&perm)[9])
+{
+    // pivot = first maximum of |A[i][j]|, i >= K, j >= K, in (i, j) scan order
+    // (the maximum first -- fmax skips NaNs as the oracle's `v > best` does --, then the first entry that equals it: the scan runs
+    // backwards so that the last assignment is the first position; three instructions per entry instead of four)
+    double best = -1.0; int pij = K * 16 + K;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            M[r][0] = fv[3 * r] * s1; M[r][1] = fv[3 * r + 1] * s1;
-            M[r][2] = (fv[3 * r] * t1x + fv[3 * r + 1] * t1y) + fv[3 * r + 2];
-        }
-        double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
-        double Fv[9];
+    for (int i = K; i < 8; i++) {
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-            Fv[cc] = s2 * M[0][cc]; Fv[3 + cc] = s2 * M[1][cc];
-            Fv[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
-        }
-#pragma unroll
-        for (int j = 0; j < 9; j++) F[j] = Fv[j];
-        // guards of the matrix-core line evaluation in k_ransac_count (see there): E bounds how far its numerators can be from
-        // the oracle's operation order, given coordinates inside the image; a side is trusted when |l| >= 2^28 E
-        double aF[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) aF[j] = fabs(Fv[j]);
-        const double X = (double)c.W, Y = (double)c.H, u = 1.7763568394002505e-15;          // 2^-49
-        const double EB = u * (X * (aF[0] * X + aF[1] * Y + aF[2]) + Y * (aF[3] * X + aF[4] * Y + aF[5]) + (aF[6] * X + aF[7] * Y + aF[8]));
-        const double EA = u * (X * (aF[0] * X + aF[3] * Y + aF[6]) + Y * (aF[1] * X + aF[4] * Y + aF[7]) + (aF[2] * X + aF[5] * Y + aF[8]));
-        double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 2;
-        const double gA = 268435456.0 * EA, gB = 268435456.0 * EB;
-        Gd[0] = gA * gA; Gd[1] = gB * gB;            // an overflow or a NaN here makes every comparison against it false: the side is never trusted
+        for (int j = K; j < 9; j++) best = fmax(best, fabs(A[i][j]));
     }
+#pragma unroll
+    for (int i = 7; i >= K; i--) {
+#pragma unroll
+        for (int j = 8; j >= K; j--) if (fabs(A[i][j]) == best) pij = i * 16 + j;
+    }
+    const int pi = pij >> 4, pj = pij & 15;
+#pragma unroll
+    for (int i = K + 1; i < 8; i++) if (pi == i) {
+#pragma unroll
+        for (int j = K; j < 9; j++) { const double t = A[K][j]; A[K][j] = A[i][j]; A[i][j] = t; }
+    }
+#pragma unroll
+    for (int j = K + 1; j < 9; j++) if (pj == j) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const double t = A[i][K]; A[i][K] = A[i][j]; A[i][j] = t; }
+        const int t = perm[K]; perm[K] = perm[j]; perm[j] = t;
+    }
+    const double piv = A[K][K];
+#pragma unroll
+    for (int j = K + 1; j < 9; j++) A[K][j] = A[K][j] / piv;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i == K) continue;
+        const double f = A[i][K];
+#pragma unroll
+        for (int j = K + 1; j < 9; j++) A[i][j] = A[i][j] - f * A[K][j];
+    }
+}
+
+// The same hypotheses with ONE THREAD each, for launches that fill the GPU anyway (many lanes): the 16-lane form above spends
+// 1500 wave-instructions on four hypotheses (nine of sixteen lanes hold a column, every step pays its DPP all-reduce and
+// sixteen cross-lane broadcasts) -- it is built for the latency of one stream.  Here the 8x9 system sits in the thread's own
+// registers (every loop unrolled, no dynamic index), the oracle's Gauss-Jordan runs on it literally -- physical row and column
+// swaps under the pivot's predicate (exec-masked register swaps), the elimination restricted to the columns that are still
+// read (column k of the other rows becomes an exact 0 that nothing looks at again; columns left of k are dead) -- and a wave
+// turns out 64 hypotheses in ~3500 instructions: about a sixth of the instructions per hypothesis.
+__global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
+{
+    const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int n = c.trk_nk[vl];
+    if (n < 8) return;
+    const int gen = chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk);
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
+    if (h >= gen) return;
+    const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
+    int s[8];
+    {
+        unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
+        if (!st) st = 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int v; bool dup;
+            do {
+                v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < j && s[k] == v) dup = true;
+            } while (dup);
+            s[j] = v;
+        }
+    }
+    float4 P[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) P[i] = pts[s[i]];
+    double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
+    c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
+    double d1 = 0, d2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double ax = (double)P[i].x - c1x, ay = (double)P[i].y - c1y, bx = (double)P[i].z - c2x, by = (double)P[i].w - c2y;
+        d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
+    }
+    const double s1 = 11.313708498984761 / d1, s2 = 11.313708498984761 / d2;
+    double A[8][9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double x1 = ((double)P[i].x - c1x) * s1, y1 = ((double)P[i].y - c1y) * s1, x2 = ((double)P[i].z - c2x) * s2, y2 = ((double)P[i].w - c2y) * s2;
+        A[i][0] = x2 * x1; A[i][1] = x2 * y1; A[i][2] = x2; A[i][3] = y2 * x1; A[i][4] = y2 * y1; A[i][5] = y2; A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
+    }
+    int perm[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) perm[j] = j;
+    gj_step<0>(A, perm); gj_step<1>(A, perm); gj_step<2>(A, perm); gj_step<3>(A, perm);
+    gj_step<4>(A, perm); gj_step<5>(A, perm); gj_step<6>(A, perm); gj_step<7>(A, perm);
+    // f[perm[8]] = 1, f[perm[i]] = -A[i][8]
+    double fv[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        double v = 1.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (perm[i] == j) v = -A[i][8];
+        fv[j] = v;
+    }
+    store_hypothesis(c, vl, side, h, fv, s1, s2, c1x, c1y, c2x, c2y);
 }
 
 // Symmetric epipolar test e = max(dA^2 / |lA|^2, dB^2 / |lB|^2) <= 1 with the oracle's arithmetic, minus its two f64
@@ -1222,7 +1337,11 @@ void launch_track_filter(const DevCtx& c, hipStream_t st)
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
     const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
-    hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    // one stream (few lanes): 16 lanes per hypothesis, for latency; many lanes: one thread per hypothesis, for instruction count
+    // (debug_mode 17 forces the 16-lane form, 18 the one-thread form: tests/test_gpu_parity.py runs both against the oracle)
+    const bool per_thread = c.debug_mode == 18 || (c.debug_mode != 17 && c.n_lanes * c.n_oct > 8);
+    if (per_thread) hipLaunchKernelGGL(k_ransac_hyp_thread, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
+    else hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {

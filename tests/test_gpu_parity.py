@@ -101,6 +101,34 @@ def test_pyramid_and_detector_stage_outputs(golden_dir, monkeypatch):
     ctx.close(); ctx2.close()
 
 
+@pytest.mark.parametrize("mode", ["17", "18"])
+def test_both_hypothesis_kernels_give_the_oracle_models(golden_dir, monkeypatch, mode):
+    """k_ransac_hyp (16 lanes per hypothesis, the one-stream form: debug mode 17) and k_ransac_hyp_thread (one thread per
+    hypothesis, the many-lane form: 18) both repeat the oracle's eight_point operation for operation: same fundamental
+    matrices, hence same inlier counts, masks, tracked pairs and stage-4 counters, whichever form the lane count selects."""
+    monkeypatch.setenv("SVO_DEBUG_MODE", mode)
+    g, cam, p = load_small(golden_dir)
+    ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(4):
+        ctx.process_host([(g["L%d" % t], g["R%d" % t])])
+        assert_same_frame(ctx, 0, orc, ctx.result(0), orc.process(g["L%d" % t], g["R%d" % t], cam), "mode %s t=%d" % (mode, t))
+    ctx.close()
+    w, h = 1280, 960
+    world = SyntheticStereoWorld(w, h, 800.0, 0.12, seed=321, n_frames=3)
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=2000)
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=4096)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(3):
+        L, R = (x.numpy() for x in world.render(t))
+        ctx.process_host([(L, R)])
+        assert_same_frame(ctx, 0, orc, ctx.result(0), orc.process(L, R, cam), "mode %s full size t=%d" % (mode, t))
+    ctx.close()
+
+
 @pytest.mark.parametrize("w,h,f,cx,cy,B,nfe", [(1280, 960, 800.0, None, None, 0.12, 2000), (1241, 376, 718.856, 607.19, 185.22, 0.537, 900)])
 def test_full_size_streams_match_oracle(w, h, f, cx, cy, B, nfe):
     """BASELINE.json configs[1] (1280x960, ~2000 kps) and configs[2] (KITTI-00 shape), 2 lanes x 3 frames."""
