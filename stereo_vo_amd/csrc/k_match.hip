@@ -622,7 +622,7 @@ __device__ __forceinline__ void store_hypothesis(const DevCtx& c, int vl, int si
     double aF[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) aF[j] = fabs(Fv[j]);
-    const double X = (double)c.W, Y = (double)c.H, u = 1.7763568394002505e-15;          // 2^-49
+    const double X = (double)c.W, Y = (double)c.H, u = 3.552713678800501e-15;           // 2^-48
     const double EB = u * (X * (aF[0] * X + aF[1] * Y + aF[2]) + Y * (aF[3] * X + aF[4] * Y + aF[5]) + (aF[6] * X + aF[7] * Y + aF[8]));
     const double EA = u * (X * (aF[0] * X + aF[3] * Y + aF[6]) + Y * (aF[1] * X + aF[4] * Y + aF[7]) + (aF[2] * X + aF[5] * Y + aF[8]));
     double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 2;
@@ -1006,6 +1006,141 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
     }
 }
 
+// The count for launches that fill the GPU (many lanes): SIXTEEN hypotheses x sixteen pairs per matrix-core tile, and the
+// numerator on the matrix cores as well.  d = x2^T F x1 is one bilinear form -- the oracle's dA and dB are two roundings of it --
+// so with phi = (x1 x2, y1 x2, x2, x1 y2 | y1 y2, y2, x1, y1 | 1) it is a [16 hypotheses x 9] x [9 x 16 pairs] product (three
+// chained v_mfma_f64_16x16x4_f64), and the four line components a, b of l = F x1 and l' = F^T x2 are four more [16 x 3] x
+// [3 x 16] products.  What is left on the VALU per test is the two norms, d^2, the band products and the comparisons: ~19
+// instructions against ~45 of k_ransac_count_mfma (whose tiles are 4 hypotheses x 4 line components, numerators on the VALU),
+// and the B operands (built once per block and 256 pairs in LDS, in operand layout) serve 64 hypotheses.  The step is bound by
+// VALU issue, the matrix pipe is otherwise idle: the instructions move to where there is room.
+// Exactness as in k_ransac_count_mfma: E (store_hypothesis) bounds |d - dA|, |d - dB| for coordinates inside the image whatever
+// the summation order (<= 18 roundings of the nine terms against the oracle's six: u = 2^-48 there), a side is trusted only
+// when |l| >= 2^28 E, a verdict is given only when d^2 and |l|^2 differ by more than 2^-26 relatively, and everything else
+// -- a failed guard, a NaN, a borderline pair -- replays the oracle's own expression (fm_inlier).
+// Result layout of the tile (pinned on the hardware, see above): lane l = j + 16 q, register r  <->  hypothesis 4 r + q, pair j.
+#define RC16_SUPER 256
+__global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk)
+{
+    __shared__ double ops[(RC16_SUPER / 16) * 256];            // per tile of 16 pairs: B1 | B2 | phi[0..3] | phi[4..7], each [k][j]
+    __shared__ int cnt_s[64];
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64, tid = threadIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int n = c.trk_nk[vl];
+    if (n < 8) return;
+    int* bound = c.rs_bound + vl * 2 + side;
+    if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
+    const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
+    const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15;
+    const int hw = h0 + 16 * w;                                 // this wave's sixteen hypotheses
+    bool dead = hw >= RS_CHUNK_END(chunk) || (chunk && hw >= *(volatile int*)bound);
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + min(hw, SVO_RANSAC_PAD - 16)) * 9;
+    const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + min(hw, SVO_RANSAC_PAD - 16)) * 2;
+    // operand A of the seven products: lane l holds row i = l % 16 (a hypothesis), column k = l / 16
+    const double* Fa = F + 9 * j;
+    const bool k3 = q < 3;
+    const double a1 = k3 ? Fa[q] : 0.0, a2 = k3 ? Fa[3 + q] : 0.0;                 // (F0 F1 F2), (F3 F4 F5): a, b of l  = F (x1 y1 1)
+    const double a3 = k3 ? Fa[3 * q] : 0.0, a4 = k3 ? Fa[3 * q + 1] : 0.0;         // (F0 F3 F6), (F1 F4 F7): a, b of l' = F^T (x2 y2 1)
+    const double a5 = Fa[q], a6 = Fa[4 + q], a7 = q == 0 ? Fa[8] : 0.0;            // F0..F3 | F4..F7 | F8: the bilinear form
+    const double b7 = q == 0 ? 1.0 : 0.0;
+    // the four hypotheses this lane gets verdicts for: 4 r + q
+    double dminA[4], dminB[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { dminA[r] = Gd[2 * (4 * r + q)]; dminB[r] = Gd[2 * (4 * r + q) + 1]; }
+    const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
+    const int floor_cnt = chunk ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
+    int cnt[4] = { 0, 0, 0, 0 };
+    for (int sb = 0; sb < n; sb += RC16_SUPER) {
+        __syncthreads();                                                         // the previous 256 pairs have been consumed
+        {
+            const float4 p = pts[min(sb + tid, n - 1)];
+            const double x1 = (double)p.x, y1 = (double)p.y, x2 = (double)p.z, y2 = (double)p.w;
+            double* o = ops + (tid >> 4) * 256 + (tid & 15);
+            o[0] = x1; o[16] = y1; o[32] = 1.0; o[48] = 0.0;
+            o[64] = x2; o[80] = y2; o[96] = 1.0; o[112] = 0.0;
+            o[128] = x1 * x2; o[144] = y1 * x2; o[160] = x2; o[176] = x1 * y2;     // products of two floats: exact in double
+            o[192] = y1 * y2; o[208] = y2; o[224] = x1; o[240] = y1;
+        }
+        __syncthreads();
+        if (dead) continue;
+        const int ntile = min(RC16_SUPER / 16, (n - sb + 15) >> 4);
+        for (int t = 0; t < ntile; t++) {
+            const int base = sb + 16 * t;
+            if (chunk && base && (t & 7) == 0) {
+                // records only (see k_ransac_count_mfma): a wave stops once none of its sixteen hypotheses can exceed the floor
+                bool hopeless = true;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int gsum = cnt[r];
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0xB1, 0xF, 0xF, false);
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x4E, 0xF, 0xF, false);
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x141, 0xF, 0xF, false);
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x140, 0xF, 0xF, false);
+                    hopeless = hopeless && (gsum + (n - base) <= floor_cnt);
+                }
+                if (__ballot(hopeless) == ~0ull && c.debug_mode != 16) { dead = true; break; }
+            }
+            const double* ot = ops + t * 256 + l;
+            const double b1 = ot[0], b2 = ot[64], b5 = ot[128], b6 = ot[192];
+            const rc_d4 z = { 0.0, 0.0, 0.0, 0.0 };
+            const rc_d4 aB = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, z, 0, 0, 0);
+            const rc_d4 bB = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, z, 0, 0, 0);
+            const rc_d4 aA = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b2, z, 0, 0, 0);
+            const rc_d4 bA = __builtin_amdgcn_mfma_f64_16x16x4f64(a4, b2, z, 0, 0, 0);
+            rc_d4 D = __builtin_amdgcn_mfma_f64_16x16x4f64(a5, b5, z, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(a6, b6, D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(a7, b7, D, 0, 0, 0);
+            const bool valid = base + j < n;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double denB = aB[r] * aB[r] + bB[r] * bB[r], denA = aA[r] * aA[r] + bA[r] * bA[r], dd = D[r] * D[r];
+                const bool okA = denA >= dminA[r], okB = denB >= dminB[r];
+                const bool inA = okA & (dd <= denA * lo), inB = okB & (dd <= denB * lo);
+                const bool outA = okA & (dd >= denA * hi), outB = okB & (dd >= denB * hi);
+                int v = (inA & inB) ? 1 : 0;
+                if (__builtin_expect((valid & !((inA & inB) | outA | outB)) || c.debug_mode == 13 || c.debug_mode == 54, 0)) {
+                    const float4 p = pts[min(base + j, n - 1)];
+                    v = fm_inlier(F + 9 * (4 * r + q), p.x, p.y, p.z, p.w);
+                }
+                cnt[r] += valid ? v : 0;
+            }
+        }
+    }
+    // the 16 lanes of a DPP row hold the partial counts of hypotheses 4 r + q
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int v = cnt[r];
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+        if (j == 0) {
+            cnt_s[16 * w + 4 * r + q] = v;
+            if (hw + 4 * r + q < SVO_RANSAC_PAD) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + hw + 4 * r + q] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // only hypotheses this chunk really generated count: beyond rs_gen the F matrices are leftovers of an earlier frame.
+        // best count, FIRST hypothesis that has it: max over (count << 6 | 63 - h)
+        const int gen = c.rs_gen[vl * 2 + side];
+        int key = (h0 + tid < gen && cnt_s[tid] > 0) ? ((cnt_s[tid] << 6) | (63 - tid)) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
+        if (tid == 0) {
+            const int best = key >> 6, best_h = h0 + 63 - (key & 63);
+            const int cur = *(volatile int*)bound;
+            if (best > 8 && best_h + 1 < cur) {
+                const int K = ransac_niters(best - 1, n, cur);
+                if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
+            }
+            // the floors of the later chunks: best count of chunk 0 (for chunk 1), of chunks 0 and 1 (for chunk 2)
+            if (chunk == 0 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2], best);
+            if (chunk <= 1 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2 + 1], best);
+        }
+    }
+}
+
 // inlier counts: RC_HB hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
 // a wave-uniform address (scalar loads into SGPRs: a VALU operand each, no LDS round trip per use).  The block's best
 // hypothesis then tightens rs_bound (see above), so that later blocks of the launch and the next chunk stop earlier.
@@ -1338,17 +1473,24 @@ void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
     const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
     // one stream (few lanes): 16 lanes per hypothesis, for latency; many lanes: one thread per hypothesis, for instruction count
-    // (debug_mode 17 forces the 16-lane form, 18 the one-thread form: tests/test_gpu_parity.py runs both against the oracle)
-    const bool per_thread = c.debug_mode == 18 || (c.debug_mode != 17 && c.n_lanes * c.n_oct > 8);
+    // (debug_mode 50 forces the 16-lane form, 51 the one-thread form: tests/test_gpu_parity.py runs both against the oracle)
+    const bool per_thread = c.debug_mode == 51 || (c.debug_mode != 50 && c.n_lanes * c.n_oct > 8);
     if (per_thread) hipLaunchKernelGGL(k_ransac_hyp_thread, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
     else hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {
-    const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
-    if (c.n_lanes * c.n_oct <= 8) hipLaunchKernelGGL(k_ransac_count<4>, dim3((nh + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
-    else if (c.debug_mode == 14) hipLaunchKernelGGL(k_ransac_count<16>, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
-    else hipLaunchKernelGGL(k_ransac_count_mfma, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    // one stream (few lanes): four hypotheses per block on the VALU, for latency; many lanes: 16 x 16 matrix-core tiles.
+    // debug modes (tests/test_gpu_parity.py runs each against the oracle): 14 = sixteen hypotheses per block on the VALU,
+    // 52 = the 4 x 4-component matrix-core tiles, 53 = the 16 x 16 tiles whatever the lane count, 54 = the same with every
+    // verdict replayed through the oracle's own expression
+    const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk), dm = c.debug_mode;
+    const dim3 g16((nh + 15) / 16, 2, c.n_lanes * c.oct_cap);
+    const bool many = c.n_lanes * c.n_oct > 8;
+    if (dm == 14) hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk);
+    else if (dm == 52) hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk);
+    else if (many || dm == 53 || dm == 54) hipLaunchKernelGGL(k_ransac_count_mfma16, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else hipLaunchKernelGGL(k_ransac_count<4>, dim3((nh + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {

@@ -101,11 +101,14 @@ def test_pyramid_and_detector_stage_outputs(golden_dir, monkeypatch):
     ctx.close(); ctx2.close()
 
 
-@pytest.mark.parametrize("mode", ["17", "18"])
-def test_both_hypothesis_kernels_give_the_oracle_models(golden_dir, monkeypatch, mode):
-    """k_ransac_hyp (16 lanes per hypothesis, the one-stream form: debug mode 17) and k_ransac_hyp_thread (one thread per
-    hypothesis, the many-lane form: 18) both repeat the oracle's eight_point operation for operation: same fundamental
-    matrices, hence same inlier counts, masks, tracked pairs and stage-4 counters, whichever form the lane count selects."""
+@pytest.mark.parametrize("mode", ["50", "51", "14", "52", "53", "54"])
+def test_every_ransac_kernel_form_gives_the_oracle_models(golden_dir, monkeypatch, mode):
+    """k_ransac_hyp (16 lanes per hypothesis, the one-stream form: debug mode 50) and k_ransac_hyp_thread (one thread per
+    hypothesis, the many-lane form: 51) both repeat the oracle's eight_point operation for operation: same fundamental
+    matrices, hence same inlier counts, masks, tracked pairs and stage-4 counters, whichever form the lane count selects.
+    Likewise the inlier counts: sixteen hypotheses per block on the VALU (14), matrix-core tiles of 4 hypotheses x 4 line
+    components (52), of 16 hypotheses x 16 pairs with the numerator on the matrix cores too (53: the many-lane default), and
+    the latter with every verdict replayed through the oracle's own expression (54)."""
     monkeypatch.setenv("SVO_DEBUG_MODE", mode)
     g, cam, p = load_small(golden_dir)
     ctx = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
