@@ -113,9 +113,10 @@ def main():
     ap.add_argument("--exclusive", type=int, default=1, help="1: after the timed region, time the roofline kernel again with one context alone on the GPU (roofline.exclusive); 0 = skip (profiling runs)")
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
-    ap.add_argument("--post-on-rest", type=int, default=0, help="1: the NMS / row-sort block of stage 2 runs on the overlap stream with stages 3-5; 2: on a third stream of its own")
+    ap.add_argument("--post-on-rest", type=int, default=1, help="0: all of stage 2 on the detect stream; 1 (default): the NMS / row-sort block of stage 2 and the description run on the overlap stream(s) with stages 3-5; 2: on a third stream of its own; 3: as 1, together with the per-level selection (the detect stream keeps pyramid + FAST only)")
     ap.add_argument("--det-priority", default="low", choices=["low", "high"], help="which of the two streams of the pipelined schedule gets the high HIP priority: the stage 3-5 stream (default 'low' = detect stream at normal priority: the latency-bound stage 3-5 kernels get their few workgroups placed at once and the detect kernels, which fill every wave slot they are given, take the rest; 53.3 k vs 47.1 k pairs/s measured with the two-wave k_fast) or the detect stream")
     ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
+    ap.add_argument("--rest-streams", type=int, default=0, help="HIP streams stages 3-5 of the contexts alternate over (pipelined schedule); 0 = one per context")
     ap.add_argument("--scene", default="planes", choices=["planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): planes = wall + ground + facades (every earlier round's numbers), relief = the same plus 28 billboards at 4..22 m (non-planar depth)")
     ap.add_argument("--relief-lanes", type=int, default=16, help="N=1, config2: streams of the extra leg on the OTHER scene type (reported as `other_scene`: pass-through counters and pose error against ground truth beside the timed scene's); 0 = skip")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
@@ -165,8 +166,8 @@ def main():
         from stereo_vo_amd.abi import DM_FAST_ORB
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
     NC = max(1, args.contexts)
-    batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else bool(args.post_on_rest)),
-                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams)
+    batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else ("select" if args.post_on_rest == 3 else bool(args.post_on_rest))),
+                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams)
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
     ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
     gathered = torch.cuda.Event()
@@ -198,7 +199,7 @@ def main():
     kt_warm = batch.pooled_kernel_times()
     detect_kernels = ("resize", "fast", "select", "describe") + (() if args.post_on_rest else ("nms_rowsort",))
     pool = [k for k in kt_warm if kt_warm[k][1] > 0 and (k in detect_kernels or not pipelined)]
-    dom = max(pool, key=lambda k: kt_warm[k][0] / kt_warm[k][1]) if pool else "fast"
+    dom = max(pool, key=lambda k: kt_warm[k][0] / kt_warm[k][1] / (7 if k == "resize" else 1)) if pool else "fast"      # per LAUNCH: the resize span covers seven
     for c_ in ctxs:
         c_.kernel_times_select(dom)
         c_.kernel_times_reset()

@@ -35,9 +35,10 @@ typedef struct svo_batch_config {
     int32_t det_priority_high;/* 0 (default, measured best): the stage 3-5 stream gets the high HIP priority -- its few workgroups are
                                  placed at once and the detect kernels take every remaining wave slot; 1: the detect stream does */
     int32_t post_mode;        /* where the reference's own post-processing of the detector output (NMS + row sort + describe) runs:
-                                 0 on the detect stream (default), 1 on the stage 3-5 stream, 2 on a third stream of its own */
+                                 0 on the detect stream, 1 (default, measured best) on the stage 3-5 stream, 2 on a third stream of its own, 3 on the stage 3-5 stream TOGETHER
+                                 WITH the per-level selection (top-K, Harris, sort): the detect stream keeps the pyramid and the FAST kernel only */
     int32_t det_streams;      /* >= 1: detect phases of consecutive contexts alternate over this many streams (default 1) */
-    int32_t _pad;
+    int32_t rest_streams;     /* >= 1: stages 3-5 of consecutive contexts alternate over this many streams; 0 (default): one per context */
 } svo_batch_config;
 
 void svo_batch_config_defaults(svo_batch_config* c);

@@ -48,6 +48,9 @@ enum {
     SVO_RUN_DETECT_POST = 512,   /* that post-processing alone, ahead of the other stages of the call */
     SVO_FLAG_BGR_IMAGES = 128,   /* svo_image.data are 8-bit 3-channel BGR (stride in bytes): stage 1's grey conversion runs
                                     on the device (stage1_rectify.cpp:50-51) */
+    SVO_FLAG_DETECT_SPLIT_AT_SELECT = 2048, /* moves the split point of SVO_FLAG_DETECT_NO_POST / SVO_RUN_DETECT_POST forward: the detect call stops
+                                    after the FAST kernel (pyramid + corner candidates: the throughput half), and the post call
+                                    starts with the per-level selection (top-K, Harris, sort) -- pass it to BOTH calls; ORB mode only */
     SVO_FLAG_PINNED_IMAGES = 1024 /* svo_image.data are PAGE-LOCKED host pointers (svo_host_alloc / svo_host_register): the upload is
                                     enqueued on the context's copy stream and svo_process returns without waiting for it; the
                                     images must stay untouched until svo_wait_upload (or svo_wait) returns.  Without this flag host

@@ -255,13 +255,13 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
 // how many tiles a CU keeps in flight -- a tile lives a few microseconds of dependent loads, barriers and LDS round trips, and
 // the launch time falls as 1 / tiles-in-flight (fast_tile below: two waves per tile, 9 KB of LDS, geometry from a table).
 // So the design minimises instructions AND a tile's footprint in wave slots and LDS:
-// Tile = 64x28 interior pixels.  The 80x36 source window (3 px circle radius + 1 px NMS halo, start aligned to
+// Tile = 64x56 interior pixels (FT_W x FT_H).  The 80x64 source window (3 px circle radius + 1 px NMS halo, start aligned to
 // 8 bytes) is staged in LDS with 8-byte loads (360 of them over 128 threads).  A three-step cascade keeps the expensive work dense:
-//   (1) every position of the 68x30 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
+//   (1) every position of the 68x58 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
 //       contains two ADJACENT compass points, so a corner needs two adjacent compass pixels both brighter than
 //       c+t or both darker than c-t.  It runs on FOUR positions per lane-op: the centre row / N / S come in as
 //       aligned LDS dwords, E / W by v_alignbyte, and the comparisons are saturating packed-16-bit subtractions
-//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  30 rows x 17 groups = 2 x 255 tasks in pairs 15 rows apart
+//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  58 rows x 17 groups = 2 x 493 tasks in pairs 29 rows apart
 //       (the index arithmetic is shared), two pairs per thread.  Survivors are compacted into an LDS list by one scan;
 //   (2) only the listed positions compute the arc-min score (both polarities through one packed min network);
 //   (3) the 3x3 NMS also walks the list; survivors are appended to the level's candidate list with one global
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
 #define FT_SP 72              // score map pitch
 #define FT_NG (FT_SW / 4)     // 17 groups of four positions per row
 #define FT_CHUNK 32            // consecutive tiles per XCD turn
-static_assert(FT_SH == 30 && FT_NG == 17 && FT_LH == 36, "k_fast's thread mapping is written for the 64x28 tile");
+static_assert(FT_NG == 17 && FT_W == 64, "k_fast's thread mapping is written for 64-pixel-wide tiles (17 groups of four positions per row)");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
@@ -339,21 +339,31 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* win, int off, int t
     return best > th ? best - 1 : 0;
 }
 
+#define FT_NT 128
+#define FT_HALF (FT_SH / 2)                          // the two rows of a pair-task are FT_HALF apart
+#define FT_TASKS (FT_HALF * FT_NG)                   // pair-tasks (r0, gq) + (r0 + FT_HALF, gq)
+#define FT_TURNS ((FT_TASKS + FT_NT - 1) / FT_NT)    // per thread
+#define FT_LIST_CAP 1024                             // LDS list of the cardinal test's survivors (~80 per tile on a textured scene)
+#define FT_CHUNKS (FT_LH * 5)                        // 16-byte DMA chunks of the window
+static_assert(FT_SH % 2 == 0 && FT_TURNS * 2 * 4 <= 32, "a thread's verdicts must fit one 32-bit mask");
+static_assert(FT_TASKS * 3856 < (1 << 28) && FT_TURNS * FT_NT < 4100, "pt / 17 by multiplication");
+
 struct FastSmem {
     __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
     __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 16];
-    unsigned short list[FT_SH * FT_SW];
+    unsigned short list[FT_LIST_CAP];
     unsigned s_count, s_nout;
 };
-// the NMS survivors' keys (3x3 NMS leaves at most one per 2x2 block) go where the window was: it is dead once the scores exist,
-// and 2 KB less per tile is two more tiles per CU
+// the NMS survivors' keys (3x3 NMS leaves at most one per 2x2 block) go where the window was: it is dead once the scores exist
 static_assert((FT_W * FT_H / 4 + 64) * 4 <= FT_LH * FT_LW, "out_keys aliases the window");
 
-// one 64x28 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
+// one 64x56 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
 // (src, pitch, gw, gh: the level's image; x0, y0: the tile's interior origin -- the caller has them from the tile table)
-// FT_NT threads per tile: the launch is latency-bound (T = 0.095 ms + 2.51 ms / tiles in flight per CU, measured by padding the
-// LDS allocation), and a CU's 32 wave slots hold 8 tiles with four waves each but 14 (the LDS limit) with two.
-#define FT_NT 128
+// FT_NT = 128 threads per tile, two waves: the kernel is bound by VALU issue (SQ_INSTS_VALU x 4 cycles = 97 % of its duration,
+// profiles/r03_pmc.json), and what does not scale with the pixels -- staging, the fixed part of the compaction, the
+// publication -- is paid per tile: 56 rows instead of 28 halve it (and the halo rows: 64 / 56 window rows per interior row
+// instead of 36 / 28).  The list of the cardinal test's survivors is capped (LDS per tile decides how many tiles a CU holds);
+// what does not fit stays with the thread that found it and is scored / suppressed by its owner after the listed ones.
 __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
 {
     uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = (uint32_t*)sm.tile;
@@ -362,18 +372,17 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     if (tid == 0) { s_nout = 0; s_count = 0; }
     // the score map is cleared BEFORE the DMA is issued: the compiler orders every LDS store behind an outstanding LDS-DMA
     // (s_waitcnt vmcnt(0)), so a store placed after it would wait out the whole fetch
-    static_assert((FT_SH * FT_SP + 15) / 16 <= FT_NT + 8, "score-map clear: one 16-byte store per thread + 8");
-    ((uint4*)score)[tid] = make_uint4(0, 0, 0, 0);
-    if (tid < (FT_SH * FT_SP + 15) / 16 - FT_NT) ((uint4*)score)[FT_NT + tid] = make_uint4(0, 0, 0, 0);
-    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+32) with the LDS-DMA path (global_load_lds_dwordx4): a wave-instruction
+    constexpr int N16 = (FT_SH * FT_SP + 15) / 16;
+#pragma unroll
+    for (int i = 0; i < (N16 + FT_NT - 1) / FT_NT; i++) if (i * FT_NT + tid < N16) ((uint4*)score)[i * FT_NT + tid] = make_uint4(0, 0, 0, 0);
+    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+FT_H+4) with the LDS-DMA path (global_load_lds_dwordx4): a wave-instruction
     //      lands 64 x 16 bytes at LDS base + lane * 16 straight from the lanes' global addresses, no VGPR round trip and no
-    //      ds_write.  The window is 36 rows x 5 chunks of 16 bytes = 180 chunks, chunk i at LDS byte 16 i (pitch 80): three
-    //      wave-instructions per tile (chunks 0..63 by wave 0, 64..127 by wave 1, 128..179 by wave 0 again) where the
-    //      register path spent ~50 VALU instructions per wave on address arithmetic, clamps and 8-byte ds_writes.
-    //      The source may sit at ANY byte alignment and the destination base at any dword (tools/ubench/glds_align.hip pins
-    //      both on the hardware), so one path serves every pointer / stride.  Chunks are clamped to the image proper
-    //      (x <= gw - 16, y <= gh - 1): a clamped chunk holds shifted bytes, but only columns >= gw - 16 can be affected and
-    //      nothing right of column gw - 28 is ever read by an interior position (EDGE 31 - radius 3 - NMS halo 1).
+    //      ds_write.  The window is FT_LH rows x 5 chunks of 16 bytes, chunk i at LDS byte 16 i (pitch 80): wave w takes chunks
+    //      128 j + 64 w + lane.  The source may sit at ANY byte alignment and the destination base at any dword
+    //      (tools/ubench/glds_align.hip pins both on the hardware), so one path serves every pointer / stride.  Chunks are
+    //      clamped to the image proper (x <= gw - 16, y <= gh - 1): a clamped chunk holds shifted bytes, but only columns
+    //      >= gw - 16 can be affected and nothing right of column gw - 28 is ever read by an interior position (EDGE 31 -
+    //      radius 3 - NMS halo 1).
     {
         const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         auto chunk_src = [&](int i) -> const uint8_t* {
@@ -383,26 +392,28 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
         };
         typedef const void __attribute__((address_space(1)))* gptr_t;
         typedef void __attribute__((address_space(3)))* lptr_t;
-        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(tid), (lptr_t)(tile + wid * 1024), 16, 0, 0);
-        if (tid < 180 - FT_NT) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(FT_NT + tid), (lptr_t)(tile + 2048), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < (FT_CHUNKS + FT_NT - 1) / FT_NT; j++) {
+            if (j * FT_NT + FT_NT <= FT_CHUNKS) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(j * FT_NT + tid), (lptr_t)(tile + j * (FT_NT * 16) + wid * 1024), 16, 0, 0);
+            else if (j * FT_NT + tid < FT_CHUNKS) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(j * FT_NT + tid), (lptr_t)(tile + j * (FT_NT * 16) + wid * 1024), 16, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's DMA chunks have landed; the barrier covers the other wave's
     __syncthreads();
     if (c.debug_mode == 1) return;
-    // ---- (1) packed cardinal test: 30 rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + 15, gq) ----
+    // ---- (1) packed cardinal test: FT_SH rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + FT_HALF, gq) ----
     const uint32_t* T32 = (const uint32_t*)tile;
     const uint32_t th = (uint32_t)th_fast;
     const u16x2 t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
-    constexpr int FT_TURNS = 256 / FT_NT;                               // 255 pair-tasks (r0, gq) + (r0 + 15, gq): FT_TURNS per thread
     uint32_t pe[2 * FT_TURNS], po[2 * FT_TURNS];                        // nonzero halves = passing positions
 #pragma unroll
     for (int u = 0; u < FT_TURNS; u++) {
-        const int pt = tid + u * FT_NT, r0 = pt / FT_NG, gq = pt - r0 * FT_NG;
+        const int pt = tid + u * FT_NT, r0 = (pt * 3856) >> 16, gq = pt - r0 * FT_NG;       // pt / 17, pt % 17
         pe[2 * u] = pe[2 * u + 1] = po[2 * u] = po[2 * u + 1] = 0;
-        if (pt < 15 * FT_NG) {
+        if (pt < FT_TASKS) {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint32_t* row = T32 + (r0 + 15 * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
+                const uint32_t* row = T32 + (r0 + FT_HALF * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
                 const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
                 // The test compares 16-bit halves whose HIGH byte is the pixel of interest; the low byte is whatever sits next to it
                 // and only matters when the high bytes tie at exactly the threshold, where it can let a position through that the
@@ -416,11 +427,19 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             }
         }
     }
-    {   // compaction: the thread's 16 verdicts become one bit mask (bit 8 p + g: position p of group g = 2 u + k), a DPP scan of
-        // the popcounts gives every lane its first list slot, ONE LDS atomic per wave reserves the wave's range, and each lane
-        // writes its own survivors.  (Sixteen ballots with their mbcnt pairs and conditional stores cost ~100 VALU instructions
-        // per wave whether the tile held one candidate or fifty; this costs ~25 plus ~12 per survivor of the busiest lane, and
-        // at the speculated thresholds 2 % of the positions survive.)  List order is irrelevant.  Entry = r << 8 | q.
+    // compaction: the thread's verdicts become one bit mask (bit 8 p + g: position p of group g = 2 u + k), a DPP scan of
+    // the popcounts gives every lane its first list slot, ONE LDS atomic per wave reserves the wave's range, and each lane
+    // writes its own survivors.  (Ballots with their mbcnt pairs and conditional stores cost ~100 VALU instructions
+    // per wave whether the tile held one candidate or fifty; this costs ~35 plus ~14 per survivor of the busiest lane, and
+    // at the speculated thresholds 2 % of the positions survive.)  List order is irrelevant.  Entry = r << 8 | q.
+    // Survivors beyond FT_LIST_CAP stay in m_left: their owner scores and suppresses them after the listed ones.
+    auto entry_of = [&](int b) -> int {
+        // (recomputed from the task index: a select among the turns' precomputed entries becomes an indexed scratch load)
+        const int g = b & 7, pt = tid + (g >> 1) * FT_NT, r0 = (pt * 3856) >> 16, gq = pt - r0 * FT_NG;
+        return ((r0 + (g & 1) * FT_HALF) << 8) + 4 * gq + (b >> 3);
+    };
+    uint32_t m_left = 0;
+    {
         const u16x2 one2 = { 1, 1 };
         uint32_t m = 0;
 #pragma unroll
@@ -434,33 +453,35 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             unsigned wbase = 0;
             if ((tid & 63) == 0) wbase = atomicAdd(&s_count, (unsigned)total);
             unsigned idx = (unsigned)__builtin_amdgcn_readfirstlane((int)wbase) + (unsigned)(inc - cnt);
-            int eb[FT_TURNS];
-#pragma unroll
-            for (int u = 0; u < FT_TURNS; u++) { const int pt = tid + u * FT_NT, r0 = pt / FT_NG, gq = pt - r0 * FT_NG; eb[u] = (r0 << 8) | (4 * gq); }
-            static_assert(FT_TURNS == 2, "the decode below selects between two turns");
-            while (m) {
+            while (m && idx < FT_LIST_CAP) {
                 const int b = __builtin_ctz(m); m &= m - 1;
-                const int g = b & 7;
-                list[idx++] = (unsigned short)(((g & 2) ? eb[1] : eb[0]) + (g & 1) * (15 << 8) + (b >> 3));
+                list[idx++] = (unsigned short)entry_of(b);
             }
+            m_left = m;
         }
     }
     __syncthreads();
-    const int ns = (int)s_count;
+    const int ns_all = (int)s_count, ns = min(ns_all, FT_LIST_CAP);
+    const bool overflow = ns_all > FT_LIST_CAP;                              // block-uniform
     if (c.debug_mode == 2) return;
     // ---- (2) score on the survivors only ----
     for (int i = tid; i < ns; i += FT_NT) {
         const int e = list[i], r = e >> 8, q = e & 0xFF;
         score[r * FT_SP + q] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
     }
+    if (__builtin_expect(overflow, 0)) {
+        for (uint32_t m = m_left; m; m &= m - 1) {
+            const int e = entry_of(__builtin_ctz(m)), r = e >> 8, q = e & 0xFF;
+            score[r * FT_SP + q] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
+        }
+    }
     __syncthreads();
     if (c.debug_mode == 3) return;
     // ---- (3) 3x3 NMS on the listed interior positions; one global atomic per tile ----
-    for (int base = 0; base < ns; base += FT_NT) {
-        const int i = base + tid;
+    auto nms_round = [&](bool has, int e) {
         bool keep = false; uint32_t key = 0;
-        if (i < ns) {
-            const int e = list[i], r = e >> 8, q = e & 0xFF, pos = r * FT_SP + q;
+        if (has) {
+            const int r = e >> 8, q = e & 0xFF, pos = r * FT_SP + q;
             // nine byte reads at immediate offsets, issued together; the middle column goes through an opaque copy of
             // the base so that no two fuse into a misaligned ds_read_u16.  (r = 0 reads below the map: rejected below.)
             const int nb = pos - FT_SP - 1; int nbm = nb; asm volatile("" : "+v"(nbm));
@@ -480,9 +501,23 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             b2 = __shfl(b2, leader, 64);
             if (keep) out_keys[b2 + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = key;
         }
+    };
+    // out_keys aliases the window, which the overflow path still scores from: every score is in the map by now (barrier above)
+    for (int base = 0; base < ns; base += FT_NT) {
+        const int i = base + tid;
+        nms_round(i < ns, i < ns ? (int)list[i] : 0);
+    }
+    if (__builtin_expect(overflow, 0)) {
+        uint32_t m = m_left;
+        while (__ballot(m != 0)) {                                           // wave-uniform trip count: the ballots inside need every lane
+            const bool has = m != 0;
+            const int e = has ? entry_of(__builtin_ctz(m)) : 0;
+            m &= m - 1;
+            nms_round(has, e);
+        }
     }
     __syncthreads();
-    // only the first wave publishes: the other three retire here, so the returning global atomic (a ~2-3 us round trip)
+    // only the first wave publishes: the other retires here, so the returning global atomic (a ~2-3 us round trip)
     // stalls one wave per tile instead of the whole workgroup
     if (tid < 64) {
         const unsigned nout = s_nout;

@@ -846,7 +846,8 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         } else {                // stage2_detect.cpp:458-497
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
-            { Span s(ctx, KT_SELECT); launch_select(d, st); }
+            const bool split_early = (flags & SVO_FLAG_DETECT_NO_POST) && (flags & SVO_FLAG_DETECT_SPLIT_AT_SELECT);
+            if (!split_early) { Span s(ctx, KT_SELECT); launch_select(d, st); }
             // The reference's NMS needs positions and responses only, so it runs BEFORE orientation + description and only
             // its survivors are described (debug mode 9 keeps the detector's order: describe everything, then NMS --
             // that is what svo_debug_get_raw_keypoints shows)
@@ -862,6 +863,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     } else if (flags & SVO_RUN_DETECT_POST) {       // the post-processing a SVO_FLAG_DETECT_NO_POST call left out
         if (!ctx->geom_ready) return SVO_ERR_STATE;
         const int nms_mode = p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0;
+        if ((flags & SVO_FLAG_DETECT_SPLIT_AT_SELECT) && !d.fast_orb) { Span s(ctx, KT_SELECT); launch_select(d, st); }
         if (d.fast_orb || d.debug_mode == 9) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, d.fast_orb ? (p.non_maximal_suppression ? 0 : 3) : nms_mode, p.min_distance, 0, st); }
         else {
             { Span s(ctx, KT_NMS); launch_nms_rowsort(d, nms_mode, p.min_distance, 1, st); }

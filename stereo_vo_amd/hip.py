@@ -51,7 +51,7 @@ class Config(C.Structure):
 class BatchConfig(C.Structure):
     """svo_batch_config (include/svo_batch.h)"""
     _fields_ = [("ctx", Config), ("n_contexts", C.c_int32), ("schedule", C.c_int32), ("det_priority_high", C.c_int32),
-                ("post_mode", C.c_int32), ("det_streams", C.c_int32), ("_pad", C.c_int32)]
+                ("post_mode", C.c_int32), ("det_streams", C.c_int32), ("rest_streams", C.c_int32)]
 
 
 class Image(C.Structure):

@@ -28,8 +28,8 @@ def _frames(ptrs, w, h, stride):
 
 
 class StreamBatch:
-    def __init__(self, params, cam, width, height, lanes, contexts=1, device=0, schedule="pipelined", post_on_rest=False,
-                 det_priority="low", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1):
+    def __init__(self, params, cam, width, height, lanes, contexts=1, device=0, schedule="pipelined", post_on_rest=True,
+                 det_priority="low", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1, rest_streams=0):
         assert contexts >= 1 and lanes % contexts == 0 and lanes // contexts <= hip.MAX_LANES, \
             "lanes must split evenly over the contexts, at most %d streams per context" % hip.MAX_LANES
         self.L = hip.lib()
@@ -47,8 +47,9 @@ class StreamBatch:
         cfg.schedule = 0 if schedule == "pipelined" else 1
         cfg.det_priority_high = int(det_priority == "high")
         # post_on_rest: False = NMS + describe stay on the detect stream; True = on the stage 3-5 stream; "own" = on a third stream
-        cfg.post_mode = 2 if post_on_rest == "own" else int(bool(post_on_rest))
+        cfg.post_mode = 2 if post_on_rest == "own" else (3 if post_on_rest == "select" else int(bool(post_on_rest)))
         cfg.det_streams = max(1, det_streams)
+        cfg.rest_streams = max(0, rest_streams)          # 0 = one stage 3-5 stream per context
         h = C.c_void_p()
         rc = self.L.svo_batch_create(C.byref(cfg), C.byref(h))
         self.h = h

@@ -132,6 +132,28 @@ def test_every_ransac_kernel_form_gives_the_oracle_models(golden_dir, monkeypatc
     ctx.close()
 
 
+def test_noise_images_overflow_the_fast_tile_list():
+    """White noise lets most positions through k_fast's cardinal pre-test: far more than the 1024-entry LDS list of a 64x56
+    tile holds, so the survivors beyond it are scored and suppressed by the threads that found them (the overflow path of
+    fast_tile).  Same corners, keypoints, descriptors, pairings as the oracle; second frame = speculated thresholds."""
+    w, h = 640, 480
+    rng = np.random.RandomState(77)
+    cam = StereoCamera.simple(500.0, w / 2.0, h / 2.0, 0.12, w, h)
+    p = north_star_params(hip.default_params(), orb_nfeats=1000)
+    ctx = hip.Context(n_lanes=1, max_w=w, max_h=h, max_kps=2048, max_cand=1 << 18)
+    ctx.set_params(p); ctx.set_camera(cam)
+    orc = O().Oracle(p)
+    for t in range(2):
+        L = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        R = np.roll(L, -7, axis=1).copy()
+        if t == 1:
+            L[100:300, 200:500] = 128; R[100:300, 193:493] = 128                    # a flat patch: tiles with and without overflow
+        ctx.process_host([(L, R)])
+        assert_same_frame(ctx, 0, orc, ctx.result(0), orc.process(L, R, cam), "noise t=%d" % t)
+        assert ctx.status_word(0) == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("w,h,f,cx,cy,B,nfe", [(1280, 960, 800.0, None, None, 0.12, 2000), (1241, 376, 718.856, 607.19, 185.22, 0.537, 900)])
 def test_full_size_streams_match_oracle(w, h, f, cx, cy, B, nfe):
     """BASELINE.json configs[1] (1280x960, ~2000 kps) and configs[2] (KITTI-00 shape), 2 lanes x 3 frames."""
