@@ -36,7 +36,7 @@ from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 import ctypes as C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_PROFILES = ("r03_pmc.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")    # newest first; tools/pmc_passes.py writes them
+PMC_PROFILES = ("r03d_pmc.json", "r03_pmc.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")    # newest first; tools/pmc_passes.py writes them
 
 
 def lane_seeds(rank, world_size, lanes):
@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--dump-records", default="", help="test hook: every rank writes its own and the gathered result records of the last step to <path>.rank<r>.npz")
     ap.add_argument("--schedule", default="pipelined", choices=["pipelined", "free"], help="pipelined: detect phases of the contexts serialised, stages 3-5 overlap the next context's detect; free: contexts run unsynchronised")
     ap.add_argument("--post-on-rest", type=int, default=1, help="0: all of stage 2 on the detect stream; 1 (default): the NMS / row-sort block of stage 2 and the description run on the overlap stream(s) with stages 3-5; 2: on a third stream of its own; 3: as 1, together with the per-level selection (the detect stream keeps pyramid + FAST only)")
-    ap.add_argument("--det-priority", default="low", choices=["low", "high"], help="which of the two streams of the pipelined schedule gets the high HIP priority: the stage 3-5 stream (default 'low' = detect stream at normal priority: the latency-bound stage 3-5 kernels get their few workgroups placed at once and the detect kernels, which fill every wave slot they are given, take the rest; 53.3 k vs 47.1 k pairs/s measured with the two-wave k_fast) or the detect stream")
+    ap.add_argument("--det-priority", default="high", choices=["low", "high"], help="which side of the pipelined schedule gets the high HIP stream priority: 'high' (default) = the detect stream, the serial chain of a step once the NMS, the description and stages 3-5 run on one stream per context (66.4 k against 64.9 k pairs/s); 'low' = the stage 3-5 streams (the better choice when ONE stream carries all of them: 53.3 k vs 47.1 k in round 2)")
     ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
     ap.add_argument("--rest-streams", type=int, default=0, help="HIP streams stages 3-5 of the contexts alternate over (pipelined schedule); 0 = one per context")
     ap.add_argument("--scene", default="planes", choices=["planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): planes = wall + ground + facades (every earlier round's numbers), relief = the same plus 28 billboards at 4..22 m (non-planar depth)")
@@ -197,7 +197,7 @@ def main():
     for c_ in ctxs:
         c_.wait()
     kt_warm = batch.pooled_kernel_times()
-    detect_kernels = ("resize", "fast", "select", "describe") + (() if args.post_on_rest else ("nms_rowsort",))
+    detect_kernels = ("resize", "fast", "select") + (() if args.post_on_rest else ("describe", "nms_rowsort"))      # what the detect stream carries
     pool = [k for k in kt_warm if kt_warm[k][1] > 0 and (k in detect_kernels or not pipelined)]
     dom = max(pool, key=lambda k: kt_warm[k][0] / kt_warm[k][1] / (7 if k == "resize" else 1)) if pool else "fast"      # per LAUNCH: the resize span covers seven
     for c_ in ctxs:

@@ -32,8 +32,10 @@ typedef struct svo_batch_config {
     svo_config ctx;           /* per CONTEXT: n_lanes = streams per context (<= SVO_MAX_LANES); .stream is ignored */
     int32_t n_contexts;       /* contexts side by side on ctx.device (total streams = n_contexts * ctx.n_lanes) */
     int32_t schedule;         /* SVO_SCHED_*; a single context always runs SVO_SCHED_FREE */
-    int32_t det_priority_high;/* 0 (default, measured best): the stage 3-5 stream gets the high HIP priority -- its few workgroups are
-                                 placed at once and the detect kernels take every remaining wave slot; 1: the detect stream does */
+    int32_t det_priority_high;/* which side gets the high HIP stream priority.  1 (default): the detect stream -- with the NMS, the description
+                                 and stages 3-5 spread over one stream per context (post_mode 1) the detect stream is the serial chain of a
+                                 step, and its kernels should not queue behind three streams of everything else (66.4 k against 64.9 k
+                                 pairs/s, r03); 0: the stage 3-5 streams (the better choice when ONE stream carries all of them) */
     int32_t post_mode;        /* where the reference's own post-processing of the detector output (NMS + row sort + describe) runs:
                                  0 on the detect stream, 1 (default, measured best) on the stage 3-5 stream, 2 on a third stream of its own, 3 on the stage 3-5 stream TOGETHER
                                  WITH the per-level selection (top-K, Harris, sort): the detect stream keeps the pyramid and the FAST kernel only */

@@ -150,7 +150,7 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 }
 
 #define GN_NSUM 28
-#define GN_NT_MAX 512        // the kernel is built for 256 and for 512 threads per lane (template parameter NT): SVO_GN_NT picks, see launch_gauss_newton
+#define GN_NT_MAX 512        // the kernel is built for 256, 384 and 512 threads per lane (template parameter NT): SVO_GN_NT picks, see launch_gauss_newton
 #define GN_RED_BYTES ((size_t)GN_NSUM * GN_NT_MAX * sizeof(double))
 struct GnShared {
     double part[4][GN_NSUM];
@@ -274,13 +274,14 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
 #pragma unroll
     for (int i = 0; i < GN_NSUM; i++) red[i * GN_NT + tid] = acc[i];
     __syncthreads();
-    constexpr int PER = GN_NT / 32;                                            // threads per sum: 8 (256 threads) or 16 (512)
+    constexpr int PER = 8;                                                     // threads per sum; each adds GN_NT / 8 entries
+    static_assert(GN_NT % PER == 0 && GN_NSUM * PER <= GN_NT, "28 x 8 summing threads");
     if (tid < GN_NSUM * PER) {
         const int sidx = tid / PER, part = tid % PER;
         const double* rp = red + sidx * GN_NT + part;
         double sum = 0;
 #pragma unroll
-        for (int k = 0; k < 32; k++) sum += rp[PER * k];
+        for (int k = 0; k < GN_NT / PER; k++) sum += rp[PER * k];
 #pragma unroll
         for (int o = 1; o < PER; o <<= 1) sum += __shfl_xor(sum, o, 64);
         if (part == 0) sh.tot[sidx] = sum;
@@ -523,15 +524,21 @@ hipError_t configure_gauss_newton(int pmax)
 {
     hipError_t e = hipFuncSetAttribute((const void*)k_gauss_newton<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_gauss_newton<384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_gauss_newton<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
 }
 
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
 {
+    // threads per lane: one pass of the per-track loop covers that many tracks per iteration (config 2 tracks ~290: 256 threads walk
+    // the loop twice); SVO_GN_NT = 256 / 384 / 512 overrides the default for an A/B
     static int nt = 0;
-    if (!nt) { const char* e = getenv("SVO_GN_NT"); nt = (e && atoi(e) == 512) ? 512 : 256; }
-    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
-    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr);
+    if (!nt) { const char* e = getenv("SVO_GN_NT"); const int v = e ? atoi(e) : 0; nt = (v == 256 || v == 384 || v == 512) ? v : 256; }
+    uint8_t* big = P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr;
+    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax), st, c, P, big);
+    else if (nt == 384) hipLaunchKernelGGL(k_gauss_newton<384>, dim3(c.n_lanes), dim3(384), gn_smem(P.pmax), st, c, P, big);
+    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, big);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ extern "C" void svo_batch_config_defaults(svo_batch_config* c)
     if (!c) return;
     svo_config_defaults(&c->ctx);
     c->ctx.n_lanes = SVO_MAX_LANES;
-    c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 0; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0;
+    c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 1; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0;
 }
 
 extern "C" const char* svo_batch_last_error(const svo_batch* b) { return b ? b->last_error.c_str() : ""; }

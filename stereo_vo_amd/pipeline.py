@@ -29,7 +29,7 @@ def _frames(ptrs, w, h, stride):
 
 class StreamBatch:
     def __init__(self, params, cam, width, height, lanes, contexts=1, device=0, schedule="pipelined", post_on_rest=True,
-                 det_priority="low", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1, rest_streams=0):
+                 det_priority="high", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1, rest_streams=0):
         assert contexts >= 1 and lanes % contexts == 0 and lanes // contexts <= hip.MAX_LANES, \
             "lanes must split evenly over the contexts, at most %d streams per context" % hip.MAX_LANES
         self.L = hip.lib()
