@@ -534,7 +534,7 @@ void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
     // threads per lane: one pass of the per-track loop covers that many tracks per iteration (config 2 tracks ~290: 256 threads walk
     // the loop twice); SVO_GN_NT = 256 / 384 / 512 overrides the default for an A/B
     static int nt = 0;
-    if (!nt) { const char* e = getenv("SVO_GN_NT"); const int v = e ? atoi(e) : 0; nt = (v == 256 || v == 384 || v == 512) ? v : 256; }
+    if (!nt) { const char* e = getenv("SVO_GN_NT"); const int v = e ? atoi(e) : 0; nt = (v == 256 || v == 384 || v == 512) ? v : 384; }
     uint8_t* big = P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr;
     if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax), st, c, P, big);
     else if (nt == 384) hipLaunchKernelGGL(k_gauss_newton<384>, dim3(c.n_lanes), dim3(384), gn_smem(P.pmax), st, c, P, big);
