@@ -208,6 +208,14 @@ def fast_score_map(img, th):
     return s
 
 
+def orb_angle(img, x, y):
+    """orientation in degrees of the position (x, y) (intensity centroid over the radius-15 disc, the oracle's atan2)"""
+    img = _img(img)
+    L = lib()
+    L.svo_oracle_orb_angle.restype = C.c_float
+    return float(L.svo_oracle_orb_angle(_ptr(img, u8p), img.shape[1], int(x), int(y), None))
+
+
 def pyramid_sizes(w, h, nlevels):
     lw = (C.c_int * nlevels)()
     lh = (C.c_int * nlevels)()

@@ -352,6 +352,15 @@ static void orb_angle_desc(const uint8_t* img, int stride, int x, int y, float* 
     }
 }
 
+/* orientation (degrees, [0, 360)) and steered BRIEF-256 of ONE position: the per-keypoint step of stage 2 on its own, for the
+ * third-party cross-check (tests/test_oracle_thirdparty.py).  (x, y) must keep 18 pixels from every border. */
+float svo_oracle_orb_angle(const uint8_t* img, int stride, int x, int y, uint8_t* desc32)
+{
+    float a = 0.f; uint8_t d[32];
+    orb_angle_desc(img, stride, x, y, &a, desc32 ? desc32 : d);
+    return a;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* cv::ORB::detectAndCompute stand-in  [frozen]   (call site S2:482-493)                            */
 /* ------------------------------------------------------------------------------------------------ */

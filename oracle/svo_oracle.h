@@ -69,6 +69,7 @@ int svo_oracle_fast_orb_detect(const uint8_t* img, int w, int h, int stride, int
                                svo_keypoint* kps, uint8_t* desc, int cap);
 /* FAST-9/16 corner score map of one image (0 = not a corner at threshold th). */
 void svo_oracle_fast_score_map(const uint8_t* img, int w, int h, int stride, int th, uint8_t* score);
+float svo_oracle_orb_angle(const uint8_t* img, int stride, int x, int y, uint8_t* desc32);   /* one position's orientation (+ descriptor) */
 /* pyramid level sizes and bilinear x1/1.2 chain; level buffers are tightly packed (stride == width). */
 int svo_oracle_pyramid_sizes(int w, int h, int nlevels, int* lw, int* lh, float* scale);
 void svo_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh);
