@@ -13,16 +13,63 @@
 #include <float.h>
 #include <stdlib.h>
 
+// Reciprocal, reciprocal square root, sine and cosine for the ONE thread that solves the normal equations and rebuilds the rotation
+// between two barriers of every Gauss-Newton iteration (4.5 of the 8.3 us of an iteration were that thread: tests/dev/gn_breakdown.py).
+// An IEEE f64 division is ~10 dependent instructions and the device library's sin / cos ~100 each with their range reduction;
+// v_rcp_f64 / v_rsq_f64 plus two Newton steps are 5, and below 0.5 rad the Taylor series to x^17 / x^16 is exact to 1e-19.
+// Stage 5 is held to the oracle by a tolerance (1e-3 m / 1e-4 rad, residuals 1e-6 relative), not bit for bit: these agree with the
+// correctly rounded results to an ulp or two.
+__device__ __forceinline__ double gn_rcp(double a)
+{
+    double r = __builtin_amdgcn_rcp(a);
+    r = __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+    return __builtin_fma(r, __builtin_fma(-a, r, 1.0), r);
+}
+__device__ __forceinline__ double gn_rsqrt(double a)
+{
+    double y = __builtin_amdgcn_rsq(a);
+    y = y * __builtin_fma(-0.5 * a * y, y, 1.5);
+    return y * __builtin_fma(-0.5 * a * y, y, 1.5);
+}
+__device__ __forceinline__ void gn_sincos(double x, double& sn, double& cs)
+{
+    if (__builtin_expect(!(fabs(x) < 0.5), 0)) { sn = sin(x); cs = cos(x); return; }
+    const double z = x * x;
+    double ps = -2.8114572543455206e-15;                  // -1/17!
+    ps = __builtin_fma(ps, z, 7.6471637318198164e-13);    //  1/15!
+    ps = __builtin_fma(ps, z, -1.6059043836821613e-10);   // -1/13!
+    ps = __builtin_fma(ps, z, 2.5052108385441720e-08);    //  1/11!
+    ps = __builtin_fma(ps, z, -2.7557319223985893e-06);   // -1/9!
+    ps = __builtin_fma(ps, z, 1.9841269841269841e-04);    //  1/7!
+    ps = __builtin_fma(ps, z, -8.3333333333333332e-03);   // -1/5!
+    ps = __builtin_fma(ps, z, 1.6666666666666666e-01);    //  1/3!
+    sn = __builtin_fma(-x * z, ps, x);
+    double pc = 4.7794773323873853e-14;                   //  1/16!
+    pc = __builtin_fma(pc, z, -1.1470745597729725e-11);   // -1/14!
+    pc = __builtin_fma(pc, z, 2.0876756987868100e-09);    //  1/12!
+    pc = __builtin_fma(pc, z, -2.7557319223985888e-07);   // -1/10!
+    pc = __builtin_fma(pc, z, 2.4801587301587302e-05);    //  1/8!
+    pc = __builtin_fma(pc, z, -1.3888888888888889e-03);   // -1/6!
+    pc = __builtin_fma(pc, z, 4.1666666666666664e-02);    //  1/4!
+    pc = __builtin_fma(pc, z, -0.5);
+    cs = __builtin_fma(pc, z, 1.0);
+}
+
 struct Rot { double r[9]; double dr[3][9]; int small_angle; };
 
 // S5:45-163 (formulas kept as written, including the (w2^2+w3^2) factor of dr22dw3 at S5:162)
+template <bool FAST = true>
 __device__ void rodrigues_with_derivs(const double* dp, Rot& R)
 {
     const double w1 = dp[0], w2 = dp[1], w3 = dp[2];
     const double w12 = w1 * w1, w22 = w2 * w2, w32 = w3 * w3;
-    const double tt = sqrt(w1 * w1 + w2 * w2 + w3 * w3);
+    const double ss = w1 * w1 + w2 * w2 + w3 * w3;
+    // FAST: inside the Gauss-Newton iteration (tolerance-checked); otherwise the correctly rounded library forms, as the oracle's
+    // (getProjectedCoords is compared bit for bit)
+    double itt_, tt, sin_tt, cos_tt;
+    if (FAST) { itt_ = ss > 0.0 ? gn_rsqrt(ss) : 0.0; tt = ss * itt_; gn_sincos(tt, sin_tt, cos_tt); }
+    else { tt = sqrt(ss); itt_ = 1.0 / tt; sin_tt = sin(tt); cos_tt = cos(tt); }
     const double tt2 = tt * tt, tt3 = tt2 * tt, tt4 = tt3 * tt;
-    const double sin_tt = sin(tt), cos_tt = cos(tt);
     double* r = R.r;
     for (int i = 0; i < 9; i++) { R.dr[0][i] = 0; R.dr[1][i] = 0; R.dr[2][i] = 0; }
     if (tt < 1e-5) {
@@ -33,7 +80,7 @@ __device__ void rodrigues_with_derivs(const double* dp, Rot& R)
     R.small_angle = 0;
     // same expressions as S5:102-110 with the divisions by tt, tt2, tt3, tt4 folded into one reciprocal (an f64 divide
     // is a ~15-instruction sequence and this runs on one thread, on the critical path of every iteration)
-    const double itt = 1.0 / tt, itt2 = itt * itt, itt3 = itt2 * itt, itt4 = itt2 * itt2;
+    const double itt = itt_, itt2 = itt * itt, itt3 = itt2 * itt, itt4 = itt2 * itt2;
     const double u = (cos_tt - 1) * itt2;
     const double dudw1 = ((-sin_tt * w1 * itt) * tt2 - (cos_tt - 1) * 2 * w1) * itt4;
     const double dudw2 = ((-sin_tt * w2 * itt) * tt2 - (cos_tt - 1) * 2 * w2) * itt4;
@@ -125,6 +172,19 @@ __device__ int solve_sym6(const double* H, const double* g, double* x)
     return 1;
 }
 
+// The general path out of line, fed from the 28 block sums in LDS and answering into LDS: rarely taken, and kept away from the
+// iteration body so that neither its code nor a memory copy of H (an array whose address escapes lives in scratch) sits in it.
+__device__ __attribute__((noinline)) int solve_sym6_from_sums(const double* tot, double* x_out)
+{
+    double H[36], g[6], x[6] = { 0, 0, 0, 0, 0, 0 };
+    int h = 0;
+    for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { const double v = tot[h++]; H[a * 6 + b] = v; H[b * 6 + a] = v; }
+    for (int a = 0; a < 6; a++) g[a] = tot[21 + a];
+    const int ok = solve_sym6(H, g, x);
+    for (int a = 0; a < 6; a++) x_out[a] = x[a];
+    return ok;
+}
+
 // CPose3D(CPose3DRotVec(delta).getInverse()) -> x y z yaw pitch roll (S5:717-718; oracle's svo_oracle_delta_to_pose)
 __device__ void delta_to_pose(const double* dp, double* pose)
 {
@@ -178,15 +238,15 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
         double w[6];                                                        // w[k] = L[j][k] * d[k]
         double s = H[j * 6 + j];
 #pragma unroll
-        for (int k = 0; k < j; k++) { w[k] = L[j][k] * d[k]; s -= L[j][k] * w[k]; }
+        for (int k = 0; k < j; k++) { w[k] = L[j][k] * d[k]; s = __builtin_fma(-L[j][k], w[k], s); }
         ok = ok && (s > 1e-13 * dmax);
         d[j] = s;
-        inv[j] = 1.0 / s;
+        inv[j] = gn_rcp(s);
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double t = H[i * 6 + j];
 #pragma unroll
-            for (int k = 0; k < j; k++) t -= L[i][k] * w[k];
+            for (int k = 0; k < j; k++) t = __builtin_fma(-L[i][k], w[k], t);
             L[i][j] = t * inv[j];
         }
     }
@@ -194,12 +254,12 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
 #pragma unroll
     for (int i = 0; i < 6; i++) { double t = g[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) t -= L[i][k] * y[k];
+        for (int k = 0; k < i; k++) t = __builtin_fma(-L[i][k], y[k], t);
         y[i] = t; }
 #pragma unroll
     for (int i = 5; i >= 0; i--) { double t = y[i] * inv[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) t -= L[k][i] * x[k];
+        for (int k = i + 1; k < 6; k++) t = __builtin_fma(-L[k][i], x[k], t);
         x[i] = t; }
     return ok;
 }
@@ -208,7 +268,7 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
 // thread sees sh.ok, sh.cost, sh.step, and sh.delta / sh.R already advanced by the step (S5:576-577).
 template <int GN_NT>
 __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
-                         const double* lmk, const float* obs, double* residual, GnShared& sh, double* red)
+                         const double* lmk, const float* obs, double* residual, GnShared& sh, double* red, int dbg = 0)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const double b2 = P.use_robust_kernel ? P.kernel_param * P.kernel_param : 0;
@@ -219,7 +279,7 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
 #pragma unroll
     for (int i = 0; i < GN_NSUM; i++) acc[i] = 0;
     for (int m = tid; m < T; m += blockDim.x) {
-        if (!mask[m]) continue;
+        if (!mask[m] || dbg == 60) continue;
         const double X1p = lmk[3 * m], Y1p = lmk[3 * m + 1], Z1p = lmk[3 * m + 2];
         const double* r = sh.R.r;
         const double X1c = r[0] * X1p + r[1] * Y1p + r[2] * Z1p + t1;
@@ -227,7 +287,7 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
         const double Z1c = r[6] * X1p + r[7] * Y1p + r[8] * Z1p + t3;
         const double X2c = X1c - cam.baseline;
         // S5:189-193 and 251-254 with the 28 divisions by Z1c / Z1c^2 folded into two reciprocals
-        const double iz = 1.0 / Z1c, iz2 = iz * iz;
+        const double iz = gn_rcp(Z1c), iz2 = iz * iz;
         const float pl_x = (float)(cam.l_fx * X1c * iz + cam.l_cx), pl_y = (float)(cam.l_fy * Y1c * iz + cam.l_cy);
         const float pr_x = (float)(cam.r_fx * X2c * iz + cam.r_cx), pr_y = (float)(cam.r_fy * Y1c * iz + cam.r_cy);
         double J[4][6];
@@ -257,7 +317,7 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
         const double s = ri[0] * ri[0] + ri[1] * ri[1] + ri[2] * ri[2] + ri[3] * ri[3];
         residual[m] = s;                                                        // S5:345
         double rho_p = 1, fi;
-        if (P.use_robust_kernel) { const double nn = sqrt(1 + (s * b2_1)); rho_p = 1 / nn; fi = b2 * (nn - 1); }
+        if (P.use_robust_kernel) { const double q = 1 + (s * b2_1); rho_p = gn_rsqrt(q); const double nn = q * rho_p; fi = b2 * (nn - 1); }
         else fi = 0.5 * s;
         acc[27] += fi;
         int h = 0;
@@ -305,13 +365,16 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
         for (int i = 0; i < 36; i++) bad = bad || isnan(H[i]) || isinf(H[i]);
         int ok;
         if (bad) ok = 0;
+        else if (dbg == 61 || dbg == 63) ok = 1;
         else if (dmax > 0 && chol6(H, g, dmax, x)) ok = 1;
-        else ok = solve_sym6(H, g, x);                                          // rank-deficient: pseudo-inverse path
+        else { ok = solve_sym6_from_sums(sh.tot, sh.step);                      // rank-deficient: pseudo-inverse path (out of line)
+#pragma unroll
+            for (int a = 0; a < 6; a++) x[a] = sh.step[a]; }
         sh.ok = ok;
         sh.cost = sh.tot[27];
 #pragma unroll
         for (int a = 0; a < 6; a++) { sh.step[a] = x[a]; sh.delta[a] += x[a]; }
-        if (ok) { double d6[6]; for (int a = 0; a < 6; a++) d6[a] = sh.delta[a]; rodrigues_with_derivs(d6, sh.R); }
+        if (ok && dbg != 62 && dbg != 63) { double d6[6]; for (int a = 0; a < 6; a++) d6[a] = sh.delta[a]; rodrigues_with_derivs(d6, sh.R); }
     }
     __syncthreads();
 }
@@ -434,71 +497,66 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     double pCost = 0, cCost = 0; bool done = false, abort_ = false;
     unsigned timesInc = 0; int num_it = 0, num_it_final = 0, err_code = res.error_code;
     bool first = true;
-    // ---- phase 1 (S5:549-598) ----
-    while (num_it < P.initial_max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it >= 1)) {
-        pCost = cCost;
-        if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }                // S5:296
-        eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
-        err_code = SVO_VOEC_NONE;                                                                                    // S5:299
-        cCost = sh.cost;
-        if (!sh.ok) {                                                                                                // S5:380-386, 569-573
-            if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.error_code = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.n_residual = 0; res.n_outliers = 0; }
+    // Both phases run through ONE copy of the iteration body (a second inlined copy of eval_rgn made the kernel ~100 KB of code, more
+    // than the instruction cache holds: every iteration then fetched its code again).  phase 0 = S5:549-598, phase 1 = S5:650-700;
+    // timesInc, pCost, cCost carry over from one to the other.
+    const bool cap1 = (c.debug_mode == 11) || (c.debug_mode >= 60 && c.debug_mode <= 63);
+    int n_res = 0, n_out = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        const int limit = phase ? P.max_iters : P.initial_max_iters;
+        int it = 0;
+        done = false; abort_ = false;
+        while (it < limit && !done && !abort_ && !(cap1 && it >= 1)) {
+            pCost = cCost;
+            if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }            // S5:296
+            eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, redbuf, c.debug_mode);
+            if (phase == 0) err_code = SVO_VOEC_NONE;                                                                // S5:299
+            cCost = sh.cost;
+            if (!sh.ok) {
+                if (tid == 0) {
+                    ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = phase ? num_it : it;
+                    if (phase == 0) { res.error_code = SVO_VOEC_BAD_COND_NUMBER; res.n_residual = 0; res.n_outliers = 0; }      // S5:380-386, 569-573
+                    else { res.num_it_final = it; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }      // S5:670-675 (result.error_code untouched)
+                }
+                return;
+            }
+            double m2 = 0;
+            for (int k = 0; k < 6; k++) m2 += sh.step[k] * sh.step[k];
+            if (it > 0) {
+                done = sqrt(m2) < P.min_mod_out_vector;
+                if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { err_code = phase ? SVO_VOEC_INCR_FUNC_COST_STG2 : SVO_VOEC_INCR_FUNC_COST_STG1; abort_ = true; } }
+            }
+            it++;
+            // no barrier here: eval_rgn ends with one, and thread 0 rewrites sh.* only behind the next call's two barriers
+        }
+        if (phase) { num_it_final = it; break; }
+        num_it = it;
+        // ---- keep only the inliers (S5:601-611); "outliers" receives the INLIER cur-match indices ----
+        n_res = first ? 0 : T;
+        for (int base = 0; base < n_res; base += blockDim.x) {
+            const int i = base + tid;
+            int keep = 0;
+            if (i < n_res) { if (residual[i] > P.residual_threshold) mask[i] = 0; else keep = 1; }
+            int tot;
+            const int off = block_exclusive_scan(keep, scan, &tot);
+            if (keep) outl[n_out + off] = cur_idx[i];
+            n_out += tot;
+            __syncthreads();
+        }
+        {
+            int cnt = 0;
+            for (int m = tid; m < T; m += blockDim.x) cnt += mask[m];
+            int tot; block_exclusive_scan(cnt, scan, &tot);
+            n_non_masked = tot;
+            __syncthreads();
+        }
+        if (n_non_masked < 8) {                                                                                      // S5:616-621
+            if (tid == 0) { res.valid = 0; res.num_it = num_it; res.error_code = err_code; res.n_residual = n_res; res.n_outliers = n_out; }
             return;
         }
-        double m2 = 0;
-        for (int k = 0; k < 6; k++) m2 += sh.step[k] * sh.step[k];
-        if (num_it > 0) {
-            done = sqrt(m2) < P.min_mod_out_vector;
-            if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { err_code = SVO_VOEC_INCR_FUNC_COST_STG1; abort_ = true; } }
-        }
-        num_it++;
-        // no barrier here: eval_rgn ends with one, and thread 0 rewrites sh.* only behind the next call's two barriers
-    }
-    // ---- keep only the inliers (S5:601-611); "outliers" receives the INLIER cur-match indices ----
-    const int n_res = first ? 0 : T;
-    int n_out = 0;
-    for (int base = 0; base < n_res; base += blockDim.x) {
-        const int i = base + tid;
-        int keep = 0;
-        if (i < n_res) { if (residual[i] > P.residual_threshold) mask[i] = 0; else keep = 1; }
-        int tot;
-        const int off = block_exclusive_scan(keep, scan, &tot);
-        if (keep) outl[n_out + off] = cur_idx[i];
-        n_out += tot;
+        triangulate();                                                                                               // S5:623-638
+        __threadfence_block();
         __syncthreads();
-    }
-    {
-        int cnt = 0;
-        for (int m = tid; m < T; m += blockDim.x) cnt += mask[m];
-        int tot; block_exclusive_scan(cnt, scan, &tot);
-        n_non_masked = tot;
-        __syncthreads();
-    }
-    if (n_non_masked < 8) {                                                                                          // S5:616-621
-        if (tid == 0) { res.valid = 0; res.num_it = num_it; res.error_code = err_code; res.n_residual = n_res; res.n_outliers = n_out; }
-        return;
-    }
-    triangulate();                                                                                                   // S5:623-638
-    __threadfence_block();
-    __syncthreads();
-    done = false; abort_ = false;
-    // ---- phase 2 (S5:650-700): timesInc, pCost, cCost carry over ----
-    while (num_it_final < P.max_iters && !done && !abort_ && !(c.debug_mode == 11 && num_it_final >= 1)) {
-        pCost = cCost;
-        if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }
-        eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, redbuf);
-        cCost = sh.cost;
-        if (!sh.ok) {                                                                                                // S5:670-675 (result.error_code untouched)
-            if (tid == 0) { ls.m_error = SVO_VOEC_BAD_COND_NUMBER; res.valid = 0; res.num_it = num_it; res.num_it_final = num_it_final; res.error_code = err_code; res.n_residual = T; res.n_outliers = n_out; }
-            return;
-        }
-        double m2 = 0;
-        for (int k = 0; k < 6; k++) m2 += sh.step[k] * sh.step[k];
-        if (num_it_final > 0) {
-            done = sqrt(m2) < P.min_mod_out_vector;
-            if (pCost < cCost) { if (++timesInc > (unsigned)P.max_incr_cost) { abort_ = true; err_code = SVO_VOEC_INCR_FUNC_COST_STG2; } }
-        }
-        num_it_final++;
     }
     if (tid == 0) {
         double pose[6], delta[6];
@@ -552,7 +610,7 @@ __global__ void __launch_bounds__(256) k_project_points(const float* uvu, int n,
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Rot R; rodrigues_with_derivs(dp.v, R);
+    Rot R; rodrigues_with_derivs<false>(dp.v, R);
     const double ul = (double)uvu[3 * i], vl = (double)uvu[3 * i + 1], ur = (double)uvu[3 * i + 2];
     const double cul = cam.l_cx, cvl = cam.l_cy, fl = cam.l_fx, cur = cam.r_cx, fr = cam.r_fx;
     const double disparity = fl * (cur - ur) + fr * (ul - cul);
