@@ -270,6 +270,10 @@ template <int GN_NT>
 __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
                          const double* lmk, const float* obs, double* residual, GnShared& sh, double* red, int dbg = 0)
 {
+    // Contraction ON inside the iteration (the file is compiled with -ffp-contract=off for the kernels that are compared bit for
+    // bit): stage 5 is held to the oracle by a tolerance, and a lone wave pays ~5 cycles per instruction whatever it is, so
+    // a * b + c as one v_fma_f64 instead of two instructions is a third of this function's arithmetic.
+#pragma clang fp contract(fast)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const double b2 = P.use_robust_kernel ? P.kernel_param * P.kernel_param : 0;
     const double b2_1 = P.use_robust_kernel ? 1. / b2 : 0;
