@@ -211,7 +211,7 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 
 #define GN_NSUM 28
 #define GN_NT_MAX 512        // the kernel is built for 256, 384 and 512 threads per lane (template parameter NT): SVO_GN_NT picks, see launch_gauss_newton
-#define GN_RED_BYTES ((size_t)GN_NSUM * GN_NT_MAX * sizeof(double))
+#define GN_RED_BYTES(nt) ((size_t)GN_NSUM * (nt) * sizeof(double))      // the 28 x NT reduction buffer
 struct GnShared {
     double part[4][GN_NSUM];
     double tot[GN_NSUM];
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     uint32_t* hval = hkey + 2 * PM;
     uint32_t* cellxy = hval + 2 * PM;
     // the sort/hash arrays are dead once the NMS mask exists; the same bytes then hold the 28 x GN_NT reduction buffer
-    const size_t region = (!big && (size_t)PM * 28 > GN_RED_BYTES) ? (size_t)PM * 28 : GN_RED_BYTES;
+    const size_t region = (!big && (size_t)PM * 28 > GN_RED_BYTES(GN_NT)) ? (size_t)PM * 28 : GN_RED_BYTES(GN_NT);
     unsigned char* state = smem + region;
     unsigned char* mask = state + PM;
     int* scan = (int*)(((uintptr_t)(mask + PM) + 15) & ~(uintptr_t)15);
@@ -576,19 +576,19 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     }
 }
 
-static size_t gn_smem(int pmax)
+static size_t gn_smem(int pmax, int nt)
 {
-    const size_t region = (pmax <= 4096 && (size_t)pmax * 28 > GN_RED_BYTES) ? (size_t)pmax * 28 : GN_RED_BYTES;
+    const size_t region = (pmax <= 4096 && (size_t)pmax * 28 > GN_RED_BYTES(nt)) ? (size_t)pmax * 28 : GN_RED_BYTES(nt);
     return region + (size_t)pmax * 2 + 16 + sizeof(int) * 40 + sizeof(GnShared) + 16;
 }
 
 hipError_t configure_gauss_newton(int pmax)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gauss_newton<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+    hipError_t e = hipFuncSetAttribute((const void*)k_gauss_newton<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax, 256));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_gauss_newton<384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+    e = hipFuncSetAttribute((const void*)k_gauss_newton<384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax, 384));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_gauss_newton<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax));
+    return hipFuncSetAttribute((const void*)k_gauss_newton<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax, 512));
 }
 
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
@@ -598,9 +598,9 @@ void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
     static int nt = 0;
     if (!nt) { const char* e = getenv("SVO_GN_NT"); const int v = e ? atoi(e) : 0; nt = (v == 256 || v == 384 || v == 512) ? v : 384; }
     uint8_t* big = P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr;
-    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax), st, c, P, big);
-    else if (nt == 384) hipLaunchKernelGGL(k_gauss_newton<384>, dim3(c.n_lanes), dim3(384), gn_smem(P.pmax), st, c, P, big);
-    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, big);
+    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax, 512), st, c, P, big);
+    else if (nt == 384) hipLaunchKernelGGL(k_gauss_newton<384>, dim3(c.n_lanes), dim3(384), gn_smem(P.pmax, 384), st, c, P, big);
+    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax, 256), st, c, P, big);
 }
 
 // ------------------------------------------------------------------------------------------------------------
