@@ -5,6 +5,7 @@
 // reference's m_non_max_sup (stage2_detect.cpp:296-370) + m_update_indexes (stage2_detect.cpp:65-130).
 // Every formula is the one frozen in oracle/svo_oracle.c; integer work is bit-exact by construction and the few
 // float expressions are written one IEEE operation per operator (compiled with -ffp-contract=off).
+#include <algorithm>
 #include "svo_device.h"
 #include "svo_kernels.h"
 #include "../../include/svo_orb_tables.h"
@@ -61,6 +62,17 @@ struct ImgPtrs { const uint8_t* p[2 * SVO_MAX_LANES]; };
 __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // The brute-force result words are atomicMin keys and start from all ones: filled here, ahead of the matchers of the same call
+    // (it was a launch of its own; a kernel and not hipMemsetAsync because a captured byte memset of more than 64 KB came back
+    // incomplete on graph replay: two lanes x two octaves x 2048 keypoints was the first configuration to cross that size, its pairings
+    // went wrong and the stale indices walked k_track_filter out of its tables -- test_adaptive_nms_after_fast_orb_matches_oracle[True]).  The three regions per lane-octave (left/right, track left, track
+    // right) are written by different launches, so one fill per call serves them all.
+    if (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK)) {
+        const size_t n_words = (size_t)c.n_lanes * c.oct_cap * 3 * c.max_kps, n16 = n_words / 4;
+        uint4* p16 = (uint4*)c.bf_idx;
+        for (size_t i = (size_t)t; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if ((size_t)t < n_words - 4 * n16) c.bf_idx[4 * n16 + t] = -1;
+    }
     const bool detect = flags & SVO_RUN_DETECT, do_shift = !(flags & SVO_FLAG_NO_SHIFT), repeat = flags & SVO_FLAG_REPEAT;
     if (detect) {
         if (t < c.n_img) { c.img0[t] = ptrs.p[t]; c.raw_n[t] = 0; }
@@ -1789,7 +1801,12 @@ void launch_begin_frame(const DevCtx& c, const uint8_t* const* ptrs, unsigned fl
     ImgPtrs ip;
     for (int i = 0; i < 2 * SVO_MAX_LANES; i++) ip.p[i] = (ptrs && i < c.n_img) ? ptrs[i] : nullptr;
     const int n = c.n_img * SVO_MAX_LEVELS;
-    hipLaunchKernelGGL(k_begin_frame, dim3((n + 255) / 256), dim3(256), 0, st, c, ip, flags);
+    int blocks = (n + 255) / 256;
+    if (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK)) {          // + the fill of the brute-force result words: 4 x 16 bytes per thread
+        const size_t n16 = (size_t)c.n_lanes * c.oct_cap * 3 * c.max_kps / 4;
+        blocks = std::max(blocks, (int)std::min<size_t>((n16 + 1023) / 1024, 2048));
+    }
+    hipLaunchKernelGGL(k_begin_frame, dim3(blocks), dim3(256), 0, st, c, ip, flags);
 }
 
 void launch_resize(const DevCtx& c, int level, hipStream_t st)

@@ -1199,7 +1199,9 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 // pick the model a sequential RANSAC with the 0.99-confidence stop would have returned, apply both masks
 // (S4:243-255), the consistency check (S4:282), and write tracked_pairs; then the bad-tracking gate (P:326-330)
 // and the first-frame rule (P:348-352).
-__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
+// gate_th >= 0 (single-octave contexts): the bad-tracking gate and the first-frame rule of k_track_gate, applied by this block itself
+// (one launch less per frame); gate_th < 0: k_track_gate follows, after the blocks of all octaves
+__global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, int gate_th)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* in_l = smem;                         // max_kps
@@ -1209,7 +1211,10 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
     const int vl = blockIdx.x, lane_id = vl / c.oct_cap, oct = vl % c.oct_cap, tid = threadIdx.x;
     if (oct >= c.n_oct) return;
     LaneState& ls = c.lane[lane_id];
-    if (!ls.has_prev) { if (tid == 0) c.n_tracked[vl] = 0; return; }
+    if (!ls.has_prev) {
+        if (tid == 0) { c.n_tracked[vl] = 0; if (gate_th >= 0) { svo_result& res = c.results[lane_id]; res.error_code = SVO_VOEC_FIRST_ITERATION; res.valid = 0; } }       // P:348-352
+        return;
+    }
     const int n = c.trk_nk[vl];
     // The sequential scan (records in hypothesis order, each shrinking the budget) without its serial cost: the counts
     // below rs_bound are all there; a hypothesis is a RECORD when its count exceeds every earlier one (and 7); only records
@@ -1320,6 +1325,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode)
         atomicAdd(&ts[SVO_TS_INLIERS_L], s_cnt[0]); atomicAdd(&ts[SVO_TS_INLIERS_R], s_cnt[1]);
         atomicAdd(&ts[SVO_TS_HYP_L], s_vis[0]); atomicAdd(&ts[SVO_TS_HYP_R], s_vis[1]);
         atomicAdd(&ts[SVO_TS_BOTH_MASKS], s_both); atomicAdd(&ts[SVO_TS_TRACKED], t_total);
+        if (gate_th >= 0 && t_total < gate_th) { ls.m_error = SVO_VOEC_BAD_TRACKING; c.results[lane_id].error_code = SVO_VOEC_BAD_TRACKING; }      // P:326-330
     }
 }
 
@@ -1421,23 +1427,6 @@ hipError_t configure_match(int max_kps)
     return e;
 }
 
-// The brute-force results are atomicMin keys and start from all ones.  A kernel, not hipMemsetAsync: captured into a hipGraph
-// (svo_use_graphs) a byte memset of more than 64 KB came back incomplete on replay -- two lanes x two octaves x 2048 keypoints
-// was the first configuration to cross that size, its pairings went wrong and the stale indices walked k_track_filter out of
-// its tables (tests/test_gpu_parity.py::test_adaptive_nms_after_fast_orb_matches_oracle[True]).
-__global__ void __launch_bounds__(256) k_fill_ones(uint4* p, size_t n16, int* tail, int n_tail)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n16) p[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (i < (size_t)n_tail) tail[i] = -1;
-}
-void launch_fill_ones(int* p, size_t n_words, hipStream_t st)
-{
-    const size_t n16 = n_words / 4;
-    const size_t n = n16 > 4 ? n16 : 4;
-    hipLaunchKernelGGL(k_fill_ones, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint4*)p, n16, p + 4 * n16, (int)(n_words - 4 * n16));
-}
-
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
@@ -1494,8 +1483,9 @@ void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c, win_mode);
-    hipLaunchKernelGGL(k_track_gate, dim3((c.n_lanes + 63) / 64), dim3(64), 0, st, c, bad_tracking_th);
+    const bool fold = c.oct_cap == 1;
+    hipLaunchKernelGGL(k_track_finalize, dim3(c.n_lanes * c.oct_cap), dim3(256), (size_t)c.max_kps * 2 + sizeof(int) * 32, st, c, win_mode, fold ? bad_tracking_th : -1);
+    if (!fold) hipLaunchKernelGGL(k_track_gate, dim3((c.n_lanes + 63) / 64), dim3(64), 0, st, c, bad_tracking_th);
 }
 
 // ------------------------------------------------------------------------------------------------------------

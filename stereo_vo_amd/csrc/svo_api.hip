@@ -872,7 +872,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     }
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {
-        launch_fill_ones(d.bf_idx, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps, st);      // a kernel, not hipMemsetAsync: see launch_fill_ones
+        // (the brute-force result words were set to all ones by k_begin_frame)
         if (p.match_method == SVO_SM_DESC_BF) {
             { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
             { Span s(ctx, KT_LR_FILTER); launch_match_lr_filter(d, p.enable_robust_1to1_match, p.max_y_diff, st); }
@@ -885,7 +885,6 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if (flags & SVO_RUN_TRACK) {
         const int win = p.ifm_method == SVO_IFM_DESC_WIN;
         if (!win) {
-            if (!(flags & SVO_RUN_MATCH) || p.match_method != SVO_SM_DESC_BF) launch_fill_ones(d.bf_idx, (size_t)d.n_lanes * d.oct_cap * 3 * d.max_kps, st);
             { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
             { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
         } else {                                                // ifmDescWin (stage4_match_consecutive.cpp:435-738)

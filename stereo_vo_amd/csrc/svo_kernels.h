@@ -38,7 +38,6 @@ void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, 
 void launch_half(const DevCtx& c, int level, hipStream_t st);
 void launch_fastorb_anms(const DevCtx& c, uint32_t* scratch3, hipStream_t st);     // scratch3: 3 x n_img x cand_total words
 void launch_fastorb_nms(const DevCtx& c, int do_nms, int min_distance, hipStream_t st);
-void launch_fill_ones(int* p, size_t n_words, hipStream_t st);
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st);
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st);
 void launch_track_filter(const DevCtx& c, hipStream_t st);
