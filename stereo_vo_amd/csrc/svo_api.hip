@@ -655,7 +655,13 @@ static int hamming_splits(const svo_ctx* ctx)
 static int ensure_upload(svo_ctx* ctx)
 {
     if (ctx->up_ready) return SVO_OK;
-    HIPCHECK(hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    {   // the upload stream at the highest priority: when a caller's compute stream is a high-priority one (svo_batch's detect stream),
+        // an upload queued at normal priority was scheduled behind it (host-fed batch: 21.3 k -> 16.1 k pairs/s, 52 -> 40 GB/s)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const char* e = getenv("SVO_COPY_PRIO");
+        HIPCHECK(hipStreamCreateWithPriority(&ctx->s_copy, hipStreamNonBlocking, (e && atoi(e) == 0) ? 0 : greatest));
+    }
     for (int i = 0; i < 2; i++) { HIPCHECK(hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&ctx->ev_det[i], hipEventDisableTiming)); }
     ctx->slot_bytes = (size_t)2 * ctx->cfg.n_lanes * ctx->img0_pitch_internal * ctx->cfg.max_h;
     ctx->d_img0_ring[0] = ctx->d_img0;

@@ -65,3 +65,13 @@ def test_no_cpu_fallback():
 
 def test_strerror():
     assert hip.lib().svo_strerror(0) == b"ok" and b"fallback" in hip.lib().svo_strerror(-4)
+
+
+def test_batch_config_defaults_are_the_measured_schedule():
+    """svo_batch_config_defaults: three contexts, pipelined, NMS + describe + stages 3-5 on one stream per context (post_mode 1,
+    rest_streams 0), one detect stream at high priority -- the schedule bench.py times (include/svo_batch.h)"""
+    from stereo_vo_amd import hip
+    cfg = hip.BatchConfig()
+    hip.lib().svo_batch_config_defaults(C.byref(cfg))
+    assert (cfg.n_contexts, cfg.schedule, cfg.det_priority_high, cfg.post_mode, cfg.det_streams, cfg.rest_streams) == (3, 0, 1, 1, 1, 0)
+    assert cfg.ctx.n_lanes == 64

@@ -234,3 +234,37 @@ def test_frame_parallel_across_two_ranks():
     assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
     line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
     assert line["identical_to_sequential"] is True and line["frame_parallel_ranks"] == 2 and line["valid_frames"] >= 7
+
+
+def test_every_schedule_of_the_batch_gives_the_same_records():
+    """svo_batch's knobs only move launches between streams: where the NMS / describe block runs (post_mode 0..3, incl. the split at
+    the per-level selection), how many stage 3-5 and detect streams there are, which side has the priority, pipelined or free --
+    the result records of every stream must be the same bytes under all of them (and valid)."""
+    import torch
+    from stereo_vo_amd.pipeline import StreamBatch
+    W, H, B, NC, F, STEPS = 640, 480, 6, 3, 3, 5
+    dev = torch.device("cuda", 0)
+    worlds = [SyntheticStereoWorld(W, H, 400.0, 0.12, seed=500 + s, n_frames=F, device=dev) for s in range(B)]
+    frames = [[w.render(t) for t in range(F)] for w in worlds]
+    cam = worlds[0].camera()
+    torch.cuda.synchronize()
+    p = north_star_params(hip.default_params(), orb_nfeats=600)
+    ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
+    variants = [dict(),                                                                   # the default: post on one stream per context, detect high
+                dict(post_on_rest=False, rest_streams=1, det_priority="low"),             # rounds 1-2
+                dict(post_on_rest="own"), dict(post_on_rest="select"),
+                dict(rest_streams=2, det_streams=2), dict(schedule="free")]
+    ref = None
+    for kw in variants:
+        batch = StreamBatch(p, cam, W, H, B, NC, max_kps=1024, max_cand=1 << 15, **kw)
+        for i in range(STEPS):
+            batch.step(ptrs_at[[0, 1, 2, 1, 0][i]])
+        batch.synchronize()
+        rec = batch.rec.cpu().numpy().copy()
+        res = [Result.from_buffer_copy(rec[g].tobytes()) for g in range(B)]
+        assert all(r.valid and r.status == 0 for r in res), kw
+        if ref is None:
+            ref = rec
+        else:
+            assert rec.tobytes() == ref.tobytes(), kw
+        batch.close()
