@@ -622,7 +622,7 @@ __device__ __forceinline__ void store_hypothesis(const DevCtx& c, int vl, int si
     double aF[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) aF[j] = fabs(Fv[j]);
-    const double X = (double)c.W, Y = (double)c.H, u = 3.552713678800501e-15;           // 2^-48
+    const double X = (double)c.W, Y = (double)c.H, u = 7.105427357601002e-15;           // 2^-47
     const double EB = u * (X * (aF[0] * X + aF[1] * Y + aF[2]) + Y * (aF[3] * X + aF[4] * Y + aF[5]) + (aF[6] * X + aF[7] * Y + aF[8]));
     const double EA = u * (X * (aF[0] * X + aF[3] * Y + aF[6]) + Y * (aF[1] * X + aF[4] * Y + aF[7]) + (aF[2] * X + aF[5] * Y + aF[8]));
     double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 2;
@@ -1015,7 +1015,8 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 // and the B operands (built once per block and 256 pairs in LDS, in operand layout) serve 64 hypotheses.  The step is bound by
 // VALU issue, the matrix pipe is otherwise idle: the instructions move to where there is room.
 // Exactness as in k_ransac_count_mfma: E (store_hypothesis) bounds |d - dA|, |d - dB| for coordinates inside the image whatever
-// the summation order (<= 18 roundings of the nine terms against the oracle's six: u = 2^-48 there), a side is trusted only
+// the summation order (the oracle's dA / dB carry <= 6 roundings of the nine terms, three chained matrix-core products <= 12 if
+// they are fused multiply-adds and <= 24 if products and sums round separately: 30 u_53 <= 2^-47 x 2^53 = 64, the factor there), a side is trusted only
 // when |l| >= 2^28 E, a verdict is given only when d^2 and |l|^2 differ by more than 2^-26 relatively, and everything else
 // -- a failed guard, a NaN, a borderline pair -- replays the oracle's own expression (fm_inlier).
 // Result layout of the tile (pinned on the hardware, see above): lane l = j + 16 q, register r  <->  hypothesis 4 r + q, pair j.
