@@ -33,7 +33,9 @@ def lib(native=False):
     both, so they agree bit for bit (bench.py checks that before it uses the native one)."""
     if native not in _LIB:
         path = os.path.join(_HERE, "_native", "libsvo_oracle.so") if native else os.path.join(_HERE, "libsvo_oracle.so")
-        if native or not os.path.exists(path):
+        if not native and os.environ.get("SVO_ORACLE_SO"):      # tools/oracle_sanitize.sh: the sanitizer build of the same source
+            path = os.environ["SVO_ORACLE_SO"]
+        elif native or not os.path.exists(path):
             build(native)
         L = C.CDLL(path)
         L.svo_oracle_create.restype = C.c_void_p
