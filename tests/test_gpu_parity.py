@@ -343,6 +343,12 @@ def test_cpp_estimator_demo_matches_oracle_chain(tmp_path):
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     subprocess.check_call([exe, seq, out, "500"])
     got = np.loadtxt(out)
+    # the same run configured as the reference's demo is: from its application INI (demo-main.cpp:154-167, --opt)
+    ini, out2 = tmp_path / "demo-stereo-odometry-config.ini", str(tmp_path / "camera_pose_ini.txt")
+    ini.write_text("[DETECT]\ndetect_method = 0\norb_nfeats = 500   // ORB\n[MATCH]\nmatch_method = 0\nmax_y_diff = 1.0\nenable_robust_1to1_match = true\n"
+                   "orb_max_distance = 60\n[IF-MATCH]\nif_match_method = 0\n[GENERAL]\nvo_use_matches_ids = false\n")
+    subprocess.check_call([exe, seq, out2, "--opt", str(ini)])
+    assert open(out2).read() == open(out).read()
     orc = O().Oracle(north_star_params(hip.default_params(), orb_nfeats=500))
     pose = np.eye(4); rows = []
     from stereo_vo_amd.synth import _rot_zyx
