@@ -7,6 +7,9 @@ outputs are committed as data in tests/golden/thirdparty_skimage.npz and tests/t
 them.  This narrows "parity unpinned"  for the pieces the two implementations define identically:
   * the FAST-9/16 segment test at a given threshold (corner set, and through several thresholds the corner score);
   * the intensity-centroid orientation over the radius-15 disc (same umax table as cv::ORB);
+  * brute-force Hamming matching (match_descriptors, first minimum) on 256-bit descriptors with planted ties;
+  * one x1/1.2 bilinear pyramid step (skimage.transform.resize, order 1, half-pixel centres: cv::resize INTER_LINEAR's geometry) to +-1
+    grey level away from the borders (float weights against the oracle's 11-bit fixed point, other border rule);
   * the normalised 8-point fundamental matrix with rank-2 enforcement (Hartley), for exactly eight correspondences
     (scikit-image scales to an RMS distance of sqrt 2, cv::findFundamentalMat and the oracle to a MEAN distance of sqrt 2: the
     null vector of eight exact correspondences is the same, the rank-2 projection of noisy ones is taken in slightly different
@@ -20,7 +23,8 @@ import numpy as np
 import skimage
 from skimage.feature import corner_fast, corner_orientations
 from skimage.feature.orb import OFAST_MASK
-from skimage.transform import FundamentalMatrixTransform
+from skimage.transform import FundamentalMatrixTransform, resize
+from skimage.feature import match_descriptors
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -80,5 +84,19 @@ for k in range(40):
     assert tf.estimate(p1.astype(np.float64), p2.astype(np.float64))      # dst^T F src = 0
     F_sets.append(tf.params); P1.append(p1); P2.append(p2)
 out["f8_p1"] = np.array(P1); out["f8_p2"] = np.array(P2); out["f8_F"] = np.array(F_sets)
+
+# brute-force Hamming: for every query the FIRST train row of minimum distance (numpy argmin), as cv::BFMatcher::match
+rng = np.random.RandomState(11)
+q = rng.randint(0, 2, (300, 256)).astype(bool); t = rng.randint(0, 2, (400, 256)).astype(bool)
+t[399] = t[3]; q[0] = t[3]; t[17] = t[5]; q[1] = t[5]; q[1, 0] ^= True                   # exact duplicates and a tie at distance 1
+m = match_descriptors(q, t, metric="hamming", cross_check=False)
+assert (m[:, 0] == np.arange(300)).all()
+out["ham_q"] = np.packbits(q, axis=1, bitorder="little"); out["ham_t"] = np.packbits(t, axis=1, bitorder="little"); out["ham_idx"] = m[:, 1].astype(np.int32)
+
+# one pyramid step: level 1 of image 0 (size by the oracle's rule round(dim / 1.2), passed in), bilinear, no anti-aliasing
+img = out["img0"]
+dh, dw = int(np.rint(np.float32(img.shape[0]) / np.float32(1.2))), int(np.rint(np.float32(img.shape[1]) / np.float32(1.2)))
+r = resize(img.astype(np.float64), (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True)
+out["resize_src"] = img; out["resize_dst"] = r.astype(np.float32)
 np.savez_compressed(os.path.join(HERE, "thirdparty_skimage.npz"), **out)
 print("wrote thirdparty_skimage.npz:", {k: v.shape for k, v in out.items() if k.startswith(("ori_angles", "f8_F"))})

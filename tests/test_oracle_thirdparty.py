@@ -77,3 +77,21 @@ def test_eight_point_fundamental_matrix_matches_skimage(tp):
     l = x1 @ F.T
     d = np.abs(np.sum(x2 * l, axis=1)) / np.hypot(l[:, 0], l[:, 1])
     assert d.max() < 1.0
+
+
+def test_brute_force_hamming_matches_skimage_first_minimum(tp):
+    """first minimum of the Hamming distance over the train set, ties and exact duplicates planted (cv::BFMatcher::match's rule)"""
+    idx, dist = O.hamming_bf(tp["ham_q"], tp["ham_t"])
+    assert (idx == tp["ham_idx"]).all()
+    assert idx[0] == 3 and dist[0] == 0 and idx[1] == 5 and dist[1] == 1
+
+
+def test_one_pyramid_step_matches_skimage_bilinear(tp):
+    """x1/1.2 with half-pixel centres: skimage's float bilinear against the oracle's 11-bit fixed-point weights, away from the
+    borders (clamping differs there): within one grey level everywhere, identical on the large majority of the pixels"""
+    src, want = tp["resize_src"], tp["resize_dst"]
+    dh, dw = want.shape
+    got = O.resize(src, dw, dh).astype(np.float32)
+    d = np.abs(got - want)[2:-2, 2:-2]
+    assert d.max() <= 1.0, d.max()
+    assert (np.abs(got - np.rint(want))[2:-2, 2:-2] == 0).mean() > 0.9
