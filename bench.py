@@ -171,17 +171,23 @@ def main():
                         det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams, max_kps=args.max_kps)
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
     ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
-    gathered = torch.cuda.Event()
+
+    gather_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     def step(i):
-        """One frame of every stream of this rank (stereo_vo_amd/pipeline.py), then the all-gather of the result records."""
+        """One frame of every stream of this rank (stereo_vo_amd/pipeline.py), then the all-gather of the result records.
+        N > 1: the records alternate between two buffers, so that step i + 1 of this rank does not wait for the all-gather of step i
+        (which needs every rank to have finished step i): only the buffer's previous use, two steps back, has to be over."""
+        if world > 1:
+            batch.flip_records()
+            if i >= 2:
+                batch.hold_for(gather_done[i & 1])       # the all-gather that read this buffer two steps ago
         batch.step(ptrs_at[frame_schedule(i, F)])
         if world > 1:          # the all-gather runs on torch's current stream: it waits for every context's last work
             batch.make_wait(torch.cuda.current_stream(dev))
         out = gather_records(batch.rec, world)
-        if world > 1:          # the next step's result copies must not overwrite `rec` while the all-gather still reads it
-            gathered.record(torch.cuda.current_stream(dev))
-            batch.hold_for(gathered)
+        if world > 1:
+            gather_done[i & 1].record(torch.cuda.current_stream(dev))
         return out
 
     def barrier():

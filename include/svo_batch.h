@@ -58,6 +58,10 @@ int  svo_batch_set_camera(svo_batch* b, int lane, const svo_stereo_camera* cam);
  * lane order (lane = context * lanes_per_context + lane_in_context) -- e.g. this rank's slot of an all-gather buffer.
  * NULL: a buffer of the batch's own (svo_batch_results reads it). */
 int  svo_batch_set_results_buffer(svo_batch* b, void* dev_records, size_t bytes);
+/* The same without waiting for the work in flight: takes effect for the steps enqueued AFTER the call (a step's copy is bound to the
+ * buffer when it is enqueued).  For alternating between two buffers -- step t + 1 writes one while an all-gather still reads step t's
+ * from the other; only step t + 2 has to wait for that all-gather (svo_batch_hold_for_event), which is long over by then. */
+int  svo_batch_switch_results_buffer(svo_batch* b, void* dev_records, size_t bytes);
 /* processNewImagePair for every stream: frames[lane], lane in [0, svo_batch_lanes).  `flags`: SVO_FLAG_DEVICE_IMAGES,
  * SVO_FLAG_PINNED_IMAGES or neither (pageable host images), | SVO_FLAG_BGR_IMAGES.  ENQUEUES and returns. */
 int  svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags);

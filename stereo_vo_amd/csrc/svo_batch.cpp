@@ -134,6 +134,13 @@ extern "C" int svo_batch_set_results_buffer(svo_batch* b, void* dev_records, siz
     return SVO_OK;
 }
 
+extern "C" int svo_batch_switch_results_buffer(svo_batch* b, void* dev_records, size_t bytes)
+{
+    if (!b || (dev_records && bytes < (size_t)b->B * sizeof(svo_result))) return SVO_ERR_ARG;
+    b->rec = dev_records ? (uint8_t*)dev_records : b->own_rec;
+    return SVO_OK;
+}
+
 extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags)
 {
     if (!b || !frames || (flags & ~IMG_FLAGS)) return SVO_ERR_ARG;

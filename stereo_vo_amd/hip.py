@@ -35,7 +35,7 @@ EXPORTS = [
 
 BATCH_EXPORTS = [
     "svo_batch_config_defaults", "svo_batch_create", "svo_batch_destroy", "svo_batch_last_error", "svo_batch_lanes", "svo_batch_contexts",
-    "svo_batch_context", "svo_batch_set_params", "svo_batch_set_camera", "svo_batch_set_results_buffer", "svo_batch_step",
+    "svo_batch_context", "svo_batch_set_params", "svo_batch_set_camera", "svo_batch_set_results_buffer", "svo_batch_switch_results_buffer", "svo_batch_step",
     "svo_batch_wait_on_stream", "svo_batch_hold_for_event", "svo_batch_synchronize", "svo_batch_results", "svo_batch_reset",
     "svo_fpstream_create", "svo_fpstream_destroy", "svo_fpstream_last_error", "svo_fpstream_contexts", "svo_fpstream_context",
     "svo_fpstream_last_owner", "svo_fpstream_set_params", "svo_fpstream_set_camera", "svo_fpstream_push", "svo_fpstream_synchronize",

@@ -86,6 +86,14 @@ class StreamBatch:
         fr = _frames(ptrs, self.W, self.H, self.W if stride is None else stride)
         self._ck(self.L.svo_batch_step(self.h, fr, C.c_uint32(hip.FLAG_PINNED_IMAGES if pinned_host else hip.FLAG_DEVICE_IMAGES)), "svo_batch_step")
 
+    def flip_records(self):
+        """Later steps leave their records in the OTHER of two buffers (self.rec afterwards): an all-gather may still be reading the
+        one the last step wrote (svo_batch_switch_results_buffer: no synchronisation)."""
+        if getattr(self, "_rec_alt", None) is None:
+            self._rec_alt = torch.zeros_like(self.rec)
+        self.rec, self._rec_alt = self._rec_alt, self.rec
+        self._ck(self.L.svo_batch_switch_results_buffer(self.h, C.c_void_p(self.rec.data_ptr()), C.c_size_t(self.rec.numel())), "svo_batch_switch_results_buffer")
+
     def make_wait(self, stream):
         """`stream` (torch) waits for the last step's work of every context (e.g. before an all-gather of self.rec)."""
         self._ck(self.L.svo_batch_wait_on_stream(self.h, C.c_void_p(stream.cuda_stream)), "svo_batch_wait_on_stream")
