@@ -81,11 +81,14 @@ static void rank_main(Rank* r)
     cam.l_fx = cam.l_fy = cam.r_fx = cam.r_fy = seqs[0].fx; cam.l_cx = cam.r_cx = seqs[0].cx; cam.l_cy = cam.r_cy = seqs[0].cy; cam.baseline = seqs[0].baseline; cam.ncols = W; cam.nrows = H;
     CHECK_B(svo_batch_set_camera(b, -1, &cam));
     // records of ALL ranks' streams: this rank's batch writes its slot, the all-gather fills the others
-    uint8_t* d_table = nullptr; hipStream_t s_gather = nullptr; hipEvent_t gathered = nullptr;
+    // (two tables, used alternately: step t + 1 writes the other one while the all-gather of step t -- which needs every rank to have
+    // finished step t -- still reads the first, so the ranks do not fall into lock step; only step t + 2 waits for that gather)
+    uint8_t* d_tables[2] = { nullptr, nullptr }; hipStream_t s_gather = nullptr; hipEvent_t gathered[2] = { nullptr, nullptr };
     const size_t chunk = (size_t)B * sizeof(svo_result);
-    CHECK_HIP(hipMalloc((void**)&d_table, chunk * G)); CHECK_HIP(hipMemset(d_table, 0, chunk * G));
-    CHECK_HIP(hipStreamCreateWithFlags(&s_gather, hipStreamNonBlocking)); CHECK_HIP(hipEventCreateWithFlags(&gathered, hipEventDisableTiming));
-    CHECK_B(svo_batch_set_results_buffer(b, d_table + chunk * r->rank, chunk));
+    for (int k = 0; k < 2; k++) { CHECK_HIP(hipMalloc((void**)&d_tables[k], chunk * G)); CHECK_HIP(hipMemset(d_tables[k], 0, chunk * G)); CHECK_HIP(hipEventCreateWithFlags(&gathered[k], hipEventDisableTiming)); }
+    CHECK_HIP(hipStreamCreateWithFlags(&s_gather, hipStreamNonBlocking));
+    CHECK_B(svo_batch_set_results_buffer(b, d_tables[0] + chunk * r->rank, chunk));
+    uint8_t* d_table = d_tables[0];                                   // the table the last step wrote
     std::vector<svo_frame> frames((size_t)B);
     auto fill = [&](int step) {
         for (int l = 0; l < B; l++) {
@@ -97,11 +100,17 @@ static void rank_main(Rank* r)
     };
     auto step = [&](int i) -> bool {
         fill(i);
+        const int k = i & 1;
+        if (o.rccl) {
+            d_table = d_tables[k];
+            if (svo_batch_switch_results_buffer(b, d_table + chunk * r->rank, chunk) < 0) { r->err = "svo_batch_switch_results_buffer"; return false; }
+            if (i >= 2 && svo_batch_hold_for_event(b, gathered[k]) < 0) { r->err = "ordering the step behind the gather that read its table"; return false; }
+        }
         if (svo_batch_step(b, frames.data(), SVO_FLAG_DEVICE_IMAGES) < 0) { r->err = std::string("svo_batch_step: ") + svo_batch_last_error(b); return false; }
         if (o.rccl) {
             if (svo_batch_wait_on_stream(b, s_gather) < 0) { r->err = "svo_batch_wait_on_stream"; return false; }
             if (svo_group_allgather_inplace(r->group, r->rank, d_table, chunk * G, s_gather) != SVO_OK) { r->err = std::string("svo_group_allgather_inplace: ") + svo_group_last_error(r->group); return false; }
-            if (hipEventRecord(gathered, s_gather) != hipSuccess || svo_batch_hold_for_event(b, gathered) < 0) { r->err = "ordering the next step behind the gather"; return false; }
+            if (hipEventRecord(gathered[k], s_gather) != hipSuccess) { r->err = "recording the gather"; return false; }
         }
         return true;
     };
@@ -148,7 +157,7 @@ static void rank_main(Rank* r)
     }
     svo_batch_destroy(b);
     for (uint8_t* d : d_seq) (void)hipFree(d);
-    (void)hipFree(d_table); (void)hipStreamDestroy(s_gather); (void)hipEventDestroy(gathered);
+    for (int k = 0; k < 2; k++) { (void)hipFree(d_tables[k]); (void)hipEventDestroy(gathered[k]); } (void)hipStreamDestroy(s_gather);
     r->rc = 0;
 }
 
