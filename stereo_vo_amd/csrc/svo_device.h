@@ -93,7 +93,19 @@ struct DevCtx {
     uint8_t* gn_scratch;      // the same for k_gauss_newton
     FastDiv div_tiles;        // / n_tiles
     int fast_th, orb_th;
-    int debug_mode;           // SVO_DEBUG_MODE env (kernel ablations while tuning; 0 in production)
+    int debug_mode;           // SVO_DEBUG_MODE in the environment of svo_create; 0 in production.  Timing ablations (results are then
+                              // meaningless) and forced kernel forms (results unchanged: the parity tests run them):
+                              //   1 / 2 / 3 / 4  k_fast returns after staging / compaction / scores, or publishes nothing
+                              //   5 / 6 / 7      k_resize without staging / without the blend / without the store
+                              //   8              linear (not XCD-chunked) tile orders              [results unchanged]
+                              //   9              detector order: describe every raw keypoint, then NMS   [results unchanged]
+                              //   10 / 11        k_gauss_newton returns after its set-up / runs one iteration per phase
+                              //   12             no speculative FAST threshold                     [results unchanged]
+                              //   13 / 16        RANSAC count replays every verdict / never stops early   [results unchanged]
+                              //   14, 50-54      forced RANSAC kernel forms (k_match.hip launchers)        [results unchanged]
+                              //   21-26          k_nms_rowsort returns after a phase (tests/dev/nms_breakdown.py)
+                              //   31, 41-45      k_select / k_select_sort return after a phase
+                              //   60-63          k_gauss_newton without its per-track loop / solve / rotation update (tests/dev/gn_breakdown.py)
     long long pyr_bytes;
     LevelGeom lv[SVO_MAX_LEVELS];
     // buffers
