@@ -29,6 +29,7 @@ def test_batch_scheduler_exports_every_declared_symbol():
     for name in declared:
         assert getattr(L, name) is not None
     assert L.svo_batch_lanes(None) < 0 and L.svo_batch_create(None, None) < 0 and L.svo_fpstream_push(None, None, 0) < 0
+    assert L.svo_batch_switch_results_buffer(None, None, 0) < 0 and L.svo_batch_set_results_buffer(None, None, 0) < 0
 
 
 def test_rccl_companion_exports_every_declared_symbol():
