@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--det-priority", default="high", choices=["low", "high"], help="which side of the pipelined schedule gets the high HIP stream priority: 'high' (default) = the detect stream, the serial chain of a step once the NMS, the description and stages 3-5 run on one stream per context (66.4 k against 64.9 k pairs/s); 'low' = the stage 3-5 streams (the better choice when ONE stream carries all of them: 53.3 k vs 47.1 k in round 2)")
     ap.add_argument("--det-streams", type=int, default=1, help="HIP streams the detect phases of the contexts alternate over (pipelined schedule)")
     ap.add_argument("--rest-streams", type=int, default=0, help="HIP streams stages 3-5 of the contexts alternate over (pipelined schedule); 0 = one per context")
+    ap.add_argument("--detect-ahead", type=int, default=1, help="1 (default): a context's detector of frame t + 1 starts once the description of frame t has read the detector's scratch (it overlaps that context's own stages 3-5); 0: it waits for the whole frame t (rounds 1-3)")
     ap.add_argument("--max-kps", type=int, default=4096, help="keypoint capacity per image of the contexts (svo_config.max_kps)")
     ap.add_argument("--scene", default="planes", choices=["planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): planes = wall + ground + facades (every earlier round's numbers), relief = the same plus 28 billboards at 4..22 m (non-planar depth)")
     ap.add_argument("--relief-lanes", type=int, default=16, help="N=1, config2: streams of the extra leg on the OTHER scene type (reported as `other_scene`: pass-through counters and pose error against ground truth beside the timed scene's); 0 = skip")
@@ -168,7 +169,7 @@ def main():
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
     NC = max(1, args.contexts)
     batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else ("select" if args.post_on_rest == 3 else bool(args.post_on_rest))),
-                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams, max_kps=args.max_kps)
+                        det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams, max_kps=args.max_kps, detect_ahead=bool(args.detect_ahead))
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
     ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
 

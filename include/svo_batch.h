@@ -41,6 +41,9 @@ typedef struct svo_batch_config {
                                  WITH the per-level selection (top-K, Harris, sort): the detect stream keeps the pyramid and the FAST kernel only */
     int32_t det_streams;      /* >= 1: detect phases of consecutive contexts alternate over this many streams (default 1) */
     int32_t rest_streams;     /* >= 1: stages 3-5 of consecutive contexts alternate over this many streams; 0 (default): one per context */
+    int32_t no_detect_ahead;  /* 0 (default): with post_mode 1 / 3 the detector of a context's next frame starts as soon as the description of
+                                 its current frame has read the detector's scratch (SVO_FLAG_DETECT_AHEAD, svo_record_after_post), i.e. it
+                                 overlaps that context's own stages 3-5; 1: it waits for the whole frame, as rounds 1-3 did */
 } svo_batch_config;
 
 void svo_batch_config_defaults(svo_batch_config* c);
@@ -67,7 +70,8 @@ int  svo_batch_switch_results_buffer(svo_batch* b, void* dev_records, size_t byt
 int  svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags);
 /* make the caller's hipStream_t wait for the last step's work of every context (e.g. before an all-gather of the records) */
 int  svo_batch_wait_on_stream(svo_batch* b, void* stream);
-/* the NEXT step's result copies wait for this hipEvent_t (e.g. the all-gather that still reads the records buffer) */
+/* the NEXT step's result copies -- and nothing ahead of them in that step -- wait for this hipEvent_t (e.g. the all-gather that
+ * still reads the records buffer); one event, consumed by that step */
 int  svo_batch_hold_for_event(svo_batch* b, void* event);
 int  svo_batch_synchronize(svo_batch* b);
 int  svo_batch_results(svo_batch* b, svo_result* res /* svo_batch_lanes() entries */);    /* implies svo_batch_synchronize */

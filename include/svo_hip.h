@@ -51,6 +51,14 @@ enum {
     SVO_FLAG_DETECT_SPLIT_AT_SELECT = 2048, /* moves the split point of SVO_FLAG_DETECT_NO_POST / SVO_RUN_DETECT_POST forward: the detect call stops
                                     after the FAST kernel (pyramid + corner candidates: the throughput half), and the post call
                                     starts with the per-level selection (top-K, Harris, sort) -- pass it to BOTH calls; ORB mode only */
+    SVO_FLAG_DETECT_AHEAD = 4096, /* a detect call that may run AHEAD of the stages 3-5 of the frame before it (svo_batch's pipelined
+                                    schedule, round 4).  With SVO_RUN_DETECT | SVO_FLAG_DETECT_NO_POST: the call writes the detector's
+                                    per-image scratch ONLY (level-0 pointer table, pyramid, candidates, per-level winners) -- no lane
+                                    state, no result record, no status word; capacity bits it raises are staged.  The matching
+                                    SVO_RUN_DETECT_POST call carries the flag too and is issued WITHOUT SVO_FLAG_NO_SHIFT: it runs the
+                                    prev/cur shift of P:86-100, clears the record and folds the staged bits in.  Everything the ahead
+                                    call overwrites is last read by the post-processing of the previous frame: svo_record_after_post
+                                    hands the caller an event for exactly that point */
     SVO_FLAG_PINNED_IMAGES = 1024 /* svo_image.data are PAGE-LOCKED host pointers (svo_host_alloc / svo_host_register): the upload is
                                     enqueued on the context's copy stream and svo_process returns without waiting for it; the
                                     images must stay untouched until svo_wait_upload (or svo_wait) returns.  Without this flag host
@@ -114,6 +122,11 @@ int svo_get_orb_threshold(const svo_ctx* ctx);
  * context-owned events recorded behind the work, never on the stream handle. */
 int svo_set_stream(svo_ctx* ctx, void* stream);
 int svo_get_device(const svo_ctx* ctx);           /* HIP device ordinal of the context (svo_config.device); < 0 on error */
+/* Arms ONE hipEvent_t: the next svo_process call that runs the detector's post-processing (SVO_RUN_DETECT_POST, or SVO_RUN_DETECT
+ * without SVO_FLAG_DETECT_NO_POST) records it on its stream right behind the last kernel that reads the detector's per-image
+ * scratch (NMS / row sort + description), i.e. BEFORE stages 3-5 of the same call.  A detect call with SVO_FLAG_DETECT_AHEAD for
+ * the next frame need wait for nothing later.  (Inside a hipGraph replay the event is recorded behind the whole graph.) */
+int svo_record_after_post(svo_ctx* ctx, void* event);
 /* the hipStream_t later calls enqueue on (so that a caller can order its own work -- an RCCL call, an event -- after a frame) */
 int svo_get_stream(svo_ctx* ctx, void** stream);
 /* request_data.stereo_cam (H:211), per lane; lane = -1 sets every lane */

@@ -218,6 +218,42 @@ def orb_angle(img, x, y):
     return float(L.svo_oracle_orb_angle(_ptr(img, u8p), img.shape[1], int(x), int(y), None))
 
 
+def steered_brief(blurred, x, y, angle_deg):
+    """the 256 steered tests alone (cv::ORB's computeOrbDescriptor) on an ALREADY blurred image; angle in degrees (float32)"""
+    img = _img(blurred)
+    d = np.zeros(32, np.uint8)
+    f = lib().svo_oracle_steered_brief
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    f(img.ctypes.data, img.shape[1], int(x), int(y), float(np.float32(angle_deg)), d.ctypes.data)
+    return d
+
+
+def sincosf(x):
+    """the frozen single-precision (sin, cos) of the steering"""
+    f = lib().svo_oracle_sincosf
+    f.restype = None
+    f.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    s, c = C.c_float(), C.c_float()
+    f(float(np.float32(x)), C.byref(s), C.byref(c))
+    return float(s.value), float(c.value)
+
+
+def harris(img, x, y):
+    """cv::ORB's HarrisResponses at one position (7 x 7 block, k = 0.04)"""
+    img = _img(img)
+    f = lib().svo_oracle_harris
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return float(f(img.ctypes.data, img.shape[1], int(x), int(y)))
+
+
+def level_quota(nfeatures, nlevels):
+    q = (C.c_int * nlevels)()
+    lib().svo_oracle_level_quota(int(nfeatures), int(nlevels), q)
+    return list(q)
+
+
 def pyramid_sizes(w, h, nlevels):
     lw = (C.c_int * nlevels)()
     lh = (C.c_int * nlevels)()
@@ -309,6 +345,16 @@ def ransac_fundamental(p1, p2):
     nu = C.c_int(0)
     cnt = lib().svo_oracle_ransac_fundamental(_ptr(p1, f32p), _ptr(p2, f32p), n, _ptr(mask, u8p), _ptr(F, f64p), C.byref(bh), C.byref(nu))
     return cnt, mask[:n].copy(), F.reshape(3, 3), bh.value, nu.value
+
+
+def seven_point(p1, p2):
+    """the models (1 or 3, 3x3 each) of the 7-point algorithm for the first seven correspondences"""
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    assert len(p1) >= 7 and len(p2) >= 7
+    F = np.zeros(27, np.float64)
+    n = lib().svo_oracle_seven_point(_ptr(p1, f32p), _ptr(p2, f32p), _ptr(F, f64p))
+    return F.reshape(3, 3, 3)[:n].copy()
 
 
 def track(params, orb_th, pkl, pdl, pkr, pdr, pm, pri, ckl, cdl, ckr, cdr, cm, cri, img_w, img_h):

@@ -285,15 +285,16 @@ static float harris_response(const uint8_t* img, int stride, int x, int y)
             int Iy = ((int)p[stride] - (int)p[-stride]) * 2 + ((int)p[stride - 1] - (int)p[-stride - 1]) + ((int)p[stride + 1] - (int)p[-stride + 1]);
             a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
         }
+    /* cv::ORB's HarrisResponses, operator for operator: scale = 1.f / ((1 << 2) * blockSize * 255.f), scale_sq_sq = scale * scale * scale * scale
+     * (left to right), response = ((float)a * b - (float)c * c - harris_k * ((float)a + b) * ((float)a + b)) * scale_sq_sq */
     const float s = 1.0f / (4.0f * 7.0f * 255.0f);
-    const float s2 = s * s;
-    const float s4 = s2 * s2;
+    const float s4 = s * s * s * s;
     const float fa = (float)a, fb = (float)b, fc = (float)c;
-    const float det = fa * fb - fc * fc;
     const float tr = fa + fb;
-    const float k = 0.04f * (tr * tr);
-    return (det - k) * s4;
+    return (fa * fb - fc * fc - 0.04f * tr * tr) * s4;
 }
+
+float svo_oracle_harris(const uint8_t* img, int stride, int x, int y) { return harris_response(img, stride, x, y); }
 
 /* polynomial atan2 in degrees, 0..360 (the classic 7th-order minimax fit used by fast image-processing
  * libraries; ~0.3 deg max error).  One IEEE float operation per operator. */
@@ -315,6 +316,49 @@ static float atan2_deg(float y, float x)
     return a;
 }
 
+/* [frozen] sine and cosine of a float angle in [0, 2 pi] in single precision, one IEEE operation per operator (+ - * only, so that
+ * the device computes the same bits): Cody-Waite reduction by pi/2 in three parts, then the Cephes single-precision minimax
+ * polynomials on |r| <= pi/4.  Stands in for `(float)cos(angle), (float)sin(angle)` of cv::ORB's computeOrbDescriptor: within one
+ * unit in the last place of the correctly rounded value (tests/test_oracle_units.py), i.e. a sample coordinate moves by < 2e-6 px. */
+void svo_oracle_sincosf(float x, float* sn, float* cs)
+{
+    const int k = (int)(x * 0.63661977f + 0.5f);                     /* nearest multiple of pi/2: 0..4 */
+    const float fk = (float)k;
+    const float r = ((x - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    switch (k & 3) {
+    case 0: *sn = sp; *cs = cp; break;
+    case 1: *sn = cp; *cs = -sp; break;
+    case 2: *sn = -sp; *cs = -cp; break;
+    default: *sn = -cp; *cs = sp; break;
+    }
+}
+
+/* cv::ORB per keypoint (OpenCV >= 2.4 orb.cpp): IC_Angle -- integer moments over the radius-15 disc, angle = fastAtan2(m01, m10) --
+ * and computeOrbDescriptor on the level blurred by GaussianBlur(7x7, sigma 2): the 256 pairs of bit_pattern_31_ rotated by the
+ * CONTINUOUS angle (a = cos, b = sin of angle * (float)(CV_PI / 180); x = px * a - py * b, y = px * b + py * a in float, cvRound =
+ * round half to even), bit i = blurred(p0) < blurred(p1), LSB first.  Only the (2 * 18 + 1)^2 blurred pixels a rotated pair can
+ * reach are computed, from the (2 * 21 + 1)^2 raw window; keypoints keep 31 px from every border, so no border rule is involved.
+ * Blur: 8-bit fixed point of cv::sepFilter2D's CV_8U path -- taps cvRound(256 g), both passes in integers, one rounding
+ * (sum + 2^15) >> 16, saturated. */
+#define DESC_R SVO_BRIEF_REACH
+#define DESC_W (2 * DESC_R + 1)
+/* computeOrbDescriptor's sampling: `center` points at the keypoint in a blurred image of row pitch `stride` */
+static void steered_brief(const uint8_t* center, int stride, float angle_deg, uint8_t* desc)
+{
+    float a, b;
+    svo_oracle_sincosf(angle_deg * 0.017453292f, &b, &a);          /* angle *= (float)(CV_PI / 180.f); a = cos, b = sin */
+    memset(desc, 0, SVO_DESC_BYTES);
+    for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) {
+        const int8_t* pr = svo_brief_pat[i];
+        const float x0 = (float)pr[0] * a - (float)pr[1] * b, y0 = (float)pr[0] * b + (float)pr[1] * a;
+        const float x1 = (float)pr[2] * a - (float)pr[3] * b, y1 = (float)pr[2] * b + (float)pr[3] * a;
+        const int t0 = center[(int)lrintf(y0) * stride + (int)lrintf(x0)], t1 = center[(int)lrintf(y1) * stride + (int)lrintf(x1)];
+        if (t0 < t1) desc[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+}
 static void orb_angle_desc(const uint8_t* img, int stride, int x, int y, float* angle_out, uint8_t* desc)
 {
     const uint8_t* c = img + (size_t)y * stride + x;
@@ -326,34 +370,34 @@ static void orb_angle_desc(const uint8_t* img, int stride, int x, int y, float* 
     }
     float angle = atan2_deg((float)m01, (float)m10);
     *angle_out = angle;
-    int bin = (int)(angle * (1.0f / 12.0f) + 0.5f);
-    if (bin >= SVO_BRIEF_NBINS) bin -= SVO_BRIEF_NBINS;
-    /* 7x7 sigma=2 integer Gaussian of the 31x31 patch (separable, exact integer sums, one rounding) */
-    int tmp[37][31];
-    uint8_t bl[31][31];
-    for (int r = 0; r < 37; r++)
-        for (int q = 0; q < 31; q++) {
-            const uint8_t* p = c + (r - 18) * stride + (q - 15);
+    int tmp[DESC_W + 6][DESC_W];
+    uint8_t bl[DESC_W][DESC_W];
+    for (int r = 0; r < DESC_W + 6; r++)
+        for (int q = 0; q < DESC_W; q++) {
+            const uint8_t* p = c + (r - DESC_R - 3) * stride + (q - DESC_R);
             int s = 0;
             for (int k = 0; k < 7; k++) s += svo_gauss7[k] * p[k - 3];
             tmp[r][q] = s;
         }
-    for (int r = 0; r < 31; r++)
-        for (int q = 0; q < 31; q++) {
+    for (int r = 0; r < DESC_W; r++)
+        for (int q = 0; q < DESC_W; q++) {
             int s = 0;
             for (int k = 0; k < 7; k++) s += svo_gauss7[k] * tmp[r + k][q];
-            bl[r][q] = (uint8_t)((s + 32768) >> 16);
+            s = (s + 32768) >> 16;
+            bl[r][q] = (uint8_t)(s > 255 ? 255 : s);
         }
-    memset(desc, 0, SVO_DESC_BYTES);
-    for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) {
-        const int8_t* pr = svo_brief_rot[bin][i];
-        int a = bl[pr[1] + 15][pr[0] + 15], b = bl[pr[3] + 15][pr[2] + 15];
-        if (a < b) desc[i >> 3] |= (uint8_t)(1u << (i & 7));
-    }
+    steered_brief(&bl[DESC_R][DESC_R], DESC_W, angle, desc);
+}
+
+/* the steering alone, on an image that is ALREADY blurred (third-party cross-check against scikit-image's _orb_loop, which applies
+ * the same table with the same rotation to whatever image it is given); (x, y) must keep 18 pixels from every border */
+void svo_oracle_steered_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t* desc32)
+{
+    steered_brief(blurred + (size_t)y * stride + x, stride, angle_deg, desc32);
 }
 
 /* orientation (degrees, [0, 360)) and steered BRIEF-256 of ONE position: the per-keypoint step of stage 2 on its own, for the
- * third-party cross-check (tests/test_oracle_thirdparty.py).  (x, y) must keep 18 pixels from every border. */
+ * third-party cross-check (tests/test_oracle_thirdparty.py).  (x, y) must keep 21 pixels from every border. */
 float svo_oracle_orb_angle(const uint8_t* img, int stride, int x, int y, uint8_t* desc32)
 {
     float a = 0.f; uint8_t d[32];
@@ -372,6 +416,8 @@ static void orb_level_quota(int nfeatures, int nlevels, int* q)
     for (int l = 0; l < nlevels - 1; l++) { q[l] = (int)lrintf(nd); sum += q[l]; nd *= factor; }
     q[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
 }
+
+void svo_oracle_level_quota(int nfeatures, int nlevels, int* q) { orb_level_quota(nfeatures, nlevels, q); }
 
 int svo_oracle_orb_detect(const uint8_t* img, int w, int h, int stride, int nfeatures, int nlevels,
                           int fast_th, svo_keypoint* kps, uint8_t* desc, int cap)
@@ -749,97 +795,129 @@ static void ransac_sample(int h, int n, int* idx)
 {
     uint64_t s = splitmix64(RANSAC_SEED + (uint64_t)h);
     if (!s) s = 1;
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < 7; j++) {                 /* the minimal sample of cv::findFundamentalMat's RANSAC: modelPoints = 7 */
         int v, dup;
         do { v = (int)((uint32_t)(xs64star(&s) >> 32) % (uint32_t)n); dup = 0; for (int k = 0; k < j; k++) if (idx[k] == v) dup = 1; } while (dup);
         idx[j] = v;
     }
 }
 
-/* Rank-2 enforcement of a (normalised) 3x3 fundamental matrix f, row-major [frozen]: cv::findFundamentalMat returns rank-2
- * models (its 7-point solver by construction, its 8-point solver by zeroing the smallest singular value, S4:202, 237).  Zeroing
- * the smallest singular value is f <- f (I - v v^T) with v the right singular vector of the smallest singular value, i.e. the
- * eigenvector of S = f^T f for its smallest eigenvalue.  That eigenvalue is the smallest root of the characteristic cubic
- * q(t) = t^3 - c2 t^2 + c1 t - c0; S is positive semi-definite, so q is increasing and concave left of it and Newton's
- * iteration from t = 0 climbs to it monotonically (eight fixed steps; quadratic convergence).  v is the cross product of two
- * rows of S - t I, the pair with the largest norm (first maximum).  +, -, *, / only, one IEEE operation per operator: the HIP
- * kernel repeats the expressions verbatim and both sides get the same bits.  A degenerate f (double smallest root, zero
- * matrix) yields 0 / 0 = NaN entries; fm_inlier then counts no inliers for that hypothesis, on both sides alike. */
-static void rank2_enforce(double* f)
+/* The 7-point algorithm (cv::findFundamentalMat's run7Point, what its RANSAC solves per sample: S4:202, 237): the seven epipolar
+ * constraints leave a two-dimensional null space {f1, f2}; det(lambda (f1 - f2) + f2) = 0 is a cubic in lambda with one or three
+ * real roots, each a rank-2 fundamental matrix.  OpenCV takes the null space from an SVD of the raw-pixel system and the roots
+ * from Cardano's formulas (acos / cos / cbrt); the MODELS do not depend on either choice -- the set {F : F in the null space,
+ * det F = 0} is what it is, in whatever basis and coordinates -- so they are computed here in a form the device can repeat bit for
+ * bit: Hartley-normalised coordinates (conditioning only; the solutions map back exactly), Gauss-Jordan with full pivoting for the
+ * null space, and for the cubic Newton's iteration from a guaranteed upper bound of its largest-magnitude root (convex side:
+ * monotone, quadratic), deflation, and two polishing steps on the other two roots.  +, -, *, /, sqrt only, one IEEE operation per
+ * operator.  Returns the number of models (1 or 3), written to Fm[3][9] in the order: root of largest magnitude (of the depressed
+ * cubic), then (-t1 + sqrt D) / 2, (-t1 - sqrt D) / 2.  A degenerate sample yields NaN entries: no inliers, on both sides alike. */
+static double cbrt_rough(double x)          /* x >= 0: within ~4 % of the cube root (exponent / 3 on the bit pattern: integer arithmetic) */
 {
-    const double s00 = (f[0] * f[0] + f[3] * f[3]) + f[6] * f[6], s01 = (f[0] * f[1] + f[3] * f[4]) + f[6] * f[7], s02 = (f[0] * f[2] + f[3] * f[5]) + f[6] * f[8];
-    const double s11 = (f[1] * f[1] + f[4] * f[4]) + f[7] * f[7], s12 = (f[1] * f[2] + f[4] * f[5]) + f[7] * f[8], s22 = (f[2] * f[2] + f[5] * f[5]) + f[8] * f[8];
-    const double c2 = (s00 + s11) + s22;
-    const double m00 = s11 * s22 - s12 * s12, m11 = s00 * s22 - s02 * s02, m22 = s00 * s11 - s01 * s01;
-    const double c1 = (m00 + m11) + m22;
-    const double c0 = (s00 * m00 - s01 * (s01 * s22 - s12 * s02)) + s02 * (s01 * s12 - s11 * s02);
-    double t = 0.0;
-    for (int it = 0; it < 8; it++) {
-        const double q = ((t - c2) * t + c1) * t - c0, dq = (3.0 * t - 2.0 * c2) * t + c1;
-        if (!(dq > 0.0)) break;
-        t = t - q / dq;
-    }
-    const double a00 = s00 - t, a11 = s11 - t, a22 = s22 - t;
-    /* rows r0 = (a00 s01 s02), r1 = (s01 a11 s12), r2 = (s02 s12 a22) */
-    const double x0 = s01 * s12 - s02 * a11, y0 = s02 * s01 - a00 * s12, z0 = a00 * a11 - s01 * s01;       /* r0 x r1 */
-    const double x1 = s01 * a22 - s02 * s12, y1 = s02 * s02 - a00 * a22, z1 = a00 * s12 - s01 * s02;       /* r0 x r2 */
-    const double x2 = a11 * a22 - s12 * s12, y2 = s12 * s02 - s01 * a22, z2 = s01 * s12 - a11 * s02;       /* r1 x r2 */
-    const double n0 = (x0 * x0 + y0 * y0) + z0 * z0, n1 = (x1 * x1 + y1 * y1) + z1 * z1, n2 = (x2 * x2 + y2 * y2) + z2 * z2;
-    double vx = x0, vy = y0, vz = z0, nn = n0;
-    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
-    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
-    for (int r = 0; r < 3; r++) {
-        const double w = ((f[3 * r] * vx + f[3 * r + 1] * vy) + f[3 * r + 2] * vz) / nn;
-        f[3 * r] = f[3 * r] - w * vx; f[3 * r + 1] = f[3 * r + 1] - w * vy; f[3 * r + 2] = f[3 * r + 2] - w * vz;
-    }
+    union { double d; uint64_t u; } v; v.d = x;
+    v.u = ((v.u >> 32) / 3u + 715094163u) << 32;
+    return v.d;
 }
 
-/* normalised linear 8-point solution (Hartley) through the null vector of the 8x9 system, found by
- * Gauss-Jordan elimination with full pivoting, then made rank 2 (rank2_enforce) before it is denormalised. */
-static void eight_point(const float* p1, const float* p2, const int* s, double* F)
+static int seven_point(const float* p1, const float* p2, const int* s, double* Fm)
 {
     double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
-    for (int i = 0; i < 8; i++) { c1x += (double)p1[2 * s[i]]; c1y += (double)p1[2 * s[i] + 1]; c2x += (double)p2[2 * s[i]]; c2y += (double)p2[2 * s[i] + 1]; }
-    c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
+    for (int i = 0; i < 7; i++) { c1x += (double)p1[2 * s[i]]; c1y += (double)p1[2 * s[i] + 1]; c2x += (double)p2[2 * s[i]]; c2y += (double)p2[2 * s[i] + 1]; }
+    c1x = c1x / 7.0; c1y = c1y / 7.0; c2x = c2x / 7.0; c2y = c2y / 7.0;
     double d1 = 0, d2 = 0;
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 7; i++) {
         double ax = (double)p1[2 * s[i]] - c1x, ay = (double)p1[2 * s[i] + 1] - c1y;
         double bx = (double)p2[2 * s[i]] - c2x, by = (double)p2[2 * s[i] + 1] - c2y;
         d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
     }
-    const double s1 = 11.313708498984761 / d1;    /* sqrt(2) / (d1/8) */
-    const double s2 = 11.313708498984761 / d2;
-    double A[8][9];
-    for (int i = 0; i < 8; i++) {
+    const double s1 = 9.8994949366116654 / d1;    /* sqrt(2) / (d1 / 7) */
+    const double s2 = 9.8994949366116654 / d2;
+    double A[7][9];
+    for (int i = 0; i < 7; i++) {
         double x1 = ((double)p1[2 * s[i]] - c1x) * s1, y1 = ((double)p1[2 * s[i] + 1] - c1y) * s1;
         double x2 = ((double)p2[2 * s[i]] - c2x) * s2, y2 = ((double)p2[2 * s[i] + 1] - c2y) * s2;
         A[i][0] = x2 * x1; A[i][1] = x2 * y1; A[i][2] = x2; A[i][3] = y2 * x1; A[i][4] = y2 * y1; A[i][5] = y2; A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
     }
     int perm[9]; for (int j = 0; j < 9; j++) perm[j] = j;
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 7; k++) {
         double best = -1.0; int pi = k, pj = k;
-        for (int i = k; i < 8; i++) for (int j = k; j < 9; j++) { double v = fabs(A[i][j]); if (v > best) { best = v; pi = i; pj = j; } }
+        for (int i = k; i < 7; i++) for (int j = k; j < 9; j++) { double v = fabs(A[i][j]); if (v > best) { best = v; pi = i; pj = j; } }
         if (pi != k) for (int j = 0; j < 9; j++) { double t = A[k][j]; A[k][j] = A[pi][j]; A[pi][j] = t; }
-        if (pj != k) { for (int i = 0; i < 8; i++) { double t = A[i][k]; A[i][k] = A[i][pj]; A[i][pj] = t; } int t = perm[k]; perm[k] = perm[pj]; perm[pj] = t; }
+        if (pj != k) { for (int i = 0; i < 7; i++) { double t = A[i][k]; A[i][k] = A[i][pj]; A[i][pj] = t; } int t = perm[k]; perm[k] = perm[pj]; perm[pj] = t; }
         const double piv = A[k][k];
         for (int j = k; j < 9; j++) A[k][j] = A[k][j] / piv;
-        for (int i = 0; i < 8; i++) { if (i == k) continue; const double f = A[i][k]; for (int j = k; j < 9; j++) A[i][j] = A[i][j] - f * A[k][j]; }
+        for (int i = 0; i < 7; i++) { if (i == k) continue; const double f = A[i][k]; for (int j = k; j < 9; j++) A[i][j] = A[i][j] - f * A[k][j]; }
     }
-    double f[9];
-    f[perm[8]] = 1.0;
-    for (int i = 0; i < 8; i++) f[perm[i]] = -A[i][8];
-    rank2_enforce(f);
-    /* F = T2^T * F0 * T1 */
+    /* null space: the two free unknowns sit at positions 7 and 8; g = f1 - f2 (run7Point's "f1[i] -= f2[i]") */
+    double g[9], f2[9];
+    g[perm[7]] = 1.0; g[perm[8]] = -1.0; f2[perm[7]] = 0.0; f2[perm[8]] = 1.0;
+    for (int i = 0; i < 7; i++) { f2[perm[i]] = -A[i][8]; g[perm[i]] = A[i][8] - A[i][7]; }
+    /* det(lambda g + f2) = a3 lambda^3 + a2 lambda^2 + a1 lambda + a0, by cofactors along the first row */
+    const double g00 = g[4] * g[8] - g[5] * g[7], g01 = g[3] * g[8] - g[5] * g[6], g02 = g[3] * g[7] - g[4] * g[6];
+    const double h00 = f2[4] * f2[8] - f2[5] * f2[7], h01 = f2[3] * f2[8] - f2[5] * f2[6], h02 = f2[3] * f2[7] - f2[4] * f2[6];
+    /* mixed minors: d/d(lambda) of the 2x2 minors at lambda = 0 */
+    const double m00 = (g[4] * f2[8] + f2[4] * g[8]) - (g[5] * f2[7] + f2[5] * g[7]);
+    const double m01 = (g[3] * f2[8] + f2[3] * g[8]) - (g[5] * f2[6] + f2[5] * g[6]);
+    const double m02 = (g[3] * f2[7] + f2[3] * g[7]) - (g[4] * f2[6] + f2[4] * g[6]);
+    const double a3 = (g[0] * g00 - g[1] * g01) + g[2] * g02;
+    const double a0 = (f2[0] * h00 - f2[1] * h01) + f2[2] * h02;
+    const double a2 = ((f2[0] * g00 - f2[1] * g01) + f2[2] * g02) + ((g[0] * m00 - g[1] * m01) + g[2] * m02);
+    const double a1 = ((g[0] * h00 - g[1] * h01) + g[2] * h02) + ((f2[0] * m00 - f2[1] * m01) + f2[2] * m02);
+    /* monic, then depressed: lambda = t - A / 3,  t^3 + p t + q = 0 */
+    const double Am = a2 / a3, Bm = a1 / a3, Cm = a0 / a3;
+    const double sh = Am / 3.0;
+    const double p = Bm - Am * sh;
+    const double q = ((2.0 * sh) * sh) * sh - sh * Bm + Cm;
+    /* its root of largest magnitude has the sign of -q: u = |t| is the largest root of u^3 + p u - Q, Q = |q| */
+    const double Q = fabs(q), pn = p < 0.0 ? -p : 0.0;
+    double u = cbrt_rough(2.0 * Q);
+    const double ub = sqrt(2.0 * pn);
+    if (ub > u) u = ub;
+    u = u * 1.1;                                   /* >= the root: u^3 = Q + |p| u <= 2 max(Q, |p| u) */
+    for (int it = 0; it < 12; it++) {
+        const double f = (u * u + p) * u - Q, d = (3.0 * u) * u + p;
+        if (!(d > 0.0)) break;
+        u = u - f / d;
+    }
+    const double t1 = q > 0.0 ? -u : u;
+    const double disc = (-3.0 * t1) * t1 - 4.0 * p;
+    double t[3]; int n = 1;
+    t[0] = t1;
+    if (disc >= 0.0) {
+        const double sq = sqrt(disc);
+        t[1] = (sq - t1) * 0.5; t[2] = (-sq - t1) * 0.5;
+        for (int k = 1; k < 3; k++)
+            for (int it = 0; it < 2; it++) {
+                const double f = (t[k] * t[k] + p) * t[k] + q, d = (3.0 * t[k]) * t[k] + p;
+                if (d != 0.0) t[k] = t[k] - f / d;
+            }
+        n = 3;
+    }
     const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
-    double M[3][3];
-    for (int r = 0; r < 3; r++) {
-        M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
-        M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
+    for (int k = 0; k < n; k++) {
+        const double lam = t[k] - sh;
+        double f[9];
+        for (int i = 0; i < 9; i++) f[i] = g[i] * lam + f2[i];
+        /* F = T2^T * f * T1 */
+        double M[3][3];
+        for (int r = 0; r < 3; r++) {
+            M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
+            M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
+        }
+        double* F = Fm + 9 * k;
+        for (int c = 0; c < 3; c++) {
+            F[c] = s2 * M[0][c]; F[3 + c] = s2 * M[1][c];
+            F[6 + c] = (t2x * M[0][c] + t2y * M[1][c]) + M[2][c];
+        }
     }
-    for (int c = 0; c < 3; c++) {
-        F[c] = s2 * M[0][c]; F[3 + c] = s2 * M[1][c];
-        F[6 + c] = (t2x * M[0][c] + t2y * M[1][c]) + M[2][c];
-    }
+    return n;
+}
+
+/* test hook: the models of the 7-point algorithm for correspondences 0..6 of the given lists */
+int svo_oracle_seven_point(const float* p1, const float* p2, double* F27)
+{
+    const int s[7] = { 0, 1, 2, 3, 4, 5, 6 };
+    return seven_point(p1, p2, s, F27);
 }
 
 /* symmetric point-to-epipolar-line error, max of the two squared distances */
@@ -878,13 +956,13 @@ static double svo_ln(double x)
     return (double)e * 0.69314718055994529 + 2.0 * (s * p);
 }
 
-/* cv::RANSACUpdateNumIters(p = 0.99, ep = 1 - cnt / n, modelPoints = 8, maxIters) as OpenCV's ptsetreg.cpp writes it
+/* cv::RANSACUpdateNumIters(p = 0.99, ep = 1 - cnt / n, modelPoints = 7, maxIters) as OpenCV's ptsetreg.cpp writes it
  * [frozen; recalled, the source is not in /root/reference]: 0 when every point is an inlier, maxIters when the
  * estimate is no smaller, else cvRound(log(1 - p) / log(1 - (1 - ep)^modelPoints)). */
 static int ransac_update_niters(int cnt, int n, int max_iters)
 {
-    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
-    const double denom = 1.0 - w8;
+    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w7 = (w4 * w2) * w;
+    const double denom = 1.0 - w7;
     if (denom < 2.2250738585072014e-308) return 0;
     const double num = -4.6051701859880909;          /* log(1 - 0.99) */
     const double d = svo_ln(denom);
@@ -892,24 +970,31 @@ static int ransac_update_niters(int cnt, int n, int max_iters)
     return (int)rint(num / d);
 }
 
+/* cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) (RANSACPointSetRegistrator::run with modelPoints = 7): per iteration one minimal
+ * sample, every model the 7-point solver returns for it is scored in turn, a model with more inliers than any before (and than
+ * modelPoints - 1) becomes the result and shrinks the iteration budget; the budget is tested once per iteration, so all models
+ * of a sample are scored.  best_hyp = the SAMPLE the winning model came from, n_hyp_used = samples visited. */
 int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9, int* best_hyp, int* n_hyp_used)
 {
     for (int i = 0; i < n; i++) mask[i] = 0;
     if (best_hyp) *best_hyp = -1;
     if (n_hyp_used) *n_hyp_used = 0;
-    if (n < 8) return 0;
+    if (n < 7) return 0;
     int niters = RANSAC_MAX_HYP, best_cnt = 0, best_k = -1;
     double Fbest[9] = { 0 };
     int k;
     for (k = 0; k < niters; k++) {
-        int s[8]; double F[9];
+        int s[7]; double Fm[27];
         ransac_sample(k, n, s);
-        eight_point(p1, p2, s, F);
-        int cnt = 0;
-        for (int i = 0; i < n; i++) cnt += fm_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
-        if (cnt > (best_cnt > 7 ? best_cnt : 7)) {
-            best_cnt = cnt; best_k = k; memcpy(Fbest, F, sizeof(F));
-            niters = ransac_update_niters(cnt, n, niters);      /* confidence 0.99 */
+        const int nm = seven_point(p1, p2, s, Fm);
+        for (int j = 0; j < nm; j++) {
+            const double* F = Fm + 9 * j;
+            int cnt = 0;
+            for (int i = 0; i < n; i++) cnt += fm_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+            if (cnt > (best_cnt > 6 ? best_cnt : 6)) {
+                best_cnt = cnt; best_k = k; memcpy(Fbest, F, 9 * sizeof(double));
+                niters = ransac_update_niters(cnt, n, niters);      /* confidence 0.99 */
+            }
         }
     }
     if (n_hyp_used) *n_hyp_used = k;

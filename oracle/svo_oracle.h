@@ -24,8 +24,14 @@ extern "C" {
  * itself).  Bumped whenever one of them changes, stored in every tests/golden/oracle_*.npz and printed in the bench line, so
  * that a change of the yardstick is visible in the record:
  *   1  round 1;  2  round 2 (RANSAC schedule 256 -> 1000 with cv::RANSACUpdateNumIters, retainBest keeps ties);
- *   3  round 3 (rank-2 enforcement of the 8-point fundamental matrix, as cv::findFundamentalMat returns rank-2 models) */
-#define SVO_ORACLE_VERSION 3
+ *   3  round 3 (rank-2 enforcement of the 8-point fundamental matrix, as cv::findFundamentalMat returns rank-2 models);
+ *   4  round 4, ONE bump for everything that could be moved onto OpenCV's own definitions: the descriptor is cv::ORB's -- OpenCV's
+ *      learned pair table bit_pattern_31_ steered by the CONTINUOUS angle in single precision with cvRound (the 30 bins of the paper
+ *      are commented out in OpenCV's computeOrbDescriptor), on a blur whose taps are cvRound(256 g) = {18, 34, 49, 55, ...} (sum 257,
+ *      saturated) -- pinned bit for bit to scikit-image's _orb_loop (tests/test_oracle_thirdparty.py); HarrisResponses' float
+ *      expression in OpenCV's operator order; the RANSAC solves the MINIMAL sample of 7 points (run7Point: null space + cubic, one or
+ *      three models per sample, every model scored, modelPoints = 7 in the stop rule) instead of 8 points + rank-2 projection */
+#define SVO_ORACLE_VERSION 4
 int svo_oracle_version(void);
 
 typedef struct svo_oracle svo_oracle;
@@ -70,6 +76,11 @@ int svo_oracle_fast_orb_detect(const uint8_t* img, int w, int h, int stride, int
 /* FAST-9/16 corner score map of one image (0 = not a corner at threshold th). */
 void svo_oracle_fast_score_map(const uint8_t* img, int w, int h, int stride, int th, uint8_t* score);
 float svo_oracle_orb_angle(const uint8_t* img, int stride, int x, int y, uint8_t* desc32);   /* one position's orientation (+ descriptor) */
+void svo_oracle_sincosf(float x, float* sn, float* cs);   /* the frozen single-precision sine / cosine of the steering (x in [0, 2 pi]) */
+void svo_oracle_steered_brief(const uint8_t* blurred, int stride, int x, int y, float angle_deg, uint8_t* desc32);   /* the 256 tests alone, on an already blurred image */
+float svo_oracle_harris(const uint8_t* img, int stride, int x, int y);   /* cv::ORB's HarrisResponses at one position */
+void svo_oracle_level_quota(int nfeatures, int nlevels, int* q);         /* cv::ORB's nfeaturesPerLevel */
+int svo_oracle_seven_point(const float* p1, const float* p2, double* F27);   /* the 7-point models (1 or 3, row-major 3x3 each) of correspondences 0..6 */
 /* pyramid level sizes and bilinear x1/1.2 chain; level buffers are tightly packed (stride == width). */
 int svo_oracle_pyramid_sizes(int w, int h, int nlevels, int* lw, int* lh, float* scale);
 void svo_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh);

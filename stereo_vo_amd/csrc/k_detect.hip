@@ -10,32 +10,52 @@
 #include "svo_kernels.h"
 #include "../../include/svo_orb_tables.h"
 
-// device copies of the frozen tables
+// device copies of the constant tables
 __constant__ int c_umax[16];
-__constant__ int c_gauss7[7];
-// steered BRIEF pairs as byte offsets into the 31x32 blurred patch: offA | offB << 16, off = (y + 15) * 32 + x + 15
-__device__ __attribute__((aligned(16))) uint32_t g_brief_off[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS];
+// cv::ORB's 256 test pairs (bit_pattern_31_) as floats, (x0, y0, x1, y1) per pair: k_describe rotates them by the keypoint's angle
+__device__ __attribute__((aligned(16))) float4 g_brief_patf[SVO_BRIEF_NPAIRS];
+// The 7 x 7 Gaussian of k_describe as two banded matrices in matrix-core operand layout (v_mfma_i32_16x16x64_i8: lane l carries
+// the 16 bytes of k-group l / 16 for row / column l % 16; byte b of a group in A meets byte b of the same group in B):
+//   g_blur_gh[nt][l]  horizontal pass H = X Gh:  column n = 16 nt + l % 16 of Gh, byte b <-> window byte 16 (l / 16) + b
+//   g_blur_gv[ot][l]  vertical pass  B^T = H^T Gv^T:  column = output row o = 16 ot + l % 16, byte s <-> H row
+//                     16 (s / 4) + 4 (l / 16) + s % 4 for s < 12 (where the horizontal pass left its results), 0 for s >= 12
+__device__ __attribute__((aligned(16))) uint4 g_blur_gh[3 * 64], g_blur_gv[3 * 64];
 // the radius-15 disc by rows of the describe window, for v_dot4_u32_u8: entry e = (v + 15) * 8 + d covers the window
-// bytes 4 + 4d .. 7 + 4d of row v + 18 (columns u = 4d - 15 .. 4d - 12); g_disc_m holds 1 per disc pixel,
+// bytes 8 + 4d .. 11 + 4d of row v + 21 (columns u = 4d - 15 .. 4d - 12); g_disc_m holds 1 per disc pixel,
 // g_disc_x holds u + 15 per disc pixel (0 outside), one byte each
 #define SVO_DISC_E 256
 __device__ uint32_t g_disc_m[SVO_DISC_E], g_disc_x[SVO_DISC_E];
+#define DP_REACH SVO_BRIEF_REACH          // 18: the blurred pixels a rotated pair can reach are (x, y) +- 18
+#define DP_BW (2 * DP_REACH + 1)          // 37 x 37 blurred window
+#define DP_RW (DP_BW + 6)                 // 43 raw rows y - 21 .. y + 21
+#define DP_X0 (DP_REACH + 5)              // window byte 0 = column x - 23, so that the disc's first column x - 15 is byte 8 (a dword boundary)
 
 hipError_t svo_upload_tables()
 {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_umax), svo_umax, sizeof(svo_umax));
     if (e != hipSuccess) return e;
-    e = hipMemcpyToSymbol(HIP_SYMBOL(c_gauss7), svo_gauss7, sizeof(svo_gauss7));
-    if (e != hipSuccess) return e;
     {
-        static uint32_t off[SVO_BRIEF_NBINS * SVO_BRIEF_NPAIRS];
-        for (int b = 0; b < SVO_BRIEF_NBINS; b++)
-            for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) {
-                const int8_t* pr = svo_brief_rot[b][i];
-                const uint32_t oa = (uint32_t)((pr[1] + 15) * 32 + pr[0] + 15), ob = (uint32_t)((pr[3] + 15) * 32 + pr[2] + 15);
-                off[b * SVO_BRIEF_NPAIRS + i] = oa | (ob << 16);
-            }
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_off), off, sizeof(off));
+        static float4 pf[SVO_BRIEF_NPAIRS];
+        for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) pf[i] = make_float4((float)svo_brief_pat[i][0], (float)svo_brief_pat[i][1], (float)svo_brief_pat[i][2], (float)svo_brief_pat[i][3]);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_patf), pf, sizeof(pf));
+        if (e != hipSuccess) return e;
+    }
+    {
+        static uint8_t gh[3 * 64 * 16], gv[3 * 64 * 16];
+        for (int t = 0; t < 3; t++)
+            for (int l = 0; l < 64; l++)
+                for (int b = 0; b < 16; b++) {
+                    const int q = l >> 4, i = l & 15;
+                    // horizontal: output column n (blurred column x - 18 + n) sums window bytes n + 2 .. n + 8 (columns x - 21 + n .. x - 15 + n)
+                    const int n = 16 * t + i, kb = 16 * q + b, dh = kb - (n + DP_X0 - DP_REACH - 3);
+                    gh[(t * 64 + l) * 16 + b] = (uint8_t)((n < DP_BW && dh >= 0 && dh < 7) ? svo_gauss7[dh] : 0);
+                    // vertical: output row o (blurred row y - 18 + o) sums H rows o .. o + 6 (window rows y - 21 + o ..)
+                    const int o = 16 * t + i, rho = 16 * (b >> 2) + 4 * q + (b & 3), dv = rho - o;
+                    gv[(t * 64 + l) * 16 + b] = (uint8_t)((b < 12 && o < DP_BW && dv >= 0 && dv < 7) ? svo_gauss7[dv] : 0);
+                }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_blur_gh), gh, sizeof(gh));
+        if (e != hipSuccess) return e;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_blur_gv), gv, sizeof(gv));
         if (e != hipSuccess) return e;
     }
     uint32_t dm[SVO_DISC_E], dx[SVO_DISC_E];
@@ -74,6 +94,9 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
         if ((size_t)t < n_words - 4 * n16) c.bf_idx[4 * n16 + t] = -1;
     }
     const bool detect = flags & SVO_RUN_DETECT, do_shift = !(flags & SVO_FLAG_NO_SHIFT), repeat = flags & SVO_FLAG_REPEAT;
+    // SVO_FLAG_DETECT_AHEAD: a detect call that may overlap stages 3-5 of the frame before it -- it initialises the detector's
+    // per-image scratch and nothing else; its post call (SVO_RUN_DETECT_POST with the same flag) does the lane part below
+    const bool ahead = flags & SVO_FLAG_DETECT_AHEAD, ahead_post = ahead && !detect;
     if (detect) {
         if (t < c.n_img) { c.img0[t] = ptrs.p[t]; c.raw_n[t] = 0; }
         if (t < c.n_img * SVO_MAX_LEVELS) {
@@ -85,8 +108,9 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
             c.redo_flag[t] = 0;
         }
         if (t == 0) *c.redo_n = 0;
+        if (ahead && t < c.n_lanes) c.det_status[t] = 0;
     }
-    if (t < c.n_lanes) {
+    if (t < c.n_lanes && !(ahead && detect)) {
         LaneState& s = c.lane[t];
         if (do_shift) {
             if (!repeat && s.m_error != SVO_VOEC_BAD_TRACKING && s.m_error != SVO_VOEC_BAD_COND_NUMBER) {
@@ -103,11 +127,12 @@ __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
             if (!repeat) s.it_counter++;                                               // P:380-381
         }
         if (flags & SVO_RUN_TRACK) for (int o = 0; o < c.oct_cap; o++) c.n_tracked[t * c.oct_cap + o] = 0;
-        if (detect) c.status[t] = 0;
+        const uint32_t st0 = ahead_post ? c.det_status[t] : 0u;                        // what the ahead half of this frame raised
+        if (detect || ahead_post) c.status[t] = st0;
         svo_result& r = c.results[t];
         r.error_code = SVO_VOEC_NONE;                                                  // P:50
         r.valid = 0; r.num_it = 0; r.num_it_final = 0; r.n_outliers = 0; r.n_residual = 0; r.n_octaves = c.n_oct;
-        if (detect) r.status = 0;
+        if (detect || ahead_post) r.status = (int)st0;
         r.tracked_feats_from_last_frame = 0; r.tracked_feats_from_last_KF = 0;
         for (int k = 0; k < 8; k++) r.track_stats[k] = 0;
         for (int k = 0; k < 6; k++) { r.outPose[k] = 0; r.delta[k] = 0; }
@@ -541,7 +566,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
             uint32_t* dst = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
             for (unsigned i = tid; i < nout; i += 64) {
                 if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
-                else { atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW); atomicOr(&c.results[img >> 1].status, (int)SVO_ST_CAND_OVERFLOW); }
+                else raise_detect_status(c, img >> 1, SVO_ST_CAND_OVERFLOW);
             }
         }
     }
@@ -767,7 +792,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
         if (tid == 0) c.sel_n[il] = (int)K_ties;
         return;
     }
-    if (tid == 0) { atomicOr(&c.status[img >> 1], SVO_ST_CAND_OVERFLOW); atomicOr(&c.results[img >> 1].status, (int)SVO_ST_CAND_OVERFLOW); }
+    if (tid == 0) raise_detect_status(c, img >> 1, SVO_ST_CAND_OVERFLOW);
     if (n_tie <= SEL_TIE_MAX) {
         for (unsigned base = tid; base < nc; base += 8 * 512) {
             uint32_t k[8];
@@ -935,25 +960,29 @@ __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K4+K5: orientation (intensity centroid, radius 15) and steered BRIEF-256 from an LDS-staged 37x40 window.
-// One wave per keypoint slot, 4 independent waves per block (no block barriers: every wave owns its LDS region).
-// VALU issue bounds this kernel (PMC: ~85 % busy), so every phase is written for instruction count:
-//   A  window rows y-18..y+18, columns x-19..x+28 by LDS-DMA (global_load_lds_dwordx4): 37 rows x 3 chunks of 16 bytes land
-//      at LDS pitch 48 straight from their (byte-unaligned) global addresses -- two wave-instructions per keypoint where
-//      the register path spent 14 loads, 7 funnel shifts and 7 ds_writes; columns beyond x+20 are padding;
-//   B  moments by v_dot4_u32_u8: the disc starts on a dword boundary (column x-15 = byte 4), one lane = one
-//      (row, dword) with a 0/1 weight dword (row sums -> m01) and a (u+15) weight dword (-> m10 + 15 * sum);
-//      248 lane-tasks, 4 per lane; wave sums by DPP + readlane;
-//   C  horizontal 7-tap pass by two v_dot4_u32_u8 per output (taps 18,33,49,56 | 49,33,18,0 on bytes funnel-shifted
-//      into place), 4 outputs per lane-task, 4 x u16 out as one b64;
-//   D  vertical 7-tap pass over the whole 31x32 patch, lane = (column pair, 8-row segment), 14 row reads in order, the rows
-//      re-paired per column by v_perm so that v_dot2_u32_u16 applies two taps at once (4 dot ops per output instead of
-//      7 multiply-adds), blurred BYTES written over the raw window; the horizontal pass's rows sit at a pitch of 18 dwords
-//      so that the four row segments of a wave read disjoint LDS banks (at 16 they were a 2-way conflict on every read);
-//   E  256 tests: one byte gather per sample point (LDS byte offsets from a per-bin table), four wave ballots.
+// K4+K5: cv::ORB per keypoint (oracle: orb_angle_desc): orientation (intensity centroid, radius 15) and the 256 tests of
+// OpenCV's learned pair table, steered by the keypoint's CONTINUOUS angle, on the 7x7 sigma-2 blur of its level.
+// One wave per keypoint, 4 independent waves per block (no block barriers: every wave owns its LDS region).
+// VALU issue bounds this kernel, so the Gaussian -- two banded matrix products -- runs on the matrix cores, which are idle here:
+//   A  raw window rows y-21..y+21, columns x-23..x+24 by LDS-DMA (global_load_lds_dwordx4): 43 rows x 3 chunks of 16 bytes land
+//      at LDS pitch 48 straight from their (byte-unaligned) global addresses, three wave-instructions per keypoint;
+//   B  moments by v_dot4_u32_u8: the disc starts on a dword boundary (column x-15 = byte 8), one lane = one (row, dword) with a
+//      0/1 weight dword (row sums -> m01) and a (u+15) weight dword (-> m10 + 15 * sum); wave sums by DPP + readlane;
+//      angle = the oracle's atan2_deg, then its single-precision sine / cosine (svo_oracle_sincosf, operator for operator);
+//   C  horizontal pass H = X Gh on v_mfma_i32_16x16x64_i8: operand A = 16 window rows x 64 window bytes (one ds_read_b128 per
+//      lane, pixels re-biased to signed by xor 0x80), operand B = the banded tap matrix (g_blur_gh), accumulator seeded with 128
+//      so that a result IS H - 32768 as a signed 16-bit number: 3 x 3 tiles, 9 MFMAs;
+//   D  vertical pass B^T = H^T Gv^T: lane (n, q) of a horizontal tile already holds the H values of column n that make up
+//      k-group q of the vertical product's operand A -- no cross-lane movement; their high bytes (signed) and low bytes (re-biased)
+//      are two operands, 256 D_hi + D_lo is the exact integer sum; 18 MFMAs.  The accumulator of the low product starts at
+//      257 * 32896 + 32768 (the two biases and the rounding), (t >> 16) saturated to a byte is the blurred pixel, and a lane's
+//      four results are four consecutive columns of one row: one ds_write_b32 into the 37 x 48 blurred window (over the raw one);
+//   E  256 tests: pair (px, py) -> (px a - py b, px b + py a) in single precision, round half to even by the 1.5 * 2^23 trick
+//      (the mantissa then holds the integer), one byte gather per sample point, four wave ballots.
 // ------------------------------------------------------------------------------------------------------------
-#define DP_PW 12     // LDS row pitch of the raw window in dwords (3 DMA chunks of 16 bytes; 10 dwords are used)
-#define DP_HP 36     // row pitch of the horizontal pass in u16 (18 dwords: see D)
+#define DP_PW 12            // LDS row pitch of the raw / blurred window in dwords (3 DMA chunks of 16 bytes)
+#define DP_LROWS 48         // rows the matrix-core tiles cover (43 hold pixels; the rest meet zero taps)
+typedef int dp_v4i __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float atan2_deg(float y, float x)
 {
@@ -970,6 +999,21 @@ __device__ __forceinline__ float atan2_deg(float y, float x)
     return a;
 }
 
+// svo_oracle_sincosf, operator for operator (x in [0, 2 pi]; compiled with -ffp-contract=off)
+__device__ __forceinline__ void sincos_f32(float x, float& sn, float& cs)
+{
+    const int k = (int)(x * 0.63661977f + 0.5f);
+    const float fk = (float)k;
+    const float r = ((x - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188216e-8f;
+    const float z = r * r;
+    const float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    const bool odd = k & 1;
+    const float s0 = odd ? cp : sp, c0 = odd ? sp : cp;
+    sn = (k & 2) ? -s0 : s0;                                   // k & 3:  0 (sp, cp)   1 (cp, -sp)   2 (-sp, -cp)   3 (-cp, sp)
+    cs = (((k + 1) & 2) != 0) ? -c0 : c0;
+}
+
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
 {
     // the builtin, not inline asm: the hazard recogniser must see a DOT op to pad its result's wait states
@@ -978,16 +1022,14 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
 
 __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int pre)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][37 * DP_PW + 4];
-    __shared__ __attribute__((aligned(16))) unsigned short hb[4][37 * DP_HP]; // horizontal pass, 32 columns (31 used) at pitch 36
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     // XCD affinity by IMAGE: workgroup ids go round-robin over the 8 XCDs, so id -> (image, slot group) is laid out so
-    // that every XCD works through whole images (image = 8 * group + id % 8).  A keypoint window costs 37 rows x one or
+    // that every XCD works through whole images (image = 8 * group + id % 8).  A keypoint window costs 43 rows x one or
     // two 128-byte lines and neighbouring keypoints share most of them; with an image's keypoints spread over eight
-    // L2s each line was fetched again per XCD (1.32 GB per launch for 0.38 GB of windows), through one L2 the image's
-    // pyramid (3.8 MB < 4 MB) is fetched about once.
+    // L2s each line was fetched again per XCD, through one L2 the image's pyramid (3.8 MB < 4 MB) is fetched about once.
     int img, bx;
     if (c.debug_mode == 8) { img = blockIdx.x / gx_div.d; bx = blockIdx.x - img * gx_div.d; }
     else { const uint32_t r = blockIdx.x >> 3, grp = fastdiv(r, gx_div); bx = (int)(r - grp * gx_div.d); img = (int)(grp * 8 + (blockIdx.x & 7)); }
@@ -1020,17 +1062,25 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     uint32_t* R32 = raw32[wid];
-    // ---- A: window rows y-18..y+18, columns x-19..x+28 (x+20 needed), LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) ----
+    // the constant operands of the two passes and this lane's four test pairs: issued ahead of the window so that everything is in flight at once
+    dp_v4i GH[3], GV[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) { GH[t] = *(const dp_v4i*)&g_blur_gh[t * 64 + lane]; GV[t] = *(const dp_v4i*)&g_blur_gv[t * 64 + lane]; }
+    float4 pat[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pat[k] = g_brief_patf[k * 64 + lane];
+    // ---- A: window rows y-21..y+21, columns x-23..x+24, LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) ----
     //      every byte read lies inside the image: keypoints keep EDGE = 31 pixels from every border
     {
         typedef const void __attribute__((address_space(1)))* gptr_t;
         typedef void __attribute__((address_space(3)))* lptr_t;
         auto chunk_src = [&](int i) -> const uint8_t* {
-            const int r = (i * 171) >> 9, q = i - 3 * r;                    // i / 3, i % 3 for i < 128
-            return lim + (uint32_t)((y - 18 + r) * pitch + (x - 19) + 16 * q);
+            const int r = (i * 171) >> 9, q = i - 3 * r;                    // i / 3, i % 3 for i <= 128
+            return lim + (uint32_t)((y - (DP_REACH + 3) + r) * pitch + (x - DP_X0) + 16 * q);
         };
         __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(lane), (lptr_t)R32, 16, 0, 0);
-        if (lane < 37 * 3 - 64) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(64 + lane), (lptr_t)(R32 + 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(64 + lane), (lptr_t)(R32 + 256), 16, 0, 0);
+        if (lane < DP_RW * 3 - 128) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(128 + lane), (lptr_t)(R32 + 512), 16, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     wave_lds_sync();
@@ -1038,9 +1088,9 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     uint32_t m10u = 0; int m01 = 0, msum = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read rows that exist
-        const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 3 (vr = 31: row 34)
-        const uint32_t px = R32[(vr + 3) * DP_PW + 1 + d];
+        const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read a row that exists
+        const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 6
+        const uint32_t px = R32[(vr + 6) * DP_PW + 2 + d];
         const uint32_t s = udot4(px, g_disc_m[en], 0u);
         m10u = udot4(px, g_disc_x[en], m10u);
         msum += (int)s;
@@ -1049,64 +1099,68 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
     m01 = wave_sum_uniform(m01);
     const float angle = atan2_deg((float)m01, (float)m10);
-    int bin = (int)(angle * (1.0f / 12.0f) + 0.5f);
-    if (bin >= SVO_BRIEF_NBINS) bin -= SVO_BRIEF_NBINS;
-    // ---- C: horizontal pass; Hb[r][q] = sum_k g[k] * raw[r][q + 1 + k], q = 0..31 (column x - 15 + q) ----
-    const uint32_t GA = (uint32_t)c_gauss7[0] | ((uint32_t)c_gauss7[1] << 8) | ((uint32_t)c_gauss7[2] << 16) | ((uint32_t)c_gauss7[3] << 24);
-    const uint32_t GB = (uint32_t)c_gauss7[4] | ((uint32_t)c_gauss7[5] << 8) | ((uint32_t)c_gauss7[6] << 16);
-    unsigned short* Hb = hb[wid];
-    for (int t = lane; t < 37 * 8; t += 64) {
-        const int r = t >> 3, gq = t & 7;
-        const uint32_t w0 = R32[r * DP_PW + gq], w1 = R32[r * DP_PW + gq + 1], w2 = R32[r * DP_PW + gq + 2];
-        const uint32_t o0 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), GA, 0u));
-        const uint32_t o1 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), GA, 0u));
-        const uint32_t o2 = udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), GB, udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), GA, 0u));
-        const uint32_t o3 = udot4(w2, GB, udot4(w1, GA, 0u));
-        uint2 pk; pk.x = o0 | (o1 << 16); pk.y = o2 | (o3 << 16);
-        *(uint2*)&Hb[r * DP_HP + gq * 4] = pk;
+    float sn, cs;
+    sincos_f32(angle * 0.017453292f, sn, cs);
+    // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
+    const int n16 = lane & 15, q4 = lane >> 4;
+    dp_v4i S[3][3];
+    {
+        const dp_v4i seed = { 128, 128, 128, 128 };
+#pragma unroll
+        for (int mt = 0; mt < 3; mt++) {
+            dp_v4i X = *(const dp_v4i*)&R32[(16 * mt + n16) * DP_PW + 4 * q4];
+            X ^= (int)0x80808080;
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) S[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, GH[nt], seed, 0, 0, 0);
+        }
     }
-    wave_lds_sync();
-    // ---- D: vertical 7-tap pass over the whole 31 x 32 patch -> blurred bytes Bl (aliases the raw window, no longer
-    //      needed).  LDS is what bounds this kernel (SQ_LDS_IDX_ACTIVE ~ 93 % of its duration, two thirds of it bank
-    //      conflicts, when the vertical pass was evaluated at the 512 sample points only: 56 scattered ds_read_u16 per
-    //      lane); the full pass reads each lane's 14 input rows once, in order, and leaves ONE byte gather per sample.
-    //      Exact: sum_r g[r] * Hb is the same integer whichever pass runs first; one rounding, (s + 32768) >> 16.
-    const uint32_t G0 = (uint32_t)c_gauss7[0], G1 = (uint32_t)c_gauss7[1], G2 = (uint32_t)c_gauss7[2], G3 = (uint32_t)c_gauss7[3];
-    const rz_u16x2 T01 = __builtin_bit_cast(rz_u16x2, G0 | (G1 << 16)), T23 = __builtin_bit_cast(rz_u16x2, G2 | (G3 << 16));
-    const rz_u16x2 T21 = __builtin_bit_cast(rz_u16x2, G2 | (G1 << 16)), T0x = __builtin_bit_cast(rz_u16x2, G0);
+    wave_lds_sync();                                       // every lane has read the raw window: the blurred one may overwrite it
+    // ---- D: vertical pass; lane (n16, q4) owns k-group q4 of column n16 already ----
     uint8_t* Bl = (uint8_t*)R32;
     {
-        const int cp = lane & 15, sg = lane >> 4;                          // column pair 2cp, 2cp+1; output rows 8 sg .. 8 sg + 7
-        const uint32_t* H32 = (const uint32_t*)Hb;
-        uint32_t w[15];
+        const int c2 = 257 * 32896 + 32768;
+        const dp_v4i seed_lo = { c2, c2, c2, c2 }, zero = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int i = 0; i < 14; i++) w[i] = H32[min(8 * sg + i, 36) * (DP_HP / 2) + cp];
-        w[14] = 0;                                                         // partner of row 13 in its pair: weight 0
-        wave_lds_sync();                                                   // every lane has read: the raw window may be overwritten
-        // pa[j] = rows (j, j + 1) of column 2cp, pb[j] = the same of column 2cp + 1: out(o) = (G0 G1).P[o] + (G2 G3).P[o+2] + (G2 G1).P[o+4] + (G0 0).P[o+6]
-        rz_u16x2 pa[14], pb[14];
+        for (int nt = 0; nt < 3; nt++) {
+            dp_v4i Alo, Ahi;
 #pragma unroll
-        for (int j = 0; j < 14; j++) {
-            pa[j] = __builtin_bit_cast(rz_u16x2, __builtin_amdgcn_perm(w[j + 1], w[j], 0x05040100u));
-            pb[j] = __builtin_bit_cast(rz_u16x2, __builtin_amdgcn_perm(w[j + 1], w[j], 0x07060302u));
-        }
+            for (int mt = 0; mt < 3; mt++) {
+                const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)S[mt][nt][1], (uint32_t)S[mt][nt][0], 0x05010400u);     // lo0 lo1 hi0 hi1
+                const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)S[mt][nt][3], (uint32_t)S[mt][nt][2], 0x05010400u);
+                Alo[mt] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+                Ahi[mt] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+            }
+            Alo[3] = 0; Ahi[3] = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            // same integer sum as g0 (r0 + r6) + g1 (r1 + r5) + g2 (r2 + r4) + g3 r3, + 32768 for the one rounding; < 2^24, so the result is byte 2
-            const uint32_t sa = __builtin_amdgcn_udot2(pa[i + 6], T0x, __builtin_amdgcn_udot2(pa[i + 4], T21, __builtin_amdgcn_udot2(pa[i + 2], T23, __builtin_amdgcn_udot2(pa[i], T01, 32768u, false), false), false), false);
-            const uint32_t sb = __builtin_amdgcn_udot2(pb[i + 6], T0x, __builtin_amdgcn_udot2(pb[i + 4], T21, __builtin_amdgcn_udot2(pb[i + 2], T23, __builtin_amdgcn_udot2(pb[i], T01, 32768u, false), false), false), false);
-            const uint32_t v = __builtin_amdgcn_perm(sb, sa, 0x0c0c0602u);
-            if (8 * sg + i < 31) *(unsigned short*)&Bl[(8 * sg + i) * 32 + 2 * cp] = (unsigned short)v;
+            for (int ot = 0; ot < 3; ot++) {
+                const dp_v4i Dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ahi, GV[ot], zero, 0, 0, 0);
+                const dp_v4i Dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(Alo, GV[ot], seed_lo, 0, 0, 0);
+                uint32_t t[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) t[r] = ((uint32_t)Dhi[r] << 8) + (uint32_t)Dlo[r];
+                // (t >> 16) is 0..257: saturate the 16-bit halves to bytes (v_sat_pk_u8_i16), four columns of one row per lane
+                uint32_t h01 = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u), h23 = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u), s01, s23;
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s01) : "v"(h01));
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s23) : "v"(h23));
+                *(uint32_t*)&Bl[(16 * ot + n16) * (4 * DP_PW) + 16 * nt + 4 * q4] = (s23 << 16) | (s01 & 0xFFFFu);
+            }
         }
     }
     wave_lds_sync();
     // ---- E: 256 tests, one byte gather per sample point, packed with four wave ballots ----
-    const uint32_t* pat = g_brief_off + bin * SVO_BRIEF_NPAIRS;
+    // x + 1.5 * 2^23 rounds to the nearest integer, ties to even (cvRound), and leaves it in the mantissa: bits = 0x4B400000 + ix.
+    // The offsets of the window centre and of this wave's LDS region ride in the magic constants; the products with the pitch
+    // take the low 24 bits (v_mad_u32_u24), the sum's low 16 bits are the LDS address.
+    const float MX = 12582912.0f + (float)(DP_REACH + (int)((uint8_t*)R32 - (uint8_t*)&raw32[0][0])), MY = 12582912.0f + (float)DP_REACH;
+    const uint8_t* lds0 = (const uint8_t*)&raw32[0][0];
     unsigned long long bits[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t pr = pat[k * 64 + lane];
-        const int a = Bl[pr & 0xFFFFu], b = Bl[pr >> 16];
+        const float x0 = pat[k].x * cs - pat[k].y * sn, y0 = pat[k].x * sn + pat[k].y * cs;
+        const float x1 = pat[k].z * cs - pat[k].w * sn, y1 = pat[k].z * sn + pat[k].w * cs;
+        const uint32_t o0 = (__umul24(__float_as_uint(y0 + MY), 4 * DP_PW) + __float_as_uint(x0 + MX)) & 0xFFFFu;
+        const uint32_t o1 = (__umul24(__float_as_uint(y1 + MY), 4 * DP_PW) + __float_as_uint(x1 + MX)) & 0xFFFFu;
+        const int a = lds0[o0], b = lds0[o1];
         bits[k] = __ballot(a < b);
     }
     if (lane == 0) {
@@ -1508,7 +1562,7 @@ __global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance
     if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
     // quota = slots reserved for this octave; the reference's cap kps_to_detect belongs to its NMS (S2:342), without NMS every corner stays
     const int cap = do_nms ? min(min(c.kps_to_detect[level], g.quota), ACC_MAX) : min(g.quota, ACC_MAX);
-    if (!do_nms && nc > (unsigned)cap && tid == 0) { atomicOr(&c.status[img >> 1], SVO_ST_KPS_OVERFLOW); atomicOr(&c.results[img >> 1].status, (int)SVO_ST_KPS_OVERFLOW); }
+    if (!do_nms && nc > (unsigned)cap && tid == 0) raise_detect_status(c, img >> 1, SVO_ST_KPS_OVERFLOW);
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
     const unsigned cell = (unsigned)((double)min_distance / 2.0);
     const float inv = 1.0f / (float)cell;

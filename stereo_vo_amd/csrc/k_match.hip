@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
         __syncthreads();
     }
     if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], np_total); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], np_total); }
-    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 7; }
+    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -510,13 +510,21 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
         __syncthreads();
     }
     if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], s_th); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], nk); }
-    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 7; }
+    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K9: fundamental-matrix RANSAC (cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) stand-in; S4:202, 237).
-// Fixed schedule of SVO_RANSAC_HYP seeded samples evaluated in parallel; the adaptive stop of a sequential
-// RANSAC is emulated afterwards by scanning the inlier counts in hypothesis order.
+// K9: fundamental-matrix RANSAC -- cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) as called at S4:202, 237 (oracle:
+// svo_oracle_ransac_fundamental).  Fixed schedule of SVO_RANSAC_HYP seeded MINIMAL samples of seven pairs; each sample yields
+// one or three models (the 7-point algorithm: null space of the 7x9 system + the cubic det = 0), every model is scored, and
+// the adaptive stop of the sequential loop is emulated afterwards by scanning the counts in (sample, model) order.
+//
+// Where the models live: SAMPLES are grouped in regions of SVO_RANSAC_REG = 16 consecutive ones, a region owns
+// SVO_RANSAC_RSLOTS = 48 model SLOTS (3 per sample), and the models of a region's samples are packed to the front of its slots
+// in (sample, root) order -- rs_nvalid[region] of them, rs_k[slot] naming the sample of each.  The count kernels work on groups
+// of 4 / 16 consecutive slots and drop a group that starts beyond rs_nvalid; the unused slots of a live group of 16 hold a filler
+// matrix that no pair fits (count 0), and every count of a region is zeroed when it is generated, so a slot that was never
+// scored reads as 0 = "no record".  Budgets and bounds (rs_bound, rs_gen, K(count)) are in SAMPLES, as the oracle's loop counter.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
 {
@@ -527,11 +535,9 @@ __device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
     unsigned long long x = s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; s = x; return x * 0x2545F4914F6CDD1DULL;
 }
 
-// one thread per hypothesis: sample 8 pairs, normalised linear 8-point solution through the null vector of the
-// 8x9 system (Gauss-Jordan, full pivoting).  The 8x9 matrix lives in LDS, one column of doubles per thread slot.
-// The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): hypotheses are visited in order; a count
-// above the best so far (and above 7) becomes the model and shrinks the iteration budget to
-// cv::RANSACUpdateNumIters(0.99, 1 - count / n, 8, budget).  svo_ln / ransac_niters repeat the oracle's functions operation
+// The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): samples are visited in order; a model whose count
+// exceeds the best so far (and 6 = modelPoints - 1) becomes the result and shrinks the iteration budget to
+// cv::RANSACUpdateNumIters(0.99, 1 - count / n, 7, budget).  svo_ln / ransac_niters repeat the oracle's functions operation
 // by operation (+, -, *, / only, no contraction), so both sides round alike.
 __device__ __forceinline__ double svo_ln(double x)
 {
@@ -554,8 +560,8 @@ __device__ __forceinline__ double svo_ln(double x)
 }
 __device__ __forceinline__ int ransac_niters(int cnt, int n, int max_iters)
 {
-    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w8 = w4 * w4;
-    const double denom = 1.0 - w8;
+    const double w = (double)cnt / (double)n, w2 = w * w, w4 = w2 * w2, w7 = (w4 * w2) * w;
+    const double denom = 1.0 - w7;
     if (denom < 2.2250738585072014e-308) return 0;
     const double num = -4.6051701859880909;
     const double d = svo_ln(denom);
@@ -563,60 +569,109 @@ __device__ __forceinline__ int ransac_niters(int cnt, int n, int max_iters)
     return (int)rint(num / d);
 }
 
-// Rank-2 enforcement of the normalised 8-point solution (oracle: rank2_enforce, operation for operation): f <- f (I - v v^T / v.v)
-// with v the eigenvector of f^T f for its smallest eigenvalue -- the smallest root of the characteristic cubic by eight Newton
-// steps from 0 (monotone: f^T f is positive semi-definite), v = the largest of the three row cross products of f^T f - t I.
-__device__ __forceinline__ void rank2_enforce(double* f)
+// oracle: ransac_sample -- seven distinct indices below n from the sample's own generator
+__device__ __forceinline__ void ransac_sample7(int h, int n, int (&s)[7])
 {
-    const double s00 = (f[0] * f[0] + f[3] * f[3]) + f[6] * f[6], s01 = (f[0] * f[1] + f[3] * f[4]) + f[6] * f[7], s02 = (f[0] * f[2] + f[3] * f[5]) + f[6] * f[8];
-    const double s11 = (f[1] * f[1] + f[4] * f[4]) + f[7] * f[7], s12 = (f[1] * f[2] + f[4] * f[5]) + f[7] * f[8], s22 = (f[2] * f[2] + f[5] * f[5]) + f[8] * f[8];
-    const double c2 = (s00 + s11) + s22;
-    const double m00 = s11 * s22 - s12 * s12, m11 = s00 * s22 - s02 * s02, m22 = s00 * s11 - s01 * s01;
-    const double c1 = (m00 + m11) + m22;
-    const double c0 = (s00 * m00 - s01 * (s01 * s22 - s12 * s02)) + s02 * (s01 * s12 - s11 * s02);
-    double t = 0.0;
-    bool go = true;
+    unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
+    if (!st) st = 1;
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const double q = ((t - c2) * t + c1) * t - c0, dq = (3.0 * t - 2.0 * c2) * t + c1;
-        go = go && dq > 0.0;                                               // the oracle's `break`: once stopped, t stays
-        if (go) t = t - q / dq;
-    }
-    const double a00 = s00 - t, a11 = s11 - t, a22 = s22 - t;
-    const double x0 = s01 * s12 - s02 * a11, y0 = s02 * s01 - a00 * s12, z0 = a00 * a11 - s01 * s01;
-    const double x1 = s01 * a22 - s02 * s12, y1 = s02 * s02 - a00 * a22, z1 = a00 * s12 - s01 * s02;
-    const double x2 = a11 * a22 - s12 * s12, y2 = s12 * s02 - s01 * a22, z2 = s01 * s12 - a11 * s02;
-    const double n0 = (x0 * x0 + y0 * y0) + z0 * z0, n1 = (x1 * x1 + y1 * y1) + z1 * z1, n2 = (x2 * x2 + y2 * y2) + z2 * z2;
-    double vx = x0, vy = y0, vz = z0, nn = n0;
-    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
-    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+    for (int j = 0; j < 7; j++) {
+        int v; bool dup;
+        do {
+            v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false;
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const double w = ((f[3 * r] * vx + f[3 * r + 1] * vy) + f[3 * r + 2] * vz) / nn;
-        f[3 * r] = f[3 * r] - w * vx; f[3 * r + 1] = f[3 * r + 1] - w * vy; f[3 * r + 2] = f[3 * r + 2] - w * vz;
+            for (int k = 0; k < 7; k++) if (k < j && s[k] == v) dup = true;
+        } while (dup);
+        s[j] = v;
     }
 }
 
-// the tail of eight_point (oracle): rank-2 enforcement, F = T2^T f T1, and the guards of the matrix-core line evaluation
-__device__ __forceinline__ void store_hypothesis(const DevCtx& c, int vl, int side, int h, double* fv, double s1, double s2, double c1x, double c1y, double c2x, double c2y)
+// oracle: cbrt_rough (exponent / 3 on the bit pattern; integer arithmetic, hence the same bits)
+__device__ __forceinline__ double cbrt_rough(double x)
 {
-    rank2_enforce(fv);
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    u = (unsigned long long)((unsigned)(u >> 32) / 3u + 715094163u) << 32;
+    return __longlong_as_double((long long)u);
+}
+
+// The tail of the oracle's seven_point, operation for operation: g = f1 - f2 and f2 span the null space of the normalised 7x9
+// system; the cubic det(lambda g + f2) = 0 (cofactors along the first row), made monic and depressed, its root of largest
+// magnitude by twelve Newton steps from an upper bound, the other two (when the discriminant allows) by deflation + two
+// polishing steps; each root's matrix denormalised F = T2^T f T1.  Returns the number of models (1 or 3), Fm[k][0..8].
+__device__ __forceinline__ int seven_point_models(const double (&g)[9], const double (&f2)[9], double s1, double s2, double c1x, double c1y, double c2x, double c2y, double (&Fm)[3][9])
+{
+    const double g00 = g[4] * g[8] - g[5] * g[7], g01 = g[3] * g[8] - g[5] * g[6], g02 = g[3] * g[7] - g[4] * g[6];
+    const double h00 = f2[4] * f2[8] - f2[5] * f2[7], h01 = f2[3] * f2[8] - f2[5] * f2[6], h02 = f2[3] * f2[7] - f2[4] * f2[6];
+    const double m00 = (g[4] * f2[8] + f2[4] * g[8]) - (g[5] * f2[7] + f2[5] * g[7]);
+    const double m01 = (g[3] * f2[8] + f2[3] * g[8]) - (g[5] * f2[6] + f2[5] * g[6]);
+    const double m02 = (g[3] * f2[7] + f2[3] * g[7]) - (g[4] * f2[6] + f2[4] * g[6]);
+    const double a3 = (g[0] * g00 - g[1] * g01) + g[2] * g02;
+    const double a0 = (f2[0] * h00 - f2[1] * h01) + f2[2] * h02;
+    const double a2 = ((f2[0] * g00 - f2[1] * g01) + f2[2] * g02) + ((g[0] * m00 - g[1] * m01) + g[2] * m02);
+    const double a1 = ((g[0] * h00 - g[1] * h01) + g[2] * h02) + ((f2[0] * m00 - f2[1] * m01) + f2[2] * m02);
+    const double Am = a2 / a3, Bm = a1 / a3, Cm = a0 / a3;
+    const double sh = Am / 3.0;
+    const double p = Bm - Am * sh;
+    const double q = ((2.0 * sh) * sh) * sh - sh * Bm + Cm;
+    const double Q = fabs(q), pn = p < 0.0 ? -p : 0.0;
+    double u = cbrt_rough(2.0 * Q);
+    const double ub = sqrt(2.0 * pn);
+    if (ub > u) u = ub;
+    u = u * 1.1;
+    bool go = true;
+#pragma unroll 1
+    for (int it = 0; it < 12; it++) {
+        const double f = (u * u + p) * u - Q, d = (3.0 * u) * u + p;
+        go = go && d > 0.0;                                                // the oracle's `break`: once stopped, u stays
+        if (go) u = u - f / d;
+    }
+    const double t1 = q > 0.0 ? -u : u;
+    const double disc = (-3.0 * t1) * t1 - 4.0 * p;
+    double t[3]; int n = 1;
+    t[0] = t1; t[1] = 0.0; t[2] = 0.0;
+    if (disc >= 0.0) {
+        const double sq = sqrt(disc);
+        t[1] = (sq - t1) * 0.5; t[2] = (-sq - t1) * 0.5;
+#pragma unroll
+        for (int k = 1; k < 3; k++) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const double f = (t[k] * t[k] + p) * t[k] + q, d = (3.0 * t[k]) * t[k] + p;
+                if (d != 0.0) t[k] = t[k] - f / d;
+            }
+        }
+        n = 3;
+    }
     const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
-    double M[3][3];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        M[r][0] = fv[3 * r] * s1; M[r][1] = fv[3 * r + 1] * s1;
-        M[r][2] = (fv[3 * r] * t1x + fv[3 * r + 1] * t1y) + fv[3 * r + 2];
-    }
-    double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 9;
-    double Fv[9];
+    for (int k = 0; k < 3; k++) {
+        const double lam = t[k] - sh;
+        double f[9];
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) {
-        Fv[cc] = s2 * M[0][cc]; Fv[3 + cc] = s2 * M[1][cc];
-        Fv[6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+        for (int i = 0; i < 9; i++) f[i] = g[i] * lam + f2[i];
+        double M[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
+            M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            Fm[k][cc] = s2 * M[0][cc]; Fm[k][3 + cc] = s2 * M[1][cc];
+            Fm[k][6 + cc] = (t2x * M[0][cc] + t2y * M[1][cc]) + M[2][cc];
+        }
     }
+    return n;
+}
+
+// one model into its slot: the matrix, the sample it came from, and the guards of the matrix-core line evaluation
+__device__ __forceinline__ void store_model(const DevCtx& c, int vl, int side, int slot, int sample, const double (&Fv)[9])
+{
+    const long long o = ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + slot;
+    double* F = c.rs_F + o * 9;
 #pragma unroll
     for (int j = 0; j < 9; j++) F[j] = Fv[j];
+    c.rs_k[o] = sample;
     // guards of the matrix-core line evaluation in k_ransac_count (see there): E bounds how far its numerators can be from
     // the oracle's operation order, given coordinates inside the image; a side is trusted when |l| >= 2^28 E
     double aF[9];
@@ -625,32 +680,71 @@ __device__ __forceinline__ void store_hypothesis(const DevCtx& c, int vl, int si
     const double X = (double)c.W, Y = (double)c.H, u = 7.105427357601002e-15;           // 2^-47
     const double EB = u * (X * (aF[0] * X + aF[1] * Y + aF[2]) + Y * (aF[3] * X + aF[4] * Y + aF[5]) + (aF[6] * X + aF[7] * Y + aF[8]));
     const double EA = u * (X * (aF[0] * X + aF[3] * Y + aF[6]) + Y * (aF[1] * X + aF[4] * Y + aF[7]) + (aF[2] * X + aF[5] * Y + aF[8]));
-    double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 2;
+    double* Gd = c.rs_guard + o * 2;
     const double gA = 268435456.0 * EA, gB = 268435456.0 * EB;
     Gd[0] = gA * gA; Gd[1] = gB * gB;            // an overflow or a NaN here makes every comparison against it false: the side is never trusted
 }
+// The filler of an unused slot inside a live group of sixteen: l = F x1 = (1, 1, 0) for every x1, so the distance of x2 from it is
+// (x2 + y2) / sqrt 2 -- tens of pixels for anything a tracker hands over (keypoints keep 31 px from every border): "outlier" on the
+// fast path of every count kernel, count 0, never a record.
+__device__ __forceinline__ void store_filler(const DevCtx& c, int vl, int side, int slot)
+{
+    const double Fd[9] = { 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0 };
+    store_model(c, vl, side, slot, 0x3FFFFFFF, Fd);
+}
 
-// Evaluating hypotheses OUT OF ORDER still bounds what the sequential scan visits.  The scan visits [0, E), E = the first k
-// that is no longer below the budget (a record at k may cut the budget below k itself: k is still visited, so E can exceed the
-// final budget).  A visited hypothesis h with count c > 7 leaves a budget <= K(c) whether it is a record or not (a record
-// before it had a count >= c, and K falls with the count), so the scan ends by max(h + 1, K(c)); an unvisited one has
-// E <= h.  Hence E <= max(h + 1, K(c)) for EVERY evaluated h, and the minimum of those over whatever has been evaluated so
-// far (rs_bound) is a safe limit: hypotheses at or beyond it are never visited, everything below it is evaluated.
+// Evaluating models OUT OF ORDER still bounds what the sequential scan visits.  The scan visits the samples [0, E), E = the first
+// k that is no longer below the budget (a record in sample k may cut the budget below k itself: k is still visited -- all its
+// models are --, so E can exceed the final budget).  A visited model of sample h with count c > 6 leaves a budget <= K(c) whether
+// it is a record or not (a record before it had a count >= c, and K falls with the count), so the scan ends by max(h + 1, K(c));
+// a model of an unvisited sample has E <= h.  Hence E <= max(h + 1, K(c)) for EVERY scored model, and the minimum of those over
+// whatever has been scored so far (rs_bound) is a safe limit: samples at or beyond it are never visited, every model of every
+// sample below it is scored.
 // (The tightening uses K(c - 1): one inlier less moves num / d by far more than svo_ln's rounding error, so the
 // "K falls with the count" step holds for the computed values too, not only in exact arithmetic.)
 #define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1))
 #define RS_CHUNK_END(ch) ((ch) == 0 ? SVO_RANSAC_CHUNK0 : ((ch) == 1 ? SVO_RANSAC_CHUNK1 : SVO_RANSAC_HYP))
+#define RS_SLOT_END(ch) (((RS_CHUNK_END(ch) + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG) * SVO_RANSAC_RSLOTS)      // end of the chunk's model slots (whole regions)
+static_assert(SVO_RANSAC_CHUNK0 % SVO_RANSAC_REG == 0 && SVO_RANSAC_CHUNK1 % SVO_RANSAC_REG == 0 && SVO_RANSAC_RSLOTS == 3 * SVO_RANSAC_REG && SVO_RANSAC_REG == 16,
+              "chunks are whole regions; a region is one DPP row of samples");
 
-// chunk 0: hypotheses [0, CHUNK0) always; chunks 1, 2: only below rs_bound.
+// What a group of consecutive slots starting at s0 (a multiple of 4 inside one region) still has to offer: the number of models
+// at or after s0 in its region, 0 when the region was not generated by this chunk's hypothesis kernel (beyond rs_gen), when the
+// group starts beyond the region's models, or when its first sample is one the sequential stop can no longer reach.
+__device__ __forceinline__ int rs_group_live(const DevCtx& c, int vl, int side, int s0)
+{
+    const int reg = s0 / SVO_RANSAC_RSLOTS, off = s0 - reg * SVO_RANSAC_RSLOTS;
+    if (reg * SVO_RANSAC_REG >= c.rs_gen[vl * 2 + side]) return 0;
+    const int nv = c.rs_nvalid[((long long)vl * 2 + side) * (SVO_RANSAC_PAD / SVO_RANSAC_REG) + reg];
+    if (off >= nv) return 0;
+    if (c.rs_k[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + s0] >= *(volatile int*)(c.rs_bound + vl * 2 + side)) return 0;
+    return nv - off;
+}
+// after a block has its counts: its best model tightens rs_bound and raises the floors of the later chunks
+__device__ __forceinline__ void rs_publish_best(const DevCtx& c, int vl, int side, int chunk, int n, int best, int best_slot)
+{
+    int* bound = c.rs_bound + vl * 2 + side;
+    if (best > 7) {
+        const int cur = *(volatile int*)bound, k = c.rs_k[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + best_slot];
+        if (k + 1 < cur) {
+            const int K = ransac_niters(best - 1, n, cur);
+            if (max(k + 1, K) < cur) atomicMin(bound, max(k + 1, K));
+        }
+    }
+    // the floors of the later chunks: best count of chunk 0 (for chunk 1), of chunks 0 and 1 (for chunk 2)
+    if (chunk == 0 && best > 6) atomicMax(&c.rs_floor[(vl * 2 + side) * 2], best);
+    if (chunk <= 1 && best > 6) atomicMax(&c.rs_floor[(vl * 2 + side) * 2 + 1], best);
+}
+
+// chunk 0: samples [0, CHUNK0) always; chunks 1, 2: only below rs_bound.
 //
-// One hypothesis = 16 lanes (a DPP row), four hypotheses per wave, sixteen per 256-thread block.  Lane c < 9 of a group holds
-// COLUMN c of the 8x9 system in registers; the oracle's Gauss-Jordan with full pivoting (eight_point) then runs without any
+// One sample = 16 lanes (a DPP row), four samples per wave, sixteen per 256-thread block = one region.  Lane c < 9 of a group
+// holds COLUMN c of the 7x9 system in registers; the oracle's Gauss-Jordan with full pivoting (seven_point) then runs without any
 // memory traffic: the pivot search is a per-lane scan plus a 16-lane all-reduce on the DPP network, rows are swapped in
 // registers, columns are swapped VIRTUALLY (vcol = a lane's current column position; the data never moves), the pivot
 // column's entries reach the other lanes by ds_bpermute.  Every arithmetic step is element-wise and uses the oracle's
 // expression, so the matrices agree bit for bit; ties in the pivot search resolve to the oracle's scan order (row, then
-// column position).  The one-thread-per-hypothesis version this replaces walked ~1500 dependent LDS accesses per hypothesis:
-// ~45 us of latency per launch whatever the hypothesis count, three launches per frame.
+// column position).  The group's first lane then solves the cubic and writes the models.
 typedef struct { double v; int key; } PivotCand;
 __device__ __forceinline__ double dpp_f64(double v, const int ctrl_tag)
 {
@@ -675,13 +769,32 @@ __device__ __forceinline__ int dpp_i32(int v, const int ctrl_tag)
 // value of `v` in lane `src` (0..15) of this lane's group of 16
 __device__ __forceinline__ double group_bcast(double v, int src) { return __shfl(v, src, 16); }
 
+// the models of one region, packed: nm[i] models of sample i (0 for a sample that was not generated) at the running offset.
+// Called by the lane that owns sample i of the region (all sixteen owners take part); `prefix` = models of the samples before it.
+__device__ __forceinline__ void store_region_models(const DevCtx& c, int vl, int side, int reg, int sample, int prefix, int nm, const double (&Fm)[3][9])
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++) if (j < nm) store_model(c, vl, side, reg * SVO_RANSAC_RSLOTS + prefix + j, sample, Fm[j]);
+}
+// ... and what the owners do together once the region's total is known (lane i of the sixteen): zero every count, fill the tail
+// of the last live group of sixteen slots, publish the total
+__device__ __forceinline__ void finish_region(const DevCtx& c, int vl, int side, int reg, int i16, int total)
+{
+    const long long o = ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + (long long)reg * SVO_RANSAC_RSLOTS;
+    c.rs_cnt[o + i16] = 0; c.rs_cnt[o + 16 + i16] = 0; c.rs_cnt[o + 32 + i16] = 0;
+    const int s = total + i16;
+    if (s < ((total + 15) & ~15)) store_filler(c, vl, side, reg * SVO_RANSAC_RSLOTS + s);
+    if (i16 == 0) c.rs_nvalid[((long long)vl * 2 + side) * (SVO_RANSAC_PAD / SVO_RANSAC_REG) + reg] = total;
+}
+
 __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
 {
+    __shared__ int nm_s[16];
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16 + grp, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;
+    if (n < 7) return;
     // rs_bound is stable while this kernel runs (only k_ransac_count lowers it, and the previous chunk's has finished): what
     // this chunk generates is [begin, gen) with gen = min(end, rs_bound); k_ransac_count must not trust anything beyond it
     const int gen = chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk);
@@ -689,57 +802,44 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
     if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 16 >= gen) return;          // block-uniform; inside a live block every lane stays (DPP)
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     // ---- the sample (oracle: ransac_sample), computed redundantly by the 16 lanes of the group ----
-    int s[8];
-    {
-        unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
-        if (!st) st = 1;
+    int s[7];
+    ransac_sample7(h, n, s);
+    float4 P[7];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int v; bool dup;
-            do {
-                v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false;
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (k < j && s[k] == v) dup = true;
-            } while (dup);
-            s[j] = v;
-        }
-    }
-    float4 P[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) P[i] = pts[s[i]];
+    for (int i = 0; i < 7; i++) P[i] = pts[s[i]];
     double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
-    c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
-    // the sixteen square roots of the mean-distance normalisation: lane i < 8 of the group takes point i, the sums then run over
-    // the lanes' values in the oracle's order (a double-precision sqrt is ~30 instructions; sixteen per lane were a fifth of the kernel)
+    for (int i = 0; i < 7; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
+    c1x = c1x / 7.0; c1y = c1y / 7.0; c2x = c2x / 7.0; c2y = c2y / 7.0;
+    // the fourteen square roots of the mean-distance normalisation: lane i < 7 of the group takes point i, the sums then run over
+    // the lanes' values in the oracle's order (a double-precision sqrt is ~30 instructions)
     double d1 = 0, d2 = 0;
     {
         float4 Pm = P[0];
 #pragma unroll
-        for (int i = 1; i < 8; i++) if ((gl & 7) == i) Pm = P[i];
+        for (int i = 1; i < 7; i++) if ((gl & 7) == i) Pm = P[i];
         const double ax = (double)Pm.x - c1x, ay = (double)Pm.y - c1y, bx = (double)Pm.z - c2x, by = (double)Pm.w - c2y;
         const double r1 = sqrt(ax * ax + ay * ay), r2 = sqrt(bx * bx + by * by);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { d1 += group_bcast(r1, i); d2 += group_bcast(r2, i); }
+        for (int i = 0; i < 7; i++) { d1 += group_bcast(r1, i); d2 += group_bcast(r2, i); }
     }
-    const double s1 = 11.313708498984761 / d1, s2 = 11.313708498984761 / d2;
+    const double s1 = 9.8994949366116654 / d1, s2 = 9.8994949366116654 / d2;
     // ---- column gl of the system: A[i][0..8] = x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1 ----
-    double col[8];
+    double col[7];
     const int cu = gl / 3, cv = gl - 3 * cu;                                  // column = (x2 | y2 | 1) * (x1 | y1 | 1)
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 7; i++) {
         const double x1 = ((double)P[i].x - c1x) * s1, y1 = ((double)P[i].y - c1y) * s1, x2 = ((double)P[i].z - c2x) * s2, y2 = ((double)P[i].w - c2y) * s2;
         const double u = cu == 0 ? x2 : (cu == 1 ? y2 : 1.0), v = cv == 0 ? x1 : (cv == 1 ? y1 : 1.0);
         col[i] = gl < 9 ? u * v : 0.0;                                          // x * 1.0 == x exactly: same entries as the oracle's
     }
     int vcol = gl < 9 ? gl : 64;                                              // lanes 9..15 hold no column
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 7; k++) {
         // pivot = first maximum of |A[i][j]|, i >= k, j >= k, in (i, j) scan order
         double bv = -1.0; int bi = k;
 #pragma unroll
-        for (int i = k; i < 8; i++) { const double a = fabs(col[i]); if (a > bv) { bv = a; bi = i; } }
+        for (int i = k; i < 7; i++) { const double a = fabs(col[i]); if (a > bv) { bv = a; bi = i; } }
         const bool active = vcol >= k && vcol <= 8;
         if (!active) bv = -2.0;
         int bkey = (bi << 8) | ((vcol & 63) << 4) | gl;
@@ -752,68 +852,80 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
         const int pi = bkey >> 8, pjv = (bkey >> 4) & 15, plane = bkey & 15;
         // row swap k <-> pi in every column
 #pragma unroll
-        for (int i = k + 1; i < 8; i++) if (i == pi) { const double t = col[i]; col[i] = col[k]; col[k] = t; }
+        for (int i = k + 1; i < 7; i++) if (i == pi) { const double t = col[i]; col[i] = col[k]; col[k] = t; }
         // column swap k <-> pjv, virtual
         if (vcol == pjv) vcol = k; else if (vcol == k) vcol = pjv;
         const double piv = group_bcast(col[k], plane);
         const bool act2 = vcol >= k && vcol <= 8;
         if (act2) col[k] = col[k] / piv;
-        double f[8];
+        double f[7];
 #pragma unroll
-        for (int i = 0; i < 8; i++) f[i] = i == k ? 0.0 : group_bcast(col[i], plane);       // A[i][k], read before anything below changes it
+        for (int i = 0; i < 7; i++) f[i] = i == k ? 0.0 : group_bcast(col[i], plane);       // A[i][k], read before anything below changes it
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i != k && act2) col[i] = col[i] - f[i] * col[k];
+        for (int i = 0; i < 7; i++) if (i != k && act2) col[i] = col[i] - f[i] * col[k];
     }
-    // f[perm[8]] = 1, f[perm[i]] = -A[i][8]: lane L (original column L) sits at position vcol, the lane at position 8 holds A[.][8]
-    const unsigned long long at8 = __ballot(vcol == 8);
-    const int lane8 = __ffs((unsigned)((at8 >> (16 * (threadIdx.x >> 4 & 3))) & 0xFFFFu)) - 1;
-    double a8[8];
+    // the free unknowns sit at positions 7 and 8: g[perm[7]] = 1, g[perm[8]] = -1, g[perm[i]] = A[i][8] - A[i][7];
+    // f2[perm[7]] = 0, f2[perm[8]] = 1, f2[perm[i]] = -A[i][8].  Lane L (original column L) sits at position vcol.
+    const unsigned rowmask_shift = 16 * (threadIdx.x >> 4 & 3);
+    const int lane7 = __ffs((unsigned)((__ballot(vcol == 7) >> rowmask_shift) & 0xFFFFu)) - 1;
+    const int lane8 = __ffs((unsigned)((__ballot(vcol == 8) >> rowmask_shift) & 0xFFFFu)) - 1;
+    double a7[7], a8[7];
 #pragma unroll
-    for (int i = 0; i < 8; i++) a8[i] = group_bcast(col[i], lane8);
-    double fmine = 1.0;
+    for (int i = 0; i < 7; i++) { a7[i] = group_bcast(col[i], lane7); a8[i] = group_bcast(col[i], lane8); }
+    double gmine = vcol == 7 ? 1.0 : -1.0, fmine = vcol == 7 ? 0.0 : 1.0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) if (vcol == i) fmine = -a8[i];
-    double fv[9];
+    for (int i = 0; i < 7; i++) if (vcol == i) { gmine = a8[i] - a7[i]; fmine = -a8[i]; }
+    double gv[9], fv[9];
 #pragma unroll
-    for (int j = 0; j < 9; j++) fv[j] = group_bcast(fmine, j);
-    if (gl == 0 && h < gen) store_hypothesis(c, vl, side, h, fv, s1, s2, c1x, c1y, c2x, c2y);
+    for (int j = 0; j < 9; j++) { gv[j] = group_bcast(gmine, j); fv[j] = group_bcast(fmine, j); }
+    double Fm[3][9];
+    const bool live = h < gen;
+    const int nm = seven_point_models(gv, fv, s1, s2, c1x, c1y, c2x, c2y, Fm);
+    if (gl == 0) nm_s[grp] = live ? nm : 0;
+    __syncthreads();
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const int v = nm_s[i]; if (i < grp) prefix += v; total += v; }
+    const int reg = (RS_CHUNK_BEGIN(chunk) >> 4) + blockIdx.x;
+    if (gl == 0 && live) store_region_models(c, vl, side, reg, h, prefix, nm, Fm);
+    if (threadIdx.x < 16) finish_region(c, vl, side, reg, threadIdx.x, total);
 }
 
-// step K of the oracle's Gauss-Jordan elimination with full pivoting (eight_point) on a thread's own registers
+// step K of the oracle's Gauss-Jordan elimination with full pivoting (seven_point) on a thread's own registers
 template <int K>
-__device__ __forceinline__ void gj_step(double (&A)[8][9], int (&perm)[9])
+__device__ __forceinline__ void gj_step(double (&A)[7][9], int (&perm)[9])
 {
     // pivot = first maximum of |A[i][j]|, i >= K, j >= K, in (i, j) scan order
     // (the maximum first -- fmax skips NaNs as the oracle's `v > best` does --, then the first entry that equals it: the scan runs
     // backwards so that the last assignment is the first position; three instructions per entry instead of four)
     double best = -1.0; int pij = K * 16 + K;
 #pragma unroll
-    for (int i = K; i < 8; i++) {
+    for (int i = K; i < 7; i++) {
 #pragma unroll
         for (int j = K; j < 9; j++) best = fmax(best, fabs(A[i][j]));
     }
 #pragma unroll
-    for (int i = 7; i >= K; i--) {
+    for (int i = 6; i >= K; i--) {
 #pragma unroll
         for (int j = 8; j >= K; j--) if (fabs(A[i][j]) == best) pij = i * 16 + j;
     }
     const int pi = pij >> 4, pj = pij & 15;
 #pragma unroll
-    for (int i = K + 1; i < 8; i++) if (pi == i) {
+    for (int i = K + 1; i < 7; i++) if (pi == i) {
 #pragma unroll
         for (int j = K; j < 9; j++) { const double t = A[K][j]; A[K][j] = A[i][j]; A[i][j] = t; }
     }
 #pragma unroll
     for (int j = K + 1; j < 9; j++) if (pj == j) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) { const double t = A[i][K]; A[i][K] = A[i][j]; A[i][j] = t; }
+        for (int i = 0; i < 7; i++) { const double t = A[i][K]; A[i][K] = A[i][j]; A[i][j] = t; }
         const int t = perm[K]; perm[K] = perm[j]; perm[j] = t;
     }
     const double piv = A[K][K];
 #pragma unroll
     for (int j = K + 1; j < 9; j++) A[K][j] = A[K][j] / piv;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 7; i++) {
         if (i == K) continue;
         const double f = A[i][K];
 #pragma unroll
@@ -821,55 +933,43 @@ __device__ __forceinline__ void gj_step(double (&A)[8][9], int (&perm)[9])
     }
 }
 
-// The same hypotheses with ONE THREAD each, for launches that fill the GPU anyway (many lanes): the 16-lane form above spends
-// 1500 wave-instructions on four hypotheses (nine of sixteen lanes hold a column, every step pays its DPP all-reduce and
-// sixteen cross-lane broadcasts) -- it is built for the latency of one stream.  Here the 8x9 system sits in the thread's own
+// The same samples with ONE THREAD each, for launches that fill the GPU anyway (many lanes): the 16-lane form above spends
+// ~1500 wave-instructions on four samples (nine of sixteen lanes hold a column, every step pays its DPP all-reduce and
+// sixteen cross-lane broadcasts) -- it is built for the latency of one stream.  Here the 7x9 system sits in the thread's own
 // registers (every loop unrolled, no dynamic index), the oracle's Gauss-Jordan runs on it literally -- physical row and column
 // swaps under the pivot's predicate (exec-masked register swaps), the elimination restricted to the columns that are still
-// read (column k of the other rows becomes an exact 0 that nothing looks at again; columns left of k are dead) -- and a wave
-// turns out 64 hypotheses in ~3500 instructions: about a sixth of the instructions per hypothesis.
+// read (column k of the other rows becomes an exact 0 that nothing looks at again; columns left of k are dead).  A DPP row of
+// sixteen threads is one region: its models are packed by a row scan of the model counts.
 __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
 {
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;
+    if (n < 7) return;
     const int gen = chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk);
     if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
-    if (h >= gen) return;
+    if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 64 >= gen) return;          // wave-uniform: inside a live wave every lane stays (DPP scan)
+    const bool live = h < gen;
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
-    int s[8];
-    {
-        unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
-        if (!st) st = 1;
+    int s[7];
+    ransac_sample7(live ? h : 0, n, s);
+    float4 P[7];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int v; bool dup;
-            do {
-                v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false;
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (k < j && s[k] == v) dup = true;
-            } while (dup);
-            s[j] = v;
-        }
-    }
-    float4 P[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) P[i] = pts[s[i]];
+    for (int i = 0; i < 7; i++) P[i] = pts[s[i]];
     double c1x = 0, c1y = 0, c2x = 0, c2y = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
-    c1x = c1x / 8.0; c1y = c1y / 8.0; c2x = c2x / 8.0; c2y = c2y / 8.0;
+    for (int i = 0; i < 7; i++) { c1x += (double)P[i].x; c1y += (double)P[i].y; c2x += (double)P[i].z; c2y += (double)P[i].w; }
+    c1x = c1x / 7.0; c1y = c1y / 7.0; c2x = c2x / 7.0; c2y = c2y / 7.0;
     double d1 = 0, d2 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 7; i++) {
         const double ax = (double)P[i].x - c1x, ay = (double)P[i].y - c1y, bx = (double)P[i].z - c2x, by = (double)P[i].w - c2y;
         d1 += sqrt(ax * ax + ay * ay); d2 += sqrt(bx * bx + by * by);
     }
-    const double s1 = 11.313708498984761 / d1, s2 = 11.313708498984761 / d2;
-    double A[8][9];
+    const double s1 = 9.8994949366116654 / d1, s2 = 9.8994949366116654 / d2;
+    double A[7][9];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 7; i++) {
         const double x1 = ((double)P[i].x - c1x) * s1, y1 = ((double)P[i].y - c1y) * s1, x2 = ((double)P[i].z - c2x) * s2, y2 = ((double)P[i].w - c2y) * s2;
         A[i][0] = x2 * x1; A[i][1] = x2 * y1; A[i][2] = x2; A[i][3] = y2 * x1; A[i][4] = y2 * y1; A[i][5] = y2; A[i][6] = x1; A[i][7] = y1; A[i][8] = 1.0;
     }
@@ -877,17 +977,30 @@ __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
 #pragma unroll
     for (int j = 0; j < 9; j++) perm[j] = j;
     gj_step<0>(A, perm); gj_step<1>(A, perm); gj_step<2>(A, perm); gj_step<3>(A, perm);
-    gj_step<4>(A, perm); gj_step<5>(A, perm); gj_step<6>(A, perm); gj_step<7>(A, perm);
-    // f[perm[8]] = 1, f[perm[i]] = -A[i][8]
-    double fv[9];
+    gj_step<4>(A, perm); gj_step<5>(A, perm); gj_step<6>(A, perm);
+    // g[perm[7]] = 1, g[perm[8]] = -1, g[perm[i]] = A[i][8] - A[i][7];  f2[perm[7]] = 0, f2[perm[8]] = 1, f2[perm[i]] = -A[i][8]
+    double gv[9], fv[9];
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-        double v = 1.0;
+        double gj = perm[7] == j ? 1.0 : -1.0, fj = perm[7] == j ? 0.0 : 1.0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (perm[i] == j) v = -A[i][8];
-        fv[j] = v;
+        for (int i = 0; i < 7; i++) if (perm[i] == j) { gj = A[i][8] - A[i][7]; fj = -A[i][8]; }
+        gv[j] = gj; fv[j] = fj;
     }
-    store_hypothesis(c, vl, side, h, fv, s1, s2, c1x, c1y, c2x, c2y);
+    double Fm[3][9];
+    int nm = seven_point_models(gv, fv, s1, s2, c1x, c1y, c2x, c2y, Fm);
+    if (!live) nm = 0;
+    // inclusive scan of the model counts inside the DPP row of sixteen = the region
+    int inc = nm;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);      // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);      // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);      // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);      // row_shr:8
+    const int total = __shfl(inc, 15, 16);
+    const int reg = (h >> 4);
+    if (reg >= SVO_RANSAC_PAD / SVO_RANSAC_REG) return;                       // (lanes past the padded schedule: nm = 0, nothing to say)
+    store_region_models(c, vl, side, reg, h, inc - nm, nm, Fm);
+    finish_region(c, vl, side, reg, threadIdx.x & 15, total);
 }
 
 // Symmetric epipolar test e = max(dA^2 / |lA|^2, dB^2 / |lB|^2) <= 1 with the oracle's arithmetic, minus its two f64
@@ -912,14 +1025,14 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
     return e <= 1.0;
 }
 
-// Inlier counts on the MATRIX CORES: the two epipolar lines of every (hypothesis, pair), l = F x1 and l' = F^T x2, are small
-// dense products -- [16 rows = 4 hypotheses x (a, b, c, -)] x [4 = (x, y, 1, 0)] x [16 pairs] -- i.e. one
-// v_mfma_f64_16x16x4_f64 each per wave and tile of 16 pairs, after which lane (g, j) holds (a, b, c) of hypothesis g for pair j
+// Inlier counts on the MATRIX CORES: the two epipolar lines of every (model, pair), l = F x1 and l' = F^T x2, are small
+// dense products -- [16 rows = 4 models x (a, b, c, -)] x [4 = (x, y, 1, 0)] x [16 pairs] -- i.e. one
+// v_mfma_f64_16x16x4_f64 each per wave and tile of 16 pairs, after which lane (g, j) holds (a, b, c) of model g for pair j
 // in its own registers (result layout, pinned on the hardware: row i of the 16x16 tile sits in register i / 4 of lane
 // j + 16 (i % 4); operands: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k).  What is left per test on the VALU is the two
 // norms, the two numerators and the comparisons: about 45 instructions against 78.
 // The matrix core sums its four products in an order of its own, so a, b, c can differ from the oracle's ((F0 x + F1 y) + F2)
-// in the last bits.  E (k_ransac_hyp, per hypothesis and side) bounds the resulting shift of a numerator for coordinates
+// in the last bits.  E (store_model, per model and side) bounds the resulting shift of a numerator for coordinates
 // inside the image; a side is trusted only when |l| >= 2^28 E, which keeps d to 2^-28 |l| and |l|^2 to 2^-28 relatively, and a
 // verdict is given only when d^2 and |l|^2 differ by more than 2^-26: anything closer, and any failed guard or NaN, replays the
 // oracle's own expression (fm_inlier).  In practice nothing is ever that close; the replay is there so that the counts are
@@ -928,31 +1041,32 @@ typedef double rc_d4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 {
     __shared__ int cnt_s[16];
-    const int side = blockIdx.y, vl = blockIdx.z, h0 = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;
-    int* bound = c.rs_bound + vl * 2 + side;
-    if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
+    if (n < 7) return;
+    if (h0 >= RS_SLOT_END(chunk)) return;
+    const int nlive = rs_group_live(c, vl, side, h0);
+    if (nlive <= 0) return;                                                   // nothing generated here, or samples the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
-    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 9;
-    const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 2;
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0) * 9;
+    const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0) * 2;
     const int w = tid >> 6, l = tid & 63, k = l >> 4, j = l & 15;
-    // operand A of the two products: lane l holds row i = l % 16 = 4 r + g (component r of hypothesis g of this wave), column k
+    // operand A of the two products: lane l holds row i = l % 16 = 4 r + g (component r of model g of this wave), column k
     const int ga = l & 3, ra = (l & 15) >> 2;
     const double* Fa = F + 9 * (4 * w + ga);
     const bool liveA = ra < 3 && k < 3;
     const double a1 = liveA ? Fa[3 * ra + k] : 0.0;            // F[r][k]:   l  = F   (x1 y1 1)
     const double a2 = liveA ? Fa[3 * k + ra] : 0.0;            // F[k][r]:   l' = F^T (x2 y2 1)
-    // the hypothesis this lane evaluates: g = l / 16
+    // the model this lane evaluates: g = l / 16
     const double* Fe = F + 9 * (4 * w + k);
     const double dminA = Gd[2 * (4 * w + k)], dminB = Gd[2 * (4 * w + k) + 1];
     const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
-    // A hypothesis matters only if it is a RECORD (its count exceeds that of every earlier hypothesis, k_track_finalize), and
-    // every hypothesis of chunks 1, 2 comes after all of chunk 0 (chunk 2: after all of chunk 1 as well), whose best count is
-    // known by now: once a hypothesis cannot exceed that floor even if every remaining pair were an inlier, its exact count is
+    // A model matters only if it is a RECORD (its count exceeds that of every earlier model, k_track_finalize), and
+    // every model of chunks 1, 2 comes after all of chunk 0 (chunk 2: after all of chunk 1 as well), whose best count is
+    // known by now: once a model cannot exceed that floor even if every remaining pair were an inlier, its exact count is
     // of no consequence -- the partial count it leaves is below the floor too, so it is no record, and as an under-estimate it
-    // only loosens the rs_bound it feeds.  A wave stops when all four of its hypotheses are there (a contaminated sample
+    // only loosens the rs_bound it feeds.  A wave stops when all four of its models are there (a contaminated sample
     // explains 10-20 % of the pairs against the floor's 50-60 %: about half way through the list).
     const int floor_cnt = chunk ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
     int cnt = 0;
@@ -983,71 +1097,75 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
         if (__builtin_expect(!((inA & inB) | outA | outB) || c.debug_mode == 13, 0)) v = fm_inlier(Fe, p.x, p.y, p.z, p.w);
         cnt += pi < n ? v : 0;
     }
-    // the 16 lanes of a group hold the partial counts of one hypothesis
+    // the 16 lanes of a group hold the partial counts of one model
     cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, false);
     cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xF, 0xF, false);
     cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xF, 0xF, false);
     cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x140, 0xF, 0xF, false);
-    if (j == 0) { cnt_s[4 * w + k] = cnt; c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0 + 4 * w + k] = cnt; }
+    if (j == 0) { cnt_s[4 * w + k] = cnt; c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0 + 4 * w + k] = cnt; }
     __syncthreads();
     if (tid == 0) {
-        // only hypotheses this chunk really generated count: beyond rs_gen the F matrices are leftovers of an earlier frame
-        const int gen = c.rs_gen[vl * 2 + side];
-        int best = 0, best_h = 0;
-        for (int h = 0; h < 16; h++) if (cnt_s[h] > best && h0 + h < gen) { best = cnt_s[h]; best_h = h0 + h; }
-        const int cur = *(volatile int*)bound;
-        if (best > 8 && best_h + 1 < cur) {
-            const int K = ransac_niters(best - 1, n, cur);
-            if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
-        }
-        // the floors of the later chunks: best count of chunk 0 (for chunk 1), of chunks 0 and 1 (for chunk 2)
-        if (chunk == 0 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2], best);
-        if (chunk <= 1 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2 + 1], best);
+        int best = 0, best_h = h0;
+        for (int h = 0; h < 16; h++) if (h < nlive && cnt_s[h] > best) { best = cnt_s[h]; best_h = h0 + h; }
+        rs_publish_best(c, vl, side, chunk, n, best, best_h);
     }
 }
 
-// The count for launches that fill the GPU (many lanes): SIXTEEN hypotheses x sixteen pairs per matrix-core tile, and the
+// The count for launches that fill the GPU (many lanes): SIXTEEN models x sixteen pairs per matrix-core tile, and the
 // numerator on the matrix cores as well.  d = x2^T F x1 is one bilinear form -- the oracle's dA and dB are two roundings of it --
-// so with phi = (x1 x2, y1 x2, x2, x1 y2 | y1 y2, y2, x1, y1 | 1) it is a [16 hypotheses x 9] x [9 x 16 pairs] product (three
+// so with phi = (x1 x2, y1 x2, x2, x1 y2 | y1 y2, y2, x1, y1 | 1) it is a [16 models x 9] x [9 x 16 pairs] product (three
 // chained v_mfma_f64_16x16x4_f64), and the four line components a, b of l = F x1 and l' = F^T x2 are four more [16 x 3] x
 // [3 x 16] products.  What is left on the VALU per test is the two norms, d^2, the band products and the comparisons: ~19
-// instructions against ~45 of k_ransac_count_mfma (whose tiles are 4 hypotheses x 4 line components, numerators on the VALU),
-// and the B operands (built once per block and 256 pairs in LDS, in operand layout) serve 64 hypotheses.  The step is bound by
+// instructions against ~45 of k_ransac_count_mfma (whose tiles are 4 models x 4 line components, numerators on the VALU),
+// and the B operands (built once per block and 256 pairs in LDS, in operand layout) serve 64 slots.  The step is bound by
 // VALU issue, the matrix pipe is otherwise idle: the instructions move to where there is room.
-// Exactness as in k_ransac_count_mfma: E (store_hypothesis) bounds |d - dA|, |d - dB| for coordinates inside the image whatever
+// Exactness as in k_ransac_count_mfma: E (store_model) bounds |d - dA|, |d - dB| for coordinates inside the image whatever
 // the summation order (the oracle's dA / dB carry <= 6 roundings of the nine terms, three chained matrix-core products <= 12 if
 // they are fused multiply-adds and <= 24 if products and sums round separately: 30 u_53 <= 2^-47 x 2^53 = 64, the factor there), a side is trusted only
 // when |l| >= 2^28 E, a verdict is given only when d^2 and |l|^2 differ by more than 2^-26 relatively, and everything else
 // -- a failed guard, a NaN, a borderline pair -- replays the oracle's own expression (fm_inlier).
-// Result layout of the tile (pinned on the hardware, see above): lane l = j + 16 q, register r  <->  hypothesis 4 r + q, pair j.
+// Result layout of the tile (pinned on the hardware, see above): lane l = j + 16 q, register r  <->  model 4 r + q, pair j.
 #define RC16_SUPER 256
 __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk)
 {
     __shared__ double ops[(RC16_SUPER / 16) * 256];            // per tile of 16 pairs: B1 | B2 | phi[0..3] | phi[4..7], each [k][j]
     __shared__ int cnt_s[64];
-    const int side = blockIdx.y, vl = blockIdx.z, h0 = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64, tid = threadIdx.x;
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64, tid = threadIdx.x;     // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;
-    int* bound = c.rs_bound + vl * 2 + side;
-    if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
+    if (n < 7) return;
+    if (h0 >= RS_SLOT_END(chunk)) return;
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15;
-    const int hw = h0 + 16 * w;                                 // this wave's sixteen hypotheses
-    bool dead = hw >= RS_CHUNK_END(chunk) || (chunk && hw >= *(volatile int*)bound);
-    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + min(hw, SVO_RANSAC_PAD - 16)) * 9;
-    const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + min(hw, SVO_RANSAC_PAD - 16)) * 2;
-    // operand A of the seven products: lane l holds row i = l % 16 (a hypothesis), column k = l / 16
+    const int hw = h0 + 16 * w;                                 // this wave's sixteen slots (one group: never across a region)
+    // the block leaves when none of its four groups has anything to score (block-uniform: every wave computes all four)
+    int nlive_w = 0; bool any = false;
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++) {
+        const int s0 = h0 + 16 * ww;
+        const int nl = (s0 < RS_SLOT_END(chunk) && s0 + 16 <= SVO_RANSAC_SLOTS) ? rs_group_live(c, vl, side, s0) : 0;
+        any = any || nl > 0;
+        if (ww == w) nlive_w = nl;
+    }
+    if (!any) return;
+    bool dead = nlive_w <= 0;
+    const int hs = min(hw, SVO_RANSAC_SLOTS - 16);
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hs) * 9;
+    const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hs) * 2;
+    // operand A of the seven products: lane l holds row i = l % 16 (a model), column k = l / 16
     const double* Fa = F + 9 * j;
     const bool k3 = q < 3;
-    const double a1 = k3 ? Fa[q] : 0.0, a2 = k3 ? Fa[3 + q] : 0.0;                 // (F0 F1 F2), (F3 F4 F5): a, b of l  = F (x1 y1 1)
-    const double a3 = k3 ? Fa[3 * q] : 0.0, a4 = k3 ? Fa[3 * q + 1] : 0.0;         // (F0 F3 F6), (F1 F4 F7): a, b of l' = F^T (x2 y2 1)
-    const double a5 = Fa[q], a6 = Fa[4 + q], a7 = q == 0 ? Fa[8] : 0.0;            // F0..F3 | F4..F7 | F8: the bilinear form
-    const double b7 = q == 0 ? 1.0 : 0.0;
-    // the four hypotheses this lane gets verdicts for: 4 r + q
-    double dminA[4], dminB[4];
+    double a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    double dminA[4] = { 0, 0, 0, 0 }, dminB[4] = { 0, 0, 0, 0 };
+    if (!dead) {                                                // (a dead group's slots hold leftovers of earlier frames: not even read)
+        a1 = k3 ? Fa[q] : 0.0; a2 = k3 ? Fa[3 + q] : 0.0;                 // (F0 F1 F2), (F3 F4 F5): a, b of l  = F (x1 y1 1)
+        a3 = k3 ? Fa[3 * q] : 0.0; a4 = k3 ? Fa[3 * q + 1] : 0.0;         // (F0 F3 F6), (F1 F4 F7): a, b of l' = F^T (x2 y2 1)
+        a5 = Fa[q]; a6 = Fa[4 + q]; a7 = q == 0 ? Fa[8] : 0.0;            // F0..F3 | F4..F7 | F8: the bilinear form
+        // the four models this lane gets verdicts for: 4 r + q
 #pragma unroll
-    for (int r = 0; r < 4; r++) { dminA[r] = Gd[2 * (4 * r + q)]; dminB[r] = Gd[2 * (4 * r + q) + 1]; }
+        for (int r = 0; r < 4; r++) { dminA[r] = Gd[2 * (4 * r + q)]; dminB[r] = Gd[2 * (4 * r + q) + 1]; }
+    }
+    const double b7 = q == 0 ? 1.0 : 0.0;
     const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
     const int floor_cnt = chunk ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
     int cnt[4] = { 0, 0, 0, 0 };
@@ -1068,7 +1186,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         for (int t = 0; t < ntile; t++) {
             const int base = sb + 16 * t;
             if (chunk && base && (t & 7) == 0) {
-                // records only (see k_ransac_count_mfma): a wave stops once none of its sixteen hypotheses can exceed the floor
+                // records only (see k_ransac_count_mfma): a wave stops once none of its sixteen models can exceed the floor
                 bool hopeless = true;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1107,7 +1225,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
             }
         }
     }
-    // the 16 lanes of a DPP row hold the partial counts of hypotheses 4 r + q
+    // the 16 lanes of a DPP row hold the partial counts of models 4 r + q
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int v = cnt[r];
@@ -1116,55 +1234,45 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
         v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
         if (j == 0) {
-            cnt_s[16 * w + 4 * r + q] = v;
-            if (hw + 4 * r + q < SVO_RANSAC_PAD) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + hw + 4 * r + q] = v;
+            const bool mine = nlive_w > 0 && 4 * r + q < nlive_w;            // a real model of a live group (not filler, not a leftover)
+            cnt_s[16 * w + 4 * r + q] = mine ? v : 0;
+            if (nlive_w > 0) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hw + 4 * r + q] = mine ? v : 0;
         }
     }
     __syncthreads();
     if (tid < 64) {
-        // only hypotheses this chunk really generated count: beyond rs_gen the F matrices are leftovers of an earlier frame.
-        // best count, FIRST hypothesis that has it: max over (count << 6 | 63 - h)
-        const int gen = c.rs_gen[vl * 2 + side];
-        int key = (h0 + tid < gen && cnt_s[tid] > 0) ? ((cnt_s[tid] << 6) | (63 - tid)) : 0;
+        // best count, FIRST slot that has it: max over (count << 6 | 63 - slot)
+        int key = cnt_s[tid] > 0 ? ((cnt_s[tid] << 6) | (63 - tid)) : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
-        if (tid == 0) {
-            const int best = key >> 6, best_h = h0 + 63 - (key & 63);
-            const int cur = *(volatile int*)bound;
-            if (best > 8 && best_h + 1 < cur) {
-                const int K = ransac_niters(best - 1, n, cur);
-                if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
-            }
-            // the floors of the later chunks: best count of chunk 0 (for chunk 1), of chunks 0 and 1 (for chunk 2)
-            if (chunk == 0 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2], best);
-            if (chunk <= 1 && best > 7) atomicMax(&c.rs_floor[(vl * 2 + side) * 2 + 1], best);
-        }
+        if (tid == 0 && key > 0) rs_publish_best(c, vl, side, chunk, n, key >> 6, h0 + 63 - (key & 63));
     }
 }
 
-// inlier counts: RC_HB hypotheses per 256-thread block, points streamed once per thread.  The F matrices are read through
+// inlier counts: RC_HB models per 256-thread block, points streamed once per thread.  The F matrices are read through
 // a wave-uniform address (scalar loads into SGPRs: a VALU operand each, no LDS round trip per use).  The block's best
-// hypothesis then tightens rs_bound (see above), so that later blocks of the launch and the next chunk stop earlier.
-// RC_HB hypotheses per block: 16 when many lanes fill the GPU anyway (one fetch of the points serves 16 matrices), 4 when a
+// model then tightens rs_bound (see above), so that later blocks of the launch and the next chunk stop earlier.
+// RC_HB models per block: 16 when many lanes fill the GPU anyway (one fetch of the points serves 16 matrices), 4 when a
 // few lanes leave it empty and the block's own latency is what a frame waits for
 template <int RC_HB>
 __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 {
     __shared__ int cnt_s[RC_HB];
-    const int side = blockIdx.y, vl = blockIdx.z, h0 = RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;
-    int* bound = c.rs_bound + vl * 2 + side;
-    if (h0 >= RS_CHUNK_END(chunk) || (chunk && h0 >= *(volatile int*)bound)) return;      // hypotheses the sequential stop never reaches
+    if (n < 7) return;
+    if (h0 >= RS_SLOT_END(chunk)) return;
+    const int nlive = rs_group_live(c, vl, side, h0);
+    if (nlive <= 0) return;                                                   // nothing generated here, or samples the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
-    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0) * 9;
+    const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0) * 9;
     if (tid < RC_HB) cnt_s[tid] = 0;
     __syncthreads();
     int cnt[RC_HB];
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) cnt[h] = 0;
-    // four points per thread in registers, hypotheses in the outer loop: one scalar fetch of a hypothesis' matrix serves 1024
+    // four points per thread in registers, models in the outer loop: one scalar fetch of a model's matrix serves 1024
     // point tests (with the points outermost the sixteen matrices, 288 SGPRs' worth, were fetched again for every point)
     for (int base = 0; base < n; base += 4 * 256) {
         float4 p[4];
@@ -1183,17 +1291,11 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) { const int v = wave_sum_uniform(cnt[h]); if ((tid & 63) == 0) atomicAdd(&cnt_s[h], v); }
     __syncthreads();
-    if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_PAD + h0 + tid] = cnt_s[tid];
+    if (tid < RC_HB) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0 + tid] = tid < nlive ? cnt_s[tid] : 0;
     if (tid == 0) {
-        // only hypotheses this chunk really generated count: beyond rs_gen the F matrices are leftovers of an earlier frame
-        const int gen = c.rs_gen[vl * 2 + side];
-        int best = 0, best_h = 0;
-        for (int h = 0; h < RC_HB; h++) if (cnt_s[h] > best && h0 + h < gen) { best = cnt_s[h]; best_h = h0 + h; }
-        const int cur = *(volatile int*)bound;
-        if (best > 8 && best_h + 1 < cur) {
-            const int K = ransac_niters(best - 1, n, cur);
-            if (max(best_h + 1, K) < cur) atomicMin(bound, max(best_h + 1, K));
-        }
+        int best = 0, best_h = h0;
+        for (int h = 0; h < RC_HB; h++) if (h < nlive && cnt_s[h] > best) { best = cnt_s[h]; best_h = h0 + h; }
+        rs_publish_best(c, vl, side, chunk, n, best, best_h);
     }
 }
 
@@ -1217,21 +1319,24 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         return;
     }
     const int n = c.trk_nk[vl];
-    // The sequential scan (records in hypothesis order, each shrinking the budget) without its serial cost: the counts
-    // below rs_bound are all there; a hypothesis is a RECORD when its count exceeds every earlier one (and 7); only records
-    // can change the model or the budget.  Waves 0-1 / 2-3 take the two sides: strict prefix maxima by a wave scan over
-    // chunks of 128, the records' budgets K(count) computed in parallel, then
-    // one thread walks the handful of records in order.
+    // The sequential scan (records in (sample, model) order, each shrinking the budget) without its serial cost: the counts of
+    // every model of every sample below rs_bound are all there (a slot that holds no model reads 0); a model is a RECORD when its
+    // count exceeds every earlier one (and 6); only records can change the result or the budget.  Waves 0-1 / 2-3 take the two
+    // sides: strict prefix maxima by a wave scan over chunks of 128 slots, the records' budgets K(count) computed in parallel,
+    // then one thread walks the handful of records in order.
     __shared__ int rec_k[2][64], rec_c[2][64], rec_K[2][64], rec_n[2];
     {
         const int side = tid >> 7, t = tid & 127, wv = (tid >> 6) & 1, ln = tid & 63;
         __shared__ int run_max[2], wave_max[2][2];
-        if (tid < 2) { rec_n[tid] = 0; run_max[tid] = 7; }
+        if (tid < 2) { rec_n[tid] = 0; run_max[tid] = 6; }
         if (tid == 0) s_both = 0;
         __syncthreads();
-        const int lim = n >= 8 ? min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP) : 0;
-        const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_PAD;
-        for (int base = 0; base < SVO_RANSAC_PAD; base += 128) {            // uniform trip count: barriers inside
+        // samples the scan can still reach -> the slots of their regions (all generated and zeroed this frame: see rs_bound)
+        const int lim_k = n >= 7 ? min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP) : 0;
+        const int lim = lim_k > 0 ? ((lim_k - 1) / SVO_RANSAC_REG + 1) * SVO_RANSAC_RSLOTS : 0;
+        const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
+        const int* gk = c.rs_k + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
+        for (int base = 0; base < SVO_RANSAC_SLOTS; base += 128) {          // uniform trip count: barriers inside
             const int k = base + t;
             const int v = k < lim ? gc[k] : 0;
             // inclusive prefix max inside the wave, then across the side's two waves
@@ -1242,7 +1347,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
             __syncthreads();
             const int before_wave = wv ? max(run_max[side], wave_max[side][0]) : run_max[side];
             int prev = __shfl_up(m, 1, 64); if (ln == 0) prev = 0;
-            const int excl = max(before_wave, prev);                         // max of everything before k (and 7)
+            const int excl = max(before_wave, prev);                         // max of everything before k (and 6)
             if (v > excl) { const int slot = atomicAdd(&rec_n[side], 1); if (slot < 64) { rec_k[side][slot] = k; rec_c[side][slot] = v; } }
             __syncthreads();
             if (t == 0) run_max[side] = max(run_max[side], max(wave_max[side][0], wave_max[side][1]));
@@ -1252,35 +1357,45 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         const int nr = min(rec_n[side], 64);
         if (t < nr) rec_K[side][t] = ransac_niters(rec_c[side][t], n, SVO_RANSAC_HYP);
         __syncthreads();
+        // The walk, in the oracle's terms: the budget is tested once per SAMPLE, before its models are scored, so a record in
+        // sample k counts iff k is below the budget left by the records of the samples before k (a record of the same sample
+        // does not stop its later models).  `start` = that budget for the sample of the record at hand.
         if (t == 0 && rec_n[side] > 64) {                                   // more records than slots (a count creeping up one by one): the plain scan
-            int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP;
-            for (int k = 0; k < niters && k < lim; k++) {
-                const int cnt = gc[k];
-                if (cnt > (best_cnt > 7 ? best_cnt : 7)) { best_cnt = cnt; best_k = k; niters = ransac_niters(cnt, n, niters); }
+            int best_s = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, ks = -1, start = SVO_RANSAC_HYP;
+            for (int sl = 0; sl < lim; sl++) {
+                const int cnt = gc[sl];
+                if (cnt <= (best_cnt > 6 ? best_cnt : 6)) continue;
+                const int k = gk[sl];
+                if (k != ks) start = niters;
+                if (k >= start) break;
+                best_cnt = cnt; best_s = sl; ks = k; niters = ransac_niters(cnt, n, niters);
             }
-            s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
-            s_vis[side] = n >= 8 ? max(best_k + 1, niters) : 0;
+            s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
+            s_vis[side] = n >= 7 ? max(ks + 1, niters) : 0;
         } else if (t == 0) {
-            int best_k = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1;
-            for (int r = 0; r < nr; r++) {                                   // next record in index order = smallest index above `last`
-                int sel = -1, selk = 0x7FFFFFFF;
-                for (int q = 0; q < nr; q++) if (rec_k[side][q] > last && rec_k[side][q] < selk) { selk = rec_k[side][q]; sel = q; }
-                if (sel < 0 || selk >= niters) break;
-                last = selk; best_k = selk; best_cnt = rec_c[side][sel];
+            int best_s = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1, ks = -1, start = SVO_RANSAC_HYP;
+            for (int r = 0; r < nr; r++) {                                   // next record in slot order = smallest slot above `last`
+                int sel = -1, sels = 0x7FFFFFFF;
+                for (int q = 0; q < nr; q++) if (rec_k[side][q] > last && rec_k[side][q] < sels) { sels = rec_k[side][q]; sel = q; }
+                if (sel < 0) break;
+                const int k = gk[sels];
+                if (k != ks) start = niters;
+                if (k >= start) break;
+                last = sels; best_s = sels; best_cnt = rec_c[side][sel]; ks = k;
                 niters = min(niters, rec_K[side][sel]);
             }
-            s_best[side] = best_k; s_cnt[side] = best_k >= 0 ? best_cnt : 0;
-            // hypotheses the sequential loop visits: it leaves at the first k that is no longer below the budget, and a record may
-            // cut the budget below its own index (oracle: svo_oracle_ransac_fundamental's n_hyp_used)
-            s_vis[side] = n >= 8 ? max(last + 1, niters) : 0;
+            s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
+            // samples the sequential loop visits: it leaves at the first k that is no longer below the budget, and a record may
+            // cut the budget below its own sample (oracle: svo_oracle_ransac_fundamental's n_hyp_used)
+            s_vis[side] = n >= 7 ? max(ks + 1, niters) : 0;
         }
         __syncthreads();
     }
     const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
     const bool use_f = goodFL && goodFR;                             // S4:243
     if (use_f) {
-        const double* FL = c.rs_F + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + s_best[0]) * 9;
-        const double* FR = c.rs_F + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + s_best[1]) * 9;
+        const double* FL = c.rs_F + (((long long)vl * 2 + 0) * SVO_RANSAC_SLOTS + s_best[0]) * 9;
+        const double* FR = c.rs_F + (((long long)vl * 2 + 1) * SVO_RANSAC_SLOTS + s_best[1]) * 9;
         double fl[9], fr[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) { fl[i] = FL[i]; fr[i] = FR[i]; }
@@ -1462,7 +1577,7 @@ void launch_track_filter(const DevCtx& c, hipStream_t st)
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 {
     const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk);
-    // one stream (few lanes): 16 lanes per hypothesis, for latency; many lanes: one thread per hypothesis, for instruction count
+    // one stream (few lanes): 16 lanes per sample, for latency; many lanes: one thread per sample, for instruction count
     // (debug_mode 50 forces the 16-lane form, 51 the one-thread form: tests/test_gpu_parity.py runs both against the oracle)
     const bool per_thread = c.debug_mode == 51 || (c.debug_mode != 50 && c.n_lanes * c.n_oct > 8);
     if (per_thread) hipLaunchKernelGGL(k_ransac_hyp_thread, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
@@ -1470,17 +1585,17 @@ void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
 }
 void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
 {
-    // one stream (few lanes): four hypotheses per block on the VALU, for latency; many lanes: 16 x 16 matrix-core tiles.
-    // debug modes (tests/test_gpu_parity.py runs each against the oracle): 14 = sixteen hypotheses per block on the VALU,
+    // one stream (few lanes): four models per block on the VALU, for latency; many lanes: 16 x 16 matrix-core tiles.
+    // debug modes (tests/test_gpu_parity.py runs each against the oracle): 14 = sixteen models per block on the VALU,
     // 52 = the 4 x 4-component matrix-core tiles, 53 = the 16 x 16 tiles whatever the lane count, 54 = the same with every
-    // verdict replayed through the oracle's own expression
-    const int nh = RS_CHUNK_END(chunk) - RS_CHUNK_BEGIN(chunk), dm = c.debug_mode;
-    const dim3 g16((nh + 15) / 16, 2, c.n_lanes * c.oct_cap);
+    // verdict replayed through the oracle's own expression.  The grids cover the chunk's model SLOTS (three per sample).
+    const int ns = 3 * (((RS_CHUNK_END(chunk) + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG) * SVO_RANSAC_REG - RS_CHUNK_BEGIN(chunk)), dm = c.debug_mode;
+    const dim3 g16((ns + 15) / 16, 2, c.n_lanes * c.oct_cap);
     const bool many = c.n_lanes * c.n_oct > 8;
     if (dm == 14) hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk);
     else if (dm == 52) hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk);
-    else if (many || dm == 53 || dm == 54) hipLaunchKernelGGL(k_ransac_count_mfma16, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
-    else hipLaunchKernelGGL(k_ransac_count<4>, dim3((nh + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else if (many || dm == 53 || dm == 54) hipLaunchKernelGGL(k_ransac_count_mfma16, dim3((ns + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else hipLaunchKernelGGL(k_ransac_count<4>, dim3((ns + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)
 {

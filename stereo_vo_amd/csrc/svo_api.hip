@@ -52,6 +52,7 @@ struct svo_ctx {
     uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
     uint32_t* d_anms;                                  // scratch of k_fastorb_anms (3 x n_img x cand_total), allocated on first use
     bool imported_pending;                             // svo_import_frame ran since the last svo_process
+    hipEvent_t post_event;                             // svo_record_after_post: armed for the next call that runs the detector's post-processing
     // svo_use_graphs: the kernel sequence of a frame captured once per (flags, ring slot, thresholds) and replayed
     struct GraphEntry { uint32_t flags; int slot, fast_th, orb_th; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs; bool use_graphs;
@@ -68,14 +69,19 @@ static void note_stream(svo_ctx* ctx)
 {
     for (auto& u : ctx->used_streams) if (u.s == ctx->stream) { u.dirty = true; return; }
     hipEvent_t ev = nullptr;
-    (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;      // mark_stream then synchronises the stream itself
     ctx->used_streams.push_back({ ctx->stream, ev, true });
 }
-// record "everything enqueued so far" on the current stream (after the last launch of an entry point; never while capturing)
+// record "everything enqueued so far" on the current stream (behind the last launch of an entry point, on its error exits too;
+// never while capturing)
 static void mark_stream(svo_ctx* ctx)
 {
     if (ctx->stream == ctx->stream0 && ctx->own_stream) return;  // the context's own stream is synchronised by handle
-    for (auto& u : ctx->used_streams) if (u.s == ctx->stream && u.ev) { (void)hipEventRecord(u.ev, ctx->stream); return; }
+    for (auto& u : ctx->used_streams) if (u.s == ctx->stream) {
+        if (u.ev) (void)hipEventRecord(u.ev, ctx->stream);
+        else { (void)hipStreamSynchronize(ctx->stream); u.dirty = false; }   // no event to leave behind: wait now, while the handle is certainly alive
+        return;
+    }
 }
 // wait for what this context left on streams other than the current one
 static hipError_t sync_foreign(svo_ctx* ctx)
@@ -83,7 +89,9 @@ static hipError_t sync_foreign(svo_ctx* ctx)
     hipError_t first = hipSuccess;
     for (auto& u : ctx->used_streams) {
         if (!u.dirty || u.s == ctx->stream) continue;
-        const hipError_t e = ((u.s == ctx->stream0 && ctx->own_stream) || !u.ev) ? hipStreamSynchronize(u.s) : hipEventSynchronize(u.ev);
+        hipError_t e = hipSuccess;
+        if (u.s == ctx->stream0 && ctx->own_stream) e = hipStreamSynchronize(u.s);
+        else if (u.ev) e = hipEventSynchronize(u.ev);                    // (an entry without an event was synchronised when it was marked)
         if (first == hipSuccess) first = e;
         u.dirty = false;
     }
@@ -97,7 +105,15 @@ static hipError_t sync_all(svo_ctx* ctx)
     if (ctx->up_ready) { const hipError_t e2 = hipStreamSynchronize(ctx->s_copy); if (first == hipSuccess) first = e2; }
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (first == hipSuccess) first = e;
-    for (auto& u : ctx->used_streams) u.dirty = false;
+    // everything is complete: forget the foreign streams the caller has switched away from (a host that makes a stream per frame
+    // would otherwise leave one entry and one event behind per frame)
+    size_t keep = 0;
+    for (auto& u : ctx->used_streams) {
+        u.dirty = false;
+        if (u.s == ctx->stream || (u.s == ctx->stream0 && ctx->own_stream)) ctx->used_streams[keep++] = u;
+        else if (u.ev) (void)hipEventDestroy(u.ev);
+    }
+    ctx->used_streams.resize(keep);
     return first;
 }
 
@@ -201,7 +217,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
-    ctx->imported_pending = false; ctx->use_graphs = false; ctx->d_anms = nullptr;
+    ctx->imported_pending = false; ctx->use_graphs = false; ctx->d_anms = nullptr; ctx->post_event = nullptr;
     ctx->cip_ready = false; ctx->d_vals = nullptr; ctx->h_vals = nullptr; ctx->vals_bytes = 0;
     ctx->up_ready = false; ctx->up_slot = 0; ctx->det_slot = -1; ctx->s_copy = nullptr; ctx->slot_bytes = 0;
     for (int i = 0; i < 2; i++) { ctx->d_img0_ring[i] = nullptr; ctx->h_stage[i] = nullptr; ctx->ev_det_valid[i] = ctx->ev_h2d_valid[i] = false; }
@@ -268,9 +284,11 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.trk_kq, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.trk_nk, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.trk_pts, (size_t)NV * 2 * MK * 4));
-    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)NV * 2 * SVO_RANSAC_PAD * 9));
-    HIPCHECK(dev_alloc(ctx, &d.rs_guard, (size_t)NV * 2 * SVO_RANSAC_PAD * 2));
-    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)NV * 2 * SVO_RANSAC_PAD));
+    HIPCHECK(dev_alloc(ctx, &d.rs_F, (size_t)NV * 2 * SVO_RANSAC_SLOTS * 9));
+    HIPCHECK(dev_alloc(ctx, &d.rs_guard, (size_t)NV * 2 * SVO_RANSAC_SLOTS * 2));
+    HIPCHECK(dev_alloc(ctx, &d.rs_cnt, (size_t)NV * 2 * SVO_RANSAC_SLOTS));
+    HIPCHECK(dev_alloc(ctx, &d.rs_k, (size_t)NV * 2 * SVO_RANSAC_SLOTS));
+    HIPCHECK(dev_alloc(ctx, &d.rs_nvalid, (size_t)NV * 2 * (SVO_RANSAC_PAD / SVO_RANSAC_REG)));
     HIPCHECK(dev_alloc(ctx, &d.rs_bound, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_gen, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_floor, (size_t)NV * 4));
@@ -284,6 +302,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.lane, (size_t)L));
     HIPCHECK(dev_alloc(ctx, &d.results, (size_t)L));
     HIPCHECK(dev_alloc(ctx, &d.status, (size_t)L));
+    HIPCHECK(dev_alloc(ctx, &d.det_status, (size_t)L)); d.det_ahead = 0;
     d.bf_dist = nullptr;
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
     HIPCHECK(configure_gauss_newton(MK));
@@ -756,9 +775,20 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if ((flags & SVO_RUN_TRACK) && p.ifm_method != SVO_IFM_DESC_BF && p.ifm_method != SVO_IFM_DESC_WIN) return SVO_ERR_UNSUPPORTED;      // ifmSAD / optical flow: out of scope
     if (p.non_maximal_suppression && p.nmsMethod != SVO_NMS_STANDARD && p.nmsMethod != SVO_NMS_ADAPTIVE) return SVO_ERR_ARG;          // S2:608
     if (p.min_distance < 2) return SVO_ERR_ARG;            // cell size 0 divides by zero in the reference (S2:331-332)
+    // SVO_FLAG_DETECT_AHEAD: a detect call that leaves lane state and records alone (it may overlap stages 3-5 of the frame before),
+    // or the post call that completes it (and therefore runs the shift itself)
+    const bool ahead = (flags & SVO_FLAG_DETECT_AHEAD) != 0;
+    if (ahead) {
+        if (flags & SVO_RUN_DETECT) { if (!(flags & SVO_FLAG_DETECT_NO_POST) || (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_RUN_DETECT_POST))) return SVO_ERR_ARG; }
+        else if (!(flags & SVO_RUN_DETECT_POST) || (flags & SVO_FLAG_NO_SHIFT)) return SVO_ERR_ARG;
+    }
     DevCtx& d = ctx->dc;
     const hipStream_t st = ctx->stream;
     note_stream(ctx);
+    bool capturing = false;
+    // whatever was enqueued before an error exit is still covered by the stream's event (declared before the capture guard: a
+    // capture is closed first)
+    struct MarkGuard { svo_ctx* c; ~MarkGuard() { mark_stream(c); } } mark_guard{ ctx };
     const uint8_t* ptrs[2 * SVO_MAX_LANES];
     PrepArgs prep; memset(&prep, 0, sizeof(prep)); bool prepare = false;
     if (flags & SVO_RUN_DETECT) {
@@ -822,7 +852,6 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     // capturing thread and would invalidate the capture (the adaptive NMS after the FAST+ORB detector has such a buffer)
     if ((flags & SVO_RUN_DETECT) && d.fast_orb && p.non_maximal_suppression && p.nmsMethod == SVO_NMS_ADAPTIVE && !ctx->d_anms)
         HIPCHECK(dev_alloc(ctx, &ctx->d_anms, (size_t)3 * d.n_img * ctx->cand_total_alloc));
-    bool capturing = false;
     const bool graph_ok = ctx->use_graphs && !prepare && !ctx->cfg.kernel_times && (!(flags & SVO_RUN_DETECT) || ctx->det_slot >= 0);
     const uint32_t gflags = flags & ~(uint32_t)(SVO_FLAG_DEVICE_IMAGES | SVO_FLAG_PINNED_IMAGES);
     const int gslot = (flags & SVO_RUN_DETECT) ? ctx->det_slot : -1;
@@ -833,13 +862,21 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
                 HIPCHECK(hipGraphLaunch(g.exec, st));
                 ctx->imported_pending = false;
                 if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) { HIPCHECK(hipEventRecord(ctx->ev_det[ctx->det_slot], st)); ctx->ev_det_valid[ctx->det_slot] = true; }
-                mark_stream(ctx);
+                if (ctx->post_event && ((flags & SVO_RUN_DETECT_POST) || ((flags & SVO_RUN_DETECT) && !(flags & SVO_FLAG_DETECT_NO_POST)))) { HIPCHECK(hipEventRecord(ctx->post_event, st)); ctx->post_event = nullptr; }
                 return SVO_OK;
             }
         if (!ids_first) { HIPCHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); capturing = true; }
     }
     struct CaptureGuard { hipStream_t st; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; hipStreamEndCapture(st, &g); if (g) hipGraphDestroy(g); *on = false; } } } guard{ st, &capturing };
+    d.det_ahead = (ahead && (flags & SVO_RUN_DETECT)) ? 1 : 0;
     { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); if (prepare) launch_prepare(prep, 2 * d.n_lanes, st); }
+    // the detector's per-image scratch has had its last reader: the armed event (svo_record_after_post) goes here
+    auto after_post = [&]() -> hipError_t {
+        if (!ctx->post_event || capturing) return hipSuccess;
+        const hipError_t e = hipEventRecord(ctx->post_event, st);
+        ctx->post_event = nullptr;
+        return e;
+    };
     if (flags & SVO_RUN_DETECT) {
         if (d.fast_orb) {       // stage2_detect.cpp:502-515 on the x1/2 octave pyramid
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }
@@ -876,6 +913,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, 1, st); }
         }
     }
+    if ((flags & SVO_RUN_DETECT_POST) || ((flags & SVO_RUN_DETECT) && !(flags & SVO_FLAG_DETECT_NO_POST))) HIPCHECK(after_post());
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {
         // (the brute-force result words were set to all ones by k_begin_frame)
@@ -929,13 +967,20 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         HIPCHECK(e);
         ctx->graphs.push_back({ gflags, gslot, ctx->fast_th, ctx->orb_th, exec });
         HIPCHECK(hipGraphLaunch(exec, st));
+        if ((flags & SVO_RUN_DETECT_POST) || ((flags & SVO_RUN_DETECT) && !(flags & SVO_FLAG_DETECT_NO_POST))) HIPCHECK(after_post());
     }
     // stage 2 is the only reader of the level-0 images: once it is through, the ring slot may take the next upload
     if ((flags & (SVO_RUN_DETECT | SVO_RUN_DETECT_POST)) && ctx->up_ready && ctx->det_slot >= 0) {
         HIPCHECK(hipEventRecord(ctx->ev_det[ctx->det_slot], st)); ctx->ev_det_valid[ctx->det_slot] = true;
     }
-    mark_stream(ctx);
     HIPCHECK(hipGetLastError());
+    return SVO_OK;
+}
+
+extern "C" int svo_record_after_post(svo_ctx* ctx, void* event)
+{
+    if (!ctx) return SVO_ERR_ARG;
+    ctx->post_event = (hipEvent_t)event;
     return SVO_OK;
 }
 

@@ -4,14 +4,20 @@
 // No reference counterpart: the reference runs one estimator on one thread (demo-main.cpp:210-220).  What makes the lanes and
 // contexts independent is that all estimator state is per instance (libstereo-odometry.h:732-831).
 //
-// Pipelined schedule, per step and context k:
-//     detect stream:      [wait rest_done[k] of the previous step]  stage 2 of context k                  -> det_done[k]
-//     stage 3-5 stream:   [wait det_done[k]]  stages 3-5 of context k, result records -> records buffer  -> rest_done[k]
-// so stages 3-5 of context k overlap stage 2 of context k + 1.  Default split (post_mode 1, one stage 3-5 stream per context):
-// the detect stream carries the pyramid, FAST and the per-level selection; the reference's own NMS / row sort (one latency-bound
-// block per image), the description of its survivors and stages 3-5 run on the context's own stream, so the latency-bound
-// kernels of three contexts overlap each other as well as the next detect (62.3 k against 60.3 k pairs/s, r03).  Stage 4 reads the feature slot that the NEXT detect of the
-// same context overwrites, hence the wait on rest_done[k].
+// Pipelined schedule, per step and context k (round 4):
+//     detect stream:      [wait scratch_free[k] of the previous step]  detector of context k, AHEAD     -> det_done[k]
+//     stage 3-5 stream:   [wait det_done[k]]  shift, NMS / row sort + description -> scratch_free[k];
+//                         stages 3-5 of context k, result records -> records buffer                      -> rest_done[k]
+// The detect call (SVO_FLAG_DETECT_AHEAD) writes the detector's per-image scratch only -- level-0 pointer table, pyramid,
+// candidates, per-level winners -- and the last reader of that scratch is the description of the frame before, so the detector of
+// frame t + 1 starts while the matchers, both RANSACs and the Gauss-Newton solve of frame t are still running on the context's own
+// stream: a context's cycle is max(detector + NMS + description, its stage 3-5 chain) instead of their sum (rounds 1-3 waited for
+// rest_done[k]: 2.915 ms per step = 0.904 ms of detector + 2.002 ms of the rest).  The prev/cur shift, the record
+// clear and the status word move to the stage 3-5 call; the two feature slots are touched by that stream alone.
+// post_mode 0 / 2 (the detect call describes too, or a third stream does) keep the old wait on rest_done[k].
+// Default split (post_mode 1, one stage 3-5 stream per context): the detect stream carries the pyramid, FAST and the per-level
+// selection; the reference's own NMS / row sort (one latency-bound block per image), the description of its survivors and stages
+// 3-5 run on the context's own stream, so the latency-bound kernels of the contexts overlap each other as well as the next detect.
 #include "../../include/svo_batch.h"
 #include <hip/hip_runtime.h>
 #include <string>
@@ -33,7 +39,9 @@ struct svo_batch {
     std::vector<svo_ctx*> ctx;
     std::vector<hipStream_t> own;                    // one per context: the stream it was created with (free schedule)
     std::vector<hipStream_t> s_dets, s_rests; hipStream_t s_post = nullptr;
-    std::vector<hipEvent_t> det_done, rest_done, done, pre_done;
+    std::vector<hipEvent_t> det_done, rest_done, done, pre_done, scratch_free;
+    bool ahead = false;                              // the detect calls run ahead of the previous frame's stages 3-5 (post_mode 1 / 3)
+    hipEvent_t held = nullptr;                       // svo_batch_hold_for_event: what the next step's record copies wait for
     uint8_t* rec = nullptr; uint8_t* own_rec = nullptr;
     std::string last_error;
 };
@@ -43,7 +51,7 @@ extern "C" void svo_batch_config_defaults(svo_batch_config* c)
     if (!c) return;
     svo_config_defaults(&c->ctx);
     c->ctx.n_lanes = SVO_MAX_LANES;
-    c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 1; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0;
+    c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 1; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0; c->no_detect_ahead = 0;
 }
 
 extern "C" const char* svo_batch_last_error(const svo_batch* b) { return b ? b->last_error.c_str() : ""; }
@@ -65,6 +73,7 @@ extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
     *out = nullptr;
     if (cfg->n_contexts < 1 || cfg->ctx.n_lanes < 1 || cfg->ctx.n_lanes > SVO_MAX_LANES || cfg->post_mode < 0 || cfg->post_mode > 3) return SVO_ERR_ARG;
     int ndev = 0;
+    if (cfg->ctx.device < 0) return SVO_ERR_ARG;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->ctx.device >= ndev) return SVO_ERR_NO_DEVICE;
     svo_batch* b = new svo_batch();
     *out = b;                                                                    // so that the caller can read last_error and destroy
@@ -80,10 +89,13 @@ extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
         const int rc = svo_create(&c, &x);
         if (rc != SVO_OK) { b->last_error = std::string("svo_create: ") + svo_strerror(rc) + (x ? std::string(" [") + svo_last_error(x) + "]" : std::string()); if (x) svo_destroy(x); return rc; }
         b->ctx.push_back(x);
-        hipEvent_t e[4];
-        for (int i = 0; i < 4; i++) BHIP(b, hipEventCreateWithFlags(&e[i], hipEventDisableTiming));
-        b->det_done.push_back(e[0]); b->rest_done.push_back(e[1]); b->done.push_back(e[2]); b->pre_done.push_back(e[3]);
+        for (auto* v : { &b->det_done, &b->rest_done, &b->done, &b->pre_done, &b->scratch_free }) {   // pushed as created: a failure half way leaks nothing
+            hipEvent_t e = nullptr;
+            BHIP(b, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            v->push_back(e);
+        }
     }
+    b->ahead = b->pipelined && (cfg->post_mode == 1 || cfg->post_mode == 3) && !cfg->no_detect_ahead;
     const int nd = cfg->det_streams > 1 ? cfg->det_streams : 1;
     for (int i = 0; i < nd; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high != 0); if (rc) return rc; b->s_dets.push_back(s); }
     const int nr = cfg->rest_streams > 0 ? cfg->rest_streams : b->NC;
@@ -105,7 +117,7 @@ extern "C" void svo_batch_destroy(svo_batch* b)
     for (hipStream_t s : b->s_rests) (void)hipStreamDestroy(s);
     if (b->s_post) (void)hipStreamDestroy(b->s_post);
     for (hipStream_t s : b->own) (void)hipStreamDestroy(s);
-    for (auto* v : { &b->det_done, &b->rest_done, &b->done, &b->pre_done }) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
+    for (auto* v : { &b->det_done, &b->rest_done, &b->done, &b->pre_done, &b->scratch_free }) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     if (b->own_rec) (void)hipFree(b->own_rec);
     delete b;
 }
@@ -146,7 +158,8 @@ extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t fl
     if (!b || !frames || (flags & ~IMG_FLAGS)) return SVO_ERR_ARG;
     BHIP(b, hipSetDevice(b->cfg.ctx.device));
     const size_t rsz = sizeof(svo_result);
-    const uint32_t REST = SVO_RUN_MATCH | SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_FLAG_NO_SHIFT | (b->cfg.post_mode == 1 ? (uint32_t)SVO_RUN_DETECT_POST : 0u)
+    const uint32_t AH = b->ahead ? (uint32_t)SVO_FLAG_DETECT_AHEAD : 0u;
+    const uint32_t REST = SVO_RUN_MATCH | SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | (b->ahead ? AH : (uint32_t)SVO_FLAG_NO_SHIFT) | (b->cfg.post_mode == 1 ? (uint32_t)SVO_RUN_DETECT_POST : 0u)
                         | (b->cfg.post_mode == 3 ? (uint32_t)(SVO_RUN_DETECT_POST | SVO_FLAG_DETECT_SPLIT_AT_SELECT) : 0u);
     for (int k = 0; k < b->NC; k++) {
         svo_ctx* c = b->ctx[(size_t)k];
@@ -154,9 +167,9 @@ extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t fl
         uint8_t* dst = b->rec + (size_t)k * b->Bc * rsz;
         if (b->pipelined) {
             hipStream_t s_det = b->s_dets[(size_t)k % b->s_dets.size()], s_rest = b->s_rests[(size_t)k % b->s_rests.size()];
-            if (!b->first) BHIP(b, hipStreamWaitEvent(s_det, b->rest_done[(size_t)k], 0));
+            if (!b->first) BHIP(b, hipStreamWaitEvent(s_det, b->ahead ? b->scratch_free[(size_t)k] : b->rest_done[(size_t)k], 0));
             BSVO(b, c, svo_set_stream(c, s_det));
-            BSVO(b, c, svo_process(c, pk, SVO_RUN_DETECT | (b->cfg.post_mode ? (uint32_t)SVO_FLAG_DETECT_NO_POST : 0u) | (b->cfg.post_mode == 3 ? (uint32_t)SVO_FLAG_DETECT_SPLIT_AT_SELECT : 0u) | flags));
+            BSVO(b, c, svo_process(c, pk, SVO_RUN_DETECT | AH | (b->ahead ? (uint32_t)SVO_FLAG_NO_SHIFT : 0u) | (b->cfg.post_mode ? (uint32_t)SVO_FLAG_DETECT_NO_POST : 0u) | (b->cfg.post_mode == 3 ? (uint32_t)SVO_FLAG_DETECT_SPLIT_AT_SELECT : 0u) | flags));
             if (b->cfg.post_mode == 2) {
                 BHIP(b, hipEventRecord(b->pre_done[(size_t)k], s_det));
                 BHIP(b, hipStreamWaitEvent(b->s_post, b->pre_done[(size_t)k], 0));
@@ -166,17 +179,20 @@ extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t fl
             } else BHIP(b, hipEventRecord(b->det_done[(size_t)k], s_det));
             BHIP(b, hipStreamWaitEvent(s_rest, b->det_done[(size_t)k], 0));
             BSVO(b, c, svo_set_stream(c, s_rest));
+            if (b->ahead) BSVO(b, c, svo_record_after_post(c, b->scratch_free[(size_t)k]));
             BSVO(b, c, svo_process(c, nullptr, REST));
+            if (b->held) BHIP(b, hipStreamWaitEvent(s_rest, b->held, 0));       // only the record copy waits for a reader of the records buffer
             BSVO(b, c, svo_copy_results_async(c, dst, (size_t)b->Bc * rsz));
             BHIP(b, hipEventRecord(b->rest_done[(size_t)k], s_rest));
         } else {
             BSVO(b, c, svo_set_stream(c, nullptr));
             BSVO(b, c, svo_process(c, pk, SVO_RUN_ALL | flags));
+            if (b->held) BHIP(b, hipStreamWaitEvent(b->own[(size_t)k], b->held, 0));
             BSVO(b, c, svo_copy_results_async(c, dst, (size_t)b->Bc * rsz));
             BHIP(b, hipEventRecord(b->done[(size_t)k], b->own[(size_t)k]));
         }
     }
-    b->first = false;
+    b->first = false; b->held = nullptr;
     return SVO_OK;
 }
 
@@ -191,8 +207,7 @@ extern "C" int svo_batch_wait_on_stream(svo_batch* b, void* stream)
 extern "C" int svo_batch_hold_for_event(svo_batch* b, void* event)
 {
     if (!b || !event) return SVO_ERR_ARG;
-    if (b->pipelined) { for (hipStream_t s : b->s_rests) BHIP(b, hipStreamWaitEvent(s, (hipEvent_t)event, 0)); }
-    else for (hipStream_t s : b->own) BHIP(b, hipStreamWaitEvent(s, (hipEvent_t)event, 0));
+    b->held = (hipEvent_t)event;          // the next svo_batch_step makes each context's record copy -- and nothing before it -- wait
     return SVO_OK;
 }
 

@@ -15,10 +15,13 @@
 #include "../../include/svo_hip.h"
 
 #define SVO_EDGE 31
-#define SVO_RANSAC_HYP 1000         // hypothesis schedule of one F-matrix RANSAC (oracle: RANSAC_MAX_HYP)
-#define SVO_RANSAC_PAD 1024         // stride of the per-(lane, side) hypothesis arrays
-#define SVO_RANSAC_CHUNK0 32        // hypotheses [0, CHUNK0) are evaluated unconditionally, [CHUNK0, CHUNK1) and [CHUNK1, HYP) only as far as
-#define SVO_RANSAC_CHUNK1 288       // the 0.99-confidence stop of the sequential algorithm can still reach (rs_bound)
+#define SVO_RANSAC_HYP 1000         // sample schedule of one F-matrix RANSAC (oracle: RANSAC_MAX_HYP): minimal samples of seven pairs
+#define SVO_RANSAC_PAD 1024         // ... padded to whole regions
+#define SVO_RANSAC_REG 16           // samples per region (one DPP row of k_ransac_hyp_thread, one block of k_ransac_hyp)
+#define SVO_RANSAC_RSLOTS 48        // model slots per region: a sample has one or three models (the real roots of the 7-point cubic)
+#define SVO_RANSAC_SLOTS (SVO_RANSAC_PAD / SVO_RANSAC_REG * SVO_RANSAC_RSLOTS)     // stride of the per-(lane, side) model arrays
+#define SVO_RANSAC_CHUNK0 32        // samples [0, CHUNK0) are evaluated unconditionally, [CHUNK0, CHUNK1) and [CHUNK1, HYP) only as far as
+#define SVO_RANSAC_CHUNK1 160       // the 0.99-confidence stop of the sequential algorithm can still reach (rs_bound)
 #define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) ranked by their Harris response
 #define SVO_FT_W 64          // k_fast tile (interior pixels)
 #define SVO_FT_H 56
@@ -150,12 +153,14 @@ struct DevCtx {
     int* trk_kq;              // [n_lanes][max_kps]  indices k that survive the joint filter (S4:145-160)
     int* trk_nk;              // [n_lanes]
     float* trk_pts;           // [n_lanes][2 sides][max_kps][4]  (x1,y1,x2,y2) for the F-matrix RANSAC
-    double* rs_F;             // [n_lanes][2][PAD][9]
-    double* rs_guard;         // [n_lanes][2][PAD][2]  per hypothesis: the |l'|^2 and |l|^2 below which the matrix-core lines are not trusted
-    int* rs_cnt;              // [n_lanes][2][PAD]
-    int* rs_bound;            // [n_lanes][2]  upper limit of the hypotheses the sequential stop can still reach
-    int* rs_gen;              // [n_lanes][2]  end of the hypotheses the current chunk generated
-    int* rs_floor;            // [n_lanes][2][2] best inlier count of chunk 0 / of chunks 0-1: what a later hypothesis must exceed to matter
+    double* rs_F;             // [n_lanes][2][SLOTS][9]   the models, packed per region of 16 samples (k_match.hip, K9)
+    double* rs_guard;         // [n_lanes][2][SLOTS][2]   per model: the |l'|^2 and |l|^2 below which the matrix-core lines are not trusted
+    int* rs_cnt;              // [n_lanes][2][SLOTS]      inlier count of each model (0: no model here / not scored)
+    int* rs_k;                // [n_lanes][2][SLOTS]      the sample a slot's model came from
+    int* rs_nvalid;           // [n_lanes][2][PAD / 16]   models in each region
+    int* rs_bound;            // [n_lanes][2]  upper limit of the SAMPLES the sequential stop can still reach
+    int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
+    int* rs_floor;            // [n_lanes][2][2] best inlier count of chunk 0 / of chunks 0-1: what a later model must exceed to matter
     svo_index_pair* tracked;  // [n_lanes][max_kps]
     int* n_tracked;           // [n_lanes]
     // stage 5
@@ -167,7 +172,16 @@ struct DevCtx {
     LaneState* lane;
     svo_result* results;
     uint32_t* status;         // [n_lanes]
+    uint32_t* det_status;     // [n_lanes] capacity bits raised by a detect call that runs ahead (SVO_FLAG_DETECT_AHEAD): folded into status / the record by its post call
+    int det_ahead;            // 1 while launching the kernels of such a call: k_fast / k_select raise their bits in det_status
 };
+
+// where a detect-phase kernel raises a capacity bit of its lane
+__device__ __forceinline__ void raise_detect_status(const DevCtx& c, int lane, uint32_t bit)
+{
+    if (c.det_ahead) { atomicOr(&c.det_status[lane], bit); return; }
+    atomicOr(&c.status[lane], bit); atomicOr(&c.results[lane].status, (int)bit);
+}
 
 __device__ __forceinline__ const uint8_t* level_ptr(const DevCtx& c, int img, int level, int& pitch)
 {

@@ -29,7 +29,7 @@ def _frames(ptrs, w, h, stride):
 
 class StreamBatch:
     def __init__(self, params, cam, width, height, lanes, contexts=1, device=0, schedule="pipelined", post_on_rest=True,
-                 det_priority="high", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1, rest_streams=0):
+                 det_priority="high", kernel_times=False, max_octaves=1, max_kps=4096, max_cand=None, det_streams=1, rest_streams=0, detect_ahead=True):
         assert contexts >= 1 and lanes % contexts == 0 and lanes // contexts <= hip.MAX_LANES, \
             "lanes must split evenly over the contexts, at most %d streams per context" % hip.MAX_LANES
         self.L = hip.lib()
@@ -50,6 +50,7 @@ class StreamBatch:
         cfg.post_mode = 2 if post_on_rest == "own" else (3 if post_on_rest == "select" else int(bool(post_on_rest)))
         cfg.det_streams = max(1, det_streams)
         cfg.rest_streams = max(0, rest_streams)          # 0 = one stage 3-5 stream per context
+        cfg.no_detect_ahead = int(not detect_ahead)      # False: a context's detector waits for its whole previous frame (rounds 1-3)
         h = C.c_void_p()
         rc = self.L.svo_batch_create(C.byref(cfg), C.byref(h))
         self.h = h

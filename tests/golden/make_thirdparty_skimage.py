@@ -10,10 +10,16 @@ them.  This narrows "parity unpinned"  for the pieces the t
   * brute-force Hamming matching (match_descriptors, first minimum) on 256-bit descriptors with planted ties;
   * one x1/1.2 bilinear pyramid step (skimage.transform.resize, order 1, half-pixel centres: cv::resize INTER_LINEAR's geometry) to +-1
     grey level away from the borders (float weights against the oracle's 11-bit fixed point, other border rule);
-  * the normalised 8-point fundamental matrix with rank-2 enforcement (Hartley), for exactly eight correspondences
+  * the fundamental matrix of exactly eight correspondences (Hartley's normalised 8-point algorithm with rank-2 enforcement; since
+    oracle version 4 the oracle's RANSAC solves seven points per sample, as cv::findFundamentalMat does: on EXACT correspondences the
+    8-point matrix must be one of the 7-point models, tests/test_oracle_thirdparty.py)
     (scikit-image scales to an RMS distance of sqrt 2, cv::findFundamentalMat and the oracle to a MEAN distance of sqrt 2: the
     null vector of eight exact correspondences is the same, the rank-2 projection of noisy ones is taken in slightly different
     coordinates -- hence a tight comparison on exact sets and a loose one on noisy sets).
+  * (round 4) the 256 steered BRIEF tests: skimage.feature.orb_cy._orb_loop -- OpenCV's learned pair table rotated by the continuous
+    angle and rounded, cv::ORB's computeOrbDescriptor -- on an already blurred image at given positions and angles;
+  * (round 4) the RANKING of the Harris measure (k = 0.04) at FAST corners (skimage.feature.corner_harris: Gaussian window, where
+    cv::ORB sums a 7 x 7 box -- values differ, order mostly agrees).
 Run:  /opt/conda/bin/python3.9 tests/golden/make_thirdparty_skimage.py
 """
 import os
@@ -98,5 +104,38 @@ img = out["img0"]
 dh, dw = int(np.rint(np.float32(img.shape[0]) / np.float32(1.2))), int(np.rint(np.float32(img.shape[1]) / np.float32(1.2)))
 r = resize(img.astype(np.float64), (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True)
 out["resize_src"] = img; out["resize_dst"] = r.astype(np.float32)
+# ---- round 4: the steered BRIEF tests and the Harris ranking -------------------------------------------------------------
+# skimage.feature.orb_cy._orb_loop applies OpenCV's learned pair table (the same 256 rows as bit_pattern_31_) rotated by the
+# CONTINUOUS angle -- spc = round(cos * x - sin * y), spr = round(sin * x + cos * y): cv::ORB's computeOrbDescriptor with the two
+# pattern columns named (row, column) -- to whatever image it is given.  Here: an already blurred 8-bit image, 500 positions per
+# image, angles in degrees drawn as float32 (what a keypoint carries); scikit-image gets the radians the oracle forms from
+# them, angle * (float)(pi / 180) in single precision, as a double.
+from skimage.feature.orb_cy import _orb_loop
+from skimage.feature import corner_harris
+from scipy import ndimage
+rng = np.random.RandomState(23)
+for s in range(3):
+    img = out["img%d" % s]
+    bl = np.clip(np.rint(ndimage.gaussian_filter(img.astype(np.float64), 2.0, truncate=1.5)), 0, 255).astype(np.uint8)
+    h, w = bl.shape
+    ys = rng.randint(19, h - 19, 500); xs = rng.randint(19, w - 19, 500)
+    deg = rng.uniform(0.0, 360.0, 500).astype(np.float32)
+    deg[:8] = np.array([0.0, 90.0, 180.0, 270.0, 45.0, 359.99997, 12.0, 0.5], np.float32)
+    rad = (deg * np.float32(0.017453292)).astype(np.float64)          # the single-precision product, exactly, as a double
+    d = _orb_loop(np.ascontiguousarray(bl.astype(np.float64)), np.ascontiguousarray(np.stack([ys, xs], 1).astype(np.intp)), np.ascontiguousarray(rad))
+    out["brief_img%d" % s] = bl
+    out["brief_yx%d" % s] = np.stack([ys, xs], 1).astype(np.int32)
+    out["brief_deg%d" % s] = deg
+    out["brief_desc%d" % s] = np.packbits(np.asarray(d).astype(bool), axis=1, bitorder="little")
+    # Harris measure det - 0.04 trace^2 at the FAST corners of the image (skimage: Sobel derivatives, GAUSSIAN window sigma 2 where
+    # cv::ORB sums a 7 x 7 box): the values are on another scale and the windows differ, the RANKING is what the two share
+    resp = corner_fast(img, n=9, threshold=20.5 / 255.0)
+    cy, cx = np.nonzero(resp[24:-24, 24:-24] > 0)
+    pick = rng.permutation(len(cy))[:400]
+    cy, cx = cy[pick] + 24, cx[pick] + 24
+    H = corner_harris(img.astype(np.float64), method="k", k=0.04, sigma=2.0)
+    out["harris_yx%d" % s] = np.stack([cy, cx], 1).astype(np.int32)
+    out["harris_val%d" % s] = H[cy, cx].astype(np.float64)
+
 np.savez_compressed(os.path.join(HERE, "thirdparty_skimage.npz"), **out)
 print("wrote thirdparty_skimage.npz:", {k: v.shape for k, v in out.items() if k.startswith(("ori_angles", "f8_F"))})

@@ -96,18 +96,16 @@ def ic_angle_deg(img, x, y, radius=15):
 
 
 def brief_pairs():
-    """the 256 unrotated test pairs (x1 y1 x2 y2): angle bin 0 of the shared table"""
-    txt = open(os.path.join(ROOT, "include", "svo_orb_tables.h")).read()
-    body = txt[txt.index("svo_brief_rot"):]
-    nums = [int(v) for v in re.findall(r"-?\d+", body[body.index("{"):])]
-    return np.array(nums[:256 * 4], np.int64).reshape(256, 4)
+    """the 256 test pairs (x1 y1 x2 y2) of cv::ORB: OpenCV's learned table, from the committed plain-integer copy of the file
+    scikit-image ships (tests/golden/make_orb_pattern.py) -- not from the header the oracle compiles"""
+    rows = [[int(v) for v in l.split()] for l in open(os.path.join(ROOT, "tests", "golden", "orb_bit_pattern_31.txt")) if l.strip() and not l.startswith("#")]
+    return np.array(rows, np.int64).reshape(256, 4)
 
 
 def steered_brief(img, x, y, angle_deg, pairs):
     """256-bit descriptor, 32 bytes, bit i of byte i // 8 (LSB first) = smoothed I(p_i) < smoothed I(q_i); the pairs are
-    rotated by the angle quantised to 12-degree steps and rounded to pixels (half away from zero)"""
-    b = int(np.floor(angle_deg / 12.0 + 0.5)) % 30
-    th = np.radians(12.0 * b)
+    rotated by the CONTINUOUS angle (double precision) and rounded to pixels (half away from zero, as scikit-image does)"""
+    th = np.radians(angle_deg)
     R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
 
     def rnd(v):
@@ -121,7 +119,10 @@ def steered_brief(img, x, y, angle_deg, pairs):
     c = sm[24 + q[:, 1], 24 + q[:, 0]]
     bits = (a < c).astype(np.uint8)
     margin = np.abs(a - c)                                   # how decisive each test is (a float blur vs an 8-bit one)
-    return np.packbits(bits.reshape(32, 8), axis=1, bitorder="little").reshape(32), margin
+    # how close the nearest of the four rotated coordinates of each pair lies to a rounding tie
+    fr = np.abs(np.c_[pairs[:, 0:2] @ R.T, pairs[:, 2:4] @ R.T])
+    tie = np.min(np.abs(fr - np.floor(fr) - 0.5), axis=1)
+    return np.packbits(bits.reshape(32, 8), axis=1, bitorder="little").reshape(32), margin, tie
 
 
 def eight_point(p1, p2, rank2=True):
@@ -140,6 +141,29 @@ def eight_point(p1, p2, rank2=True):
         F0 = U @ np.diag([S[0], S[1], 0.0]) @ Vt
     F = T2.T @ F0 @ T1
     return F / np.linalg.norm(F)
+
+
+def seven_point(p1, p2):
+    """The 7-point algorithm as the textbooks give it (Hartley & Zisserman 11.1.2; cv::findFundamentalMat's minimal solver): null space
+    of the 7 x 9 constraint matrix by SVD, F = a F1 + (1 - a) F2, the cubic det F = 0 by numpy's companion-matrix roots.  Real
+    roots only; unit Frobenius norm each.  (Normalised coordinates for conditioning: the solution set does not depend on them.)"""
+    def norm(p):
+        c = p.mean(0)
+        s = np.sqrt(2.0) / np.mean(np.linalg.norm(p - c, axis=1))
+        return np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+    T1, T2 = norm(p1), norm(p2)
+    h1 = (np.c_[p1, np.ones(7)] @ T1.T); h2 = (np.c_[p2, np.ones(7)] @ T2.T)
+    A = np.stack([np.kron(b, a) for a, b in zip(h1, h2)])
+    V = np.linalg.svd(A)[2]
+    F1, F2 = V[7].reshape(3, 3), V[8].reshape(3, 3)
+    ls = np.array([-1.0, 0.0, 1.0, 2.0])
+    co = np.polyfit(ls, [np.linalg.det(l * F1 + (1 - l) * F2) for l in ls], 3)          # a cubic through four of its values: exact
+    out = []
+    for r in np.roots(co):
+        if abs(r.imag) < 1e-9 * max(1.0, abs(r.real)):
+            F = T2.T @ (r.real * F1 + (1 - r.real) * F2) @ T1
+            out.append(F / np.linalg.norm(F))
+    return out
 
 
 def symmetric_epipolar_sq(F, p1, p2):

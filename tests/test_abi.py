@@ -74,5 +74,5 @@ def test_batch_config_defaults_are_the_measured_schedule():
     from stereo_vo_amd import hip
     cfg = hip.BatchConfig()
     hip.lib().svo_batch_config_defaults(C.byref(cfg))
-    assert (cfg.n_contexts, cfg.schedule, cfg.det_priority_high, cfg.post_mode, cfg.det_streams, cfg.rest_streams) == (3, 0, 1, 1, 1, 0)
+    assert (cfg.n_contexts, cfg.schedule, cfg.det_priority_high, cfg.post_mode, cfg.det_streams, cfg.rest_streams, cfg.no_detect_ahead) == (3, 0, 1, 1, 1, 0, 0)
     assert cfg.ctx.n_lanes == 64

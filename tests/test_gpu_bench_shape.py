@@ -253,7 +253,8 @@ def test_every_schedule_of_the_batch_gives_the_same_records():
     variants = [dict(),                                                                   # the default: post on one stream per context, detect high
                 dict(post_on_rest=False, rest_streams=1, det_priority="low"),             # rounds 1-2
                 dict(post_on_rest="own"), dict(post_on_rest="select"),
-                dict(rest_streams=2, det_streams=2), dict(schedule="free")]
+                dict(rest_streams=2, det_streams=2), dict(schedule="free"),
+                dict(detect_ahead=False), dict(post_on_rest="select", detect_ahead=False)]      # rounds 1-3: a context's detector waits for its whole previous frame
     ref = None
     for kw in variants:
         batch = StreamBatch(p, cam, W, H, B, NC, max_kps=1024, max_cand=1 << 15, **kw)
@@ -268,3 +269,38 @@ def test_every_schedule_of_the_batch_gives_the_same_records():
         else:
             assert rec.tobytes() == ref.tobytes(), kw
         batch.close()
+
+
+def test_capacity_bits_of_a_detector_running_ahead_reach_the_right_record():
+    """SVO_FLAG_DETECT_AHEAD: the detector of frame t + 1 runs while stages 3-5 of frame t are still writing frame t's record, so the
+    capacity bits it raises are staged and folded in by its own post call.  A candidate list far too small for the image overflows
+    on every frame: bit 1 must be in every stream's record -- and in the status word -- with and without the look-ahead (which
+    corners an overflowing list keeps is a race, so only the bits are compared)."""
+    import torch
+    from stereo_vo_amd.pipeline import StreamBatch
+    W, H, B, NC, F, STEPS = 640, 480, 4, 2, 3, 4
+    dev = torch.device("cuda", 0)
+    worlds = [SyntheticStereoWorld(W, H, 400.0, 0.12, seed=700 + s, n_frames=F, device=dev) for s in range(B)]
+    frames = [[w.render(t) for t in range(F)] for w in worlds]
+    cam = worlds[0].camera()
+    torch.cuda.synchronize()
+    p = north_star_params(hip.default_params(), orb_nfeats=600)
+    ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
+    for ahead in (True, False):
+        batch = StreamBatch(p, cam, W, H, B, NC, max_kps=1024, max_cand=1 << 6, detect_ahead=ahead)
+        for i in range(STEPS):
+            batch.step(ptrs_at[[0, 1, 2, 1][i]])
+            batch.synchronize()
+            rec = batch.rec.cpu().numpy().copy()
+            res = [Result.from_buffer_copy(rec[g].tobytes()) for g in range(B)]
+            assert all(r.status & 1 for r in res), (ahead, i, [r.status for r in res])
+            assert [r.status for r in res] == [r2.status for r2 in batch.results()]
+            assert all(batch.lane(g)[0].status_word(batch.lane(g)[1]) & 1 for g in range(B))
+        batch.close()
+    # and a list that fits raises nothing
+    batch = StreamBatch(p, cam, W, H, B, NC, max_kps=1024, max_cand=1 << 15)
+    for i in range(2):
+        batch.step(ptrs_at[i])
+    batch.synchronize()
+    assert all(r.status == 0 for r in batch.results())
+    batch.close()

@@ -51,32 +51,31 @@ def test_orientation_matches_skimage_intensity_centroid(tp):
     assert worst > 0.0
 
 
-def test_eight_point_fundamental_matrix_matches_skimage(tp):
-    """Exactly eight correspondences: every RANSAC sample is those eight, so the model the oracle returns is its normalised
-    8-point solution with rank-2 enforcement; skimage.transform.FundamentalMatrixTransform.estimate is the same Hartley
-    algorithm through two SVDs.  Same matrix up to scale (dst^T F src = 0 in both), rank 2 in both."""
+def test_seven_point_models_contain_skimage_fundamental_matrix(tp):
+    """scikit-image has no minimal solver; its FundamentalMatrixTransform.estimate is Hartley's 8-point algorithm.  For eight EXACT
+    correspondences (float32 pixel coordinates) the true matrix satisfies all eight constraints, so it is one of the one-or-three
+    matrices the 7-point algorithm returns for the first seven of them -- the oracle's Gauss-Jordan / Newton version of
+    cv::findFundamentalMat's run7Point must therefore reproduce scikit-image's matrix (up to scale and the rounding of the
+    coordinates) among its models, every model must be rank 2 and pass through its seven points, and the RANSAC on all eight
+    must explain all eight from its first sample."""
     checked = 0
-    for k, (p1, p2, Fs) in enumerate(zip(tp["f8_p1"], tp["f8_p2"], tp["f8_F"])):
+    for k in range(20):
+        p1, p2, Fs = tp["f8_p1"][k], tp["f8_p2"][k], tp["f8_F"][k]
+        B = Fs / np.linalg.norm(Fs)
+        models = O.seven_point(p1[:7], p2[:7])
+        assert len(models) in (1, 3)
+        d = min(min(np.abs(F / np.linalg.norm(F) - B).max(), np.abs(F / np.linalg.norm(F) + B).max()) for F in models)
+        assert d < 2e-4, (k, d)
+        x1 = np.c_[p1[:7].astype(np.float64), np.ones(7)]; x2 = np.c_[p2[:7].astype(np.float64), np.ones(7)]
+        for F in models:
+            sv = np.linalg.svd(F, compute_uv=False)
+            assert sv[2] < 1e-12 * sv[0]
+            l = x1 @ F.T
+            assert (np.abs(np.sum(x2 * l, axis=1)) / np.hypot(l[:, 0], l[:, 1])).max() < 1e-6
         cnt, mask, F, best_h, n_used = O.ransac_fundamental(p1, p2)
-        if cnt < 8:
-            continue             # noise can leave a pair beyond 1 px of its epipolar line: the model is still the eight-point one
-        A, B = F / np.linalg.norm(F), Fs / np.linalg.norm(Fs)
-        if np.sum(A * B) < 0:
-            B = -B
-        # sets 0..19 are exact correspondences (float32 coordinates): the null vector does not depend on the normalisation.
-        # sets 20..39 carry 0.3 px of noise: scikit-image normalises to an RMS distance of sqrt 2, the oracle (as
-        # cv::findFundamentalMat) to a mean distance, so the rank-2 projection is taken in slightly different coordinates
-        assert np.abs(A - B).max() < (2e-6 if k < 20 else 5e-3), (k, np.abs(A - B).max())
-        sv = np.linalg.svd(F, compute_uv=False)
-        assert sv[2] < 1e-9 * sv[0]
+        assert cnt == 8 and mask.all() and best_h == 0 and n_used == 1
         checked += 1
-    assert checked >= 25
-    # and the epipolar constraint holds for the oracle's model on its own sample
-    cnt, mask, F, _, _ = O.ransac_fundamental(tp["f8_p1"][0], tp["f8_p2"][0])
-    x1 = np.c_[tp["f8_p1"][0].astype(np.float64), np.ones(8)]; x2 = np.c_[tp["f8_p2"][0].astype(np.float64), np.ones(8)]
-    l = x1 @ F.T
-    d = np.abs(np.sum(x2 * l, axis=1)) / np.hypot(l[:, 0], l[:, 1])
-    assert d.max() < 1.0
+    assert checked == 20
 
 
 def test_brute_force_hamming_matches_skimage_first_minimum(tp):
@@ -95,3 +94,64 @@ def test_one_pyramid_step_matches_skimage_bilinear(tp):
     d = np.abs(got - want)[2:-2, 2:-2]
     assert d.max() <= 1.0, d.max()
     assert (np.abs(got - np.rint(want))[2:-2, 2:-2] == 0).mean() > 0.9
+
+
+def test_steered_brief_matches_skimage_orb_loop(tp):
+    """The 256 binary tests of cv::ORB (computeOrbDescriptor): OpenCV's learned pair table, rotated by the keypoint's CONTINUOUS angle
+    and rounded to pixels, on a blurred image.  skimage.feature.orb_cy._orb_loop is that loop (same table, same rotation) in double
+    precision with round-half-away; the oracle follows OpenCV's single precision and cvRound (half to even).  1500 positions x 256
+    tests: every bit equal, except pairs one of whose four rotated coordinates lies within 1e-5 px of a rounding tie (there the
+    float / double products and the two tie rules may round differently; counted, a handful)."""
+    rows = [[int(v) for v in l.split()] for l in open(os.path.join(os.path.dirname(__file__), "golden", "orb_bit_pattern_31.txt")) if l.strip() and not l.startswith("#")]
+    P = np.array(rows, np.float64)
+    total, near_tie, cardinal_ok = 0, 0, 0
+    for s in range(3):
+        bl, yx, deg, want = tp["brief_img%d" % s], tp["brief_yx%d" % s], tp["brief_deg%d" % s], tp["brief_desc%d" % s]
+        for i, ((y, x), a) in enumerate(zip(yx, deg)):
+            got = O.steered_brief(bl, int(x), int(y), a)
+            diff = np.unpackbits(got ^ want[i], bitorder="little").astype(bool)
+            total += 256
+            if not diff.any():
+                cardinal_ok += int(i < 4)
+                continue
+            th = float(np.float32(a) * np.float32(0.017453292))
+            c, sn = np.cos(th), np.sin(th)
+            co = np.abs(np.stack([P[:, 0] * c - P[:, 1] * sn, P[:, 0] * sn + P[:, 1] * c, P[:, 2] * c - P[:, 3] * sn, P[:, 2] * sn + P[:, 3] * c], 1))
+            tie = np.min(np.abs(co - np.floor(co) - 0.5), axis=1)
+            assert not (diff & (tie > 1e-5)).any(), (s, i, float(a), np.nonzero(diff)[0], tie[diff])
+            near_tie += int(diff.sum())
+    assert total == 3 * 500 * 256 and near_tie < 40, near_tie
+    assert cardinal_ok >= 9          # 0 / 90 / 180 / 270 degrees: exact integer coordinates on both sides
+
+
+def test_harris_ranking_agrees_with_skimage(tp):
+    """cv::ORB ranks a level's corners by HarrisResponses (7 x 7 box window, Sobel-like 3 x 3 gradients, k = 0.04).
+    skimage.feature.corner_harris(method='k', k=0.04, sigma=2) is the same measure under a Gaussian window and another overall
+    scale, so the VALUES differ; the ORDER of 400 FAST corners per image must agree closely (Spearman rank correlation), and
+    what the oracle puts in its best third is, nearly all of it, in skimage's best half."""
+    for s in range(3):
+        img, yx, want = tp["img%d" % s], tp["harris_yx%d" % s], tp["harris_val%d" % s]
+        got = np.array([O.harris(img, int(x), int(y)) for (y, x) in yx], np.float64)
+        ra, rb = np.argsort(np.argsort(got)), np.argsort(np.argsort(want))
+        rho = np.corrcoef(ra, rb)[0, 1]
+        assert rho > 0.9, (s, rho)
+        n = len(got)
+        top_mine = set(np.argsort(-got)[: n // 3].tolist()); top_theirs = set(np.argsort(-want)[: n // 2].tolist())
+        assert len(top_mine & top_theirs) >= 0.95 * len(top_mine), (s, len(top_mine & top_theirs), len(top_mine))
+        # sign convention and scale sanity: a positive response is a corner in both
+        assert ((got > 0) == (want > 0)).mean() > 0.9
+
+
+def test_per_level_quota_is_the_published_geometric_split():
+    """cv::ORB's nfeaturesPerLevel (no scikit-image counterpart: its ORB keeps the best n over all levels): n (1 - f) / (1 - f^L) f^l
+    with f = 1 / 1.2 in single precision, cvRound per level, the last level takes the remainder.  Re-derived here in numpy float32."""
+    for n, L in ((500, 8), (2000, 8), (1350, 8), (3300, 3), (77, 5), (2000, 1)):
+        f = np.float32(1.0 / 1.2)
+        nd = np.float32(n) * (np.float32(1.0) - f) / (np.float32(1.0) - np.float32(float(f) ** L))
+        want, tot = [], 0
+        for l in range(L - 1):
+            q = int(np.rint(nd)); want.append(q); tot += q
+            nd = np.float32(nd * f)
+        want.append(max(n - tot, 0))
+        assert O.level_quota(n, L) == want, (n, L, O.level_quota(n, L), want)
+        assert sum(want) == n

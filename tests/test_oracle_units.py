@@ -241,9 +241,13 @@ def test_ransac_fundamental_separates_outliers():
     good = np.ones(n, bool); good[bad] = False
     assert cnt == mask.sum() and mask[good].mean() > 0.9 and mask[~good].mean() < 0.15
     assert 0 <= best < used <= 256
-    # fewer than 8 points: no model (the caller then skips the filter, S4:205, 243)
-    cnt, mask, _, best, _ = O.ransac_fundamental(p1[:7], p2[:7])
+    # fewer than 7 points: no model (cv::findFundamentalMat returns nothing below its minimal sample; the caller then skips the
+    # filter, S4:205, 243); exactly 7: the minimal solver's models explain their own sample -- still below the caller's 8
+    cnt, mask, _, best, _ = O.ransac_fundamental(p1[:6], p2[:6])
     assert cnt == 0 and best == -1 and mask.sum() == 0
+    good7 = np.nonzero(good)[0][:7]
+    cnt, mask, _, best, _ = O.ransac_fundamental(p1[good7], p2[good7])
+    assert cnt == 7 and best == 0
     # determinism
     a = O.ransac_fundamental(p1, p2); b = O.ransac_fundamental(p1, p2)
     assert (a[1] == b[1]).all() and a[3] == b[3]
