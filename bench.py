@@ -5,6 +5,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 torch.distributed.run, one rank per GPU.  A "step" advances every lane (independent stereo stream) of every rank by
 one frame: value = N * lanes * K / t, t = max over ranks of the barrier-bracketed wall time of the K steps.
 All frames are rendered and resident in HBM before the timed region; nothing is copied host->device inside it.
+Every stream sees a NEW frame at every step of the run (round 4): --trajectories T trajectories of F frames each are rendered
+through a long "street" world (stereo_vo_amd/synth.py), stream s plays trajectory s % T from frame 7 (s // T) on, and F is
+chosen so that no stream ever wraps (F >= 200).  The speculative FAST threshold of k_fast is therefore always applied to a frame
+it has not seen: `fast_redo_rate` reports how often it failed, `scene_cuts` times the same batch with a cut every 20 frames.
 Workload at N=1: BASELINE.json configs[1] -- 1280x960 synthetic stereo streams, ~2000 ORB keypoints per image
 (orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton; 192 streams per GPU held by three
 contexts of 64 (the per-stream latency-bound kernels of stages 3-5 of one context overlap the throughput kernels of
@@ -46,12 +50,30 @@ def lane_seeds(rank, world_size, lanes):
 
 
 def frame_schedule(step, n_frames):
-    """Ping-pong 0..F-1..0.. so that consecutive steps are always consecutive poses of the trajectory."""
+    """Ping-pong 0..F-1..0.. so that consecutive steps are always consecutive poses of a trajectory (short test sequences, the host-fed ring)."""
     if n_frames <= 1:
         return 0
     period = 2 * (n_frames - 1)
     k = step % period
     return k if k < n_frames else period - k
+
+
+PHASE_STRIDE = 7       # frames between two streams that play the same trajectory
+
+
+def frames_needed(lanes, trajectories, total_steps):
+    """Frames per trajectory such that stream l = (trajectory l % T, first frame PHASE_STRIDE * (l // T)) never wraps in total_steps steps."""
+    phases = (lanes + trajectories - 1) // trajectories
+    return max(200, (phases - 1) * PHASE_STRIDE + total_steps + 1)
+
+
+def lane_frame(lane, step, trajectories, n_frames):
+    """(trajectory, frame) stream `lane` of this rank is shown at `step`: consecutive frames of its trajectory, never the same twice
+    within n_frames - phase steps (past that it plays the trajectory backwards: a test hook, the timed runs never get there)."""
+    j, k = lane % trajectories, PHASE_STRIDE * (lane // trajectories) + step
+    if n_frames <= 1:
+        return j, 0
+    return j, frame_schedule(k, n_frames)
 
 
 def gather_records(local, world_size):
@@ -99,15 +121,17 @@ def algorithmic_bytes(kernel, n_img, lv, n_kps, n_match, n_track):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--lanes", type=int, default=192, help="independent stereo streams per GPU (all contexts together)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
-    ap.add_argument("--frames", type=int, default=6, help="distinct frames rendered per stream (played ping-pong)")
+    ap.add_argument("--frames", type=int, default=0, help="frames rendered per trajectory; 0 (default) = as many as it takes for no stream ever to see a frame twice (>= 200)")
+    ap.add_argument("--trajectories", type=int, default=8, help="distinct camera trajectories rendered per rank; stream s plays trajectory s %% T from frame 7 * (s // T) on")
+    ap.add_argument("--cut-steps", type=int, default=60, help="steps of the scene-cut leg (every stream jumps to another trajectory every 20 frames, estimators reset as an application would); N=1 only; 0 = skip")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
     ap.add_argument("--orb-nfeats", type=int, default=2000)
-    ap.add_argument("--cpu-frames", type=int, default=64, help="upper bound on the frames per probe stream replayed on the CPU oracle (baseline timing + parity probe; 0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="upper bound on the frames per probe stream replayed on the CPU oracle (baseline timing + parity probe; 0 = skip)")
     ap.add_argument("--host-fed-steps", type=int, default=16, help="steps of the host-fed leg (page-locked host frames uploaded per step on the contexts' copy streams; 0 = skip); N=1 only")
     ap.add_argument("--single-stream", type=int, default=1, help="1: also time ONE stream alone (plain launches, hipGraph replay, frames dealt to 2 / 3 contexts); N=1, config2 only")
     ap.add_argument("--exclusive", type=int, default=1, help="1: after the timed region, time the roofline kernel again with one context alone on the GPU (roofline.exclusive); 0 = skip (profiling runs)")
@@ -119,8 +143,9 @@ def main():
     ap.add_argument("--rest-streams", type=int, default=0, help="HIP streams stages 3-5 of the contexts alternate over (pipelined schedule); 0 = one per context")
     ap.add_argument("--detect-ahead", type=int, default=1, help="1 (default): a context's detector of frame t + 1 starts once the description of frame t has read the detector's scratch (it overlaps that context's own stages 3-5); 0: it waits for the whole frame t (rounds 1-3)")
     ap.add_argument("--max-kps", type=int, default=4096, help="keypoint capacity per image of the contexts (svo_config.max_kps)")
-    ap.add_argument("--scene", default="planes", choices=["planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): planes = wall + ground + facades (every earlier round's numbers), relief = the same plus 28 billboards at 4..22 m (non-planar depth)")
+    ap.add_argument("--scene", default="street", choices=["street", "planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): street (default, round 4) = ground + far wall + a facade every 4.5 m along a world as long as the trajectory; planes = wall + ground + facades (rounds 1-3: a ~1 m world, needs --frames 6); relief = planes plus 28 billboards at 4..22 m")
     ap.add_argument("--relief-lanes", type=int, default=16, help="N=1, config2: streams of the extra leg on the OTHER scene type (reported as `other_scene`: pass-through counters and pose error against ground truth beside the timed scene's); 0 = skip")
+    ap.add_argument("--other-workloads", type=int, default=1, help="1: after everything else, short timed legs of the other single-GPU configurations (BASELINE.json configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB) as sub-processes, reported as `other_workloads`; N=1, config2 only")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
@@ -152,16 +177,32 @@ def main():
             dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
-    W, H, B, F = args.width, args.height, args.lanes, args.frames
+    W, H, B = args.width, args.height, args.lanes
+    T = max(1, min(args.trajectories, B))
+    total_steps = args.warmup + args.steps
+    F = args.frames if args.frames > 0 else frames_needed(B, T, total_steps)
     focal = 718.856 if kitti else 800.0 * W / 1280.0
     baseline = 0.537 if kitti else 0.12
     cxy = dict(cx=607.19, cy=185.22) if kitti else {}
     seeds = lane_seeds(rank, world, B)
-    # four scenes shared by the streams (textures are the slow part to mint), one trajectory per stream
-    worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=s, n_frames=F, device=dev, scene_seed=s % 4, scene=args.scene, **cxy) for s in seeds]
-    frames = [[w.render(t) for t in range(F)] for w in worlds]          # [lane][t] -> (L, R) uint8 on device
+    # T trajectories per rank through four scenes (textures are the slow part to mint); every stream = (trajectory, first frame)
+    worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=rank * T + j, n_frames=F, device=dev, scene_seed=j % 4, scene=args.scene, noise_on_device=True, **cxy) for j in range(T)]
+    t_render = time.perf_counter()
+    frames = [[w.render(t) for t in range(F)] for w in worlds]          # [trajectory][t] -> (L, R) uint8 on device
     cam = worlds[0].camera()
     torch.cuda.synchronize()
+    t_render = time.perf_counter() - t_render
+
+    def frame_of(lane, step):
+        j, t = lane_frame(lane, step, T, F)
+        return frames[j][t]
+
+    def ptrs_at_step(step):
+        out = []
+        for l in range(B):
+            L_, R_ = frame_of(l, step)
+            out.append((L_.data_ptr(), R_.data_ptr()))
+        return out
 
     p = north_star_params(hip.default_params(), orb_nfeats=args.orb_nfeats)
     if detect_fast_orb:
@@ -171,7 +212,7 @@ def main():
     batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else ("select" if args.post_on_rest == 3 else bool(args.post_on_rest))),
                         det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams, max_kps=args.max_kps, detect_ahead=bool(args.detect_ahead))
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
-    ptrs_at = [[(frames[l][t][0].data_ptr(), frames[l][t][1].data_ptr()) for l in range(B)] for t in range(F)]
+    ptrs_by_step = [ptrs_at_step(i) for i in range(total_steps)]         # built ahead: the timed loop only indexes it
 
     gather_done = [torch.cuda.Event(), torch.cuda.Event()]
 
@@ -183,7 +224,7 @@ def main():
             batch.flip_records()
             if i >= 2:
                 batch.hold_for(gather_done[i & 1])       # the all-gather that read this buffer two steps ago
-        batch.step(ptrs_at[frame_schedule(i, F)])
+        batch.step(ptrs_by_step[i])
         if world > 1:          # the all-gather runs on torch's current stream: it waits for every context's last work
             batch.make_wait(torch.cuda.current_stream(dev))
         out = gather_records(batch.rec, world)
@@ -211,6 +252,8 @@ def main():
     for c_ in ctxs:
         c_.kernel_times_select(dom)
         c_.kernel_times_reset()
+    for c_ in ctxs:
+        c_.redo_count(reset=True)                 # (waits for the context: the warm-up is over)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     allrec = None
@@ -221,6 +264,7 @@ def main():
     dt = reduce_max(dt, dev, world)
 
     kt = batch.pooled_kernel_times()
+    redo_pairs = sum(c_.redo_count(reset=True) for c_ in ctxs)
     results = batch.results()
     n_valid = sum(1 for r in results if r.valid)
     mean_kps = float(np.mean([r.detected_left[0] for r in results]))
@@ -254,7 +298,7 @@ def main():
             per_kernel[dom] = per_kernel_warm[dom]
         abytes = algorithmic_bytes(dom, 2 * Bc, lv, mean_kps, mean_match, mean_track)
         achieved = abytes / (per_kernel[dom]["ms_per_launch"] * 1e-3) / 1e9
-        # HBM traffic of that kernel: NOT measured in this run -- read from the committed PMC passes (tools/pmc_traffic.py:
+        # HBM traffic of that kernel: NOT measured in this run -- read from the committed PMC passes (tools/pmc_passes.py:
         # L2 memory-side read / write requests counted by size in separate rocprofv3 --pmc runs of this same command),
         # scaled from the profiled lane count to this run's; None when the profile does not cover this workload.
         # `traffic_source` names the file so that a reader can tell a carried-over constant from a live counter.
@@ -292,9 +336,9 @@ def main():
         pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
         cpu_baseline, pose_rmse, parity_probe, host_fed = None, None, None, None
         if world == 1 and args.cpu_frames > 0:
-            cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
+            cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec)
         if world == 1 and args.host_fed_steps > 0:
-            host_fed = host_fed_leg(args, batch, frames, dev)
+            host_fed = host_fed_leg(args, batch, frame_of, dev)
         other_scene = None
         if world == 1 and args.relief_lanes > 0 and args.workload == "config2":
             batch.synchronize()
@@ -302,6 +346,17 @@ def main():
                 other_scene = other_scene_leg(args, p, dev, local_rank, focal, baseline)
             except Exception as e:
                 other_scene = {"error": str(e)}
+        scene_cuts = None
+        if world == 1 and args.cut_steps > 0:
+            batch.synchronize()
+            try:
+                scene_cuts = scene_cut_leg(args, batch, frames, T, F, n_octaves if detect_fast_orb else 8)
+            except Exception as e:
+                scene_cuts = {"error": str(e)}
+        other_workloads = None
+        if world == 1 and args.other_workloads and args.workload == "config2":
+            batch.synchronize()
+            other_workloads = other_workloads_leg(args)
         single_stream = None
         if world == 1 and args.single_stream and args.workload == "config2":
             batch.synchronize()
@@ -320,10 +375,10 @@ def main():
             c0 = batch.ctxs[0]
             c0.kernel_times_select(dom)
             for i in range(3):
-                c0.process_device(ptrs_at[frame_schedule(i, F)][:Bc], W, H, W)
+                c0.process_device(ptrs_by_step[i][:Bc], W, H, W)
             c0.wait(); c0.kernel_times_reset()
             for i in range(3, 9):
-                c0.process_device(ptrs_at[frame_schedule(i, F)][:Bc], W, H, W)
+                c0.process_device(ptrs_by_step[i][:Bc], W, H, W)
             c0.wait()
             tot, calls = c0.kernel_times()[dom]
             ex_ms = tot / max(1, calls) / (7 if dom == "resize" else 1)
@@ -337,7 +392,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d synthetic stereo streams, %s, orb_nfeats %d (~%d kps/image in octave 0 after NMS), BF match, BF track, robust GN; %d independent streams per GPU in %d contexts on separate HIP streams, one frame per stream per step"
                                    % (args.workload, W, H, "FAST+ORB on %d x1/2 octaves" % n_octaves if detect_fast_orb else "ORB x 8 levels", args.orb_nfeats, int(mean_kps), B, NC),
-                       "lanes_per_gpu": B, "contexts_per_gpu": NC, "lanes_per_context": Bc, "frames_per_stream": F, "schedule": args.schedule if NC > 1 else "single stream", "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
+                       "lanes_per_gpu": B, "contexts_per_gpu": NC, "lanes_per_context": Bc, "schedule": args.schedule if NC > 1 else "single stream", "detect_ahead": bool(args.detect_ahead),
+                       "sequence": "%d trajectories x %d frames per rank (scene '%s'), stream s = trajectory s %% %d from frame %d * (s // %d) on: %d consecutive DISTINCT frames per stream over warm-up + timed steps, none seen twice"
+                                   % (T, F, args.scene, T, PHASE_STRIDE, T, total_steps),
+                       "frames_per_trajectory": F, "distinct_frames_per_stream": min(total_steps, F), "render_s": round(t_render, 1),
+                       "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
+            "timed_region_s": round(dt, 4),
+            "fast_redo_rate": round(redo_pairs / float(max(1, args.steps * 2 * B * (n_octaves if detect_fast_orb else 8))), 6),
+            "fast_redo_note": "(image, level) pairs of the timed steps whose speculative FAST threshold found too few corners and ran k_fast again at the caller's threshold (%d of %d); every frame of the run is new to its stream" % (redo_pairs, args.steps * 2 * B * (n_octaves if detect_fast_orb else 8)),
+            "scene_cuts": scene_cuts,
+            "other_workloads": other_workloads,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "pose_rmse_vs_cpu": pose_rmse,
@@ -394,8 +458,8 @@ def other_scene_leg(args, p, dev, device_index, focal, baseline):
     """The scene type the timed region did NOT use, on a small batch: where stage 4's candidates go and how far the poses are
     from the renderer's ground truth, beside the timed scene's figures.  Untimed; HIP poses against ground truth directly."""
     from stereo_vo_amd.synth import pose6_to_matrix, pose_error
-    scene = "relief" if args.scene == "planes" else "planes"
-    W, H, F, B = args.width, args.height, args.frames, args.relief_lanes
+    scene = "relief" if args.scene != "relief" else "planes"
+    W, H, F, B = args.width, args.height, 6, args.relief_lanes
     worlds = [SyntheticStereoWorld(W, H, focal, baseline, seed=1000 + s, n_frames=F, device=dev, scene_seed=s % 4, scene=scene) for s in range(B)]
     frames = [[w.render(t) for t in range(F)] for w in worlds]
     torch.cuda.synchronize()
@@ -423,31 +487,36 @@ def other_scene_leg(args, p, dev, device_index, focal, baseline):
                                      "rotation_rmse_rad": float(np.sqrt(np.mean(np.square(er)))) if er else None, "frames": len(et)}}
 
 
-def host_fed_leg(args, batch, frames, dev):
+def host_fed_leg(args, batch, frame_of, dev):
     """The reference's own contract is host images per call (process_new_image_pair.cpp:100-120).  Same batch, same
     schedule, but every step hands PAGE-LOCKED HOST frames to svo_process (SVO_FLAG_PINNED_IMAGES): each context uploads
     on its own copy stream into a two-slot device ring, so the upload of a step overlaps the kernels of the one before.
-    PCIe-bound by construction (2 * W * H bytes per pair); never part of `value`."""
-    F, B, W, H = args.frames, batch.B, args.width, args.height
+    PCIe-bound by construction (2 * W * H bytes per pair); never part of `value`.  The host ring holds the first six frames of
+    every stream, played forwards and backwards (what is uploaded does not change what an upload costs)."""
+    F, B, W, H = 6, batch.B, args.width, args.height
     try:
         host = torch.empty((F, B, 2, H, W), dtype=torch.uint8, pin_memory=True)
     except Exception as e:                                   # not enough lockable memory on this host
         return {"error": "pinned allocation failed: %s" % e}
     for l in range(B):
         for t in range(F):
-            host[t, l, 0].copy_(frames[l][t][0]); host[t, l, 1].copy_(frames[l][t][1])
+            L_, R_ = frame_of(l, t)
+            host[t, l, 0].copy_(L_); host[t, l, 1].copy_(R_)
     torch.cuda.synchronize()
     hptr = [[(host[t, l, 0].data_ptr(), host[t, l, 1].data_ptr()) for l in range(B)] for t in range(F)]
+
+    def pingpong(i):
+        return frame_schedule(i, F)
     for c_ in batch.ctxs:
         c_.kernel_times_select("fast")
     batch.reset()
     n_warm, K = 3, args.host_fed_steps
     for i in range(n_warm):
-        batch.step(hptr[frame_schedule(i, F)], pinned_host=True)
+        batch.step(hptr[pingpong(i)], pinned_host=True)
     batch.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        batch.step(hptr[frame_schedule(n_warm + i, F)], pinned_host=True)
+        batch.step(hptr[pingpong(n_warm + i)], pinned_host=True)
     batch.synchronize()
     dt = time.perf_counter() - t0
     res = batch.results()
@@ -457,7 +526,67 @@ def host_fed_leg(args, batch, frames, dev):
             "note": "page-locked host frames, one contiguous upload of %d pairs per context per step on the context's copy stream, two-slot device ring; the resident figure `value` excludes this copy" % batch.Bc}
 
 
-def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec):
+def scene_cut_leg(args, batch, frames, T, F, levels):
+    """What the speculative FAST threshold costs when it is wrong.  Same batch, --cut-steps steps; every 20th step EVERY stream
+    jumps to another trajectory (another scene: other textures, other corner statistics) at an arbitrary frame, and the estimators
+    are reset there, as an application that detects the cut would (the reference itself keeps the pre-cut frame as `previous`
+    for ever after voecBadTracking, P:86-95).  Timed like the main run, resets included."""
+    B, K = batch.B, args.cut_steps
+
+    def ptrs(step):
+        seg = step // 20
+        out = []
+        for l in range(B):
+            j = (l + seg * 3) % T                              # a new trajectory after every cut (T >= 2; with one trajectory only the frame jumps)
+            k = frame_schedule(PHASE_STRIDE * (l // T) + 53 * seg + step, F)
+            L_, R_ = frames[j][k]
+            out.append((L_.data_ptr(), R_.data_ptr()))
+        return out
+    sched = [ptrs(i) for i in range(K)]
+    batch.reset()
+    for c_ in batch.ctxs:
+        c_.kernel_times_select("fast")
+        c_.redo_count(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cuts = 0
+    for i in range(K):
+        if i and i % 20 == 0:
+            batch.reset(); cuts += 1
+        batch.step(sched[i])
+    batch.synchronize()
+    dt = time.perf_counter() - t0
+    redo = sum(c_.redo_count(reset=True) for c_ in batch.ctxs)
+    res = batch.results()
+    return {"pairs_per_s": round(B * K / dt, 1), "ms_per_step": round(1e3 * dt / K, 4), "steps": K, "cuts": cuts, "cut_every": 20,
+            "fast_redo_pairs": redo, "fast_redo_rate": round(redo / float(K * 2 * B * levels), 6),
+            "valid_last_step": "%d/%d" % (sum(1 for r in res if r.valid), B),
+            "note": "every stream jumps to another trajectory / scene every 20 frames, estimators reset at the cut (the resets and their synchronisation are inside the timed span); redo rate over ALL (image, level) pairs of the leg, the first frames (no speculation yet) included"}
+
+
+def other_workloads_leg(args):
+    """BASELINE.json configs[2] (KITTI shape) and configs[4] (2048x1536, FAST+ORB on 3 octaves) on this GPU, as short runs of this
+    same script in sub-processes (their own contexts and memory), each with its own parity probe; reported inside the default line
+    so that the driver's record holds a pairs/s figure for every single-GPU configuration."""
+    import subprocess
+    out = {}
+    for wl, extra in (("config3", ["--lanes", "192", "--contexts", "3"]), ("config5", ["--lanes", "64", "--contexts", "2"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "40", "--warmup", "6", "--cpu-frames", "12", "--host-fed-steps", "0",
+               "--single-stream", "0", "--relief-lanes", "0", "--cut-steps", "0", "--other-workloads", "0", "--exclusive", "1"] + extra
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+            out[wl] = {k: line.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "valid_last_step", "mean_kps", "mean_matches", "mean_tracked", "fast_redo_rate", "path_hbm_frac")}
+            out[wl]["workload"] = line["config"]["workload"]
+            out[wl]["roofline"] = {k: line["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "exclusive")}
+            pp = line.get("parity_probe") or {}
+            out[wl]["parity_probe"] = {k: pp.get(k) for k in ("lanes", "frames", "lists_bit_exact", "flags_equal", "pose_max_err_m", "pose_max_err_rad")}
+        except Exception as e:
+            out[wl] = {"error": str(e)}
+    return out
+
+
+def cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec):
     """N=1 only, after the timed region.  The oracle (CHECKER / BASELINE, never the thing measured) replays the first
     n frames of the run's own frame schedule for a few probe streams of every context:
       * leg (i): stream 0 alone on one host thread, timed          -> cpu_baseline.value (mirrors the single-threaded reference)
@@ -469,12 +598,15 @@ def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
     from oracle import oracle as O      # checker / baseline only; never on the product path
     from oracle import probe as PR
     from stereo_vo_amd.abi import Result
-    F, B, Bc, NC = args.frames, batch.B, batch.Bc, batch.NC
+    B, Bc, NC = batch.B, batch.Bc, batch.NC
     total = args.warmup + args.steps
     n = min(total, args.cpu_frames)
-    order = [frame_schedule(i, F) for i in range(n)]
+    order = list(range(n))              # stream g sees frame_of(g, i) at step i
     want = sorted(set(k * Bc + l for k in range(NC) for l in (0, Bc // 2 - 1 if Bc > 1 else 0, Bc - 1)))
-    host = {g: [(frames[g][t][0].cpu().numpy(), frames[g][t][1].cpu().numpy()) for t in range(F)] for g in want}
+
+    def host_frames(g, count):
+        return [tuple(x.cpu().numpy() for x in frame_of(g, i)) for i in range(count)]
+    host = {g: host_frames(g, n) for g in want}
     # the timing legs use a -march=native build of the same oracle source made on this host, if gcc is here; it must agree
     # with the portable checker build bit for bit before its digests are trusted
     native = False
@@ -525,7 +657,7 @@ def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
     n_mt = min(n, 12)
     for g in mt_streams:
         if g not in host:
-            host[g] = [(frames[g][t][0].cpu().numpy(), frames[g][t][1].cpu().numpy()) for t in range(F)]
+            host[g] = host_frames(g, n_mt)
     todo2, done2 = list(mt_streams), []
     def work2():
         while True:
@@ -567,7 +699,7 @@ def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
         c_.kernel_times_select(None)
     bad, max_t, max_r, se_t, se_r, n_pose, n_flag = [], 0.0, 0.0, 0.0, 0.0, 0, 0
     for i in range(n):
-        batch.step(ptrs_at[order[i]])
+        batch.step(ptrs_by_step[i])
         batch.synchronize()
         rec_cpu = batch.rec.cpu().numpy()
         for g in want:
@@ -587,11 +719,9 @@ def cpu_baseline_and_probe(args, batch, frames, ptrs_at, worlds, p, cam, allrec)
     gt_t, gt_r = [], []
     for i in range(1, n):
         d = ref[0][i]
-        if not d.valid or abs(order[i] - order[i - 1]) != 1:
+        if not d.valid:
             continue
-        fwd = order[i] > order[i - 1]
-        G = worlds[0].gt_delta(order[i] if fwd else order[i - 1])
-        G = G if fwd else np.linalg.inv(G)
+        G = worlds[0].gt_delta(i)                     # stream 0 = trajectory 0 from its first frame
         er_, et_ = pose_error(pose6_to_matrix(d.pose), G)
         gt_t.append(et_); gt_r.append(er_)
     pose_rmse = {"translation_m": float(np.sqrt(se_t / n_pose)) if n_pose else None, "rotation_rad": float(np.sqrt(se_r / n_pose)) if n_pose else None,

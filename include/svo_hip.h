@@ -275,6 +275,13 @@ int svo_hamming_match(svo_ctx* ctx, const uint8_t* query, int nq, const uint8_t*
 int svo_debug_get_level(svo_ctx* ctx, int lane, int side, int level, uint8_t* out, int cap, int* w, int* h);
 int svo_debug_get_raw_keypoints(svo_ctx* ctx, int lane, int side, svo_keypoint* kps, uint8_t* desc, int cap);
 int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w);   /* capacity-overflow bits */
+/* 1 when the reference's profiler sections (CTimeLogger names: "processNewImagePair", "_stg1" .. "_stg5", "stg3.find_pairings",
+ * "stg4.track") are being emitted as roctx ranges around the enqueue of each stage: SVO_ROCTX=1 in the environment, or a rocprofv3
+ * session (it sets ROCP_TOOL_LIBRARIES); the roctx library is looked up with dlopen, never linked. */
+int svo_profiler_sections_enabled(void);
+/* How often the speculative FAST threshold of k_fast failed since svo_create (or the last reset = 1 call): (image, level) pairs
+ * that a frame had to run again at the caller's threshold (k_fast_redo + the second k_select pass).  Waits for the enqueued work. */
+int svo_debug_get_redo_count(svo_ctx* ctx, uint32_t* pairs, int reset);
 
 /* per-kernel HIP-event timing (svo_config.kernel_times = 1): names[i] points to static storage.
  * total_ms[i] / calls[i] accumulate since the last svo_kernel_times_reset. Returns number of kernels. */

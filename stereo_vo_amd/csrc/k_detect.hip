@@ -648,14 +648,12 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int pitch, int x,
             a += Ix * Ix; b += Iy * Iy; cc += Ix * Iy;
         }
     }
+    // cv::ORB's HarrisResponses, operator for operator (oracle: harris_response)
     const float s = 1.0f / (4.0f * 7.0f * 255.0f);
-    const float s2 = s * s;
-    const float s4 = s2 * s2;
+    const float s4 = s * s * s * s;
     const float fa = (float)a, fb = (float)b, fc = (float)cc;
-    const float det = fa * fb - fc * fc;
     const float tr = fa + fb;
-    const float k = 0.04f * (tr * tr);
-    return (det - k) * s4;
+    return (fa * fb - fc * fc - 0.04f * tr * tr) * s4;
 }
 
 // Harris response from 27 aligned dword loads (9 rows x 12 bytes) instead of 81 byte loads; same integer sums and
@@ -685,14 +683,12 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
             a += __mul24(Ix, Ix); b += __mul24(Iy, Iy); cc += __mul24(Ix, Iy);
         }
     }
+    // cv::ORB's HarrisResponses, operator for operator (oracle: harris_response)
     const float s = 1.0f / (4.0f * 7.0f * 255.0f);
-    const float s2 = s * s;
-    const float s4 = s2 * s2;
+    const float s4 = s * s * s * s;
     const float fa = (float)a, fb = (float)b, fc = (float)cc;
-    const float det = fa * fb - fc * fc;
     const float tr = fa + fb;
-    const float k = 0.04f * (tr * tr);
-    return (det - k) * s4;
+    return (fa * fb - fc * fc - 0.04f * tr * tr) * s4;
 }
 
 // Speculative FAST threshold (exact, with fallback).  Only the 2 * quota best corners of a level survive this kernel, and
@@ -729,6 +725,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
         // the speculated threshold found too few corners: start this pair over at the caller's threshold
         if (tid == 0) {
             c.redo_flag[il] = 1; c.redo_list[atomicAdd(c.redo_n, 1u)] = (uint32_t)il;
+            atomicAdd(c.redo_n + 1, 1u);                               // running total since svo_create (svo_debug_get_redo_count)
             c.cand_cnt[il * SVO_CNT_STRIDE] = 0; c.fast_th_used[il] = th_base; c.fast_th_dyn[il] = 0;
         }
         return;

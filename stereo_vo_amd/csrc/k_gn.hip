@@ -8,6 +8,7 @@
 // Jacobian block is 4T x 6 with a 6x6 output, far too thin for an MFMA tile.
 // The reduction order differs from the reference's sequential loop, so results agree with the oracle to rounding
 // (tests: 1e-4 rad / 1e-3 m), not bit for bit.
+#include <mutex>
 #include "svo_device.h"
 #include "svo_kernels.h"
 #include <float.h>
@@ -582,13 +583,23 @@ static size_t gn_smem(int pmax, int nt)
     return region + (size_t)pmax * 2 + 16 + sizeof(int) * 40 + sizeof(GnShared) + 16;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the KERNEL, shared by every context of the process: only ever raise it
+// (a later, smaller context must not lower the limit under an earlier context's launches)
 hipError_t configure_gauss_newton(int pmax)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)k_gauss_newton<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax, 256));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_gauss_newton<384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax, 384));
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_gauss_newton<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gn_smem(pmax, 512));
+    static std::mutex mu;
+    static size_t cur[3] = { 0, 0, 0 };
+    std::lock_guard<std::mutex> lock(mu);
+    const void* fn[3] = { (const void*)k_gauss_newton<256>, (const void*)k_gauss_newton<384>, (const void*)k_gauss_newton<512> };
+    const int nt[3] = { 256, 384, 512 };
+    for (int i = 0; i < 3; i++) {
+        const size_t want = gn_smem(pmax, nt[i]);
+        if (want <= cur[i]) continue;
+        const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e != hipSuccess) return e;
+        cur[i] = want;
+    }
+    return hipSuccess;
 }
 
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)

@@ -1046,7 +1046,12 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
     const int n = c.trk_nk[vl];
     if (n < 7) return;
     if (h0 >= RS_SLOT_END(chunk)) return;
-    const int nlive = rs_group_live(c, vl, side, h0);
+    // ONE thread decides for the block (rs_bound moves while the launch runs: threads reading it themselves could disagree, and a
+    // block of which some waves have left no longer fills its shared arrays)
+    __shared__ int s_nlive;
+    if (tid == 0) s_nlive = rs_group_live(c, vl, side, h0);
+    __syncthreads();
+    const int nlive = s_nlive;
     if (nlive <= 0) return;                                                   // nothing generated here, or samples the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0) * 9;
@@ -1138,16 +1143,17 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15;
     const int hw = h0 + 16 * w;                                 // this wave's sixteen slots (one group: never across a region)
-    // the block leaves when none of its four groups has anything to score (block-uniform: every wave computes all four)
-    int nlive_w = 0; bool any = false;
-#pragma unroll
-    for (int ww = 0; ww < 4; ww++) {
-        const int s0 = h0 + 16 * ww;
-        const int nl = (s0 < RS_SLOT_END(chunk) && s0 + 16 <= SVO_RANSAC_SLOTS) ? rs_group_live(c, vl, side, s0) : 0;
-        any = any || nl > 0;
-        if (ww == w) nlive_w = nl;
+    // the block leaves when none of its four groups has anything to score.  Four threads decide, one per group, and the block reads
+    // their verdicts from LDS: rs_bound moves while the launch runs, so waves looking for themselves could disagree, and a block of
+    // which some waves have left no longer fills `ops`
+    __shared__ int s_nlive[4];
+    if (tid < 4) {
+        const int s0 = h0 + 16 * tid;
+        s_nlive[tid] = (s0 < RS_SLOT_END(chunk) && s0 + 16 <= SVO_RANSAC_SLOTS) ? rs_group_live(c, vl, side, s0) : 0;
     }
-    if (!any) return;
+    __syncthreads();
+    const int nlive_w = s_nlive[w];
+    if (s_nlive[0] <= 0 && s_nlive[1] <= 0 && s_nlive[2] <= 0 && s_nlive[3] <= 0) return;
     bool dead = nlive_w <= 0;
     const int hs = min(hw, SVO_RANSAC_SLOTS - 16);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hs) * 9;
@@ -1263,12 +1269,14 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
     const int n = c.trk_nk[vl];
     if (n < 7) return;
     if (h0 >= RS_SLOT_END(chunk)) return;
-    const int nlive = rs_group_live(c, vl, side, h0);
+    __shared__ int s_nlive;                                                   // one thread decides for the block (see k_ransac_count_mfma)
+    if (tid == 0) s_nlive = rs_group_live(c, vl, side, h0);
+    if (tid < RC_HB) cnt_s[tid] = 0;
+    __syncthreads();
+    const int nlive = s_nlive;
     if (nlive <= 0) return;                                                   // nothing generated here, or samples the sequential stop never reaches
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + h0) * 9;
-    if (tid < RC_HB) cnt_s[tid] = 0;
-    __syncthreads();
     int cnt[RC_HB];
 #pragma unroll
     for (int h = 0; h < RC_HB; h++) cnt[h] = 0;

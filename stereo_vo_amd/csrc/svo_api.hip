@@ -22,6 +22,43 @@ static const char* kt_names[KT_COUNT] = { "begin_frame", "resize", "fast", "sele
 
 struct TimedSpan { int id; hipEvent_t a, b; };
 
+// ---- profiler sections ---------------------------------------------------------------------------------------------------
+// The reference brackets its stages with mrpt's CTimeLogger: m_profiler.enter / leave("processNewImagePair", "_stg1" ... "_stg5",
+// "stg3.find_pairings", "stg4.track", ...: process_new_image_pair.cpp:79, 377; stage1_rectify.cpp:41-86; stage2_detect.cpp:392, 670;
+// stage3_match_left_right.cpp:64-473; stage4_match_consecutive.cpp:76-800; stage5_optimization.cpp:398, 729).  Here the same names
+// are roctx ranges around the ENQUEUE of each stage (the kernels run asynchronously: rocprofv3 --marker-trace --kernel-trace ties a
+// kernel to the range it was launched in).  The roctx library is looked up at run time and only when asked for (SVO_ROCTX=1, or a
+// rocprofv3 session: ROCP_TOOL_LIBRARIES is set), so libsvo_hip.so has no link-time dependency on the profiler SDK.
+#include <dlfcn.h>
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi()
+    {
+        const char* e = getenv("SVO_ROCTX");
+        if (e && e[0] == '0') return;
+        if (!(e && e[0] == '1') && !getenv("ROCP_TOOL_LIBRARIES")) return;
+        for (const char* name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+            void* h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+RoctxApi& roctx_api() { static RoctxApi a; return a; }
+struct Section {                                       // m_profiler.enter(name) ... leave(name)
+    bool on;
+    explicit Section(const char* name) : on(roctx_api().push != nullptr) { if (on) roctx_api().push(name); }
+    ~Section() { if (on) roctx_api().pop(); }
+    Section(const Section&) = delete; Section& operator=(const Section&) = delete;
+};
+}
+extern "C" int svo_profiler_sections_enabled(void) { return roctx_api().push != nullptr; }
+
 struct svo_ctx {
     svo_config cfg;
     svo_params params;
@@ -345,6 +382,7 @@ static int params_fit(svo_ctx* ctx, const svo_params& p)
     if (p.detect_method != SVO_DM_ORB && !fast_orb) return SVO_OK;          // refused as unsupported by svo_process
     char msg[256];
     const int MK = ctx->dc.max_kps;
+    if (p.orb_nfeats <= 0) { snprintf(msg, sizeof(msg), "orb_nfeats %d: the detector needs a positive feature count", p.orb_nfeats); ctx->last_error = msg; return SVO_ERR_ARG; }
     if (fast_orb) {
         const int noct = p.nOctaves < 1 ? 1 : p.nOctaves;
         if (noct > ctx->dc.oct_cap) { snprintf(msg, sizeof(msg), "nOctaves %d exceeds svo_config.max_octaves %d", noct, ctx->dc.oct_cap); ctx->last_error = msg; return SVO_ERR_CAPACITY; }
@@ -782,6 +820,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         if (flags & SVO_RUN_DETECT) { if (!(flags & SVO_FLAG_DETECT_NO_POST) || (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | SVO_RUN_DETECT_POST))) return SVO_ERR_ARG; }
         else if (!(flags & SVO_RUN_DETECT_POST) || (flags & SVO_FLAG_NO_SHIFT)) return SVO_ERR_ARG;
     }
+    Section sec_all("processNewImagePair");                                       // P:79, 377
     DevCtx& d = ctx->dc;
     const hipStream_t st = ctx->stream;
     note_stream(ctx);
@@ -869,7 +908,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     }
     struct CaptureGuard { hipStream_t st; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; hipStreamEndCapture(st, &g); if (g) hipGraphDestroy(g); *on = false; } } } guard{ st, &capturing };
     d.det_ahead = (ahead && (flags & SVO_RUN_DETECT)) ? 1 : 0;
-    { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); if (prepare) launch_prepare(prep, 2 * d.n_lanes, st); }
+    { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); if (prepare) { Section sec("_stg1"); launch_prepare(prep, 2 * d.n_lanes, st); } }
     // the detector's per-image scratch has had its last reader: the armed event (svo_record_after_post) goes here
     auto after_post = [&]() -> hipError_t {
         if (!ctx->post_event || capturing) return hipSuccess;
@@ -878,6 +917,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         return e;
     };
     if (flags & SVO_RUN_DETECT) {
+        Section sec("_stg2");                                                        // S2:392, 670
         if (d.fast_orb) {       // stage2_detect.cpp:502-515 on the x1/2 octave pyramid
             { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_half(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
@@ -905,6 +945,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         }
     } else if (flags & SVO_RUN_DETECT_POST) {       // the post-processing a SVO_FLAG_DETECT_NO_POST call left out
         if (!ctx->geom_ready) return SVO_ERR_STATE;
+        Section sec("_stg2");
         const int nms_mode = p.non_maximal_suppression ? (p.nmsMethod == SVO_NMS_ADAPTIVE ? 2 : 1) : 0;
         if ((flags & SVO_FLAG_DETECT_SPLIT_AT_SELECT) && !d.fast_orb) { Span s(ctx, KT_SELECT); launch_select(d, st); }
         if (d.fast_orb || d.debug_mode == 9) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, d.fast_orb ? (p.non_maximal_suppression ? 0 : 3) : nms_mode, p.min_distance, 0, st); }
@@ -916,6 +957,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if ((flags & SVO_RUN_DETECT_POST) || ((flags & SVO_RUN_DETECT) && !(flags & SVO_FLAG_DETECT_NO_POST))) HIPCHECK(after_post());
     const int nsplit = hamming_splits(ctx);
     if (flags & SVO_RUN_MATCH) {
+        Section sec("_stg3"), sec2("stg3.find_pairings");                           // S3:64, 77
         // (the brute-force result words were set to all ones by k_begin_frame)
         if (p.match_method == SVO_SM_DESC_BF) {
             { Span s(ctx, KT_HAM_LR); launch_hamming(d, 0, nsplit, st); }
@@ -927,6 +969,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         }
     }
     if (flags & SVO_RUN_TRACK) {
+        Section sec("_stg4"), sec2("stg4.track");                                    // S4:76, 457
         const int win = p.ifm_method == SVO_IFM_DESC_WIN;
         if (!win) {
             { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
@@ -949,6 +992,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if (p.vo_use_matches_ids && (flags & (SVO_RUN_MATCH | SVO_RUN_TRACK))) { Span s(ctx, KT_TRK_FINAL); launch_match_ids(d, flags | (ctx->imported_pending ? SVO_RUN_MATCH : 0), st); }
     ctx->imported_pending = false;
     if (flags & SVO_RUN_OPTIMIZE) {
+        Section sec("_stg5");                                                        // S5:398, 729
         GNParams g; memset(&g, 0, sizeof(g));
         g.use_robust_kernel = p.use_robust_kernel; g.max_iters = p.max_iters; g.initial_max_iters = p.initial_max_iters; g.max_incr_cost = p.max_incr_cost;
         g.use_previous_pose_as_initial = p.use_previous_pose_as_initial; g.use_custom_initial_pose = 0;   // processNewImagePair passes no initial estimate (P:338)
@@ -1639,6 +1683,16 @@ extern "C" int svo_debug_get_raw_keypoints(svo_ctx* ctx, int lane, int side, svo
         }
     }
     return n;
+}
+
+extern "C" int svo_debug_get_redo_count(svo_ctx* ctx, uint32_t* pairs, int reset)
+{
+    if (ctx) use_device(ctx);
+    if (!ctx || !pairs) return SVO_ERR_ARG;
+    HIPCHECK(sync_all(ctx));
+    HIPCHECK(hipMemcpy(pairs, ctx->dc.redo_n + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (reset) HIPCHECK(hipMemset(ctx->dc.redo_n + 1, 0, sizeof(uint32_t)));
+    return SVO_OK;
 }
 
 extern "C" int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w)

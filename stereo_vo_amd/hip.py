@@ -25,7 +25,7 @@ EXPORTS = [
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
-    "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word",
+    "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word", "svo_debug_get_redo_count", "svo_profiler_sections_enabled",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
     "svo_get_values", "svo_put_features_oct", "svo_put_matches_oct", "svo_put_match_ids_oct",
     "svo_handover_bytes", "svo_export_frame", "svo_import_frame",
@@ -350,6 +350,12 @@ class Context:
         out = np.zeros((h.value, w.value), np.uint8)
         self._ck(self.L.svo_debug_get_level(self.h, lane, side, level, _vp(out), n, C.byref(w), C.byref(h)), "svo_debug_get_level")
         return out
+
+    def redo_count(self, reset=False):
+        """(image, level) pairs whose speculative FAST threshold failed (a second FAST pass at the caller's threshold) since creation / the last reset"""
+        v = C.c_uint32(0)
+        self._ck(self.L.svo_debug_get_redo_count(self.h, C.byref(v), int(bool(reset))), "svo_debug_get_redo_count")
+        return int(v.value)
 
     def status_word(self, lane=0):
         w = C.c_uint32(0)

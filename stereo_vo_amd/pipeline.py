@@ -63,6 +63,7 @@ class StreamBatch:
         self._ck(self.L.svo_batch_set_camera(self.h, -1, C.byref(cam)), "svo_batch_set_camera")
         # the result records of every step land here (device memory the caller owns), in lane order
         self.rec = torch.zeros((lanes, C.sizeof(Result)), dtype=torch.uint8, device=self.dev)
+        torch.cuda.synchronize(self.dev)                 # torch fills it on ITS stream: through before a context's stream writes records into it
         self._ck(self.L.svo_batch_set_results_buffer(self.h, C.c_void_p(self.rec.data_ptr()), C.c_size_t(self.rec.numel())), "svo_batch_set_results_buffer")
 
     def _err(self, rc):
@@ -92,6 +93,7 @@ class StreamBatch:
         one the last step wrote (svo_batch_switch_results_buffer: no synchronisation)."""
         if getattr(self, "_rec_alt", None) is None:
             self._rec_alt = torch.zeros_like(self.rec)
+            torch.cuda.synchronize(self.dev)
         self.rec, self._rec_alt = self._rec_alt, self.rec
         self._ck(self.L.svo_batch_switch_results_buffer(self.h, C.c_void_p(self.rec.data_ptr()), C.c_size_t(self.rec.numel())), "svo_batch_switch_results_buffer")
 

@@ -1,8 +1,10 @@
 """Deterministic synthetic stereo sequences: textured planes seen by a rectified pinhole pair.
 
-Two scene types: "planes" (a far wall, the ground and three or four facades: the default, and what every committed number before
-round 3 was measured on) and "relief" (the same plus a few dozen small billboards at depths of 4 .. 22 m: depth discontinuities
-everywhere in the image, so that the scene is not a handful of planes -- a near-degenerate configuration for a fundamental matrix).
+Three scene types: "planes" (a far wall, the ground and three or four facades: the default, and what every committed number before
+round 3 was measured on), "relief" (the same plus a few dozen small billboards at depths of 4 .. 22 m: depth discontinuities
+everywhere in the image, so that the scene is not a handful of planes -- a near-degenerate configuration for a fundamental matrix)
+and "street" (round 4: the ground, a far wall beyond the end of the trajectory and a facade every 4.5 m on alternating sides all
+along it -- a world long enough for hundreds of frames of forward motion, bench.py's non-repeating sequences).
 
 Plays the role of the image source of the reference's demo (demo-stereo-odometry/demo-main.cpp:200-220,
 mrpt CCameraSensor) on inputs that can be generated on the GPU box from this repository alone.
@@ -71,8 +73,11 @@ class SyntheticStereoWorld:
     _scene_cache = {}
 
     def __init__(self, width, height, focal, baseline=0.12, seed=0, n_frames=20, device="cpu",
-                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048, scene_seed=None, scene="planes"):
-        assert scene in ("planes", "relief")
+                 cx=None, cy=None, noise_sigma=2.0, tex_size=2048, scene_seed=None, scene="planes", noise_on_device=False):
+        assert scene in ("planes", "relief", "street")
+        # noise_on_device: the pixel noise comes from torch's generator of `device` (seeded per eye) instead of the CPU generator --
+        # ~6x faster rendering on a GPU; the images then depend on the device's generator, so tests keep the default
+        self.noise_on_device = bool(noise_on_device)
         self.scene = scene
         self.w, self.h, self.f, self.B = int(width), int(height), float(focal), float(baseline)
         self.cx = (self.w - 1) / 2.0 if cx is None else float(cx)
@@ -91,7 +96,8 @@ class SyntheticStereoWorld:
         self._ray = torch.stack([(xs - self.cx) / self.f, (ys - self.cy) / self.f, torch.ones_like(xs)], dim=-1)  # h,w,3
 
     def _build_scene(self, tex_size):
-        key = (self.scene_seed, tex_size, self.scene)
+        self.length = 0.175 * self.n_frames                 # expected forward travel (0.05 .. 0.3 m per frame)
+        key = (self.scene_seed, tex_size, self.scene) + ((int(self.length),) if self.scene == "street" else ())
         if key in SyntheticStereoWorld._scene_cache:
             self.planes, texs = SyntheticStereoWorld._scene_cache[key]
             self.textures = [torch.from_numpy(t).to(self.device).float() for t in texs]
@@ -104,18 +110,44 @@ class SyntheticStereoWorld:
         planes.append((np.array([0, 0, 26.0]), np.array([0, 0, -1.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), (-60, 60, -40, 40), 0.06))
         # ground
         planes.append((np.array([0, 1.7, 0]), np.array([0, -1.0, 0]), np.array([1.0, 0, 0]), np.array([0, 0, 1.0]), (-40, 40, 0.5, 80), 0.04))
-        # a few nearer facades with small random tilt
-        n_fac = 3 + rng.randint(0, 1)
-        for k in range(n_fac):
-            z = rng.uniform(7.0, 16.0)
-            xc = rng.uniform(-7.0, 7.0)
-            half = rng.uniform(1.2, 3.0)
-            tilt = rng.uniform(-0.35, 0.35)
-            n = np.array([math.sin(tilt), 0, -math.cos(tilt)])
-            eu = np.array([math.cos(tilt), 0, math.sin(tilt)])
-            ev = np.array([0, 1.0, 0])
-            planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), 0.012 + 0.002 * k))
-        n_tex = len(planes)
+        if self.scene == "street":
+            # the same kind of world, long: far wall beyond the end of the trajectory, ground all along, a facade every 4.5 m on
+            # alternating sides (texel size grows with the distance it is first seen from; textures are shared, at random offsets)
+            L = self.length
+            planes[0] = (np.array([0, 0, L + 45.0]), np.array([0, 0, -1.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), (-120, 120, -60, 60), 0.0022 * (L + 45.0))
+            planes[1] = (np.array([0, 1.7, 0]), np.array([0, -1.0, 0]), np.array([1.0, 0, 0]), np.array([0, 0, 1.0]), (-60, 60, 0.5, L + 60.0), 0.04)
+            n_base = 6
+            k = 0
+            z = 6.0
+            while z < L + 32.0:
+                side = 1.0 if k % 2 == 0 else -1.0
+                half = rng.uniform(1.2, 3.0)
+                xc = side * (half + rng.uniform(0.6, 4.0))         # clear of the camera's path
+                tilt = rng.uniform(-0.35, 0.35)
+                n = np.array([math.sin(tilt), 0, -math.cos(tilt)])
+                eu = np.array([math.cos(tilt), 0, math.sin(tilt)])
+                ev = np.array([0, 1.0, 0])
+                mpt = max(0.012, 0.0011 * z)
+                if k < n_base - 2:
+                    planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), mpt))
+                else:
+                    planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), mpt, 2 + rng.randint(0, n_base - 3), (rng.uniform(0, tex_size), rng.uniform(0, tex_size))))
+                z += rng.uniform(3.5, 5.5)
+                k += 1
+            n_tex = n_base
+        else:
+            # a few nearer facades with small random tilt
+            n_fac = 3 + rng.randint(0, 1)
+            for k in range(n_fac):
+                z = rng.uniform(7.0, 16.0)
+                xc = rng.uniform(-7.0, 7.0)
+                half = rng.uniform(1.2, 3.0)
+                tilt = rng.uniform(-0.35, 0.35)
+                n = np.array([math.sin(tilt), 0, -math.cos(tilt)])
+                eu = np.array([math.cos(tilt), 0, math.sin(tilt)])
+                ev = np.array([0, 1.0, 0])
+                planes.append((np.array([xc, 0, z]), n, eu, ev, (-half, half, -3.5, 1.7), 0.012 + 0.002 * k))
+            n_tex = len(planes)
         if self.scene == "relief":
             # billboards: small, nearly fronto-parallel textured rectangles scattered through the viewing volume (the camera
             # advances ~1 m over a sequence).  They share the base planes' textures at random offsets (entries 6, 7 of the tuple)
@@ -174,8 +206,11 @@ class SyntheticStereoWorld:
         d = self._ray @ R.T                                        # h,w,3 world directions
         best_s = torch.full((self.h, self.w), float("inf"), device=dev)
         img = torch.full((self.h, self.w), 90.0, device=dev)
+        cam_fwd = T[:3, 2]
         for pi, pl in enumerate(self.planes):
             P, n, eu, ev, ext, mpt = pl[:6]
+            if self.scene == "street" and pi >= 2 and float(np.dot(np.asarray(P) - T[:3, 3], cam_fwd)) < -4.0:
+                continue                                           # a facade the camera has passed: behind it, cannot be seen
             tex = self.textures[pl[6] if len(pl) > 6 else pi]
             tu0, tv0 = pl[7] if len(pl) > 7 else (0.0, 0.0)
             Pt = torch.tensor(P, dtype=torch.float32, device=dev)
@@ -199,7 +234,11 @@ class SyntheticStereoWorld:
                  + tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
             img = torch.where(ok, v, img)
             best_s = torch.where(ok, s, best_s)
-        if self.noise_sigma > 0:
+        if self.noise_sigma > 0 and self.noise_on_device and dev.type != "cpu":
+            g = torch.Generator(device=dev)
+            g.manual_seed(gen_seed)
+            img = img + torch.randn((self.h, self.w), generator=g, dtype=torch.float32, device=dev) * self.noise_sigma
+        elif self.noise_sigma > 0:
             g = torch.Generator(device="cpu")
             g.manual_seed(gen_seed)
             noise = torch.randn((self.h, self.w), generator=g, dtype=torch.float32) * self.noise_sigma

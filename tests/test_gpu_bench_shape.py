@@ -67,7 +67,7 @@ def test_benchmark_shape_three_contexts_of_64_lanes_match_oracle(schedule):
             res = Result.from_buffer_copy(rec[g].tobytes())
             dg = PR.digest_of(ctx, l, res)
             lists, flags, et, er = PR.compare(dg, ref[g][i])
-            assert lists, ("lists differ", g, i, dg.n, ref[g][i].n)
+            assert lists, "lists differ: stream %d step %d gpu %s cpu %s" % (g, i, list(dg.n), list(ref[g][i].n))
             assert flags and et < 1e-3 and er < 1e-4, (g, i, et, er)
             if i:
                 assert np.allclose(dg.residual[dg.residual < 1e300], ref[g][i].residual[ref[g][i].residual < 1e300], rtol=1e-6, atol=1e-9)
@@ -271,12 +271,14 @@ def test_every_schedule_of_the_batch_gives_the_same_records():
         batch.close()
 
 
-def test_capacity_bits_of_a_detector_running_ahead_reach_the_right_record():
+def test_capacity_bits_of_a_detector_running_ahead_reach_the_right_record(monkeypatch):
     """SVO_FLAG_DETECT_AHEAD: the detector of frame t + 1 runs while stages 3-5 of frame t are still writing frame t's record, so the
     capacity bits it raises are staged and folded in by its own post call.  A candidate list far too small for the image overflows
-    on every frame: bit 1 must be in every stream's record -- and in the status word -- with and without the look-ahead (which
-    corners an overflowing list keeps is a race, so only the bits are compared)."""
+    on every frame (debug mode 12: no speculative FAST threshold, which would otherwise learn to fit the list after a few frames):
+    bit 1 must be in every stream's record -- and in the status word -- with and without the look-ahead (which corners an
+    overflowing list keeps is a race, so only the bits are compared)."""
     import torch
+    monkeypatch.setenv("SVO_DEBUG_MODE", "12")
     from stereo_vo_amd.pipeline import StreamBatch
     W, H, B, NC, F, STEPS = 640, 480, 4, 2, 3, 4
     dev = torch.device("cuda", 0)
@@ -298,6 +300,7 @@ def test_capacity_bits_of_a_detector_running_ahead_reach_the_right_record():
             assert all(batch.lane(g)[0].status_word(batch.lane(g)[1]) & 1 for g in range(B))
         batch.close()
     # and a list that fits raises nothing
+    monkeypatch.delenv("SVO_DEBUG_MODE")
     batch = StreamBatch(p, cam, W, H, B, NC, max_kps=1024, max_cand=1 << 15)
     for i in range(2):
         batch.step(ptrs_at[i])

@@ -830,6 +830,19 @@ def test_capacity_overflow_is_reported_in_the_result_record(golden_dir):
     except hip.SvoError as e:          # or the geometry is refused outright: also an explicit error, not a silent cut
         assert "capacity" in str(e)
     ctx.close()
+    # a request that FITS when the parameters are loaded and overflows at run time: FAST+ORB without the NMS keeps every corner
+    # (S2:613-614: no cap to check beforehand), far more than 128 slots here -- bit 2 in the record and in the status word
+    from stereo_vo_amd.abi import DM_FAST_ORB
+    q2 = p.copy(); q2.detect_method = DM_FAST_ORB; q2.nOctaves = 1; q2.non_maximal_suppression = 0
+    small = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=128, max_cand=1 << 15)
+    small.set_params(q2); small.set_camera(cam)
+    small.process_host([(g["L0"], g["R0"])])
+    assert small.result(0).status & 2 and small.status_word(0) & 2
+    # a feature count that is not positive is refused outright (it used to wrap through size_t)
+    q3 = p.copy(); q3.orb_nfeats = 0
+    with pytest.raises(hip.SvoError):
+        small.set_params(q3)
+    small.close()
     ok = hip.Context(n_lanes=1, max_w=int(g["W"]), max_h=int(g["H"]), max_kps=1024, max_cand=1 << 15)
     ok.set_params(p); ok.set_camera(cam)
     ok.process_host([(g["L0"], g["R0"])])
@@ -1131,6 +1144,7 @@ def test_hand_over_record_of_another_layout_is_refused(golden_dir):
         c.process_host([(g["L0"], g["R0"])]); c.process_host([(g["L1"], g["R1"])])
     nb = max(a.handover_bytes(), b.handover_bytes())
     blob = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()              # torch fills the buffer on ITS stream: it must be through before the export on the context's
     a.export_frame(blob.data_ptr(), nb); a.wait()
     before = b.keypoints(0, 1, 0)[0].tobytes()                                        # b's previous frame
     b.import_frame(blob.data_ptr(), nb); b.wait()

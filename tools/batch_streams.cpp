@@ -13,7 +13,17 @@
 //   probe streams' result records of every step and their final lists go to PREFIX.bin for a checker (tests/test_gpu_batch_host.py
 //   compares them with the CPU oracle).
 #include "../include/svo_batch.h"
+#ifdef SVO_WITH_RCCL
 #include "../include/svo_rccl.h"
+#else
+// built on a host without RCCL (stereo_vo_amd/csrc/Makefile): the one-GPU batched schedule is all there is; --gather rccl is refused
+struct svo_group;
+static int svo_group_create_local(const int*, int, svo_group** out) { if (out) *out = nullptr; return SVO_ERR_UNSUPPORTED; }
+static const char* svo_group_last_error(const svo_group*) { return "this binary was built without RCCL"; }
+static int svo_group_comm_count(const svo_group*, int) { return 0; }
+static void svo_group_destroy(svo_group*) {}
+static int svo_group_allgather_inplace(svo_group*, int, void*, size_t, void*) { return SVO_ERR_UNSUPPORTED; }
+#endif
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

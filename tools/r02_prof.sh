@@ -16,7 +16,8 @@ run_stats() {  # name, command...
 run_stats 3ctx python $R/bench.py $B
 run_stats 1ctx python $R/bench.py $B --contexts 1 --lanes 64
 run_stats single_stream python $R/tools/single_stream_bench.py
-python $R/tools/pmc_traffic.py --contexts 1 --lanes 64 --host-fed-steps 0 --single-stream 0 > $O/r02_pmc_traffic.log 2>&1
+# (round 2 ran tools/pmc_traffic.py here; that script was folded into tools/pmc_passes.py in round 3)
+python $R/tools/pmc_passes.py r02 > $O/r02_pmc_traffic.log 2>&1
 for i in 1 2; do
   if [ $i = 1 ]; then set="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; else set="SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; fi
   rm -rf /tmp/pv$i
