@@ -192,6 +192,7 @@ def main():
     cam = worlds[0].camera()
     torch.cuda.synchronize()
     t_render = time.perf_counter() - t_render
+    t_render_end = time.perf_counter()
 
     def frame_of(lane, step):
         j, t = lane_frame(lane, step, T, F)
@@ -335,10 +336,17 @@ def main():
         P = sum(a * b for a, b in lv) / float(W * H)
         pair_bytes = 2 * (3 * P - 1) * W * H + 2 * mean_kps * 60 + 16 * mean_match + 40 * mean_track * 12
         cpu_baseline, pose_rmse, parity_probe, host_fed = None, None, None, None
+        legs_s = {"render": round(t_render, 1), "warmup_and_timed": round(time.perf_counter() - t_render_end, 1)}     # wall clock of every leg of this run
+        t_leg = time.perf_counter()
+        def leg_done(name):
+            nonlocal t_leg
+            legs_s[name] = round(time.perf_counter() - t_leg, 1); t_leg = time.perf_counter()
         if world == 1 and args.cpu_frames > 0:
             cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec)
+            leg_done("cpu_baseline_and_parity_probe")
         if world == 1 and args.host_fed_steps > 0:
             host_fed = host_fed_leg(args, batch, frame_of, dev)
+            leg_done("host_fed")
         other_scene = None
         if world == 1 and args.relief_lanes > 0 and args.workload == "config2":
             batch.synchronize()
@@ -346,6 +354,7 @@ def main():
                 other_scene = other_scene_leg(args, p, dev, local_rank, focal, baseline)
             except Exception as e:
                 other_scene = {"error": str(e)}
+            leg_done("other_scene")
         scene_cuts = None
         if world == 1 and args.cut_steps > 0:
             batch.synchronize()
@@ -353,10 +362,12 @@ def main():
                 scene_cuts = scene_cut_leg(args, batch, frames, T, F, n_octaves if detect_fast_orb else 8)
             except Exception as e:
                 scene_cuts = {"error": str(e)}
+            leg_done("scene_cuts")
         other_workloads = None
         if world == 1 and args.other_workloads and args.workload == "config2":
             batch.synchronize()
             other_workloads = other_workloads_leg(args)
+            leg_done("other_workloads")
         single_stream = None
         if world == 1 and args.single_stream and args.workload == "config2":
             batch.synchronize()
@@ -366,6 +377,7 @@ def main():
                 single_stream = SSB.measure(W, H, args.orb_nfeats, n=120, device=local_rank)
             except Exception as e:
                 single_stream = {"error": str(e)}
+            leg_done("single_stream")
         # the roofline kernel once more with the GPU to itself (one context, nothing on the overlap stream): in the pipelined
         # schedule its spans are time-shared with the stage 3-5 kernels of the other contexts
         try:
@@ -418,6 +430,7 @@ def main():
             "other_scene": other_scene,
             "dist": dist_info,
             "kernels_ms_per_context_step": {k: round(v["ms_per_step"], 4) for k, v in per_kernel_warm.items()},
+            "legs_s": legs_s,
             "kernels_ms_note": "all kernels: HIP-event spans of the %d warm-up steps; roofline kernel: spans of the timed region" % args.warmup,
         }
         print(json.dumps(line))

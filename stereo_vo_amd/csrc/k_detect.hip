@@ -288,35 +288,38 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
 
 // ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
-// Two things bound this kernel: integer VALU issue (the dense test of step 1 is its throughput floor, ~0.1 ms at 64 lanes) and
-// how many tiles a CU keeps in flight -- a tile lives a few microseconds of dependent loads, barriers and LDS round trips, and
-// the launch time falls as 1 / tiles-in-flight (fast_tile below: two waves per tile, 9 KB of LDS, geometry from a table).
-// So the design minimises instructions AND a tile's footprint in wave slots and LDS:
-// Tile = 64x56 interior pixels (FT_W x FT_H).  The 80x64 source window (3 px circle radius + 1 px NMS halo, start aligned to
-// 8 bytes) is staged in LDS with 8-byte loads (360 of them over 128 threads).  A three-step cascade keeps the expensive work dense:
-//   (1) every position of the 68x58 score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
+// Integer VALU issue bounds this kernel (97-99 % of the issue slots, profiles/r03*_pmc.json), so the design minimises
+// instructions per position first and a tile's footprint in wave slots and LDS second (fast_tile below: two waves per tile,
+// 12 KB of LDS, geometry from a table).
+// Tile = 62x62 interior pixels (FT_W x FT_H); with the 1-pixel NMS halo the score window is 64x64, one byte per position,
+// entry = r * 64 + q.  The 80x70 source window (3 px circle radius around the score window, x origin x0 - 5 so that groups of
+// four positions sit on LDS dword boundaries) is staged by LDS-DMA.  A three-step cascade keeps the expensive work dense:
+//   (1) every position of the score window takes the 4-pixel cardinal test -- a 9-arc on the 16-circle always
 //       contains two ADJACENT compass points, so a corner needs two adjacent compass pixels both brighter than
 //       c+t or both darker than c-t.  It runs on FOUR positions per lane-op: the centre row / N / S come in as
 //       aligned LDS dwords, E / W by v_alignbyte, and the comparisons are saturating packed-16-bit subtractions
-//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  58 rows x 17 groups = 2 x 493 tasks in pairs 29 rows apart
-//       (the index arithmetic is shared), two pairs per thread.  Survivors are compacted into an LDS list by one scan;
+//       ("nonzero" = true, AND = pk_min, OR = bitwise or).  A thread owns one group column and EIGHT CONSECUTIVE ROWS
+//       (16 group columns x 8 row blocks = 128 threads): the centre dword of a row is the N operand of the row three below
+//       and the S operand of the row three above, so 14 centre loads (and their 14 shifted copies) serve 8 rows, and the
+//       whole index arithmetic of the phase is one base address.  Survivors are compacted into an LDS list by one scan;
 //   (2) only the listed positions compute the arc-min score (both polarities through one packed min network);
 //   (3) the 3x3 NMS also walks the list; survivors are appended to the level's candidate list with one global
 //       atomic per tile, issued by a single wave.
-// The score window is 68 columns wide (x0-3 .. x0+64) so that groups of four positions sit on dword boundaries.
+// (Rounds 2-3 ran 64x56 tiles with 17 groups x 58 rows dealt to the threads as 493 row pairs: ~70 instructions of index
+// arithmetic, bounds checks and address set-up per thread went with that, and 14 per listed survivor.)
 // No position is bounds-checked before step (3): the staged window only ever holds readable memory, and a position
 // outside [EDGE-1, dim-EDGE] is never a neighbour of an interior position, so whatever score it gets is never read.
 // ------------------------------------------------------------------------------------------------------------
 #define FT_W SVO_FT_W
 #define FT_H SVO_FT_H
-#define FT_LW 80              // LDS window pitch; window x origin = x0 - 7 (x0 = 31 + 64*bx, so x0 - 7 is a multiple of 8)
-#define FT_LH (FT_H + 8)      // window y origin = y0 - 4
-#define FT_SW 68              // score window: x = x0 - 3 + q, q in [0, 68); interior q in [3, 67)
-#define FT_SH (FT_H + 2)      // y = y0 - 1 + r, r in [0, 30); interior r in [1, 29)
-#define FT_SP 72              // score map pitch
-#define FT_NG (FT_SW / 4)     // 17 groups of four positions per row
+#define FT_LW 80              // LDS window pitch; window x origin = x0 - 5: position q sits at byte q + 4
+#define FT_LH (FT_H + 8)      // window y origin = y0 - 4: position row r sits at window row r + 3
+#define FT_SW 64              // score window: x = x0 - 1 + q, q in [0, 64); interior q in [1, 63)
+#define FT_SH 64              // y = y0 - 1 + r, r in [0, 64); interior r in [1, 63)
+#define FT_SP 64              // score map pitch: entry = r * FT_SP + q
+#define FT_NG (FT_SW / 4)     // 16 groups of four positions per row
 #define FT_CHUNK 32            // consecutive tiles per XCD turn
-static_assert(FT_NG == 17 && FT_W == 64, "k_fast's thread mapping is written for 64-pixel-wide tiles (17 groups of four positions per row)");
+static_assert(FT_W + 2 == FT_SW && FT_H + 2 == FT_SH && FT_NG == 16, "k_fast's thread mapping is written for a 64x64 score window (16 group columns x 8 blocks of 8 rows)");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
@@ -377,30 +380,27 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* win, int off, int t
 }
 
 #define FT_NT 128
-#define FT_HALF (FT_SH / 2)                          // the two rows of a pair-task are FT_HALF apart
-#define FT_TASKS (FT_HALF * FT_NG)                   // pair-tasks (r0, gq) + (r0 + FT_HALF, gq)
-#define FT_TURNS ((FT_TASKS + FT_NT - 1) / FT_NT)    // per thread
+#define FT_ROWS 8                                    // consecutive score rows per thread
 #define FT_LIST_CAP 1024                             // LDS list of the cardinal test's survivors (~80 per tile on a textured scene)
 #define FT_CHUNKS (FT_LH * 5)                        // 16-byte DMA chunks of the window
-static_assert(FT_SH % 2 == 0 && FT_TURNS * 2 * 4 <= 32, "a thread's verdicts must fit one 32-bit mask");
-static_assert(FT_TASKS * 3856 < (1 << 28) && FT_TURNS * FT_NT < 4100, "pt / 17 by multiplication");
+static_assert(FT_NG * (FT_SH / FT_ROWS) == FT_NT && FT_ROWS * 4 <= 32, "one thread per (group column, block of rows); a thread's verdicts must fit one 32-bit mask");
+static_assert(FT_SH * FT_SP <= 65536, "list entries are 16 bits");
 
 struct FastSmem {
     __attribute__((aligned(16))) uint8_t tile[FT_LH * FT_LW];
-    __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 16];
+    __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 80];      // + a row: the 3x3 reads around a position of the last (halo) row
     unsigned short list[FT_LIST_CAP];
     unsigned s_count, s_nout;
 };
 // the NMS survivors' keys (3x3 NMS leaves at most one per 2x2 block) go where the window was: it is dead once the scores exist
 static_assert((FT_W * FT_H / 4 + 64) * 4 <= FT_LH * FT_LW, "out_keys aliases the window");
 
-// one 64x56 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
+// one 62x62 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
 // (src, pitch, gw, gh: the level's image; x0, y0: the tile's interior origin -- the caller has them from the tile table)
 // FT_NT = 128 threads per tile, two waves: the kernel is bound by VALU issue (SQ_INSTS_VALU x 4 cycles = 97 % of its duration,
 // profiles/r03_pmc.json), and what does not scale with the pixels -- staging, the fixed part of the compaction, the
-// publication -- is paid per tile: 56 rows instead of 28 halve it (and the halo rows: 64 / 56 window rows per interior row
-// instead of 36 / 28).  The list of the cardinal test's survivors is capped (LDS per tile decides how many tiles a CU holds);
-// what does not fit stays with the thread that found it and is scored / suppressed by its owner after the listed ones.
+// publication -- is paid per tile.  The list of the cardinal test's survivors is capped (LDS per tile decides how many tiles a
+// CU holds); what does not fit stays with the thread that found it and is scored / suppressed by its owner after the listed ones.
 __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
 {
     uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = (uint32_t*)sm.tile;
@@ -412,7 +412,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     constexpr int N16 = (FT_SH * FT_SP + 15) / 16;
 #pragma unroll
     for (int i = 0; i < (N16 + FT_NT - 1) / FT_NT; i++) if (i * FT_NT + tid < N16) ((uint4*)score)[i * FT_NT + tid] = make_uint4(0, 0, 0, 0);
-    // ---- stage the window [x0-7, x0+73) x [y0-4, y0+FT_H+4) with the LDS-DMA path (global_load_lds_dwordx4): a wave-instruction
+    // ---- stage the window [x0-5, x0+75) x [y0-4, y0+FT_H+4) with the LDS-DMA path (global_load_lds_dwordx4): a wave-instruction
     //      lands 64 x 16 bytes at LDS base + lane * 16 straight from the lanes' global addresses, no VGPR round trip and no
     //      ds_write.  The window is FT_LH rows x 5 chunks of 16 bytes, chunk i at LDS byte 16 i (pitch 80): wave w takes chunks
     //      128 j + 64 w + lane.  The source may sit at ANY byte alignment and the destination base at any dword
@@ -424,7 +424,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
         const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         auto chunk_src = [&](int i) -> const uint8_t* {
             const int r = (i * 205) >> 10, q = i - 5 * r;                   // i / 5, i % 5 for i < 1024
-            const int yy = min(y0 - 4 + r, gh - 1), xx = min(x0 - 7 + 16 * q, gw - 16);
+            const int yy = min(y0 - 4 + r, gh - 1), xx = min(x0 - 5 + 16 * q, gw - 16);
             return src + (uint32_t)(yy * pitch + xx);                       // 32-bit offset from the level's uniform base
         };
         typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -438,52 +438,54 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's DMA chunks have landed; the barrier covers the other wave's
     __syncthreads();
     if (c.debug_mode == 1) return;
-    // ---- (1) packed cardinal test: FT_SH rows x 17 groups of four positions; thread -> (r0, gq) and (r0 + FT_HALF, gq) ----
-    const uint32_t* T32 = (const uint32_t*)tile;
+    // ---- (1) packed cardinal test: thread -> group column gq (positions q = 4 gq .. 4 gq + 3), score rows 8 rb .. 8 rb + 7 ----
     const uint32_t th = (uint32_t)th_fast;
     const u16x2 t2h = { (unsigned short)(th << 8), (unsigned short)(th << 8) };
-    uint32_t pe[2 * FT_TURNS], po[2 * FT_TURNS];                        // nonzero halves = passing positions
+    const int gq = tid & (FT_NG - 1), rb = tid >> 4;
+    const int e_base = rb * (FT_ROWS * FT_SP) + 4 * gq;                     // entry of (row 8 rb, position 4 gq)
+    uint32_t pe[FT_ROWS], po[FT_ROWS];                                      // nonzero halves = passing positions
+    {
+        // window row of score row r: r + 3; its N / S operands: window rows r, r + 6.  col[20 i + 1] = centre dword of window
+        // row 8 rb + i (bytes 4 gq + 4 ..: the group's four positions), col[20 i] / col[20 i + 2] = the dwords left / right of it
+        const uint32_t* col = (const uint32_t*)tile + rb * (FT_ROWS * (FT_LW / 4)) + gq;
+        uint32_t cc[FT_ROWS + 6];
 #pragma unroll
-    for (int u = 0; u < FT_TURNS; u++) {
-        const int pt = tid + u * FT_NT, r0 = (pt * 3856) >> 16, gq = pt - r0 * FT_NG;       // pt / 17, pt % 17
-        pe[2 * u] = pe[2 * u + 1] = po[2 * u] = po[2 * u + 1] = 0;
-        if (pt < FT_TASKS) {
+        for (int i = 0; i < FT_ROWS + 6; i++) cc[i] = col[i * (FT_LW / 4) + 1];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint32_t* row = T32 + (r0 + FT_HALF * k + 3) * (FT_LW / 4) + gq;     // row[1] = centres (tile col 4*gq + 4)
-                const uint32_t Cp = row[0], C = row[1], Cn = row[2], N = row[1 - 3 * (FT_LW / 4)], S = row[1 + 3 * (FT_LW / 4)];
-                // The test compares 16-bit halves whose HIGH byte is the pixel of interest; the low byte is whatever sits next to it
-                // and only matters when the high bytes tie at exactly the threshold, where it can let a position through that the
-                // exact score then zeroes again (a false alarm, never a miss: 16-bit max / min order by the high byte first).  So no
-                // masking: positions 1, 3 are the high bytes of the registers as loaded, positions 0, 2 those of the same registers
-                // one byte further left -- E / W come out of the funnel shifter in that alignment directly (W is simply Cp).
-                const uint32_t Eo = __builtin_amdgcn_alignbyte(Cn, C, 3), Wo = __builtin_amdgcn_alignbyte(C, Cp, 1);
-                const uint32_t Ee = __builtin_amdgcn_alignbyte(Cn, C, 2);
-                pe[2 * u + k] = quick_half(C << 8, N << 8, Ee, S << 8, Cp, t2h);              // positions 0 (low half), 2 (high half)
-                po[2 * u + k] = quick_half(C, N, Eo, S, Wo, t2h);                             // positions 1, 3
-            }
+        for (int g = 0; g < FT_ROWS; g++) {
+            const uint32_t Cp = col[(g + 3) * (FT_LW / 4)], C = cc[g + 3], Cn = col[(g + 3) * (FT_LW / 4) + 2], N = cc[g], S = cc[g + 6];
+            // The test compares 16-bit halves whose HIGH byte is the pixel of interest; the low byte is whatever sits next to it
+            // and only matters when the high bytes tie at exactly the threshold, where it can let a position through that the
+            // exact score then zeroes again (a false alarm, never a miss: 16-bit max / min order by the high byte first).  So no
+            // masking: positions 1, 3 are the high bytes of the registers as loaded, positions 0, 2 those of the same registers
+            // one byte further left -- E / W come out of the funnel shifter in that alignment directly (W is simply Cp).
+            const uint32_t Eo = __builtin_amdgcn_alignbyte(Cn, C, 3), Wo = __builtin_amdgcn_alignbyte(C, Cp, 1);
+            const uint32_t Ee = __builtin_amdgcn_alignbyte(Cn, C, 2);
+            pe[g] = quick_half(C << 8, N << 8, Ee, S << 8, Cp, t2h);         // positions 0 (low half), 2 (high half)
+            po[g] = quick_half(C, N, Eo, S, Wo, t2h);                        // positions 1, 3
         }
     }
-    // compaction: the thread's verdicts become one bit mask (bit 8 p + g: position p of group g = 2 u + k), a DPP scan of
+    // compaction: the thread's verdicts become one bit mask (bit 8 p + g: position p of row g), a DPP scan of
     // the popcounts gives every lane its first list slot, ONE LDS atomic per wave reserves the wave's range, and each lane
     // writes its own survivors.  (Ballots with their mbcnt pairs and conditional stores cost ~100 VALU instructions
-    // per wave whether the tile held one candidate or fifty; this costs ~35 plus ~14 per survivor of the busiest lane, and
-    // at the speculated thresholds 2 % of the positions survive.)  List order is irrelevant.  Entry = r << 8 | q.
+    // per wave whether the tile held one candidate or fifty; this costs ~35 plus ~7 per survivor of the busiest lane, and
+    // at the speculated thresholds 2 % of the positions survive.)  List order is irrelevant.  Entry = r * 64 + q.
     // Survivors beyond FT_LIST_CAP stay in m_left: their owner scores and suppresses them after the listed ones.
-    auto entry_of = [&](int b) -> int {
-        // (recomputed from the task index: a select among the turns' precomputed entries becomes an indexed scratch load)
-        const int g = b & 7, pt = tid + (g >> 1) * FT_NT, r0 = (pt * 3856) >> 16, gq = pt - r0 * FT_NG;
-        return ((r0 + (g & 1) * FT_HALF) << 8) + 4 * gq + (b >> 3);
-    };
+    auto entry_of = [&](int b) -> int { return e_base + ((b & 7) << 6) + (b >> 3); };
     uint32_t m_left = 0;
     {
-        const u16x2 one2 = { 1, 1 };
-        uint32_t m = 0;
+        // "half nonzero" -> 0 / 1 by ONE v_pk_min_u16 per register, written as asm: left to itself hipcc turns min(x, 1) on
+        // packed halves into two 16-bit compares, two selects and a v_perm (80 instructions per thread instead of 16)
+        const uint32_t one2 = 0x00010001u;
+        uint32_t me = 0, mo = 0;
 #pragma unroll
-        for (int g = 0; g < 2 * FT_TURNS; g++) {
-            const uint32_t fe = as_u32(__builtin_elementwise_min(as_u16x2(pe[g]), one2)), fo = as_u32(__builtin_elementwise_min(as_u16x2(po[g]), one2));
-            m |= (fe | (fo << 8)) << g;                                    // positions 0, 2 from pe's halves; 1, 3 from po's
+        for (int g = 0; g < FT_ROWS; g++) {
+            uint32_t fe, fo;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fe) : "v"(pe[g]), "s"(one2));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(fo) : "v"(po[g]), "s"(one2));
+            me |= fe << g; mo |= fo << g;                                  // positions 0, 2 from pe's halves; 1, 3 from po's
         }
+        uint32_t m = me | (mo << 8);
         const int cnt = __popc(m), inc = wave_inclusive_scan(cnt);
         const int total = __builtin_amdgcn_readlane(inc, 63);
         if (total) {
@@ -502,14 +504,15 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     const bool overflow = ns_all > FT_LIST_CAP;                              // block-uniform
     if (c.debug_mode == 2) return;
     // ---- (2) score on the survivors only ----
+    auto win_off = [&](int e) -> int { return (e >> 6) * FT_LW + (e & 63) + (3 * FT_LW + 4); };
     for (int i = tid; i < ns; i += FT_NT) {
-        const int e = list[i], r = e >> 8, q = e & 0xFF;
-        score[r * FT_SP + q] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
+        const int e = list[i];
+        score[e] = (uint8_t)fast_score_lds(tile, win_off(e), th_fast);
     }
     if (__builtin_expect(overflow, 0)) {
         for (uint32_t m = m_left; m; m &= m - 1) {
-            const int e = entry_of(__builtin_ctz(m)), r = e >> 8, q = e & 0xFF;
-            score[r * FT_SP + q] = (uint8_t)fast_score_lds(tile, (r + 3) * FT_LW + (q + 4), th_fast);
+            const int e = entry_of(__builtin_ctz(m));
+            score[e] = (uint8_t)fast_score_lds(tile, win_off(e), th_fast);
         }
     }
     __syncthreads();
@@ -518,16 +521,16 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     auto nms_round = [&](bool has, int e) {
         bool keep = false; uint32_t key = 0;
         if (has) {
-            const int r = e >> 8, q = e & 0xFF, pos = r * FT_SP + q;
+            const int r = e >> 6, q = e & 63;
             // nine byte reads at immediate offsets, issued together; the middle column goes through an opaque copy of
             // the base so that no two fuse into a misaligned ds_read_u16.  (r = 0 reads below the map: rejected below.)
-            const int nb = pos - FT_SP - 1; int nbm = nb; asm volatile("" : "+v"(nbm));
+            const int nb = e - FT_SP - 1; int nbm = nb; asm volatile("" : "+v"(nbm));
             const int v = score[nbm + FT_SP + 1];
             const int n0 = score[nb], n1 = score[nbm + 1], n2 = score[nb + 2], n3 = score[nb + FT_SP], n4 = score[nb + FT_SP + 2];
             const int n5 = score[nb + 2 * FT_SP], n6 = score[nbm + 2 * FT_SP + 1], n7 = score[nb + 2 * FT_SP + 2];
             const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-            const int x = x0 - 3 + q, y = y0 - 1 + r;
-            keep = (v > mx) & (r >= 1) & (r <= FT_H) & (q >= 3) & (q < 3 + FT_W) & (x < gw - SVO_EDGE) & (y < gh - SVO_EDGE);
+            const int x = x0 - 1 + q, y = y0 - 1 + r;
+            keep = (v > mx) & (r >= 1) & (r <= FT_H) & (q >= 1) & (q <= FT_W) & (x < gw - SVO_EDGE) & (y < gh - SVO_EDGE);
             key = ((uint32_t)v << 24) | (0xFFFFFFu - (uint32_t)(y * gw + x));
         }
         const unsigned long long m = __ballot(keep);

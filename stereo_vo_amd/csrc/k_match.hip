@@ -68,7 +68,7 @@ __device__ __forceinline__ hm_v4i hm_expand16(uint32_t bits, uint32_t base)
 
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
 {
-    __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][16 * 32];          // [buffer][(k-step * 2 + half) * 32 + row]
+    __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][16 * 32];          // [buffer][k-step * 64 + ((half * 32 + row) ^ k-step)]
     // grid = (lane-octave, query block, side x split): the query blocks past nq exit at once, and with the lane index
     // fastest they sit at the END of the dispatch order.  (With the query block fastest, live and dead workgroups
     // alternate, the dispatcher hands them to the two halves of each XCD in turn, and half the CUs idle: measured 2x.)
@@ -110,8 +110,12 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
     const uint32_t* tw = (const uint32_t*)td;
     auto fetch = [&](int j0) -> uint32_t { return tw[(long long)min(j0 + sr, nt - 1) * 8 + sg]; };
     auto stage = [&](int buf, uint32_t bits) {
-        tileA[buf][(2 * sg) * 32 + sr] = hm_expand16(bits, 0xC0C0C0C0u);
-        tileA[buf][(2 * sg + 1) * 32 + sr] = hm_expand16(bits >> 16, 0xC0C0C0C0u);
+        // slot of (k-step sg, half h, row r) = sg * 64 + ((h * 32 + r) ^ sg): a ds_write_b128 is served in groups of 8 contiguous
+        // lanes over 32 banks, and those 8 lanes hold the 8 k-steps of ONE row -- unswizzled they are 1 KB apart, i.e. on the
+        // same four banks (8-way: 70 % of the kernel's LDS cycles were conflicts, profiles/r03e_pmc.json).  The wave's reads
+        // stay a permutation of one contiguous KB per k-step.
+        tileA[buf][sg * 64 + (sr ^ sg)] = hm_expand16(bits, 0xC0C0C0C0u);
+        tileA[buf][sg * 64 + ((32 + sr) ^ sg)] = hm_expand16(bits >> 16, 0xC0C0C0C0u);
     };
     // C operand = train index of each accumulator row (advances by 32 per tile); running minima, 8 per set (v_min3 pairs)
     int tc[16], best[2][8];
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
         hm_v16i acc0 = cin, acc1 = cin;
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) {
-            const hm_v4i a = tileA[buf][(s8 * 2 + half) * 32 + col];
+            const hm_v4i a = tileA[buf][s8 * 64 + (lane ^ s8)];
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[0][s8], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[1][s8], acc1, 0, 0, 0);
         }

@@ -23,8 +23,8 @@
 #define SVO_RANSAC_CHUNK0 32        // samples [0, CHUNK0) are evaluated unconditionally, [CHUNK0, CHUNK1) and [CHUNK1, HYP) only as far as
 #define SVO_RANSAC_CHUNK1 160       // the 0.99-confidence stop of the sequential algorithm can still reach (rs_bound)
 #define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) ranked by their Harris response
-#define SVO_FT_W 64          // k_fast tile (interior pixels)
-#define SVO_FT_H 56
+#define SVO_FT_W 62          // k_fast tile (interior pixels; 64x64 score window with the NMS halo)
+#define SVO_FT_H 62
 #define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each
 #define SVO_RANSAC_SEED 0x5EEDF00DCAFE1234ULL
 

@@ -201,6 +201,8 @@ class SyntheticStereoWorld:
 
     def _render_eye(self, T, gen_seed):
         dev = self.device
+        if not hasattr(self, "_plane_dev"):
+            self._plane_dev = {}
         R = torch.tensor(T[:3, :3], dtype=torch.float32, device=dev)
         o = torch.tensor(T[:3, 3], dtype=torch.float32, device=dev)
         d = self._ray @ R.T                                        # h,w,3 world directions
@@ -213,10 +215,11 @@ class SyntheticStereoWorld:
                 continue                                           # a facade the camera has passed: behind it, cannot be seen
             tex = self.textures[pl[6] if len(pl) > 6 else pi]
             tu0, tv0 = pl[7] if len(pl) > 7 else (0.0, 0.0)
-            Pt = torch.tensor(P, dtype=torch.float32, device=dev)
-            nt = torch.tensor(n, dtype=torch.float32, device=dev)
-            eut = torch.tensor(eu, dtype=torch.float32, device=dev)
-            evt = torch.tensor(ev, dtype=torch.float32, device=dev)
+            # the planes' vectors live on the device once (four blocking host-to-device copies per plane and eye otherwise:
+            # most of the render time of a long sequence)
+            if pi not in self._plane_dev:
+                self._plane_dev[pi] = tuple(torch.tensor(v, dtype=torch.float32, device=dev) for v in (P, n, eu, ev))
+            Pt, nt, eut, evt = self._plane_dev[pi]
             denom = d @ nt
             s = torch.dot(nt, Pt - o) / denom
             X = o + s.unsqueeze(-1) * d - Pt

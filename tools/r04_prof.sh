@@ -4,6 +4,7 @@
 #     3ctx          the benchmarked shape, 3 x 64 lanes pipelined      + the bench line of that same profiled run
 #     1ctx          one context of 64 lanes alone
 #     single_stream one stream alone
+#   (--frames: just enough for no stream to see a frame twice in these short runs; the default renders >= 200 per trajectory)
 #   PMC passes (tools/pmc_passes.py): traffic by request size, VALU / LDS counters, valu_issue_frac per kernel
 # usage: bash tools/r04_prof.sh [tag]
 cd /tmp && export TMPDIR=/tmp
@@ -22,9 +23,9 @@ run_stats() {  # name, skip, total, command...
     f=$(find /tmp/ps_$name -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && python $R/tools/summarize_prof.py $f $O/${tag}_kernel_stats_${name}_whole_run.csv > /dev/null
 }
-run_stats 3ctx $W $((W+K)) python $R/bench.py $B --relief-lanes 0
+run_stats 3ctx $W $((W+K)) python $R/bench.py $B --relief-lanes 0 --frames 176
 grep '^{' $O/${tag}_prof_3ctx.log | tail -1 > $O/${tag}_bench_profiled_3ctx.json
-run_stats 1ctx $W $((W+K)) python $R/bench.py $B --contexts 1 --lanes 64 --relief-lanes 0
+run_stats 1ctx $W $((W+K)) python $R/bench.py $B --contexts 1 --lanes 64 --relief-lanes 0 --frames 64
 grep '^{' $O/${tag}_prof_1ctx.log | tail -1 > $O/${tag}_bench_profiled_1ctx.json
 run_stats single_stream 1 20 python $R/tools/single_stream_bench.py --only-plain
 timeout 900 python $R/tools/pmc_passes.py $tag > $O/${tag}_pmc.log 2>&1
