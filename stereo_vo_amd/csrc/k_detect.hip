@@ -12,7 +12,8 @@
 
 // device copies of the constant tables
 __constant__ int c_umax[16];
-// cv::ORB's 256 test pairs (bit_pattern_31_) as floats, (x0, y0, x1, y1) per pair: k_describe rotates them by the keypoint's angle
+// cv::ORB's 256 test pairs (bit_pattern_31_) as floats, (x0, x1, y0, y1) per pair -- the operand pairs of packed f32 operations:
+// k_describe rotates them by the keypoint's angle
 __device__ __attribute__((aligned(16))) float4 g_brief_patf[SVO_BRIEF_NPAIRS];
 // The 7 x 7 Gaussian of k_describe as two banded matrices in matrix-core operand layout (v_mfma_i32_16x16x64_i8: lane l carries
 // the 16 bytes of k-group l / 16 for row / column l % 16; byte b of a group in A meets byte b of the same group in B):
@@ -36,7 +37,7 @@ hipError_t svo_upload_tables()
     if (e != hipSuccess) return e;
     {
         static float4 pf[SVO_BRIEF_NPAIRS];
-        for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) pf[i] = make_float4((float)svo_brief_pat[i][0], (float)svo_brief_pat[i][1], (float)svo_brief_pat[i][2], (float)svo_brief_pat[i][3]);
+        for (int i = 0; i < SVO_BRIEF_NPAIRS; i++) pf[i] = make_float4((float)svo_brief_pat[i][0], (float)svo_brief_pat[i][2], (float)svo_brief_pat[i][1], (float)svo_brief_pat[i][3]);
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_brief_patf), pf, sizeof(pf));
         if (e != hipSuccess) return e;
     }
@@ -1154,12 +1155,16 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     const float MX = 12582912.0f + (float)(DP_REACH + (int)((uint8_t*)R32 - (uint8_t*)&raw32[0][0])), MY = 12582912.0f + (float)DP_REACH;
     const uint8_t* lds0 = (const uint8_t*)&raw32[0][0];
     unsigned long long bits[4];
+    // the two points of a pair ride in the halves of packed single-precision operations (v_pk_mul_f32 / v_pk_add_f32: each half
+    // is one IEEE operation, as the scalar form): pat = (x0, x1, y0, y1)
+    typedef float dp_f2 __attribute__((ext_vector_type(2)));
+    const dp_f2 cs2 = { cs, cs }, sn2 = { sn, sn }, MX2 = { MX, MX }, MY2 = { MY, MY };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float x0 = pat[k].x * cs - pat[k].y * sn, y0 = pat[k].x * sn + pat[k].y * cs;
-        const float x1 = pat[k].z * cs - pat[k].w * sn, y1 = pat[k].z * sn + pat[k].w * cs;
-        const uint32_t o0 = (__umul24(__float_as_uint(y0 + MY), 4 * DP_PW) + __float_as_uint(x0 + MX)) & 0xFFFFu;
-        const uint32_t o1 = (__umul24(__float_as_uint(y1 + MY), 4 * DP_PW) + __float_as_uint(x1 + MX)) & 0xFFFFu;
+        const dp_f2 px = { pat[k].x, pat[k].y }, py = { pat[k].z, pat[k].w };
+        const dp_f2 xs = (px * cs2 - py * sn2) + MX2, ys = (px * sn2 + py * cs2) + MY2;
+        const uint32_t o0 = (__umul24(__float_as_uint(ys.x), 4 * DP_PW) + __float_as_uint(xs.x)) & 0xFFFFu;
+        const uint32_t o1 = (__umul24(__float_as_uint(ys.y), 4 * DP_PW) + __float_as_uint(xs.y)) & 0xFFFFu;
         const int a = lds0[o0], b = lds0[o1];
         bits[k] = __ballot(a < b);
     }
