@@ -382,7 +382,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* win, int off, int t
 
 #define FT_NT 128
 #define FT_ROWS 8                                    // consecutive score rows per thread
-#define FT_LIST_CAP 1024                             // LDS list of the cardinal test's survivors (~80 per tile on a textured scene)
+#define FT_LIST_CAP 512                              // LDS list of the cardinal test's survivors (~80 per tile on a textured scene); 10.8 KB per tile = 15 tiles per CU
 #define FT_CHUNKS (FT_LH * 5)                        // 16-byte DMA chunks of the window
 static_assert(FT_NG * (FT_SH / FT_ROWS) == FT_NT && FT_ROWS * 4 <= 32, "one thread per (group column, block of rows); a thread's verdicts must fit one 32-bit mask");
 static_assert(FT_SH * FT_SP <= 65536, "list entries are 16 bits");
@@ -576,7 +576,7 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     }
 }
 
-__global__ void __launch_bounds__(FT_NT) k_fast(DevCtx c)
+__global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fast(DevCtx c)
 {
     __shared__ FastSmem sm;
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The global work list
@@ -1021,9 +1021,17 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
     return __builtin_amdgcn_udot4(a, b, acc, false);
 }
 
-__global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int pre)
+// NW waves (keypoints) per block.  The orientation's arctangent, sine and cosine are ~70 wave-instructions on a wave-uniform
+// value: the waves of a block leave their two moments in LDS, lanes 0 .. NW-1 of the first wave evaluate all NW keypoints in one
+// pass (block barrier 1), and the others pick their (angle, sin, cos) up after the blur (block barrier 2) -- which does not
+// depend on the angle, so only the first wave's extra pass is exposed.  A wave past the end of the list keeps walking to the
+// barriers (no early exit inside a barrier region).
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, int pre)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t raw32[4][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[NW][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
+    __shared__ int s_mom[NW][2];
+    __shared__ float s_ang[NW][4];
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1034,30 +1042,34 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     int img, bx;
     if (c.debug_mode == 8) { img = blockIdx.x / gx_div.d; bx = blockIdx.x - img * gx_div.d; }
     else { const uint32_t r = blockIdx.x >> 3, grp = fastdiv(r, gx_div); bx = (int)(r - grp * gx_div.d); img = (int)(grp * 8 + (blockIdx.x & 7)); }
-    if (img >= c.n_img) return;
+    if (img >= c.n_img) return;                                                              // block-uniform
     // pre != 0: the NMS ran first (k_nms_rowsort, pre mode); work item = final keypoint fi of the image's current list,
     // final_slot names the detector slot it came from, and only the angle and the descriptor are left to fill in
     // A wave lives ~5 us and a CU holds 32 of them, so dependent loads before the window is in flight cost throughput (see
     // k_fast).  The work item of the describe-after-NMS path comes from ONE list the NMS kernel wrote for it (position, level)
     // beside its length and the slot flag -- one round of loads; the detector-order path chains through slot -> level -> rank.
-    int slot = bx * 4 + wid;             // position in the level-segmented arrays / in the image's final list
+    int slot = bx * NW + wid;            // position in the level-segmented arrays / in the image's final list
     long long fo = 0;
     int level = 0;
-    uint32_t pos;
+    uint32_t pos = 0;
+    bool live;                           // wave-uniform
     if (pre) {
         const int lane_id = img >> 1, vl0 = lane_id * c.oct_cap;
         const int n_final = c.desc_n[img];
-        const uint2 w = c.desc_work[(long long)img * c.raw_cap + slot];
+        if (bx * NW >= n_final) return;                                                      // block-uniform: nothing left for this block
+        live = slot < n_final;
+        const uint2 w = c.desc_work[(long long)img * c.raw_cap + (live ? slot : bx * NW)];
         const int cur = 1 - c.lane[lane_id].prev_slot;
-        if (slot >= n_final) return;
         fo = feat_base(c, vl0, cur, img & 1) + slot;
         pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.x); level = __builtin_amdgcn_readfirstlane((int)w.y);
     } else {
-        if (slot >= c.n_slots) return;
+        if (bx * NW >= c.n_slots) return;                                                    // block-uniform
+        live = slot < c.n_slots;
+        if (!live) slot = bx * NW;
 #pragma unroll
         for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
-        if (slot - c.lv[level].slot_off >= c.lvl_n[img * SVO_MAX_LEVELS + level]) return;       // wave-uniform
-        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
+        if (slot - c.lv[level].slot_off >= c.lvl_n[img * SVO_MAX_LEVELS + level]) live = false;       // wave-uniform
+        pos = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]) : 0u;
     }
     const LevelGeom& g = c.lv[level];
     const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
@@ -1072,7 +1084,7 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     for (int k = 0; k < 4; k++) pat[k] = g_brief_patf[k * 64 + lane];
     // ---- A: window rows y-21..y+21, columns x-23..x+24, LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) ----
     //      every byte read lies inside the image: keypoints keep EDGE = 31 pixels from every border
-    {
+    if (live) {
         typedef const void __attribute__((address_space(1)))* gptr_t;
         typedef void __attribute__((address_space(3)))* lptr_t;
         auto chunk_src = [&](int i) -> const uint8_t* {
@@ -1086,24 +1098,33 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     }
     wave_lds_sync();
     // ---- B: moments over the disc: 31 rows x 8 dwords = 248 lane-tasks ----
-    uint32_t m10u = 0; int m01 = 0, msum = 0;
+    if (live) {
+        uint32_t m10u = 0; int m01 = 0, msum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read a row that exists
-        const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 6
-        const uint32_t px = R32[(vr + 6) * DP_PW + 2 + d];
-        const uint32_t s = udot4(px, g_disc_m[en], 0u);
-        m10u = udot4(px, g_disc_x[en], m10u);
-        msum += (int)s;
-        m01 += __mul24(vr - 15, (int)s);
+        for (int i = 0; i < 4; i++) {
+            const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read a row that exists
+            const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 6
+            const uint32_t px = R32[(vr + 6) * DP_PW + 2 + d];
+            const uint32_t s = udot4(px, g_disc_m[en], 0u);
+            m10u = udot4(px, g_disc_x[en], m10u);
+            msum += (int)s;
+            m01 += __mul24(vr - 15, (int)s);
+        }
+        const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
+        m01 = wave_sum_uniform(m01);
+        if (lane == 0) { s_mom[wid][0] = m10; s_mom[wid][1] = m01; }
     }
-    const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
-    m01 = wave_sum_uniform(m01);
-    const float angle = atan2_deg((float)m01, (float)m10);
-    float sn, cs;
-    sincos_f32(angle * 0.017453292f, sn, cs);
-    // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
+    __syncthreads();                                         // barrier 1: every wave's moments are in LDS
+    if (wid == 0 && lane < NW) {
+        const float angle = atan2_deg((float)s_mom[lane][1], (float)s_mom[lane][0]);
+        float sn, cs;
+        sincos_f32(angle * 0.017453292f, sn, cs);
+        s_ang[lane][0] = angle; s_ang[lane][1] = sn; s_ang[lane][2] = cs;
+    }
     const int n16 = lane & 15, q4 = lane >> 4;
+    uint8_t* Bl = (uint8_t*)R32;
+    if (live) {
+    // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
     dp_v4i S[3][3];
     {
         const dp_v4i seed = { 128, 128, 128, 128 };
@@ -1117,7 +1138,6 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
     }
     wave_lds_sync();                                       // every lane has read the raw window: the blurred one may overwrite it
     // ---- D: vertical pass; lane (n16, q4) owns k-group q4 of column n16 already ----
-    uint8_t* Bl = (uint8_t*)R32;
     {
         const int c2 = 257 * 32896 + 32768;
         const dp_v4i seed_lo = { c2, c2, c2, c2 }, zero = { 0, 0, 0, 0 };
@@ -1143,11 +1163,14 @@ __global__ void __launch_bounds__(256) k_describe(DevCtx c, FastDiv gx_div, int 
                 uint32_t h01 = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u), h23 = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u), s01, s23;
                 asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s01) : "v"(h01));
                 asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s23) : "v"(h23));
-                *(uint32_t*)&Bl[(16 * ot + n16) * (4 * DP_PW) + 16 * nt + 4 * q4] = (s23 << 16) | (s01 & 0xFFFFu);
+                *(uint32_t*)&Bl[(16 * ot + n16) * (4 * DP_PW) + 16 * nt + 4 * q4] = __builtin_amdgcn_perm(s23, s01, 0x05040100u);
             }
         }
     }
-    wave_lds_sync();
+    }
+    __syncthreads();                                         // barrier 2: the first wave's (angle, sin, cos); this wave's blurred window
+    if (!live) return;
+    const float angle = s_ang[wid][0], sn = s_ang[wid][1], cs = s_ang[wid][2];
     // ---- E: 256 tests, one byte gather per sample point, packed with four wave ballots ----
     // x + 1.5 * 2^23 rounds to the nearest integer, ties to even (cvRound), and leaves it in the mantissa: bits = 0x4B400000 + ix.
     // The offsets of the window centre and of this wave's LDS region ride in the magic constants; the products with the pitch
@@ -1900,8 +1923,12 @@ void launch_select(const DevCtx& c, hipStream_t st)
 void launch_describe(const DevCtx& c, int pre, hipStream_t st)
 {
     if (c.n_slots <= 0) return;
-    const int gx = (c.n_slots + 3) / 4, img8 = (c.n_img + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_describe, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0);
+    // keypoints (waves) per block: SVO_DESC_WAVES = 4 / 8 overrides the default for an A/B
+    static int nw = 0;
+    if (!nw) { const char* e = getenv("SVO_DESC_WAVES"); const int v = e ? atoi(e) : 0; nw = (v == 4 || v == 8) ? v : 4; }
+    const int gx = (c.n_slots + nw - 1) / nw, img8 = (c.n_img + 7) / 8 * 8;
+    if (nw == 8) hipLaunchKernelGGL(k_describe<8>, dim3((unsigned)((long long)gx * img8)), dim3(512), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0);
+    else hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0);
 }
 
 #define FO_PMAX 2048     // chunk size of k_fastorb_nms (LDS: 45 B per entry)

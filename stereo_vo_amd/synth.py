@@ -209,22 +209,37 @@ class SyntheticStereoWorld:
         best_s = torch.full((self.h, self.w), float("inf"), device=dev)
         img = torch.full((self.h, self.w), 90.0, device=dev)
         cam_fwd = T[:3, 2]
+        Rn, on = T[:3, :3], T[:3, 3]
         for pi, pl in enumerate(self.planes):
             P, n, eu, ev, ext, mpt = pl[:6]
             if self.scene == "street" and pi >= 2 and float(np.dot(np.asarray(P) - T[:3, 3], cam_fwd)) < -4.0:
                 continue                                           # a facade the camera has passed: behind it, cannot be seen
+            # On a GPU a plane is rendered inside the bounding box of its projected rectangle only (same arithmetic per pixel;
+            # the pixels outside cannot pass the extent test): a facade covers a small part of the image and the renderer is
+            # bound by the per-plane passes over it.  The CPU path (tests, golden vectors) keeps whole-image passes.
+            ys0, ys1, xs0, xs1 = 0, self.h, 0, self.w
+            if getattr(self, "_bbox", dev.type != "cpu"):
+                cor = np.array([np.asarray(P) + a_ * np.asarray(eu) + b_ * np.asarray(ev) for a_ in (ext[0], ext[1]) for b_ in (ext[2], ext[3])])
+                cc = (cor - on) @ Rn                               # camera coordinates of the four corners
+                if cc[:, 2].min() > 0.2:
+                    u = self.f * cc[:, 0] / cc[:, 2] + self.cx; v = self.f * cc[:, 1] / cc[:, 2] + self.cy
+                    xs0, xs1 = max(0, int(math.floor(u.min())) - 2), min(self.w, int(math.ceil(u.max())) + 3)
+                    ys0, ys1 = max(0, int(math.floor(v.min())) - 2), min(self.h, int(math.ceil(v.max())) + 3)
+                    if xs0 >= xs1 or ys0 >= ys1:
+                        continue                                   # wholly outside the image
             tex = self.textures[pl[6] if len(pl) > 6 else pi]
             tu0, tv0 = pl[7] if len(pl) > 7 else (0.0, 0.0)
-            # the planes' vectors live on the device once (four blocking host-to-device copies per plane and eye otherwise:
-            # most of the render time of a long sequence)
+            # the planes' vectors live on the device once (four blocking host-to-device copies per plane and eye otherwise)
             if pi not in self._plane_dev:
                 self._plane_dev[pi] = tuple(torch.tensor(v, dtype=torch.float32, device=dev) for v in (P, n, eu, ev))
             Pt, nt, eut, evt = self._plane_dev[pi]
-            denom = d @ nt
+            ds = d[ys0:ys1, xs0:xs1]
+            bs, im = best_s[ys0:ys1, xs0:xs1], img[ys0:ys1, xs0:xs1]
+            denom = ds @ nt
             s = torch.dot(nt, Pt - o) / denom
-            X = o + s.unsqueeze(-1) * d - Pt
+            X = o + s.unsqueeze(-1) * ds - Pt
             a, b = X @ eut, X @ evt
-            ok = (s > 0.05) & (s < best_s) & (a >= ext[0]) & (a <= ext[1]) & (b >= ext[2]) & (b <= ext[3]) & torch.isfinite(s)
+            ok = (s > 0.05) & (s < bs) & (a >= ext[0]) & (a <= ext[1]) & (b >= ext[2]) & (b <= ext[3]) & torch.isfinite(s)
             tu = a / mpt + (self.tex_size / 2.0 + tu0)
             tv = b / mpt + (self.tex_size / 2.0 + tv0)
             # wrap the texture so that large planes stay textured everywhere
@@ -235,8 +250,12 @@ class SyntheticStereoWorld:
             fx, fy = tu - x0, tv - y0
             v = (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy)
                  + tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
-            img = torch.where(ok, v, img)
-            best_s = torch.where(ok, s, best_s)
+            if (ys1 - ys0, xs1 - xs0) == (self.h, self.w):
+                img = torch.where(ok, v, img)
+                best_s = torch.where(ok, s, best_s)
+            else:
+                im.copy_(torch.where(ok, v, im))
+                bs.copy_(torch.where(ok, s, bs))
         if self.noise_sigma > 0 and self.noise_on_device and dev.type != "cpu":
             g = torch.Generator(device=dev)
             g.manual_seed(gen_seed)

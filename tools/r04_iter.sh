@@ -30,6 +30,15 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps_1ctx
 f=$(find /tmp/ps_1ctx -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python $R/tools/trace_stats.py $f $O/${tag}_kernel_stats_1ctx.csv --skip-steps 3 --total-steps 13 > /dev/null
 head -19 $O/${tag}_kernel_stats_1ctx.csv
+# A/B legs: AB="NAME=VALUE NAME2=VALUE2 ..." -> one more 1-context kernel-stats pass per assignment, the changed rows printed
+for ab in $AB; do
+  rm -rf /tmp/ps_ab
+  env $ab timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps_ab -- python $R/bench.py $B --contexts 1 --lanes 64 --frames 64 > $O/${tag}_prof_ab_${ab}.log 2>&1
+  f=$(find /tmp/ps_ab -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python $R/tools/trace_stats.py $f $O/${tag}_kernel_stats_1ctx_${ab}.csv --skip-steps 3 --total-steps 13 > /dev/null
+  echo "A/B $ab:"; head -8 $O/${tag}_kernel_stats_1ctx_${ab}.csv
+  grep '^{' $O/${tag}_prof_ab_${ab}.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   value', d['value'], 'valid', d['valid_last_step'], 'tracked', d['mean_tracked'])"
+done
 if [ -n "$PMC" ]; then
   ( time timeout 1200 python $R/tools/pmc_passes.py $tag ) > $O/${tag}_pmc.log 2>&1
   tail -4 $O/${tag}_pmc.log
