@@ -1021,17 +1021,15 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
     return __builtin_amdgcn_udot4(a, b, acc, false);
 }
 
-// NW waves (keypoints) per block.  The orientation's arctangent, sine and cosine are ~70 wave-instructions on a wave-uniform
-// value: the waves of a block leave their two moments in LDS, lanes 0 .. NW-1 of the first wave evaluate all NW keypoints in one
-// pass (block barrier 1), and the others pick their (angle, sin, cos) up after the blur (block barrier 2) -- which does not
-// depend on the angle, so only the first wave's extra pass is exposed.  A wave past the end of the list keeps walking to the
-// barriers (no early exit inside a barrier region).
+// NW waves per block, each working through `kpw` consecutive keypoints of one image (no block barrier: every wave owns its LDS
+// region).  Round 4: the kernel sat at 0.67 of its VALU issue rate -- a wave lived ~5 us of which the window fetch, the ten
+// 16-byte table loads per lane (Gaussian operands, test pairs) and the slot -> level -> geometry prologue were latency and
+// set-up paid per keypoint.  Now a wave keeps the tables in registers across its keypoints and the window of keypoint i + 1 is
+// in flight (LDS-DMA into the wave's second buffer) while keypoint i is computed.
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, int pre)
+__global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, int pre, int kpw)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t raw32[NW][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
-    __shared__ int s_mom[NW][2];
-    __shared__ float s_ang[NW][4];
+    __shared__ __attribute__((aligned(16))) uint32_t raw32[NW][2][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1042,171 +1040,166 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
     int img, bx;
     if (c.debug_mode == 8) { img = blockIdx.x / gx_div.d; bx = blockIdx.x - img * gx_div.d; }
     else { const uint32_t r = blockIdx.x >> 3, grp = fastdiv(r, gx_div); bx = (int)(r - grp * gx_div.d); img = (int)(grp * 8 + (blockIdx.x & 7)); }
-    if (img >= c.n_img) return;                                                              // block-uniform
-    // pre != 0: the NMS ran first (k_nms_rowsort, pre mode); work item = final keypoint fi of the image's current list,
-    // final_slot names the detector slot it came from, and only the angle and the descriptor are left to fill in
-    // A wave lives ~5 us and a CU holds 32 of them, so dependent loads before the window is in flight cost throughput (see
-    // k_fast).  The work item of the describe-after-NMS path comes from ONE list the NMS kernel wrote for it (position, level)
-    // beside its length and the slot flag -- one round of loads; the detector-order path chains through slot -> level -> rank.
-    int slot = bx * NW + wid;            // position in the level-segmented arrays / in the image's final list
-    long long fo = 0;
-    int level = 0;
-    uint32_t pos = 0;
-    bool live;                           // wave-uniform
-    if (pre) {
-        const int lane_id = img >> 1, vl0 = lane_id * c.oct_cap;
-        const int n_final = c.desc_n[img];
-        if (bx * NW >= n_final) return;                                                      // block-uniform: nothing left for this block
-        live = slot < n_final;
-        const uint2 w = c.desc_work[(long long)img * c.raw_cap + (live ? slot : bx * NW)];
-        const int cur = 1 - c.lane[lane_id].prev_slot;
-        fo = feat_base(c, vl0, cur, img & 1) + slot;
-        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.x); level = __builtin_amdgcn_readfirstlane((int)w.y);
-    } else {
-        if (bx * NW >= c.n_slots) return;                                                    // block-uniform
-        live = slot < c.n_slots;
-        if (!live) slot = bx * NW;
-#pragma unroll
-        for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
-        if (slot - c.lv[level].slot_off >= c.lvl_n[img * SVO_MAX_LEVELS + level]) live = false;       // wave-uniform
-        pos = live ? (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]) : 0u;
-    }
-    const LevelGeom& g = c.lv[level];
-    const int x = (int)(pos & 0xFFFFu), y = (int)(pos >> 16);
-    int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
-    uint32_t* R32 = raw32[wid];
-    // the constant operands of the two passes and this lane's four test pairs: issued ahead of the window so that everything is in flight at once
+    if (img >= c.n_img) return;
+    // pre != 0: the NMS ran first (k_nms_rowsort, pre mode); work item = final keypoint fi of the image's current list, which
+    // the NMS kernel wrote as ONE list (position, level) beside its length, and only the angle and the descriptor are left to
+    // fill in.  pre == 0: the level-segmented detector slots (quota_l slots per level, lvl_n of them live).
+    const int lane_id = img >> 1, vl0 = lane_id * c.oct_cap;
+    const int n_end = pre ? c.desc_n[img] : c.n_slots;
+    const int slot0 = (bx * NW + wid) * kpw;
+    if (slot0 >= n_end) return;                                                              // wave-uniform
+    const int slot1 = min(slot0 + kpw, n_end);
+    const long long fo0 = pre ? feat_base(c, vl0, 1 - c.lane[lane_id].prev_slot, img & 1) : 0;
+    // the constant operands of the two passes and this lane's four test pairs
     dp_v4i GH[3], GV[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) { GH[t] = *(const dp_v4i*)&g_blur_gh[t * 64 + lane]; GV[t] = *(const dp_v4i*)&g_blur_gv[t * 64 + lane]; }
     float4 pat[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) pat[k] = g_brief_patf[k * 64 + lane];
-    // ---- A: window rows y-21..y+21, columns x-23..x+24, LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) ----
+    // work item of a slot: all scalar
+    auto item = [&](int slot, bool& live, int& x, int& y, int& level) {
+        uint32_t pos = 0; level = 0; live = true;
+        if (pre) {
+            const uint2 w = c.desc_work[(long long)img * c.raw_cap + slot];
+            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.x); level = __builtin_amdgcn_readfirstlane((int)w.y);
+        } else {
+#pragma unroll
+            for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
+            live = slot - c.lv[level].slot_off < c.lvl_n[img * SVO_MAX_LEVELS + level];
+            if (live) pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
+        }
+        x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
+    };
+    // ---- A: window rows y-21..y+21, columns x-23..x+24, LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) lands at LDS byte 16 i ----
     //      every byte read lies inside the image: keypoints keep EDGE = 31 pixels from every border
-    if (live) {
+    const int cr0 = (lane * 171) >> 9, cq0 = lane - 3 * cr0, cr1 = ((lane + 64) * 171) >> 9, cq1 = lane + 64 - 3 * cr1;       // i / 3, i % 3 for i <= 128
+    auto stage = [&](uint32_t* dst, int x, int y, int level) {
         typedef const void __attribute__((address_space(1)))* gptr_t;
         typedef void __attribute__((address_space(3)))* lptr_t;
-        auto chunk_src = [&](int i) -> const uint8_t* {
-            const int r = (i * 171) >> 9, q = i - 3 * r;                    // i / 3, i % 3 for i <= 128
-            return lim + (uint32_t)((y - (DP_REACH + 3) + r) * pitch + (x - DP_X0) + 16 * q);
-        };
-        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(lane), (lptr_t)R32, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(64 + lane), (lptr_t)(R32 + 256), 16, 0, 0);
-        if (lane < DP_RW * 3 - 128) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(128 + lane), (lptr_t)(R32 + 512), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    wave_lds_sync();
-    // ---- B: moments over the disc: 31 rows x 8 dwords = 248 lane-tasks ----
-    if (live) {
-        uint32_t m10u = 0; int m01 = 0, msum = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read a row that exists
-            const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 6
-            const uint32_t px = R32[(vr + 6) * DP_PW + 2 + d];
-            const uint32_t s = udot4(px, g_disc_m[en], 0u);
-            m10u = udot4(px, g_disc_x[en], m10u);
-            msum += (int)s;
-            m01 += __mul24(vr - 15, (int)s);
-        }
-        const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
-        m01 = wave_sum_uniform(m01);
-        if (lane == 0) { s_mom[wid][0] = m10; s_mom[wid][1] = m01; }
-    }
-    __syncthreads();                                         // barrier 1: every wave's moments are in LDS
-    if (wid == 0 && lane < NW) {
-        const float angle = atan2_deg((float)s_mom[lane][1], (float)s_mom[lane][0]);
-        float sn, cs;
-        sincos_f32(angle * 0.017453292f, sn, cs);
-        s_ang[lane][0] = angle; s_ang[lane][1] = sn; s_ang[lane][2] = cs;
-    }
+        int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
+        const uint8_t* org = lim + (uint32_t)((y - (DP_REACH + 3)) * pitch + (x - DP_X0));
+        __builtin_amdgcn_global_load_lds((gptr_t)(org + (uint32_t)(cr0 * pitch + 16 * cq0)), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(org + (uint32_t)(cr1 * pitch + 16 * cq1)), (lptr_t)(dst + 256), 16, 0, 0);
+        if (lane < DP_RW * 3 - 128) __builtin_amdgcn_global_load_lds((gptr_t)(org + (uint32_t)(42 * pitch + 32)), (lptr_t)(dst + 512), 16, 0, 0);      // chunk 128 = (row 42, piece 2)
+    };
+    static_assert(DP_RW * 3 - 128 == 1, "the third DMA instruction carries chunk 128 alone");
+    bool live; int x, y, level;
+    item(slot0, live, x, y, level);
+    if (live) stage(raw32[wid][0], x, y, level);
     const int n16 = lane & 15, q4 = lane >> 4;
-    uint8_t* Bl = (uint8_t*)R32;
-    if (live) {
-    // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
-    dp_v4i S[3][3];
-    {
-        const dp_v4i seed = { 128, 128, 128, 128 };
+    for (int slot = slot0; slot < slot1; slot++) {
+        uint32_t* R32 = raw32[wid][(slot - slot0) & 1];
+        bool live_n = false; int x_n = 0, y_n = 0, level_n = 0;
+        if (slot + 1 < slot1) item(slot + 1, live_n, x_n, y_n, level_n);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this keypoint's window has landed (and the last one's stores are out)
+        wave_lds_sync();
+        // the next window goes to the other buffer, whose last reader was the test phase of the keypoint before this one
+        if (live_n) stage(raw32[wid][(slot - slot0 + 1) & 1], x_n, y_n, level_n);
+        if (live) {
+            // ---- B: moments over the disc: 31 rows x 8 dwords = 248 lane-tasks ----
+            uint32_t m10u = 0; int m01 = 0, msum = 0;
 #pragma unroll
-        for (int mt = 0; mt < 3; mt++) {
-            dp_v4i X = *(const dp_v4i*)&R32[(16 * mt + n16) * DP_PW + 4 * q4];
-            X ^= (int)0x80808080;
-#pragma unroll
-            for (int nt = 0; nt < 3; nt++) S[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, GH[nt], seed, 0, 0, 0);
-        }
-    }
-    wave_lds_sync();                                       // every lane has read the raw window: the blurred one may overwrite it
-    // ---- D: vertical pass; lane (n16, q4) owns k-group q4 of column n16 already ----
-    {
-        const int c2 = 257 * 32896 + 32768;
-        const dp_v4i seed_lo = { c2, c2, c2, c2 }, zero = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int nt = 0; nt < 3; nt++) {
-            dp_v4i Alo, Ahi;
-#pragma unroll
-            for (int mt = 0; mt < 3; mt++) {
-                const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)S[mt][nt][1], (uint32_t)S[mt][nt][0], 0x05010400u);     // lo0 lo1 hi0 hi1
-                const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)S[mt][nt][3], (uint32_t)S[mt][nt][2], 0x05010400u);
-                Alo[mt] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
-                Ahi[mt] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+            for (int i = 0; i < 4; i++) {
+                const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read a row that exists
+                const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 6
+                const uint32_t px = R32[(vr + 6) * DP_PW + 2 + d];
+                const uint32_t s = udot4(px, g_disc_m[en], 0u);
+                m10u = udot4(px, g_disc_x[en], m10u);
+                msum += (int)s;
+                m01 += __mul24(vr - 15, (int)s);
             }
-            Alo[3] = 0; Ahi[3] = 0;
+            const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
+            m01 = wave_sum_uniform(m01);
+            const float angle = atan2_deg((float)m01, (float)m10);
+            float sn, cs;
+            sincos_f32(angle * 0.017453292f, sn, cs);
+            // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
+            dp_v4i S[3][3];
+            {
+                const dp_v4i seed = { 128, 128, 128, 128 };
 #pragma unroll
-            for (int ot = 0; ot < 3; ot++) {
-                const dp_v4i Dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ahi, GV[ot], zero, 0, 0, 0);
-                const dp_v4i Dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(Alo, GV[ot], seed_lo, 0, 0, 0);
-                uint32_t t[4];
+                for (int mt = 0; mt < 3; mt++) {
+                    dp_v4i X = *(const dp_v4i*)&R32[(16 * mt + n16) * DP_PW + 4 * q4];
+                    X ^= (int)0x80808080;
 #pragma unroll
-                for (int r = 0; r < 4; r++) t[r] = ((uint32_t)Dhi[r] << 8) + (uint32_t)Dlo[r];
-                // (t >> 16) is 0..257: saturate the 16-bit halves to bytes (v_sat_pk_u8_i16), four columns of one row per lane
-                uint32_t h01 = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u), h23 = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u), s01, s23;
-                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s01) : "v"(h01));
-                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s23) : "v"(h23));
-                *(uint32_t*)&Bl[(16 * ot + n16) * (4 * DP_PW) + 16 * nt + 4 * q4] = __builtin_amdgcn_perm(s23, s01, 0x05040100u);
+                    for (int nt = 0; nt < 3; nt++) S[mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(X, GH[nt], seed, 0, 0, 0);
+                }
+            }
+            wave_lds_sync();                                       // every lane has read the raw window: the blurred one may overwrite it
+            // ---- D: vertical pass; lane (n16, q4) owns k-group q4 of column n16 already ----
+            uint8_t* Bl = (uint8_t*)R32;
+            {
+                const int c2 = 257 * 32896 + 32768;
+                const dp_v4i seed_lo = { c2, c2, c2, c2 }, zero = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int nt = 0; nt < 3; nt++) {
+                    dp_v4i Alo, Ahi;
+#pragma unroll
+                    for (int mt = 0; mt < 3; mt++) {
+                        const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)S[mt][nt][1], (uint32_t)S[mt][nt][0], 0x05010400u);     // lo0 lo1 hi0 hi1
+                        const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)S[mt][nt][3], (uint32_t)S[mt][nt][2], 0x05010400u);
+                        Alo[mt] = (int)(__builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+                        Ahi[mt] = (int)__builtin_amdgcn_perm(p23, p01, 0x07060302u);
+                    }
+                    Alo[3] = 0; Ahi[3] = 0;
+#pragma unroll
+                    for (int ot = 0; ot < 3; ot++) {
+                        const dp_v4i Dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ahi, GV[ot], zero, 0, 0, 0);
+                        const dp_v4i Dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(Alo, GV[ot], seed_lo, 0, 0, 0);
+                        uint32_t t[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) t[r] = ((uint32_t)Dhi[r] << 8) + (uint32_t)Dlo[r];
+                        // (t >> 16) is 0..257: saturate the 16-bit halves to bytes (v_sat_pk_u8_i16), four columns of one row per lane
+                        uint32_t h01 = __builtin_amdgcn_perm(t[1], t[0], 0x07060302u), h23 = __builtin_amdgcn_perm(t[3], t[2], 0x07060302u), s01, s23;
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s01) : "v"(h01));
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(s23) : "v"(h23));
+                        *(uint32_t*)&Bl[(16 * ot + n16) * (4 * DP_PW) + 16 * nt + 4 * q4] = __builtin_amdgcn_perm(s23, s01, 0x05040100u);
+                    }
+                }
+            }
+            wave_lds_sync();
+            // ---- E: 256 tests, one byte gather per sample point, packed with four wave ballots ----
+            // x + 1.5 * 2^23 rounds to the nearest integer, ties to even (cvRound), and leaves it in the mantissa: bits = 0x4B400000 + ix.
+            // The offsets of the window centre and of this wave's LDS region ride in the magic constants; the products with the pitch
+            // take the low 24 bits (v_mad_u32_u24), the sum's low 16 bits are the LDS address.
+            const float MX = 12582912.0f + (float)(DP_REACH + (int)((uint8_t*)R32 - (uint8_t*)&raw32[0][0][0])), MY = 12582912.0f + (float)DP_REACH;
+            const uint8_t* lds0 = (const uint8_t*)&raw32[0][0][0];
+            unsigned long long bits[4];
+            // the two points of a pair ride in the halves of packed single-precision operations (v_pk_mul_f32 / v_pk_add_f32: each half
+            // is one IEEE operation, as the scalar form): pat = (x0, x1, y0, y1)
+            typedef float dp_f2 __attribute__((ext_vector_type(2)));
+            const dp_f2 cs2 = { cs, cs }, sn2 = { sn, sn }, MX2 = { MX, MX }, MY2 = { MY, MY };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const dp_f2 px = { pat[k].x, pat[k].y }, py = { pat[k].z, pat[k].w };
+                const dp_f2 xs = (px * cs2 - py * sn2) + MX2, ys = (px * sn2 + py * cs2) + MY2;
+                const uint32_t o0 = (__umul24(__float_as_uint(ys.x), 4 * DP_PW) + __float_as_uint(xs.x)) & 0xFFFFu;
+                const uint32_t o1 = (__umul24(__float_as_uint(ys.y), 4 * DP_PW) + __float_as_uint(xs.y)) & 0xFFFFu;
+                const int a = lds0[o0], b = lds0[o1];
+                bits[k] = __ballot(a < b);
+            }
+            if (lane == 0) {
+                if (pre) {
+                    const long long fo = fo0 + slot;
+                    unsigned long long* d = (unsigned long long*)(c.desc + fo * 32);
+                    d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+                    c.kps[fo].angle = angle;
+                } else {
+                    const LevelGeom& g = c.lv[level];
+                    const long long o = (long long)img * c.raw_cap + slot;
+                    unsigned long long* d = (unsigned long long*)(c.raw_desc + o * 32);
+                    d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+                    svo_keypoint k;
+                    // ORB mode: level-0 coordinates, size 31*scale, octave = pyramid level.  FAST+ORB mode: cv::FAST keypoints
+                    // (octave-image coordinates, size 7, octave 0) that cv::ORB::compute only orients and describes
+                    k.x = (float)x * g.scale; k.y = (float)y * g.scale; k.size = c.fast_orb ? 7.0f : 31.0f * g.scale; k.angle = angle;
+                    k.response = c.lvl_resp[o]; k.octave = c.fast_orb ? 0 : level; k.class_id = -1;
+                    c.raw_kps[o] = k;
+                }
             }
         }
-    }
-    }
-    __syncthreads();                                         // barrier 2: the first wave's (angle, sin, cos); this wave's blurred window
-    if (!live) return;
-    const float angle = s_ang[wid][0], sn = s_ang[wid][1], cs = s_ang[wid][2];
-    // ---- E: 256 tests, one byte gather per sample point, packed with four wave ballots ----
-    // x + 1.5 * 2^23 rounds to the nearest integer, ties to even (cvRound), and leaves it in the mantissa: bits = 0x4B400000 + ix.
-    // The offsets of the window centre and of this wave's LDS region ride in the magic constants; the products with the pitch
-    // take the low 24 bits (v_mad_u32_u24), the sum's low 16 bits are the LDS address.
-    const float MX = 12582912.0f + (float)(DP_REACH + (int)((uint8_t*)R32 - (uint8_t*)&raw32[0][0])), MY = 12582912.0f + (float)DP_REACH;
-    const uint8_t* lds0 = (const uint8_t*)&raw32[0][0];
-    unsigned long long bits[4];
-    // the two points of a pair ride in the halves of packed single-precision operations (v_pk_mul_f32 / v_pk_add_f32: each half
-    // is one IEEE operation, as the scalar form): pat = (x0, x1, y0, y1)
-    typedef float dp_f2 __attribute__((ext_vector_type(2)));
-    const dp_f2 cs2 = { cs, cs }, sn2 = { sn, sn }, MX2 = { MX, MX }, MY2 = { MY, MY };
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const dp_f2 px = { pat[k].x, pat[k].y }, py = { pat[k].z, pat[k].w };
-        const dp_f2 xs = (px * cs2 - py * sn2) + MX2, ys = (px * sn2 + py * cs2) + MY2;
-        const uint32_t o0 = (__umul24(__float_as_uint(ys.x), 4 * DP_PW) + __float_as_uint(xs.x)) & 0xFFFFu;
-        const uint32_t o1 = (__umul24(__float_as_uint(ys.y), 4 * DP_PW) + __float_as_uint(xs.y)) & 0xFFFFu;
-        const int a = lds0[o0], b = lds0[o1];
-        bits[k] = __ballot(a < b);
-    }
-    if (lane == 0) {
-        if (pre) {
-            unsigned long long* d = (unsigned long long*)(c.desc + fo * 32);
-            d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
-            c.kps[fo].angle = angle;
-            return;
-        }
-        const long long o = (long long)img * c.raw_cap + slot;
-        unsigned long long* d = (unsigned long long*)(c.raw_desc + o * 32);
-        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
-        svo_keypoint k;
-        // ORB mode: level-0 coordinates, size 31*scale, octave = pyramid level.  FAST+ORB mode: cv::FAST keypoints
-        // (octave-image coordinates, size 7, octave 0) that cv::ORB::compute only orients and describes
-        k.x = (float)x * g.scale; k.y = (float)y * g.scale; k.size = c.fast_orb ? 7.0f : 31.0f * g.scale; k.angle = angle;
-        k.response = c.lvl_resp[o]; k.octave = c.fast_orb ? 0 : level; k.class_id = -1;
-        c.raw_kps[o] = k;
+        live = live_n; x = x_n; y = y_n; level = level_n;
     }
 }
 
@@ -1923,12 +1916,11 @@ void launch_select(const DevCtx& c, hipStream_t st)
 void launch_describe(const DevCtx& c, int pre, hipStream_t st)
 {
     if (c.n_slots <= 0) return;
-    // keypoints (waves) per block: SVO_DESC_WAVES = 4 / 8 overrides the default for an A/B
-    static int nw = 0;
-    if (!nw) { const char* e = getenv("SVO_DESC_WAVES"); const int v = e ? atoi(e) : 0; nw = (v == 4 || v == 8) ? v : 4; }
-    const int gx = (c.n_slots + nw - 1) / nw, img8 = (c.n_img + 7) / 8 * 8;
-    if (nw == 8) hipLaunchKernelGGL(k_describe<8>, dim3((unsigned)((long long)gx * img8)), dim3(512), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0);
-    else hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0);
+    // keypoints per wave: SVO_DESC_KPW overrides the default for an A/B (1 = a wave per keypoint, as rounds 1-3)
+    static int kpw = 0;
+    if (!kpw) { const char* e = getenv("SVO_DESC_KPW"); const int v = e ? atoi(e) : 0; kpw = (v >= 1 && v <= 64) ? v : 4; }
+    const int per = 4 * kpw, gx = (c.n_slots + per - 1) / per, img8 = (c.n_img + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0, kpw);
 }
 
 #define FO_PMAX 2048     // chunk size of k_fastorb_nms (LDS: 45 B per entry)
