@@ -1021,6 +1021,16 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
     return __builtin_amdgcn_udot4(a, b, acc, false);
 }
 
+// LDS-DMA written as asm: 16 bytes per lane from the lane's global address to LDS byte `lds_base` + 16 * lane.  Through the
+// builtin the compiler cannot tell which LDS bytes a transfer writes and puts s_waitcnt vmcnt(0) before EVERY later LDS access,
+// i.e. a window in flight for the NEXT keypoint would be waited for at once.  As asm the transfer is invisible to that logic; the
+// kernel waits for it itself (s_waitcnt vmcnt(0) at the top of the keypoint loop).  The compiler's own vmcnt arithmetic stays
+// safe: these transfers only add to the outstanding count, so its waits can only get stricter.
+__device__ __forceinline__ void glds16_asm(const uint8_t* gaddr, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gaddr), "s"(lds_base) : "memory", "m0");
+}
+
 // NW waves per block, each working through `kpw` consecutive keypoints of one image (no block barrier: every wave owns its LDS
 // region).  Round 4: the kernel sat at 0.67 of its VALU issue rate -- a wave lived ~5 us of which the window fetch, the ten
 // 16-byte table loads per lane (Gaussian operands, test pairs) and the slot -> level -> geometry prologue were latency and
@@ -1030,6 +1040,11 @@ template <int NW>
 __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, int pre, int kpw)
 {
     __shared__ __attribute__((aligned(16))) uint32_t raw32[NW][2][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
+    __shared__ __attribute__((aligned(16))) float4 s_pat[SVO_BRIEF_NPAIRS];                   // the test pairs and the disc weights: one copy per block
+    __shared__ uint32_t s_disc_m[SVO_DISC_E], s_disc_x[SVO_DISC_E];
+    static_assert(NW * 64 == SVO_BRIEF_NPAIRS && NW * 64 == SVO_DISC_E, "one table entry per thread");
+    s_pat[threadIdx.x] = g_brief_patf[threadIdx.x]; s_disc_m[threadIdx.x] = g_disc_m[threadIdx.x]; s_disc_x[threadIdx.x] = g_disc_x[threadIdx.x];
+    __syncthreads();                                         // the only block barrier: before any wave can leave
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1045,7 +1060,7 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
     // the NMS kernel wrote as ONE list (position, level) beside its length, and only the angle and the descriptor are left to
     // fill in.  pre == 0: the level-segmented detector slots (quota_l slots per level, lvl_n of them live).
     const int lane_id = img >> 1, vl0 = lane_id * c.oct_cap;
-    const int n_end = pre ? c.desc_n[img] : c.n_slots;
+    const int n_end = __builtin_amdgcn_readfirstlane(pre ? c.desc_n[img] : c.n_slots);
     const int slot0 = (bx * NW + wid) * kpw;
     if (slot0 >= n_end) return;                                                              // wave-uniform
     const int slot1 = min(slot0 + kpw, n_end);
@@ -1054,44 +1069,59 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
     dp_v4i GH[3], GV[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) { GH[t] = *(const dp_v4i*)&g_blur_gh[t * 64 + lane]; GV[t] = *(const dp_v4i*)&g_blur_gv[t * 64 + lane]; }
-    float4 pat[4];
+    // the tables are "used" here, ahead of the loop: the compiler then waits for them once, here, instead of re-stating its
+    // s_waitcnt vmcnt at their first uses inside the loop -- where it would wait out the next keypoint's window as well
 #pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = g_brief_patf[k * 64 + lane];
-    // work item of a slot: all scalar
-    auto item = [&](int slot, bool& live, int& x, int& y, int& level) {
-        uint32_t pos = 0; level = 0; live = true;
-        if (pre) {
-            const uint2 w = c.desc_work[(long long)img * c.raw_cap + slot];
-            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)w.x); level = __builtin_amdgcn_readfirstlane((int)w.y);
-        } else {
+    for (int t = 0; t < 3; t++) asm volatile("" : "+v"(GH[t]), "+v"(GV[t]));
+    // the work items of this wave's slots: lane i holds slot0 + i (one vector load ahead of the loop; an item is then two v_readlane)
+    uint32_t w_pos = 0, w_lvl = 0;
+    if (slot0 + lane < slot1) {
+        if (pre) { const uint2 w = c.desc_work[(long long)img * c.raw_cap + slot0 + lane]; w_pos = w.x; w_lvl = w.y; }
+        else w_pos = c.lvl_pos[(long long)img * c.raw_cap + slot0 + lane];
+    }
+    asm volatile("" : "+v"(w_pos), "+v"(w_lvl));             // (waited for here, once: see the tables above)
+    // (every field goes through readfirstlane / readlane: the values are uniform, and left to itself the compiler carries the
+    // level across the loop in a VGPR and fetches its geometry with vector loads -- two exposed round trips per keypoint)
+    auto item = [&](int slot, int& live, int& x, int& y, int& level) {
+        const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)w_pos, slot - slot0);
+        int lv = 0, ok = 1;
+        if (pre) lv = __builtin_amdgcn_readlane((int)w_lvl, slot - slot0);
+        else {
 #pragma unroll
-            for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) level = l;
-            live = slot - c.lv[level].slot_off < c.lvl_n[img * SVO_MAX_LEVELS + level];
-            if (live) pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.lvl_pos[(long long)img * c.raw_cap + slot]);
+            for (int l = 1; l < SVO_MAX_LEVELS; l++) if (l < c.n_levels && slot >= c.lv[l].slot_off) lv = l;
+            lv = __builtin_amdgcn_readfirstlane(lv);
+            ok = __builtin_amdgcn_readfirstlane(slot - c.lv[lv].slot_off < c.lvl_n[img * SVO_MAX_LEVELS + lv] ? 1 : 0);
         }
-        x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
+        level = lv; live = ok; x = (int)(pos & 0xFFFFu); y = (int)(pos >> 16);
     };
     // ---- A: window rows y-21..y+21, columns x-23..x+24, LDS-DMA: chunk i = (row i / 3, 16-byte piece i % 3) lands at LDS byte 16 i ----
     //      every byte read lies inside the image: keypoints keep EDGE = 31 pixels from every border
+    // level-0 pointer of the image (a table in memory) and its pyramid block: fetched once, kept in scalar registers
+    const uint8_t* base0; const uint8_t* pyr0 = c.pyr + (long long)img * c.pyr_bytes;
+    {
+        const uint64_t b = (uint64_t)(uintptr_t)c.img0[img];
+        base0 = (const uint8_t*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
+    }
     const int cr0 = (lane * 171) >> 9, cq0 = lane - 3 * cr0, cr1 = ((lane + 64) * 171) >> 9, cq1 = lane + 64 - 3 * cr1;       // i / 3, i % 3 for i <= 128
     auto stage = [&](uint32_t* dst, int x, int y, int level) {
-        typedef const void __attribute__((address_space(1)))* gptr_t;
-        typedef void __attribute__((address_space(3)))* lptr_t;
-        int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
+        const int pitch = level == 0 ? c.img0_pitch : c.lv[level].pitch;
+        const uint8_t* lim = level == 0 ? base0 : pyr0 + c.lv[level].offset;
         const uint8_t* org = lim + (uint32_t)((y - (DP_REACH + 3)) * pitch + (x - DP_X0));
-        __builtin_amdgcn_global_load_lds((gptr_t)(org + (uint32_t)(cr0 * pitch + 16 * cq0)), (lptr_t)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(org + (uint32_t)(cr1 * pitch + 16 * cq1)), (lptr_t)(dst + 256), 16, 0, 0);
-        if (lane < DP_RW * 3 - 128) __builtin_amdgcn_global_load_lds((gptr_t)(org + (uint32_t)(42 * pitch + 32)), (lptr_t)(dst + 512), 16, 0, 0);      // chunk 128 = (row 42, piece 2)
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)dst);
+        glds16_asm(org + (uint32_t)(cr0 * pitch + 16 * cq0), lb);
+        glds16_asm(org + (uint32_t)(cr1 * pitch + 16 * cq1), lb + 1024);
+        if (lane < DP_RW * 3 - 128) glds16_asm(org + (uint32_t)(42 * pitch + 32), lb + 2048);      // chunk 128 = (row 42, piece 2)
     };
     static_assert(DP_RW * 3 - 128 == 1, "the third DMA instruction carries chunk 128 alone");
-    bool live; int x, y, level;
+    int live, x, y, level;
     item(slot0, live, x, y, level);
     if (live) stage(raw32[wid][0], x, y, level);
     const int n16 = lane & 15, q4 = lane >> 4;
     for (int slot = slot0; slot < slot1; slot++) {
         uint32_t* R32 = raw32[wid][(slot - slot0) & 1];
-        bool live_n = false; int x_n = 0, y_n = 0, level_n = 0;
+        int live_n = 0, x_n = 0, y_n = 0, level_n = 0;
         if (slot + 1 < slot1) item(slot + 1, live_n, x_n, y_n, level_n);
+        live_n = __builtin_amdgcn_readfirstlane(live_n); x_n = __builtin_amdgcn_readfirstlane(x_n); y_n = __builtin_amdgcn_readfirstlane(y_n); level_n = __builtin_amdgcn_readfirstlane(level_n);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this keypoint's window has landed (and the last one's stores are out)
         wave_lds_sync();
         // the next window goes to the other buffer, whose last reader was the test phase of the keypoint before this one
@@ -1104,8 +1134,8 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
                 const int en = i * 64 + lane;                     // entries 248..255 have zero weights and read a row that exists
                 const int vr = en >> 3, d = en & 7;               // disc row v = vr - 15, window row vr + 6
                 const uint32_t px = R32[(vr + 6) * DP_PW + 2 + d];
-                const uint32_t s = udot4(px, g_disc_m[en], 0u);
-                m10u = udot4(px, g_disc_x[en], m10u);
+                const uint32_t s = udot4(px, s_disc_m[en], 0u);
+                m10u = udot4(px, s_disc_x[en], m10u);
                 msum += (int)s;
                 m01 += __mul24(vr - 15, (int)s);
             }
@@ -1172,7 +1202,8 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
             const dp_f2 cs2 = { cs, cs }, sn2 = { sn, sn }, MX2 = { MX, MX }, MY2 = { MY, MY };
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const dp_f2 px = { pat[k].x, pat[k].y }, py = { pat[k].z, pat[k].w };
+                const float4 pt = s_pat[k * 64 + lane];
+                const dp_f2 px = { pt.x, pt.y }, py = { pt.z, pt.w };
                 const dp_f2 xs = (px * cs2 - py * sn2) + MX2, ys = (px * sn2 + py * cs2) + MY2;
                 const uint32_t o0 = (__umul24(__float_as_uint(ys.x), 4 * DP_PW) + __float_as_uint(xs.x)) & 0xFFFFu;
                 const uint32_t o1 = (__umul24(__float_as_uint(ys.y), 4 * DP_PW) + __float_as_uint(xs.y)) & 0xFFFFu;
@@ -1918,7 +1949,7 @@ void launch_describe(const DevCtx& c, int pre, hipStream_t st)
     if (c.n_slots <= 0) return;
     // keypoints per wave: SVO_DESC_KPW overrides the default for an A/B (1 = a wave per keypoint, as rounds 1-3)
     static int kpw = 0;
-    if (!kpw) { const char* e = getenv("SVO_DESC_KPW"); const int v = e ? atoi(e) : 0; kpw = (v >= 1 && v <= 64) ? v : 4; }
+    if (!kpw) { const char* e = getenv("SVO_DESC_KPW"); const int v = e ? atoi(e) : 0; kpw = (v >= 1 && v <= 64) ? v : 4; }       // <= 64: a wave keeps its work items one per lane
     const int per = 4 * kpw, gx = (c.n_slots + per - 1) / per, img8 = (c.n_img + 7) / 8 * 8;
     hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0, kpw);
 }

@@ -56,7 +56,13 @@ typedef int hm_v16i __attribute__((ext_vector_type(16)));
 #define HM_QB 256          // queries per block (4 waves x 2 sets x 32)
 
 // 4 bits -> 4 bytes of 0 / 1 (LSB first), then -> bytes of base ^ 0x80 where the bit is set
-__device__ __forceinline__ uint32_t hm_spread4(uint32_t nib, uint32_t base) { return base ^ (((nib * 0x00204081u) & 0x01010101u) << 7); }
+// (v_mul_u32_u24: both factors are below 2^24 and the product below 2^32 -- the full 32-bit multiply issues at a quarter of the rate)
+__device__ __forceinline__ uint32_t hm_spread4(uint32_t nib, uint32_t base)
+{
+    uint32_t m;                                                     // (as asm: hipcc turns __umul24 of a 4-bit value back into v_mul_lo_u32)
+    asm("v_mul_u32_u24_e32 %0, 0x204081, %1" : "=v"(m) : "v"(nib));
+    return base ^ ((m & 0x01010101u) << 7);
+}
 // 16 bits (low half of `bits`) -> 16 bytes
 __device__ __forceinline__ hm_v4i hm_expand16(uint32_t bits, uint32_t base)
 {
@@ -117,14 +123,14 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
         tileA[buf][sg * 64 + (sr ^ sg)] = hm_expand16(bits, 0xC0C0C0C0u);
         tileA[buf][sg * 64 + ((32 + sr) ^ sg)] = hm_expand16(bits >> 16, 0xC0C0C0C0u);
     };
-    // C operand = train index of each accumulator row (advances by 32 per tile); running minima, 8 per set (v_min3 pairs)
-    int tc[16], best[2][8];
+    // C operand = the row of each accumulator register WITHIN its tile, the same for every tile (the matrix core reads C and
+    // writes D to other registers: nothing to re-initialise): D = row + 8192 * ham - 2^20, the tile's minimum over a query
+    // column's 16 rows is 8 v_min3, and the tile origin j0 is added to that ONE value before it meets the running minimum
+    // (rounds 1-3 advanced sixteen train-index registers per tile and copied them into both accumulators)
+    hm_v16i tc0;
 #pragma unroll
-    for (int v = 0; v < 16; v++) tc[v] = j_begin + 8 * (v >> 2) + (v & 3) + 4 * half;
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-#pragma unroll
-        for (int i = 0; i < 8; i++) best[st][i] = 0x7FFFFFFF;
+    for (int v = 0; v < 16; v++) tc0[v] = 8 * (v >> 2) + (v & 3) + 4 * half;
+    int best[2] = { 0x7FFFFFFF, 0x7FFFFFFF };
     uint32_t nxt = fetch(j_begin);
     stage(0, nxt);
     int buf = 0;
@@ -132,36 +138,31 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
         __syncthreads();                                           // tile `buf` is staged; the other buffer is free again
         const bool more = j0 + 32 < j_end;
         if (more) nxt = fetch(j0 + 32);
-        hm_v16i cin;
-        if (j0 + 32 <= j_end) {
-#pragma unroll
-            for (int v = 0; v < 16; v++) cin[v] = tc[v];
-        } else {                                                   // ragged last tile: rows past the end can never win
-#pragma unroll
-            for (int v = 0; v < 16; v++) cin[v] = tc[v] < j_end ? tc[v] : 0x3FFFFFFF;
-        }
-        hm_v16i acc0 = cin, acc1 = cin;
+        hm_v16i acc0 = tc0, acc1 = tc0;
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) {
             const hm_v4i a = tileA[buf][s8 * 64 + (lane ^ s8)];
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[0][s8], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, Bq[1][s8], acc1, 0, 0, 0);
         }
+        if (j0 + 32 > j_end) {                                     // ragged last tile: rows past the end can never win
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            best[0][i] = min(best[0][i], min(acc0[2 * i], acc0[2 * i + 1]));
-            best[1][i] = min(best[1][i], min(acc1[2 * i], acc1[2 * i + 1]));
+            for (int v = 0; v < 16; v++) { const bool in = j0 + tc0[v] < j_end; acc0[v] = in ? acc0[v] : 0x3FFFFFFF; acc1[v] = in ? acc1[v] : 0x3FFFFFFF; }
         }
-#pragma unroll
-        for (int v = 0; v < 16; v++) tc[v] += 32;
+        auto min3 = [](int a, int b, int c) -> int { return min(min(a, b), c); };        // v_min3_i32
+        auto min16 = [&](const hm_v16i& a) -> int {
+            const int t0 = min3(a[0], a[1], a[2]), t1 = min3(a[3], a[4], a[5]), t2 = min3(a[6], a[7], a[8]);
+            const int t3 = min3(a[9], a[10], a[11]), t4 = min3(a[12], a[13], a[14]);
+            return min(min3(t0, t1, a[15]), min3(t2, t3, t4));
+        };
+        best[0] = min(best[0], min16(acc0) + j0);
+        best[1] = min(best[1], min16(acc1) + j0);
         if (more) stage(buf ^ 1, nxt);
     }
-    // ---- per query column: min over the 8 registers, then over the two lane halves; D -> (distance << 16 | index) ----
+    // ---- per query column: min over the two lane halves; D -> (distance << 16 | index) ----
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-        int m = best[st][0];
-#pragma unroll
-        for (int i = 1; i < 8; i++) m = min(m, best[st][i]);
+        int m = best[st];
         m = min(m, __shfl_xor(m, 32, 64));
         const int q = (int)blockIdx.y * HM_QB + wid * 64 + st * 32 + col;
         if (half == 0 && q < nq && m < 0x30000000) {
