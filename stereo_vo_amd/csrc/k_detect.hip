@@ -1949,7 +1949,7 @@ void launch_describe(const DevCtx& c, int pre, hipStream_t st)
     if (c.n_slots <= 0) return;
     // keypoints per wave: SVO_DESC_KPW overrides the default for an A/B (1 = a wave per keypoint, as rounds 1-3)
     static int kpw = 0;
-    if (!kpw) { const char* e = getenv("SVO_DESC_KPW"); const int v = e ? atoi(e) : 0; kpw = (v >= 1 && v <= 64) ? v : 4; }       // <= 64: a wave keeps its work items one per lane
+    if (!kpw) { const char* e = getenv("SVO_DESC_KPW"); const int v = e ? atoi(e) : 0; kpw = (v >= 1 && v <= 64) ? v : 8; }       // <= 64: a wave keeps its work items one per lane
     const int per = 4 * kpw, gx = (c.n_slots + per - 1) / per, img8 = (c.n_img + 7) / 8 * 8;
     hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0, kpw);
 }

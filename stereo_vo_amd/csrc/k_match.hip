@@ -61,7 +61,8 @@ __device__ __forceinline__ uint32_t hm_spread4(uint32_t nib, uint32_t base)
 {
     uint32_t m;                                                     // (as asm: hipcc turns __umul24 of a 4-bit value back into v_mul_lo_u32)
     asm("v_mul_u32_u24_e32 %0, 0x204081, %1" : "=v"(m) : "v"(nib));
-    return base ^ ((m & 0x01010101u) << 7);
+    // base 0x40: bytes 0x40 / 0xC0 for bit 0 / 1 = 0x40 + (bit << 7); base 0xC0: 0xC0 / 0x40 = 0x40 + (!bit << 7) -- one and, one v_lshl_add
+    return base == 0x40404040u ? (((m & 0x01010101u) << 7) + 0x40404040u) : (((~m & 0x01010101u) << 7) + 0x40404040u);
 }
 // 16 bits (low half of `bits`) -> 16 bytes
 __device__ __forceinline__ hm_v4i hm_expand16(uint32_t bits, uint32_t base)
@@ -72,7 +73,7 @@ __device__ __forceinline__ hm_v4i hm_expand16(uint32_t bits, uint32_t base)
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
+__device__ __forceinline__ void hamming_body(const DevCtx& c, int mode, int nsplit)
 {
     __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][16 * 32];          // [buffer][k-step * 64 + ((half * 32 + row) ^ k-step)]
     // grid = (lane-octave, query block, side x split): the query blocks past nq exit at once, and with the lane index
@@ -173,6 +174,11 @@ __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit)
         }
     }
 }
+
+// two builds of the same body: 142 VGPRs = 3 waves per SIMD, or capped at 128 = 4 waves per SIMD at the price of one 16-byte
+// spill reloaded per train tile (SVO_HAM_WAVES = 3 / 4 picks, see launch_hamming)
+__global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit) { hamming_body(c, mode, nsplit); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_hamming_w4(DevCtx c, int mode, int nsplit) { hamming_body(c, mode, nsplit); }
 
 // ------------------------------------------------------------------------------------------------------------
 // K8a: stage-3 filters (S3:124-175), one 1024-thread block per lane.
@@ -1559,7 +1565,11 @@ hipError_t configure_match(int max_kps)
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_hamming, dim3(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
+    static int w4 = -1;
+    if (w4 < 0) { const char* e = getenv("SVO_HAM_WAVES"); w4 = (e && atoi(e) == 4) ? 1 : 0; }
+    const dim3 grid(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit);
+    if (w4) hipLaunchKernelGGL(k_hamming_w4, grid, dim3(256), 0, st, c, mode, nsplit);
+    else hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, c, mode, nsplit);
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)
