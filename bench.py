@@ -260,6 +260,7 @@ def main():
     allrec = None
     for i in range(args.steps):
         allrec = step(args.warmup + i)
+    t_enqueue = time.perf_counter() - t0          # the host's share: every launch of the timed steps is enqueued (not: executed) by now
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     dt = reduce_max(dt, dev, world)
@@ -410,6 +411,7 @@ def main():
                        "frames_per_trajectory": F, "distinct_frames_per_stream": min(total_steps, F), "render_s": round(t_render, 1),
                        "parallelism": "streams sharded across %d GPU(s), result all-gather per step" % world},
             "timed_region_s": round(dt, 4),
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4),
             "fast_redo_rate": round(redo_pairs / float(max(1, args.steps * 2 * B * (n_octaves if detect_fast_orb else 8))), 6),
             "fast_redo_note": "(image, level) pairs of the timed steps whose speculative FAST threshold found too few corners and ran k_fast again at the caller's threshold (%d of %d); every frame of the run is new to its stream" % (redo_pairs, args.steps * 2 * B * (n_octaves if detect_fast_orb else 8)),
             "scene_cuts": scene_cuts,

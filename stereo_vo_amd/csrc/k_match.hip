@@ -175,10 +175,9 @@ __device__ __forceinline__ void hamming_body(const DevCtx& c, int mode, int nspl
     }
 }
 
-// two builds of the same body: 142 VGPRs = 3 waves per SIMD, or capped at 128 = 4 waves per SIMD at the price of one 16-byte
-// spill reloaded per train tile (SVO_HAM_WAVES = 3 / 4 picks, see launch_hamming)
+// (a build capped at 128 VGPRs = 4 waves per SIMD instead of 3 pays one 16-byte spill reloaded per train tile: 50.5 against 45.4 us
+// per launch at 64 lanes, profiles/r04f -- dropped)
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit) { hamming_body(c, mode, nsplit); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_hamming_w4(DevCtx c, int mode, int nsplit) { hamming_body(c, mode, nsplit); }
 
 // ------------------------------------------------------------------------------------------------------------
 // K8a: stage-3 filters (S3:124-175), one 1024-thread block per lane.
@@ -1565,11 +1564,7 @@ hipError_t configure_match(int max_kps)
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
-    static int w4 = -1;
-    if (w4 < 0) { const char* e = getenv("SVO_HAM_WAVES"); w4 = (e && atoi(e) == 4) ? 1 : 0; }
-    const dim3 grid(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit);
-    if (w4) hipLaunchKernelGGL(k_hamming_w4, grid, dim3(256), 0, st, c, mode, nsplit);
-    else hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, c, mode, nsplit);
+    hipLaunchKernelGGL(k_hamming, dim3(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)
