@@ -1036,14 +1036,17 @@ __device__ __forceinline__ void glds16_asm(const uint8_t* gaddr, uint32_t lds_ba
 // 16-byte table loads per lane (Gaussian operands, test pairs) and the slot -> level -> geometry prologue were latency and
 // set-up paid per keypoint.  Now a wave keeps the tables in registers across its keypoints and the window of keypoint i + 1 is
 // in flight (LDS-DMA into the wave's second buffer) while keypoint i is computed.
-template <int NW>
+// TL: the Gaussian operands too live in LDS and are fetched at the head of their pass (24 VGPRs less: 5 waves per SIMD instead of 4)
+template <int NW, bool TL>
 __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, int pre, int kpw)
 {
     __shared__ __attribute__((aligned(16))) uint32_t raw32[NW][2][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
     __shared__ __attribute__((aligned(16))) float4 s_pat[SVO_BRIEF_NPAIRS];                   // the test pairs and the disc weights: one copy per block
     __shared__ uint32_t s_disc_m[SVO_DISC_E], s_disc_x[SVO_DISC_E];
     static_assert(NW * 64 == SVO_BRIEF_NPAIRS && NW * 64 == SVO_DISC_E, "one table entry per thread");
+    __shared__ __attribute__((aligned(16))) uint4 s_gh[TL ? 3 * 64 : 1], s_gv[TL ? 3 * 64 : 1];
     s_pat[threadIdx.x] = g_brief_patf[threadIdx.x]; s_disc_m[threadIdx.x] = g_disc_m[threadIdx.x]; s_disc_x[threadIdx.x] = g_disc_x[threadIdx.x];
+    if (TL && threadIdx.x < 3 * 64) { s_gh[threadIdx.x] = g_blur_gh[threadIdx.x]; s_gv[threadIdx.x] = g_blur_gv[threadIdx.x]; }
     __syncthreads();                                         // the only block barrier: before any wave can leave
     // the wave index is uniform but lives in a VGPR: readfirstlane moves the whole slot / level / geometry prologue to
     // the scalar unit
@@ -1068,11 +1071,11 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
     // the constant operands of the two passes and this lane's four test pairs
     dp_v4i GH[3], GV[3];
 #pragma unroll
-    for (int t = 0; t < 3; t++) { GH[t] = *(const dp_v4i*)&g_blur_gh[t * 64 + lane]; GV[t] = *(const dp_v4i*)&g_blur_gv[t * 64 + lane]; }
+    for (int t = 0; t < 3; t++) { if (!TL) { GH[t] = *(const dp_v4i*)&g_blur_gh[t * 64 + lane]; GV[t] = *(const dp_v4i*)&g_blur_gv[t * 64 + lane]; } else { GH[t] = dp_v4i{0, 0, 0, 0}; GV[t] = GH[t]; } }
     // the tables are "used" here, ahead of the loop: the compiler then waits for them once, here, instead of re-stating its
     // s_waitcnt vmcnt at their first uses inside the loop -- where it would wait out the next keypoint's window as well
 #pragma unroll
-    for (int t = 0; t < 3; t++) asm volatile("" : "+v"(GH[t]), "+v"(GV[t]));
+    for (int t = 0; t < 3; t++) if (!TL) asm volatile("" : "+v"(GH[t]), "+v"(GV[t]));
     // the work items of this wave's slots: lane i holds slot0 + i (one vector load ahead of the loop; an item is then two v_readlane)
     uint32_t w_pos = 0, w_lvl = 0;
     if (slot0 + lane < slot1) {
@@ -1147,6 +1150,10 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
             // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
             dp_v4i S[3][3];
             {
+                if (TL) {
+#pragma unroll
+                    for (int t = 0; t < 3; t++) GH[t] = *(const dp_v4i*)&s_gh[t * 64 + lane];
+                }
                 const dp_v4i seed = { 128, 128, 128, 128 };
 #pragma unroll
                 for (int mt = 0; mt < 3; mt++) {
@@ -1160,6 +1167,10 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
             // ---- D: vertical pass; lane (n16, q4) owns k-group q4 of column n16 already ----
             uint8_t* Bl = (uint8_t*)R32;
             {
+                if (TL) {
+#pragma unroll
+                    for (int t = 0; t < 3; t++) GV[t] = *(const dp_v4i*)&s_gv[t * 64 + lane];
+                }
                 const int c2 = 257 * 32896 + 32768;
                 const dp_v4i seed_lo = { c2, c2, c2, c2 }, zero = { 0, 0, 0, 0 };
 #pragma unroll
@@ -1951,7 +1962,10 @@ void launch_describe(const DevCtx& c, int pre, hipStream_t st)
     static int kpw = 0;
     if (!kpw) { const char* e = getenv("SVO_DESC_KPW"); const int v = e ? atoi(e) : 0; kpw = (v >= 1 && v <= 64) ? v : 8; }       // <= 64: a wave keeps its work items one per lane
     const int per = 4 * kpw, gx = (c.n_slots + per - 1) / per, img8 = (c.n_img + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0, kpw);
+    static int tl = -1;
+    if (tl < 0) { const char* e = getenv("SVO_DESC_TL"); tl = (e && atoi(e) == 1) ? 1 : 0; }
+    if (tl) hipLaunchKernelGGL((k_describe<4, true>), dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0, kpw);
+    else hipLaunchKernelGGL((k_describe<4, false>), dim3((unsigned)((long long)gx * img8)), dim3(256), 0, st, c, make_fastdiv((uint32_t)gx), (pre && !c.fast_orb) ? 1 : 0, kpw);
 }
 
 #define FO_PMAX 2048     // chunk size of k_fastorb_nms (LDS: 45 B per entry)

@@ -14,7 +14,7 @@ try:
     print(sys.argv[1], d["value"], "pairs/s", d["ms_per_step"], "ms/step;", d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], "ms;", d["valid_last_step"], "valid; kps", d["mean_kps"], "matches", d["mean_matches"], "tracked", d["mean_tracked"], "redo", d["fast_redo_rate"], "timed", d["timed_region_s"], "render", d["config"]["render_s"])
     print("   roofline", json.dumps(d["roofline"].get("exclusive")), d["roofline"]["frac"])
     print("   kernels", d["kernels_ms_per_context_step"])
-    print("   funnel", d["track_funnel_mean"])
+    print("   funnel", d["track_funnel_mean"]); print("   legs", d.get("legs_s"), "host enqueue", d.get("host_enqueue_ms_per_step"))
     for k in ("parity_probe", "scene_cuts", "other_workloads", "host_fed", "single_stream", "cpu_baseline", "pose_rmse_vs_cpu", "other_scene"):
         print("   ", k, json.dumps(d.get(k))[:900])
 except Exception as e:
