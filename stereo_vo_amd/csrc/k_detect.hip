@@ -287,6 +287,16 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
     }
 }
 
+// LDS-DMA written as asm: 16 bytes per lane from the lane's global address to LDS byte `lds_base` + 16 * lane.  Through the
+// builtin the compiler cannot tell which LDS bytes a transfer writes and puts s_waitcnt vmcnt(0) before EVERY later LDS access,
+// i.e. a window in flight for the NEXT keypoint would be waited for at once.  As asm the transfer is invisible to that logic; the
+// kernel waits for it itself (s_waitcnt vmcnt(0) at the top of the keypoint loop).  The compiler's own vmcnt arithmetic stays
+// safe: these transfers only add to the outstanding count, so its waits can only get stricter.
+__device__ __forceinline__ void glds16_asm(const uint8_t* gaddr, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gaddr), "s"(lds_base) : "memory", "m0");
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K2: FAST-9/16 score + 3x3 non-max suppression, all levels of all images in one launch.
 // Integer VALU issue bounds this kernel (97-99 % of the issue slots, profiles/r03*_pmc.json), so the design minimises
@@ -402,42 +412,65 @@ static_assert((FT_W * FT_H / 4 + 64) * 4 <= FT_LH * FT_LW, "out_keys aliases the
 // profiles/r03_pmc.json), and what does not scale with the pixels -- staging, the fixed part of the compaction, the
 // publication -- is paid per tile.  The list of the cardinal test's survivors is capped (LDS per tile decides how many tiles a
 // CU holds); what does not fit stays with the thread that found it and is scored / suppressed by its owner after the listed ones.
-__device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
+// the window [x0-5, x0+75) x [y0-4, y0+FT_H+4) by LDS-DMA (global_load_lds_dwordx4): a wave-instruction lands 64 x 16 bytes at LDS
+// base + lane * 16 straight from the lanes' global addresses, no VGPR round trip and no ds_write.  The window is FT_LH rows x 5
+// chunks of 16 bytes, chunk i at LDS byte 16 i (pitch 80): wave w takes chunks 128 j + 64 w + lane.  The source may sit at ANY byte
+// alignment and the destination base at any dword (tools/ubench/glds_align.hip pins both on the hardware), so one path serves every
+// pointer / stride.  Chunks are clamped to the image proper (x <= gw - 16, y <= gh - 1): a clamped chunk holds shifted bytes, but only
+// columns >= gw - 16 can be affected and nothing right of column gw - 28 is ever read by an interior position (EDGE 31 - radius 3 -
+// NMS halo 1).  ASM: the transfer as inline asm (glds16_asm), invisible to the compiler's LDS ordering: the persistent kernel keeps
+// the NEXT tile's window in flight and waits for it itself.
+template <bool ASM>
+__device__ __forceinline__ void fast_stage(uint8_t* tile, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0)
 {
-    uint8_t* tile = sm.tile; uint8_t* score = sm.score; unsigned short* list = sm.list; uint32_t* out_keys = (uint32_t*)sm.tile;
-    unsigned& s_count = sm.s_count; unsigned& s_nout = sm.s_nout;
+    const int tid = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto chunk_src = [&](int i) -> const uint8_t* {
+        const int r = (i * 205) >> 10, q = i - 5 * r;                   // i / 5, i % 5 for i < 1024
+        const int yy = min(y0 - 4 + r, gh - 1), xx = min(x0 - 5 + 16 * q, gw - 16);
+        return src + (uint32_t)(yy * pitch + xx);                       // 32-bit offset from the level's uniform base
+    };
+    typedef const void __attribute__((address_space(1)))* gptr_t;
+    typedef void __attribute__((address_space(3)))* lptr_t;
+    const uint32_t lb = ASM ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)tile) : 0u;
+#pragma unroll
+    for (int j = 0; j < (FT_CHUNKS + FT_NT - 1) / FT_NT; j++) {
+        if (j * FT_NT + FT_NT <= FT_CHUNKS || j * FT_NT + tid < FT_CHUNKS) {
+            if (ASM) glds16_asm(chunk_src(j * FT_NT + tid), lb + (uint32_t)(j * (FT_NT * 16) + wid * 1024));
+            else __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(j * FT_NT + tid), (lptr_t)(tile + j * (FT_NT * 16) + wid * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// counters and score map of a tile: cleared BEFORE its window is waited for (through the builtin the compiler orders every LDS
+// store behind an outstanding LDS-DMA, so a store placed after the issue would wait out the whole fetch)
+__device__ __forceinline__ void fast_reset(uint8_t* score, unsigned& s_count, unsigned& s_nout)
+{
     const int tid = threadIdx.x;
     if (tid == 0) { s_nout = 0; s_count = 0; }
-    // the score map is cleared BEFORE the DMA is issued: the compiler orders every LDS store behind an outstanding LDS-DMA
-    // (s_waitcnt vmcnt(0)), so a store placed after it would wait out the whole fetch
     constexpr int N16 = (FT_SH * FT_SP + 15) / 16;
 #pragma unroll
     for (int i = 0; i < (N16 + FT_NT - 1) / FT_NT; i++) if (i * FT_NT + tid < N16) ((uint4*)score)[i * FT_NT + tid] = make_uint4(0, 0, 0, 0);
-    // ---- stage the window [x0-5, x0+75) x [y0-4, y0+FT_H+4) with the LDS-DMA path (global_load_lds_dwordx4): a wave-instruction
-    //      lands 64 x 16 bytes at LDS base + lane * 16 straight from the lanes' global addresses, no VGPR round trip and no
-    //      ds_write.  The window is FT_LH rows x 5 chunks of 16 bytes, chunk i at LDS byte 16 i (pitch 80): wave w takes chunks
-    //      128 j + 64 w + lane.  The source may sit at ANY byte alignment and the destination base at any dword
-    //      (tools/ubench/glds_align.hip pins both on the hardware), so one path serves every pointer / stride.  Chunks are
-    //      clamped to the image proper (x <= gw - 16, y <= gh - 1): a clamped chunk holds shifted bytes, but only columns
-    //      >= gw - 16 can be affected and nothing right of column gw - 28 is ever read by an interior position (EDGE 31 -
-    //      radius 3 - NMS halo 1).
-    {
-        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-        auto chunk_src = [&](int i) -> const uint8_t* {
-            const int r = (i * 205) >> 10, q = i - 5 * r;                   // i / 5, i % 5 for i < 1024
-            const int yy = min(y0 - 4 + r, gh - 1), xx = min(x0 - 5 + 16 * q, gw - 16);
-            return src + (uint32_t)(yy * pitch + xx);                       // 32-bit offset from the level's uniform base
-        };
-        typedef const void __attribute__((address_space(1)))* gptr_t;
-        typedef void __attribute__((address_space(3)))* lptr_t;
-#pragma unroll
-        for (int j = 0; j < (FT_CHUNKS + FT_NT - 1) / FT_NT; j++) {
-            if (j * FT_NT + FT_NT <= FT_CHUNKS) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(j * FT_NT + tid), (lptr_t)(tile + j * (FT_NT * 16) + wid * 1024), 16, 0, 0);
-            else if (j * FT_NT + tid < FT_CHUNKS) __builtin_amdgcn_global_load_lds((gptr_t)chunk_src(j * FT_NT + tid), (lptr_t)(tile + j * (FT_NT * 16) + wid * 1024), 16, 0, 0);
-        }
-    }
+}
+
+__device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uint8_t* score, unsigned short* list, unsigned& s_count, unsigned& s_nout,
+                                             int img, int level, int gw, int gh, int x0, int y0, int th_fast);
+
+__device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
+{
+    fast_reset(sm.score, sm.s_count, sm.s_nout);
+    fast_stage<false>(sm.tile, src, pitch, gw, gh, x0, y0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's DMA chunks have landed; the barrier covers the other wave's
     __syncthreads();
+    fast_compute(c, sm.tile, sm.score, sm.list, sm.s_count, sm.s_nout, img, level, gw, gh, x0, y0, th_fast);
+}
+
+// everything of a tile after its window is in LDS (block-uniform early exits only; the caller's next barrier is its own)
+__device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uint8_t* score, unsigned short* list, unsigned& s_count, unsigned& s_nout,
+                                             int img, int level, int gw, int gh, int x0, int y0, int th_fast)
+{
+    uint32_t* out_keys = (uint32_t*)tile;
+    const int tid = threadIdx.x;
     if (c.debug_mode == 1) return;
     // ---- (1) packed cardinal test: thread -> group column gq (positions q = 4 gq .. 4 gq + 3), score rows 8 rb .. 8 rb + 7 ----
     const uint32_t th = (uint32_t)th_fast;
@@ -605,6 +638,62 @@ __global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint8_t* src = level == 0 ? base0 : c.pyr + (long long)img * c.pyr_bytes + e.w;
     const int pitch = level == 0 ? c.img0_pitch : (int)(e.z >> 8);
     fast_tile(c, sm, img, level, src, pitch, (int)(e.y & 0xFFFFu), (int)(e.y >> 16), (int)(e.x & 0xFFFFu), (int)(e.x >> 16), (int)th);
+}
+
+// Persistent form (round 4, SVO_FAST_TPB = tiles per workgroup): a workgroup works through FT_TPB consecutive tiles of its XCD
+// chunk with TWO window buffers -- the next tile's window is in flight (LDS-DMA as asm, see glds16_asm) while the current one is
+// tested, scored and suppressed; the kernel's own s_waitcnt + barrier at the top of a tile is the only wait.  ~1.5 us of a tile's
+// ~8 us life were the fetch.  16.4 KB of LDS per workgroup: 9 workgroups = 18 waves per CU against 30 of the one-tile form.
+struct FastSmemP {
+    __attribute__((aligned(16))) uint8_t tile[2][FT_LH * FT_LW];
+    __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 80];
+    unsigned short list[FT_LIST_CAP];
+    unsigned s_count, s_nout;
+};
+
+__global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fast_p(DevCtx c, int tpb)
+{
+    __shared__ FastSmemP sm;
+    // blockIdx -> (XCD, chunk, first tile of this workgroup inside the chunk): chunk k of FT_CHUNK consecutive tiles goes to XCD
+    // k % 8 as in k_fast; FT_CHUNK / tpb workgroups share a chunk
+    const uint32_t q = blockIdx.x >> 3, per = FT_CHUNK / (uint32_t)tpb;
+    const uint32_t work0 = ((q / per) * 8 + (blockIdx.x & 7)) * FT_CHUNK + (q % per) * (uint32_t)tpb;
+    struct Tile { int img, level, pitch, gw, gh, x0, y0, th; const uint8_t* src; bool ok; };
+    auto decode = [&](uint32_t work) -> Tile {
+        Tile t;
+        t.img = (int)fastdiv(work, c.div_tiles);
+        t.ok = t.img < c.n_img;
+        const int img = t.ok ? t.img : 0, tile_id = t.ok ? (int)work - t.img * c.n_tiles : 0;
+        const uint4 e = c.fast_tiles[tile_id];
+        const uint4 tha = ((const uint4*)(c.fast_th_used + img * SVO_MAX_LEVELS))[0], thb = ((const uint4*)(c.fast_th_used + img * SVO_MAX_LEVELS))[1];
+        const uint8_t* base0 = c.img0[img];
+        t.level = (int)(e.z & 0xFFu);
+        const uint32_t thv[8] = { tha.x, tha.y, tha.z, tha.w, thb.x, thb.y, thb.z, thb.w };
+        uint32_t th = thv[0];
+#pragma unroll
+        for (int l = 1; l < SVO_MAX_LEVELS; l++) th = t.level == l ? thv[l] : th;
+        t.th = (int)th;
+        t.src = t.level == 0 ? base0 : c.pyr + (long long)img * c.pyr_bytes + e.w;
+        t.pitch = t.level == 0 ? c.img0_pitch : (int)(e.z >> 8);
+        t.gw = (int)(e.y & 0xFFFFu); t.gh = (int)(e.y >> 16); t.x0 = (int)(e.x & 0xFFFFu); t.y0 = (int)(e.x >> 16);
+        return t;
+    };
+    Tile cur = decode(work0);
+    if (!cur.ok) return;                                                     // tiles are image-major: nothing after the last image
+    fast_stage<true>(sm.tile[0], cur.src, cur.pitch, cur.gw, cur.gh, cur.x0, cur.y0);
+    for (int i = 0; i < tpb; i++) {
+        Tile nxt; nxt.ok = false;
+        if (i + 1 < tpb) nxt = decode(work0 + (uint32_t)i + 1u);
+        // thread 0 resets the counters after ITS publication of the tile before (program order); the score map is free since the
+        // barrier behind that tile's suppression
+        fast_reset(sm.score, sm.s_count, sm.s_nout);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's chunks of the current window
+        __syncthreads();                                                     // ... and the other wave's; the other buffer's last reader (the publication two tiles back) is done
+        if (nxt.ok) fast_stage<true>(sm.tile[(i + 1) & 1], nxt.src, nxt.pitch, nxt.gw, nxt.gh, nxt.x0, nxt.y0);
+        fast_compute(c, sm.tile[i & 1], sm.score, sm.list, sm.s_count, sm.s_nout, cur.img, cur.level, cur.gw, cur.gh, cur.x0, cur.y0, cur.th);
+        if (!nxt.ok) break;                                                  // block-uniform
+        cur = nxt;
+    }
 }
 
 // The (image, level) pairs whose speculated threshold found fewer than 2 * quota corners (k_select) again, with the
@@ -1019,16 +1108,6 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
 {
     // the builtin, not inline asm: the hazard recogniser must see a DOT op to pad its result's wait states
     return __builtin_amdgcn_udot4(a, b, acc, false);
-}
-
-// LDS-DMA written as asm: 16 bytes per lane from the lane's global address to LDS byte `lds_base` + 16 * lane.  Through the
-// builtin the compiler cannot tell which LDS bytes a transfer writes and puts s_waitcnt vmcnt(0) before EVERY later LDS access,
-// i.e. a window in flight for the NEXT keypoint would be waited for at once.  As asm the transfer is invisible to that logic; the
-// kernel waits for it itself (s_waitcnt vmcnt(0) at the top of the keypoint loop).  The compiler's own vmcnt arithmetic stays
-// safe: these transfers only add to the outstanding count, so its waits can only get stricter.
-__device__ __forceinline__ void glds16_asm(const uint8_t* gaddr, uint32_t lds_base)
-{
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gaddr), "s"(lds_base) : "memory", "m0");
 }
 
 // NW waves per block, each working through `kpw` consecutive keypoints of one image (no block barrier: every wave owns its LDS
@@ -1938,7 +2017,11 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 {
     if (c.n_tiles <= 0) return;
     const long long total = (long long)c.n_tiles * c.n_img, unit = 8 * FT_CHUNK;
-    hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(FT_NT), 0, st, c);
+    // SVO_FAST_TPB = 2 / 4 / 8: the persistent form with that many tiles per workgroup (A/B); default 1 = a workgroup per tile
+    static int tpb = 0;
+    if (!tpb) { const char* e = getenv("SVO_FAST_TPB"); const int v = e ? atoi(e) : 0; tpb = (v == 2 || v == 4 || v == 8 || v == 16) ? v : 1; }
+    if (tpb > 1) hipLaunchKernelGGL(k_fast_p, dim3((unsigned)((total + unit - 1) / unit * unit / tpb)), dim3(FT_NT), 0, st, c, tpb);
+    else hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(FT_NT), 0, st, c);
 }
 
 void launch_select(const DevCtx& c, hipStream_t st)

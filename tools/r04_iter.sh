@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU box: one build -> measure iteration: the detector / matcher parity tests first (fail fast), a short bench line, the 1-context
-# kernel stats and (with PMC=1) the counter passes.  usage: gpurun -- 'PMC=1 bash tools/r04_iter.sh <tag> [extra bench args]'
+# kernel stats and (with PMC=1) the counter passes.  PARITY_ENV="NAME=VALUE": the parity subset runs under that environment.  usage: gpurun -- 'PMC=1 bash tools/r04_iter.sh <tag> [extra bench args]'
 cd ${GRAFT_REPO_ROOT:-.}
 tag=${1:-r04i}; shift
 mkdir -p gpurun_out
-( time timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "small_sequence or pyramid_and_detector or noise_images or full_size or hamming_match or speculative_fast or fast_orb_multi or random_parameter_sets_match or sixty_four" ) > gpurun_out/${tag}_first.log 2>&1
+( time timeout 900 env $PARITY_ENV python -m pytest tests/test_gpu_parity.py -x -q -k "small_sequence or pyramid_and_detector or noise_images or full_size or hamming_match or speculative_fast or fast_orb_multi or random_parameter_sets_match or sixty_four" ) > gpurun_out/${tag}_first.log 2>&1
 echo "first rc=$?" >> gpurun_out/${tag}_first.log
 tail -6 gpurun_out/${tag}_first.log
 Q="--steps 40 --warmup 6 --cpu-frames 12 --host-fed-steps 0 --single-stream 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
