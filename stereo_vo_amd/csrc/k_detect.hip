@@ -640,62 +640,10 @@ __global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8
     fast_tile(c, sm, img, level, src, pitch, (int)(e.y & 0xFFFFu), (int)(e.y >> 16), (int)(e.x & 0xFFFFu), (int)(e.x >> 16), (int)th);
 }
 
-// Persistent form (round 4, SVO_FAST_TPB = tiles per workgroup): a workgroup works through FT_TPB consecutive tiles of its XCD
-// chunk with TWO window buffers -- the next tile's window is in flight (LDS-DMA as asm, see glds16_asm) while the current one is
-// tested, scored and suppressed; the kernel's own s_waitcnt + barrier at the top of a tile is the only wait.  ~1.5 us of a tile's
-// ~8 us life were the fetch.  16.4 KB of LDS per workgroup: 9 workgroups = 18 waves per CU against 30 of the one-tile form.
-struct FastSmemP {
-    __attribute__((aligned(16))) uint8_t tile[2][FT_LH * FT_LW];
-    __attribute__((aligned(16))) uint8_t score[FT_SH * FT_SP + 80];
-    unsigned short list[FT_LIST_CAP];
-    unsigned s_count, s_nout;
-};
-
-__global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fast_p(DevCtx c, int tpb)
-{
-    __shared__ FastSmemP sm;
-    // blockIdx -> (XCD, chunk, first tile of this workgroup inside the chunk): chunk k of FT_CHUNK consecutive tiles goes to XCD
-    // k % 8 as in k_fast; FT_CHUNK / tpb workgroups share a chunk
-    const uint32_t q = blockIdx.x >> 3, per = FT_CHUNK / (uint32_t)tpb;
-    const uint32_t work0 = ((q / per) * 8 + (blockIdx.x & 7)) * FT_CHUNK + (q % per) * (uint32_t)tpb;
-    struct Tile { int img, level, pitch, gw, gh, x0, y0, th; const uint8_t* src; bool ok; };
-    auto decode = [&](uint32_t work) -> Tile {
-        Tile t;
-        t.img = (int)fastdiv(work, c.div_tiles);
-        t.ok = t.img < c.n_img;
-        const int img = t.ok ? t.img : 0, tile_id = t.ok ? (int)work - t.img * c.n_tiles : 0;
-        const uint4 e = c.fast_tiles[tile_id];
-        const uint4 tha = ((const uint4*)(c.fast_th_used + img * SVO_MAX_LEVELS))[0], thb = ((const uint4*)(c.fast_th_used + img * SVO_MAX_LEVELS))[1];
-        const uint8_t* base0 = c.img0[img];
-        t.level = (int)(e.z & 0xFFu);
-        const uint32_t thv[8] = { tha.x, tha.y, tha.z, tha.w, thb.x, thb.y, thb.z, thb.w };
-        uint32_t th = thv[0];
-#pragma unroll
-        for (int l = 1; l < SVO_MAX_LEVELS; l++) th = t.level == l ? thv[l] : th;
-        t.th = (int)th;
-        t.src = t.level == 0 ? base0 : c.pyr + (long long)img * c.pyr_bytes + e.w;
-        t.pitch = t.level == 0 ? c.img0_pitch : (int)(e.z >> 8);
-        t.gw = (int)(e.y & 0xFFFFu); t.gh = (int)(e.y >> 16); t.x0 = (int)(e.x & 0xFFFFu); t.y0 = (int)(e.x >> 16);
-        return t;
-    };
-    Tile cur = decode(work0);
-    if (!cur.ok) return;                                                     // tiles are image-major: nothing after the last image
-    fast_stage<true>(sm.tile[0], cur.src, cur.pitch, cur.gw, cur.gh, cur.x0, cur.y0);
-    for (int i = 0; i < tpb; i++) {
-        Tile nxt; nxt.ok = false;
-        if (i + 1 < tpb) nxt = decode(work0 + (uint32_t)i + 1u);
-        // thread 0 resets the counters after ITS publication of the tile before (program order); the score map is free since the
-        // barrier behind that tile's suppression
-        fast_reset(sm.score, sm.s_count, sm.s_nout);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's chunks of the current window
-        __syncthreads();                                                     // ... and the other wave's; the other buffer's last reader (the publication two tiles back) is done
-        if (nxt.ok) fast_stage<true>(sm.tile[(i + 1) & 1], nxt.src, nxt.pitch, nxt.gw, nxt.gh, nxt.x0, nxt.y0);
-        fast_compute(c, sm.tile[i & 1], sm.score, sm.list, sm.s_count, sm.s_nout, cur.img, cur.level, cur.gw, cur.gh, cur.x0, cur.y0, cur.th);
-        if (!nxt.ok) break;                                                  // block-uniform
-        cur = nxt;
-    }
-}
-
+// (A persistent form -- a workgroup working through 2 / 4 / 8 consecutive tiles with two window buffers, the next tile's window in
+// flight by asm LDS-DMA while the current one is tested -- was built in round 4, bit-exact, and measured at 0.305 / 0.313 / 0.331 ms
+// against 0.259 ms: 16.4 KB of LDS per workgroup leave 18 waves per CU where the one-tile form keeps 30, and this kernel lives on
+// occupancy (profiles/r04k_*).  Dropped; the stage / compute split below is what is left of it.)
 // The (image, level) pairs whose speculated threshold found fewer than 2 * quota corners (k_select) again, with the
 // caller's threshold.  Normally the list is empty and the launch retires at once; otherwise the workgroups stride over
 // the concatenated tile lists of the listed pairs.
@@ -2017,11 +1965,7 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 {
     if (c.n_tiles <= 0) return;
     const long long total = (long long)c.n_tiles * c.n_img, unit = 8 * FT_CHUNK;
-    // SVO_FAST_TPB = 2 / 4 / 8: the persistent form with that many tiles per workgroup (A/B); default 1 = a workgroup per tile
-    static int tpb = 0;
-    if (!tpb) { const char* e = getenv("SVO_FAST_TPB"); const int v = e ? atoi(e) : 0; tpb = (v == 2 || v == 4 || v == 8 || v == 16) ? v : 1; }
-    if (tpb > 1) hipLaunchKernelGGL(k_fast_p, dim3((unsigned)((total + unit - 1) / unit * unit / tpb)), dim3(FT_NT), 0, st, c, tpb);
-    else hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(FT_NT), 0, st, c);
+    hipLaunchKernelGGL(k_fast, dim3((unsigned)((total + unit - 1) / unit * unit)), dim3(FT_NT), 0, st, c);
 }
 
 void launch_select(const DevCtx& c, hipStream_t st)
