@@ -179,6 +179,124 @@ __device__ __forceinline__ void hamming_body(const DevCtx& c, int mode, int nspl
 // per launch at 64 lanes, profiles/r04f -- dropped)
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit) { hamming_body(c, mode, nsplit); }
 
+// ---- the same brute force on gfx950's block-scaled FP4 matrix path (round 4) ------------------------------------------------
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands FP4 (E2M1) runs at twice the int8 rate on half the operand bytes, and E2M1 holds
+// +1 (0x2) and -1 (0xA) exactly: bit b of a query -> -1 / +1 ... no: query bit 0 / 1 -> +1 / -1, train bit 0 / 1 -> -1 / +1, so a
+// product is -1 where the bits agree and the sum over the 256 bits is 2 ham - 256, exact in the f32 accumulator; both block scales are
+// 2^0 (E8M0 127).  The C operand is row / 8192 (the row inside the 32-row tile), so D = 2 ham - 256 + row / 8192 orders by distance
+// first, train index second -- cv::BFMatcher's first minimum again -- with 22 significant bits, inside f32's 24; the tile origin
+// j0 / 8192 is added to the tile's minimum (v_min3_f32 x 8), exactly.  Four MFMAs per 32 x 32 tile instead of eight.
+// Expansion: a byte of descriptor bits -> eight nibbles by ONE LDS table read (256 x 4 B, built by the block), where the int8
+// form spends four VALU instructions per nibble.  Operand element (lane, nibble n) meets element (lane', nibble n) of the other
+// operand for lanes of the same k-block (lane / 32): query and train rows are expanded by the same code, so the order of the bits
+// inside a k-block does not matter.
+typedef int hm_v8i __attribute__((ext_vector_type(8)));
+typedef float hm_v16f __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nsplit)
+{
+    __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][8 * 32];           // [buffer][(2 s + kb) * 32 + (row ^ (2 s + kb))]: MFMA s, k-block kb
+    __shared__ uint32_t lut[256];                                             // byte of TRAIN bits -> 8 nibbles (bit 1 -> +1 = 0x2, bit 0 -> -1 = 0xA); a query byte goes in complemented
+    const int vl = blockIdx.x, lane_id = vl / c.oct_cap;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int side = mode ? (blockIdx.z / nsplit) : 0, split = blockIdx.z % nsplit;
+    const LaneState& ls = c.lane[lane_id];
+    const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
+    int nq, nt; const uint8_t* qd, *td;
+    if (mode == 0) {
+        nq = c.n_kps[feat_cnt_idx(vl, cur, 0)]; nt = c.n_kps[feat_cnt_idx(vl, cur, 1)];
+        qd = c.desc + feat_base(c, vl, cur, 0) * 32; td = c.desc + feat_base(c, vl, cur, 1) * 32;
+    } else {
+        if (!ls.has_prev) return;
+        nq = c.n_matches[vl * 2 + prev]; nt = c.n_matches[vl * 2 + cur];
+        qd = c.mdesc + feat_base(c, vl, prev, side) * 32; td = c.mdesc + feat_base(c, vl, cur, side) * 32;
+    }
+    if ((int)(blockIdx.y * HM_QB) >= nq || nt <= 0) return;                  // block-uniform
+    const int per = ((nt + nsplit - 1) / nsplit + 31) & ~31;
+    const int j_begin = split * per, j_end = min(nt, j_begin + per);
+    if (j_begin >= j_end) return;                                            // block-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kb = lane >> 5;
+    {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v |= (((tid >> i) & 1) ? 0x2u : 0xAu) << (4 * i);
+        lut[tid] = v;
+    }
+    __syncthreads();
+    auto expand32 = [&](uint32_t bits) -> hm_v4i {                           // 32 bits -> 32 nibbles
+        hm_v4i r;
+        r.x = (int)lut[bits & 255u]; r.y = (int)lut[(bits >> 8) & 255u]; r.z = (int)lut[(bits >> 16) & 255u]; r.w = (int)lut[bits >> 24];
+        return r;
+    };
+    // ---- this wave's 2 x 32 queries: Bq[set][s] = dword 2 s + kb of query column col, complemented, expanded ----
+    hm_v4i Bq[2][4];
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        const int q = min((int)blockIdx.y * HM_QB + wid * 64 + st * 32 + col, nq - 1);        // past-the-end columns redo the last query, never stored
+        const uint32_t* qp = (const uint32_t*)(qd + (long long)q * 32);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) Bq[st][s4] = expand32(~qp[2 * s4 + kb]);
+    }
+    // staging role of this thread: row sr of the tile, packed dword sg = 2 s + kb
+    const int sr = tid >> 3, sg = tid & 7;
+    const uint32_t* tw = (const uint32_t*)td;
+    auto fetch = [&](int j0) -> uint32_t { return tw[(long long)min(j0 + sr, nt - 1) * 8 + sg]; };
+    auto stage = [&](int buf, uint32_t bits) { tileA[buf][sg * 32 + (sr ^ sg)] = expand32(bits); };      // (the XOR: see k_hamming's staging)
+    hm_v16f tc0;
+#pragma unroll
+    for (int v = 0; v < 16; v++) tc0[v] = (float)(8 * (v >> 2) + (v & 3) + 4 * kb) * (1.0f / 8192.0f);
+    float best[2] = { 3.0e38f, 3.0e38f };
+    const int one = 127;                                                      // E8M0 block scale 2^0
+    uint32_t nxt = fetch(j_begin);
+    stage(0, nxt);
+    int buf = 0;
+    for (int j0 = j_begin; j0 < j_end; j0 += 32, buf ^= 1) {
+        __syncthreads();                                           // tile `buf` is staged; the other buffer is free again
+        const bool more = j0 + 32 < j_end;
+        if (more) nxt = fetch(j0 + 32);
+        hm_v16f acc0 = tc0, acc1 = tc0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const hm_v4i a4 = tileA[buf][(2 * s4 + kb) * 32 + (col ^ (2 * s4 + kb))];
+            const hm_v8i a = { a4.x, a4.y, a4.z, a4.w, 0, 0, 0, 0 };
+            const hm_v8i b0 = { Bq[0][s4].x, Bq[0][s4].y, Bq[0][s4].z, Bq[0][s4].w, 0, 0, 0, 0 }, b1 = { Bq[1][s4].x, Bq[1][s4].y, Bq[1][s4].z, Bq[1][s4].w, 0, 0, 0, 0 };
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, acc0, 4, 4, 0, one, 0, one);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b1, acc1, 4, 4, 0, one, 0, one);
+        }
+        if (j0 + 32 > j_end) {                                     // ragged last tile: rows past the end can never win
+#pragma unroll
+            for (int v = 0; v < 16; v++) { const bool in = j0 + 8 * (v >> 2) + (v & 3) + 4 * kb < j_end; acc0[v] = in ? acc0[v] : 1.0e9f; acc1[v] = in ? acc1[v] : 1.0e9f; }
+        }
+        // (as asm: there are no NaNs here, and fminf's quieting adds a v_max_f32 x, x per operand)
+        auto min3 = [](float a, float b, float c) -> float { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+        auto min2 = [](float a, float b) -> float { float r; asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        auto min16 = [&](const hm_v16f& a) -> float {
+            const float t0 = min3(a[0], a[1], a[2]), t1 = min3(a[3], a[4], a[5]), t2 = min3(a[6], a[7], a[8]);
+            const float t3 = min3(a[9], a[10], a[11]), t4 = min3(a[12], a[13], a[14]);
+            return min2(min3(t0, t1, a[15]), min3(t2, t3, t4));
+        };
+        const float o = (float)j0 * (1.0f / 8192.0f);
+        best[0] = min2(best[0], min16(acc0) + o);
+        best[1] = min2(best[1], min16(acc1) + o);
+        if (more) stage(buf ^ 1, nxt);
+    }
+    // ---- per query column: min over the two lane halves; D = 2 ham - 256 + index / 8192 -> (distance << 16 | index) ----
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+        float m = best[st];
+        m = fminf(m, __shfl_xor(m, 32, 64));
+        const int q = (int)blockIdx.y * HM_QB + wid * 64 + st * 32 + col;
+        if (kb == 0 && q < nq && m < 1.0e8f) {
+            const float fl = floorf(m);
+            const unsigned ham = (unsigned)((int)fl + 256) >> 1, idx = (unsigned)(int)((m - fl) * 8192.0f);
+            const unsigned packed = (ham << 16) | idx;
+            unsigned* out = (unsigned*)c.bf_idx + ((long long)vl * 3 + (mode ? 1 + side : 0)) * c.max_kps + q;
+            if (nsplit > 1) atomicMin(out, packed); else *out = packed;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // K8a: stage-3 filters (S3:124-175), one 1024-thread block per lane.
 //   1-to-1: per right feature keep the left with the smallest (distance, left index)   [S3:127-147]
@@ -1564,7 +1682,12 @@ hipError_t configure_match(int max_kps)
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
     if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_hamming, dim3(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit), dim3(256), 0, st, c, mode, nsplit);
+    // SVO_HAM_FP4 = 1: the FP4 form of the matrix-core brute force (k_hamming_f4)
+    static int f4 = -1;
+    if (f4 < 0) { const char* e = getenv("SVO_HAM_FP4"); f4 = (e && atoi(e) == 1) ? 1 : 0; }
+    const dim3 grid(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit);
+    if (f4) hipLaunchKernelGGL(k_hamming_f4, grid, dim3(256), 0, st, c, mode, nsplit);
+    else hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, c, mode, nsplit);
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)

@@ -1163,3 +1163,34 @@ def test_hand_over_record_of_another_layout_is_refused(golden_dir):
     b.process_host([(g["L2"], g["R2"])])
     assert_same_frame(b, 0, orc, b.result(0), ro, "after a refused import")
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("env", [{"SVO_DESC_KPW": "1"}, {"SVO_DESC_KPW": "3", "SVO_DESC_TL": "0"}, {"SVO_DESC_KPW": "64"}, {"SVO_HAM_SPLITS": "1"}, {"SVO_HAM_SPLITS": "7"}, {"SVO_HAM_FP4": "0"}, {"SVO_HAM_FP4": "0", "SVO_HAM_SPLITS": "7"}])
+def test_kernel_launch_knobs_do_not_change_results(golden_dir, env):
+    """The launch-shape knobs the library reads from the environment once per process (keypoints per wave of k_describe and where
+    its Gaussian operands live, train splits of k_hamming) select other code paths of the same arithmetic: the committed small
+    sequence in a fresh process under each setting, every list against the golden vectors (= the oracle's), bit for bit."""
+    import subprocess, sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from stereo_vo_amd import hip\n"
+        "from stereo_vo_amd.abi import StereoCamera, north_star_params\n"
+        "g = np.load(os.path.join(%r, 'oracle_small_seq.npz'))\n"
+        "cam = StereoCamera.simple(float(g['F']), float(g['cx']), float(g['cy']), float(g['baseline']), int(g['W']), int(g['H']))\n"
+        "p = north_star_params(hip.default_params(), orb_nfeats=int(g['orb_nfeats']))\n"
+        "ctx = hip.Context(n_lanes=1, max_w=int(g['W']), max_h=int(g['H']), max_kps=1024, max_cand=1 << 15)\n"
+        "ctx.set_params(p); ctx.set_camera(cam)\n"
+        "for t in range(4):\n"
+        "    ctx.process_host([(g['L%%d' %% t], g['R%%d' %% t])])\n"
+        "    r = ctx.result(0)\n"
+        "    for side in (0, 1):\n"
+        "        k, d = ctx.keypoints(0, 0, side)\n"
+        "        assert k.tobytes() == g['kps%%d_%%d' %% (side, t)].tobytes() and (d == g['desc%%d_%%d' %% (side, t)]).all(), ('features', t, side)\n"
+        "    assert ctx.matches(0).tobytes() == g['matches%%d' %% t].tobytes(), ('pairings', t)\n"
+        "    assert ctx.tracked(0).tobytes() == g['tracked%%d' %% t].tobytes(), ('tracked', t)\n"
+        "    assert np.allclose(np.array(r.outPose), g['pose%%d' %% t], atol=1e-6) and ctx.status_word(0) == 0\n"
+        "ctx.close(); print('same')\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), golden_dir)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "same" in out.stdout, (env, out.stdout[-400:], out.stderr[-1200:])
