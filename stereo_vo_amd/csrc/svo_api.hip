@@ -705,7 +705,7 @@ static int hamming_splits(const svo_ctx* ctx)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("SVO_HAM_SPLITS"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return forced;
-    int s = 2048 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 8 ? 8 : s);     // train splits: enough workgroups to fill the GPU, few enough to amortise the query expansion
+    int s = 1024 / (8 * ctx->cfg.n_lanes); return s < 1 ? 1 : (s > 8 ? 8 : s);     // train splits: enough workgroups to fill the GPU, few enough to amortise the query expansion (64 lanes: 2 -- 32.1 us per launch against 34.8 with 4, 38.2 with 6: profiles/r04o)
 }
 
 // ---- host-fed frames ------------------------------------------------------------------------------------------
