@@ -202,15 +202,20 @@ __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nspl
     const int side = mode ? (blockIdx.z / nsplit) : 0, split = blockIdx.z % nsplit;
     const LaneState& ls = c.lane[lane_id];
     const int cur = 1 - ls.prev_slot, prev = ls.prev_slot;
-    int nq, nt; const uint8_t* qd, *td;
+    // mode 1 reads the descriptors of the PAIRED features straight through the pairing lists (row m of a side = the descriptor of
+    // matches[m].queryIdx / .trainIdx: the gather of S4:105-131); rounds 1-3 had a kernel of its own lay them out first
+    // (k_gather_mdesc, still what the int8 form reads)
+    int nq, nt; const uint8_t* qd, *td; const svo_dmatch* qm = nullptr, *tm = nullptr;
     if (mode == 0) {
         nq = c.n_kps[feat_cnt_idx(vl, cur, 0)]; nt = c.n_kps[feat_cnt_idx(vl, cur, 1)];
         qd = c.desc + feat_base(c, vl, cur, 0) * 32; td = c.desc + feat_base(c, vl, cur, 1) * 32;
     } else {
         if (!ls.has_prev) return;
         nq = c.n_matches[vl * 2 + prev]; nt = c.n_matches[vl * 2 + cur];
-        qd = c.mdesc + feat_base(c, vl, prev, side) * 32; td = c.mdesc + feat_base(c, vl, cur, side) * 32;
+        qd = c.desc + feat_base(c, vl, prev, side) * 32; td = c.desc + feat_base(c, vl, cur, side) * 32;
+        qm = c.matches + match_base(c, vl, prev); tm = c.matches + match_base(c, vl, cur);
     }
+    auto row_of = [&](const svo_dmatch* mm, int m) -> int { return mode ? (side ? mm[m].trainIdx : mm[m].queryIdx) : m; };
     if ((int)(blockIdx.y * HM_QB) >= nq || nt <= 0) return;                  // block-uniform
     const int per = ((nt + nsplit - 1) / nsplit + 31) & ~31;
     const int j_begin = split * per, j_end = min(nt, j_begin + per);
@@ -234,27 +239,30 @@ __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nspl
 #pragma unroll
     for (int st = 0; st < 2; st++) {
         const int q = min((int)blockIdx.y * HM_QB + wid * 64 + st * 32 + col, nq - 1);        // past-the-end columns redo the last query, never stored
-        const uint32_t* qp = (const uint32_t*)(qd + (long long)q * 32);
+        const uint32_t* qp = (const uint32_t*)(qd + (long long)row_of(qm, q) * 32);
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) Bq[st][s4] = expand32(~qp[2 * s4 + kb]);
     }
     // staging role of this thread: row sr of the tile, packed dword sg = 2 s + kb
     const int sr = tid >> 3, sg = tid & 7;
     const uint32_t* tw = (const uint32_t*)td;
-    auto fetch = [&](int j0) -> uint32_t { return tw[(long long)min(j0 + sr, nt - 1) * 8 + sg]; };
+    // the row index of a tile's staging role is fetched TWO tiles ahead, its dword one tile ahead: neither load waits for the other
+    auto fetch_row = [&](int j0) -> int { return row_of(tm, min(j0 + sr, nt - 1)); };
+    auto fetch = [&](int row) -> uint32_t { return tw[(long long)row * 8 + sg]; };
     auto stage = [&](int buf, uint32_t bits) { tileA[buf][sg * 32 + (sr ^ sg)] = expand32(bits); };      // (the XOR: see k_hamming's staging)
     hm_v16f tc0;
 #pragma unroll
     for (int v = 0; v < 16; v++) tc0[v] = (float)(8 * (v >> 2) + (v & 3) + 4 * kb) * (1.0f / 8192.0f);
     float best[2] = { 3.0e38f, 3.0e38f };
     const int one = 127;                                                      // E8M0 block scale 2^0
-    uint32_t nxt = fetch(j_begin);
+    uint32_t nxt = fetch(fetch_row(j_begin));
+    int nrow = fetch_row(min(j_begin + 32, j_end - 1));
     stage(0, nxt);
     int buf = 0;
     for (int j0 = j_begin; j0 < j_end; j0 += 32, buf ^= 1) {
         __syncthreads();                                           // tile `buf` is staged; the other buffer is free again
         const bool more = j0 + 32 < j_end;
-        if (more) nxt = fetch(j0 + 32);
+        if (more) { nxt = fetch(nrow); nrow = fetch_row(min(j0 + 64, j_end - 1)); }
         hm_v16f acc0 = tc0, acc1 = tc0;
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
@@ -1679,12 +1687,19 @@ hipError_t configure_match(int max_kps)
     return e;
 }
 
+// the FP4 form of the matrix-core brute force (k_hamming_f4) unless SVO_HAM_FP4=0
+static bool hamming_fp4()
+{
+    static int f4 = -1;
+    if (f4 < 0) { const char* e = getenv("SVO_HAM_FP4"); f4 = (e && atoi(e) == 0) ? 0 : 1; }      // default: FP4 (32.1 against 45.0 us per launch at 64 lanes, profiles/r04n, r04o); SVO_HAM_FP4=0 = the int8 form
+    return f4 != 0;
+}
+
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
-    if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
-    // the FP4 form of the matrix-core brute force (k_hamming_f4) unless SVO_HAM_FP4=0
-    static int f4 = -1;
-    if (f4 < 0) { const char* e = getenv("SVO_HAM_FP4"); f4 = (e && atoi(e) == 0) ? 0 : 1; }      // default: FP4 (35.2 against 45.0 us per launch at 64 lanes, profiles/r04n); SVO_HAM_FP4=0 = the int8 form
+    const bool f4 = hamming_fp4();
+    // (the int8 form reads the paired descriptors from a list laid out by a kernel of its own; the FP4 form gathers through the pairing lists)
+    if (mode && !f4) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
     const dim3 grid(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit);
     if (f4) hipLaunchKernelGGL(k_hamming_f4, grid, dim3(256), 0, st, c, mode, nsplit);
     else hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, c, mode, nsplit);
