@@ -40,7 +40,7 @@ from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 import ctypes as C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_PROFILES = ("r04h_pmc.json", "r03e_pmc.json", "r03d_pmc.json", "r03_pmc.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")    # newest first; tools/pmc_passes.py writes them
+PMC_PROFILES = ("r04q_pmc.json", "r04h_pmc.json", "r03e_pmc.json", "r03d_pmc.json", "r03_pmc.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")    # newest first; tools/pmc_passes.py writes them
 
 
 def lane_seeds(rank, world_size, lanes):
