@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVO_MAX_LANES 64
+#define SVO_MAX_LANES 128
 #define SVO_MAX_LEVELS 8
 
 /* status codes */

@@ -50,7 +50,7 @@ extern "C" void svo_batch_config_defaults(svo_batch_config* c)
 {
     if (!c) return;
     svo_config_defaults(&c->ctx);
-    c->ctx.n_lanes = SVO_MAX_LANES;
+    c->ctx.n_lanes = 64;                       // the measured default (3 x 64); SVO_MAX_LANES is the limit of the pointer tables in the kernel arguments
     c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 1; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0; c->no_detect_ahead = 0;
 }
 

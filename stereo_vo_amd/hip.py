@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvo_hip.so")
 _LIB = None
 
-MAX_LANES = 64
+MAX_LANES = 128
 RUN_DETECT, RUN_MATCH, RUN_TRACK, RUN_OPTIMIZE, RUN_ALL = 1, 2, 4, 8, 15
 FLAG_REPEAT, FLAG_NO_SHIFT, FLAG_DEVICE_IMAGES, FLAG_BGR_IMAGES, FLAG_DETECT_NO_POST, RUN_DETECT_POST, FLAG_PINNED_IMAGES = 16, 32, 64, 128, 256, 512, 1024
 

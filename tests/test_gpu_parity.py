@@ -684,17 +684,18 @@ def test_scheduling_hooks_streams_and_selective_timing(golden_dir):
     b.kernel_times_select(None)
 
 
-def test_sixty_four_lanes_each_match_their_own_oracle():
-    """The batched configuration bench.py runs (64 estimators per context): every kernel's lane indexing, XCD-aware tile
-    orders and the MFMA matcher's per-lane tiles, checked on lanes 0, 17, 40 and 63 against independent oracles."""
+@pytest.mark.parametrize("B", [64, hip.MAX_LANES])
+def test_sixty_four_lanes_each_match_their_own_oracle(B):
+    """The batched configuration bench.py runs (64 estimators per context) and the largest context the ABI takes (SVO_MAX_LANES): every
+    kernel's lane indexing, XCD-aware tile orders and the MFMA matcher's per-lane tiles, checked on four lanes against independent oracles."""
     import torch
-    W, H, B = 640, 480, 64
+    W, H = 640, 480
     worlds = [SyntheticStereoWorld(W, H, 400.0, 0.12, seed=100 + s, n_frames=3, device=torch.device("cuda"), scene_seed=s % 4) for s in range(B)]
     cam = worlds[0].camera()
     p = north_star_params(hip.default_params(), orb_nfeats=500)
     ctx = hip.Context(n_lanes=B, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
     ctx.set_params(p); ctx.set_camera(cam)
-    probe = (0, 17, 40, 63)
+    probe = (0, 17, B - 24, B - 1)
     orcs = {l: O().Oracle(p) for l in probe}
     for t in range(3):
         fr = [w.render(t) for w in worlds]
