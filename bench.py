@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
     ap.add_argument("--frames", type=int, default=0, help="frames rendered per trajectory; 0 (default) = as many as it takes for no stream ever to see a frame twice (>= 200)")
     ap.add_argument("--trajectories", type=int, default=8, help="distinct camera trajectories rendered per rank; stream s plays trajectory s %% T from frame 7 * (s // T) on")
+    ap.add_argument("--long-steps", type=int, default=100, help="N=1: when --steps is smaller than this, one more timed leg of this many steps (after --warmup untimed ones, estimators reset, the same streams from their first frame on: no stream sees a frame twice inside the leg), reported as `long_run` -- so that a short --steps run still carries a measurement over a few hundred milliseconds; 0 = skip")
     ap.add_argument("--cut-steps", type=int, default=60, help="steps of the scene-cut leg (every stream jumps to another trajectory every 20 frames, estimators reset as an application would); N=1 only; 0 = skip")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
@@ -180,7 +181,9 @@ def main():
     W, H, B = args.width, args.height, args.lanes
     T = max(1, min(args.trajectories, B))
     total_steps = args.warmup + args.steps
-    F = args.frames if args.frames > 0 else frames_needed(B, T, total_steps)
+    long_steps = args.long_steps if (world == 1 and args.long_steps > args.steps) else 0
+    plan_steps = max(total_steps, args.warmup + long_steps)           # frames / pointer tables cover the longer of the two legs
+    F = args.frames if args.frames > 0 else frames_needed(B, T, plan_steps)
     focal = 718.856 if kitti else 800.0 * W / 1280.0
     baseline = 0.537 if kitti else 0.12
     cxy = dict(cx=607.19, cy=185.22) if kitti else {}
@@ -213,7 +216,7 @@ def main():
     batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else ("select" if args.post_on_rest == 3 else bool(args.post_on_rest))),
                         det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams, max_kps=args.max_kps, detect_ahead=bool(args.detect_ahead))
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
-    ptrs_by_step = [ptrs_at_step(i) for i in range(total_steps)]         # built ahead: the timed loop only indexes it
+    ptrs_by_step = [ptrs_at_step(i) for i in range(plan_steps)]          # built ahead: the timed loop only indexes it
 
     gather_done = [torch.cuda.Event(), torch.cuda.Event()]
 
@@ -345,6 +348,31 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec)
             leg_done("cpu_baseline_and_parity_probe")
+        long_run = None
+        if long_steps > 0:
+            # a short --steps run (the driver's is 20 steps = ~50 ms) still gets a measurement over long_steps steps: estimators reset,
+            # the same streams from their first frame, --warmup untimed steps, then long_steps timed ones between two synchronisations
+            try:
+                batch.reset()
+                for i in range(args.warmup):
+                    step(i)
+                torch.cuda.synchronize()
+                for c_ in ctxs:
+                    c_.redo_count(reset=True)
+                tl = time.perf_counter()
+                for i in range(long_steps):
+                    step(args.warmup + i)
+                torch.cuda.synchronize()
+                tl = time.perf_counter() - tl
+                redo_l = sum(c_.redo_count(reset=True) for c_ in ctxs)
+                res_l = batch.results()
+                long_run = {"pairs_per_s": round(B * long_steps / tl, 2), "ms_per_step": round(1e3 * tl / long_steps, 4), "steps": long_steps, "warmup": args.warmup,
+                            "timed_region_s": round(tl, 4), "valid_last_step": "%d/%d" % (sum(1 for r in res_l if r.valid), B),
+                            "fast_redo_rate": round(redo_l / float(max(1, long_steps * 2 * B * (n_octaves if detect_fast_orb else 8))), 6),
+                            "note": "the same batch, reset, every stream from its first frame on (%d distinct consecutive frames per stream), timed like `value`; `value` itself is the --steps run the contract asks for" % (args.warmup + long_steps)}
+            except Exception as e:
+                long_run = {"error": str(e)}
+            leg_done("long_run")
         if world == 1 and args.host_fed_steps > 0:
             host_fed = host_fed_leg(args, batch, frame_of, dev)
             leg_done("host_fed")
@@ -414,6 +442,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / args.steps, 4),
             "fast_redo_rate": round(redo_pairs / float(max(1, args.steps * 2 * B * (n_octaves if detect_fast_orb else 8))), 6),
             "fast_redo_note": "(image, level) pairs of the timed steps whose speculative FAST threshold found too few corners and ran k_fast again at the caller's threshold (%d of %d); every frame of the run is new to its stream" % (redo_pairs, args.steps * 2 * B * (n_octaves if detect_fast_orb else 8)),
+            "long_run": long_run,
             "scene_cuts": scene_cuts,
             "other_workloads": other_workloads,
             "roofline": roofline,
@@ -586,7 +615,7 @@ def other_workloads_leg(args):
     import subprocess
     out = {}
     for wl, extra in (("config3", ["--lanes", "192", "--contexts", "3"]), ("config5", ["--lanes", "64", "--contexts", "2"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "40", "--warmup", "6", "--cpu-frames", "12", "--host-fed-steps", "0",
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "40", "--warmup", "6", "--cpu-frames", "12", "--long-steps", "0", "--host-fed-steps", "0",
                "--single-stream", "0", "--relief-lanes", "0", "--cut-steps", "0", "--other-workloads", "0", "--exclusive", "1"] + extra
         try:
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

@@ -24,7 +24,7 @@ tag = sys.argv[1]
 extra = sys.argv[2:]
 STEPS, WARM, SKIP = 5, 3, 3          # 8 steps in all, the first 3 dropped
 LANES = 64
-cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARM), "--cpu-frames", "0", "--host-fed-steps", "0",
+cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARM), "--cpu-frames", "0", "--long-steps", "0", "--host-fed-steps", "0",
        "--single-stream", "0", "--exclusive", "0", "--relief-lanes", "0", "--cut-steps", "0", "--other-workloads", "0", "--contexts", "1", "--lanes", str(LANES), "--frames", "60"] + extra
 env = dict(os.environ, TMPDIR="/tmp")
 PASSES = {

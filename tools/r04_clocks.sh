@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 tag=${1:-r04clk}; shift
 mkdir -p gpurun_out
-Q="--steps 1500 --warmup 6 --cpu-frames 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
+Q="--steps 1500 --warmup 6 --cpu-frames 0 --long-steps 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
 ( python bench.py $Q "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err ) &
 pid=$!
 : > gpurun_out/${tag}_smi.log

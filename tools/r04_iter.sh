@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 ( time timeout 900 env $PARITY_ENV python -m pytest tests/test_gpu_parity.py -x -q -k "small_sequence or pyramid_and_detector or noise_images or full_size or hamming_match or speculative_fast or fast_orb_multi or random_parameter_sets_match or sixty_four" ) > gpurun_out/${tag}_first.log 2>&1
 echo "first rc=$?" >> gpurun_out/${tag}_first.log
 tail -6 gpurun_out/${tag}_first.log
-Q="--steps 40 --warmup 6 --cpu-frames 12 --host-fed-steps 0 --single-stream 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
+Q="--steps 40 --warmup 6 --cpu-frames 12 --long-steps 0 --host-fed-steps 0 --single-stream 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
 ( time timeout 600 python bench.py $Q "$@" ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python - gpurun_out/${tag}_bench.json <<'PY'
 import json, sys
@@ -24,7 +24,7 @@ PY
 tail -4 gpurun_out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-B="--steps 10 --warmup 3 --cpu-frames 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --cut-steps 0 --other-workloads 0 --relief-lanes 0"
+B="--steps 10 --warmup 3 --cpu-frames 0 --long-steps 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --cut-steps 0 --other-workloads 0 --relief-lanes 0"
 rm -rf /tmp/ps_1ctx
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps_1ctx -- python $R/bench.py $B --contexts 1 --lanes 64 --frames 64 > $O/${tag}_prof_1ctx.log 2>&1
 f=$(find /tmp/ps_1ctx -name "*kernel_trace.csv" | head -1)

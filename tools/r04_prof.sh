@@ -13,7 +13,7 @@ O=$R/gpurun_out
 tag=${1:-r04}
 mkdir -p $O
 W=3; K=10
-B="--steps $K --warmup $W --cpu-frames 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --cut-steps 0 --other-workloads 0"
+B="--steps $K --warmup $W --cpu-frames 0 --long-steps 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --cut-steps 0 --other-workloads 0"
 run_stats() {  # name, skip, total, command...
     local name=$1 skip=$2 total=$3; shift 3
     rm -rf /tmp/ps_$name

@@ -9,7 +9,7 @@ tail -25 gpurun_out/${tag}_first.log
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > gpurun_out/${tag}_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/${tag}_tests.log
 tail -30 gpurun_out/${tag}_tests.log
-( timeout 600 python bench.py --steps 40 --warmup 6 --cpu-frames 12 --host-fed-steps 0 --single-stream 0 --relief-lanes 0 ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+( timeout 600 python bench.py --steps 40 --warmup 6 --cpu-frames 12 --long-steps 0 --host-fed-steps 0 --single-stream 0 --relief-lanes 0 ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python - gpurun_out/${tag}_bench.json <<'PY'
 import json, sys
 try:

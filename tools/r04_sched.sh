@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 ( time timeout 900 python -m pytest tests/test_gpu_bench_shape.py tests/test_gpu_batch_host.py -x -q ) > gpurun_out/${tag}_tests.log 2>&1
 echo "tests rc=$?" >> gpurun_out/${tag}_tests.log
 tail -6 gpurun_out/${tag}_tests.log
-Q="--steps 40 --warmup 6 --cpu-frames 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --relief-lanes 0"
+Q="--steps 40 --warmup 6 --cpu-frames 0 --long-steps 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --relief-lanes 0"
 run() { name=$1; shift; ( timeout 600 python bench.py $Q "$@" ) > gpurun_out/${tag}_bench_$name.json 2>> gpurun_out/${tag}_bench.err
 python - gpurun_out/${tag}_bench_$name.json <<'PY'
 import json, sys

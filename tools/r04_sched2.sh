@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 tag=${1:-r04s}
 mkdir -p gpurun_out
-Q="--steps 40 --warmup 6 --cpu-frames 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
+Q="--steps 40 --warmup 6 --cpu-frames 0 --long-steps 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --relief-lanes 0 --cut-steps 0 --other-workloads 0 --frames 210"
 run() { name=$1; shift; ( timeout 400 env $ENVX python bench.py $Q "$@" ) > gpurun_out/${tag}_bench_$name.json 2>> gpurun_out/${tag}_bench.err
 python - gpurun_out/${tag}_bench_$name.json <<'PY'
 import json, sys

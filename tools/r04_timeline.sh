@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 tag=${1:-r04t}; shift
 mkdir -p $O
-B="--steps 6 --warmup 4 --cpu-frames 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --cut-steps 0 --other-workloads 0 --relief-lanes 0 --frames 176"
+B="--steps 6 --warmup 4 --cpu-frames 0 --long-steps 0 --host-fed-steps 0 --single-stream 0 --exclusive 0 --cut-steps 0 --other-workloads 0 --relief-lanes 0 --frames 176"
 rm -rf /tmp/ps_tl
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/ps_tl -- python $R/bench.py $B "$@" > $O/${tag}_timeline.log 2>&1
 f=$(find /tmp/ps_tl -name "*kernel_trace.csv" | head -1)
