@@ -353,6 +353,12 @@ def main():
             # a short --steps run (the driver's is 20 steps = ~50 ms) still gets a measurement over long_steps steps: estimators reset,
             # the same streams from their first frame, --warmup untimed steps, then long_steps timed ones between two synchronisations
             try:
+                # (the CPU legs before this one leave the GPU idle for tens of seconds: a first untimed pass brings the clocks back up,
+                # as the warm-up of the main run does after the rendering)
+                batch.reset()
+                for i in range(min(plan_steps, args.warmup + 30)):
+                    step(i)
+                torch.cuda.synchronize()
                 batch.reset()
                 for i in range(args.warmup):
                     step(i)
