@@ -218,6 +218,7 @@ def main():
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
     ptrs_by_step = [ptrs_at_step(i) for i in range(plan_steps)]          # built ahead: the timed loop only indexes it
 
+    frames_by_step = [batch.prepare(q) for q in ptrs_by_step]            # the ctypes frame tables too: the host's share of a step is then the launches
     gather_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     def step(i):
@@ -228,7 +229,7 @@ def main():
             batch.flip_records()
             if i >= 2:
                 batch.hold_for(gather_done[i & 1])       # the all-gather that read this buffer two steps ago
-        batch.step(ptrs_by_step[i])
+        batch.step_prepared(frames_by_step[i])
         if world > 1:          # the all-gather runs on torch's current stream: it waits for every context's last work
             batch.make_wait(torch.cuda.current_stream(dev))
         out = gather_records(batch.rec, world)

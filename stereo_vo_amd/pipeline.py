@@ -88,6 +88,16 @@ class StreamBatch:
         fr = _frames(ptrs, self.W, self.H, self.W if stride is None else stride)
         self._ck(self.L.svo_batch_step(self.h, fr, C.c_uint32(hip.FLAG_PINNED_IMAGES if pinned_host else hip.FLAG_DEVICE_IMAGES)), "svo_batch_step")
 
+    def prepare(self, ptrs, stride=None):
+        """The frame table of one step built ahead of time (a few hundred ctypes structures: ~0.5 ms of Python per step otherwise, which
+        is most of what the host spends on a step besides the launches themselves); hand the result to step_prepared."""
+        assert len(ptrs) == self.B
+        return _frames(ptrs, self.W, self.H, self.W if stride is None else stride)
+
+    def step_prepared(self, fr, pinned_host=False):
+        """step() with a frame table from prepare()."""
+        self._ck(self.L.svo_batch_step(self.h, fr, C.c_uint32(hip.FLAG_PINNED_IMAGES if pinned_host else hip.FLAG_DEVICE_IMAGES)), "svo_batch_step")
+
     def flip_records(self):
         """Later steps leave their records in the OTHER of two buffers (self.rec afterwards): an all-gather may still be reading the
         one the last step wrote (svo_batch_switch_results_buffer: no synchronisation)."""
