@@ -157,9 +157,14 @@ def main():
         args.width, args.height, args.orb_nfeats, detect_fast_orb, n_octaves = 2048, 1536, 3300, True, 3
         args.lanes = min(args.lanes, 64); args.contexts = min(args.contexts, 2)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (one per GPU)
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run --nproc-per-node %d (or plainly, without WORLD_SIZE set: bench.py then launches its own ranks)" % (args.gpus, world, args.gpus))
     # test hooks (one-GPU boxes): BENCH_FORCE_DEVICE puts every rank on that device, BENCH_DIST_BACKEND=gloo replaces RCCL,
     # so that the N > 1 code path (sharding, event ordering, all-gather, MAX-time) can be exercised without N GPUs
     if os.environ.get("BENCH_FORCE_DEVICE"):
@@ -176,7 +181,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     W, H, B = args.width, args.height, args.lanes
     T = max(1, min(args.trajectories, B))
@@ -476,6 +480,29 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without torch.distributed.run around it: re-run this same command line as N ranks, one per GPU,
+    under torch.distributed.run on 127.0.0.1 (what the driver's own N > 1 invocation does), and hand back its exit code.
+    Refuses when the node shows fewer than N devices -- a one-GPU line labelled N GPUs is worse than no line.
+    BENCH_FORCE_DEVICE (test hook: every rank on that device) lifts the device-count check."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not os.environ.get("BENCH_FORCE_DEVICE"):
+        print("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to run (no silent fallback to fewer GPUs)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
 
 
 def dist_audit(allrec, local_rec, world, rank, local_rank, dev):

@@ -51,8 +51,21 @@ typedef struct svo_batch_config {
                                  overlaps that context's own stages 3-5; 1: it waits for the whole frame, as rounds 1-3 did */
 } svo_batch_config;
 
+/* Bumped whenever svo_batch_config or SVO_MAX_LANES changes (2 = round 4: `no_detect_ahead` appended, SVO_MAX_LANES 64 -> 128). */
+#define SVO_BATCH_ABI_VERSION 2
+/* out3[0] = sizeof(svo_batch_config), out3[1] = SVO_MAX_LANES, out3[2] = SVO_BATCH_ABI_VERSION as this LIBRARY was compiled: a
+ * binding checks its mirror against them (tests/test_abi.py does for the ctypes one). */
+void svo_batch_abi_sizes(int32_t* out3);
 void svo_batch_config_defaults(svo_batch_config* c);
+/* C / C++ hosts call svo_batch_create(): the macro below passes the caller's own sizeof(svo_batch_config) along, and a host built
+ * against another version of this header gets SVO_ERR_ARG (+ the two sizes in svo_batch_last_error) instead of a config whose
+ * trailing fields are read from whatever follows the shorter struct.  Bindings that cannot use the macro (ctypes) call the plain
+ * symbol after checking svo_batch_abi_sizes. */
+int  svo_batch_create_sized(const svo_batch_config* cfg, size_t cfg_bytes, svo_batch** out);
 int  svo_batch_create(const svo_batch_config* cfg, svo_batch** out);
+#ifndef SVO_BATCH_NO_SIZED_CREATE
+#define svo_batch_create(cfg, out) svo_batch_create_sized((cfg), sizeof(svo_batch_config), (out))
+#endif
 void svo_batch_destroy(svo_batch* b);
 const char* svo_batch_last_error(const svo_batch* b);
 int  svo_batch_lanes(const svo_batch* b);                       /* n_contexts * lanes per context */
@@ -76,7 +89,9 @@ int  svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags);
 /* make the caller's hipStream_t wait for the last step's work of every context (e.g. before an all-gather of the records) */
 int  svo_batch_wait_on_stream(svo_batch* b, void* stream);
 /* the NEXT step's result copies -- and nothing ahead of them in that step -- wait for this hipEvent_t (e.g. the all-gather that
- * still reads the records buffer); one event, consumed by that step */
+ * still reads the records buffer).  Several calls before one step add up (the step waits for every one of them); the list is
+ * emptied by that step whether it succeeds or not.  The events are only referenced: each must stay alive, and must not be
+ * re-recorded, until that svo_batch_step has returned. */
 int  svo_batch_hold_for_event(svo_batch* b, void* event);
 int  svo_batch_synchronize(svo_batch* b);
 int  svo_batch_results(svo_batch* b, svo_result* res /* svo_batch_lanes() entries */);    /* implies svo_batch_synchronize */

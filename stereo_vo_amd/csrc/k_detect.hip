@@ -294,7 +294,10 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
 // safe: these transfers only add to the outstanding count, so its waits can only get stricter.
 __device__ __forceinline__ void glds16_asm(const uint8_t* gaddr, uint32_t lds_base)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gaddr), "s"(lds_base) : "memory", "m0");
+    // m0 is a reserved register for hipcc: a clobber on it is ignored (with a warning), so the asm saves and restores it itself and the
+    // compiler's view "m0 unchanged" stays true whatever else in the kernel uses it (the builtin LDS-DMA form, LDS-direct, s_movrel)
+    uint32_t m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "v"(gaddr), "s"(lds_base) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2014,18 +2017,18 @@ size_t nms_rowsort_scratch_bytes(const DevCtx& c)          // global scratch of 
 
 hipError_t configure_nms_rowsort(const DevCtx& c)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)k_fastorb_nms, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fastorb_nms_smem(FO_PMAX, c.max_kps));
+    hipError_t e = svo_raise_dyn_smem((const void*)k_fastorb_nms, fastorb_nms_smem(FO_PMAX, c.max_kps));
     if (e != hipSuccess) return e;
     int kmax = 64; while (kmax < c.max_kps) kmax <<= 1;
-    e = hipFuncSetAttribute((const void*)k_fastorb_anms, hipFuncAttributeMaxDynamicSharedMemorySize, kmax * 8);
+    e = svo_raise_dyn_smem((const void*)k_fastorb_anms, (size_t)kmax * 8);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_select_sort<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16);
+    e = svo_raise_dyn_smem((const void*)k_select_sort<4096>, 4096 * 16);
     if (e != hipSuccess) return e;
     const int pmax = nms_pmax(c);
     if (pmax > 8192) return hipErrorInvalidValue;
-    e = hipFuncSetAttribute((const void*)k_nms_rowsort<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(8192));
+    e = svo_raise_dyn_smem((const void*)k_nms_rowsort<8>, nms_rowsort_smem(8192));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_nms_rowsort<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nms_rowsort_smem(pmax > 4096 ? 4096 : pmax));
+    return svo_raise_dyn_smem((const void*)k_nms_rowsort<4>, nms_rowsort_smem(pmax > 4096 ? 4096 : pmax));
 }
 
 void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st)

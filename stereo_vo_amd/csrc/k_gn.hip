@@ -9,6 +9,8 @@
 // The reduction order differs from the reference's sequential loop, so results agree with the oracle to rounding
 // (tests: 1e-4 rad / 1e-3 m), not bit for bit.
 #include <mutex>
+#include <map>
+#include <utility>
 #include "svo_device.h"
 #include "svo_kernels.h"
 #include <float.h>
@@ -583,21 +585,28 @@ static size_t gn_smem(int pmax, int nt)
     return region + (size_t)pmax * 2 + 16 + sizeof(int) * 40 + sizeof(GnShared) + 16;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the KERNEL, shared by every context of the process: only ever raise it
-// (a later, smaller context must not lower the limit under an earlier context's launches)
-hipError_t configure_gauss_newton(int pmax)
+hipError_t svo_raise_dyn_smem(const void* kernel, size_t bytes)
 {
     static std::mutex mu;
-    static size_t cur[3] = { 0, 0, 0 };
+    static std::map<std::pair<int, const void*>, size_t> cur;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
+    size_t& have = cur[std::make_pair(dev, kernel)];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
+hipError_t configure_gauss_newton(int pmax)
+{
     const void* fn[3] = { (const void*)k_gauss_newton<256>, (const void*)k_gauss_newton<384>, (const void*)k_gauss_newton<512> };
     const int nt[3] = { 256, 384, 512 };
     for (int i = 0; i < 3; i++) {
-        const size_t want = gn_smem(pmax, nt[i]);
-        if (want <= cur[i]) continue;
-        const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        const hipError_t e = svo_raise_dyn_smem(fn[i], gn_smem(pmax, nt[i]));
         if (e != hipSuccess) return e;
-        cur[i] = want;
     }
     return hipSuccess;
 }

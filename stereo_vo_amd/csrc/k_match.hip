@@ -1681,9 +1681,9 @@ __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 hipError_t configure_match(int max_kps)
 {
     if (max_kps <= 4096) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)k_track_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)(max_kps / 32) * 8 + (size_t)max_kps * 8));
+    hipError_t e = svo_raise_dyn_smem((const void*)k_track_filter<32>, (size_t)(max_kps / 32) * 8 + (size_t)max_kps * 8);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_match_lr_rbr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * 2 * max_kps + sizeof(int) * 32));
+    e = svo_raise_dyn_smem((const void*)k_match_lr_rbr, sizeof(unsigned) * 2 * max_kps + sizeof(int) * 32);
     return e;
 }
 

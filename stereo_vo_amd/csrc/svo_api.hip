@@ -805,6 +805,12 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
 {
     if (ctx) use_device(ctx);
     if (!ctx) return SVO_ERR_ARG;
+    // svo_record_after_post arms ONE call: the next one that runs the detector's post-processing.  Whatever way that call leaves --
+    // an argument check, SVO_ERR_STATE, a failed launch -- the event is recorded behind what was enqueued (possibly nothing) and
+    // disarmed, so that a waiter is released and a later, unrelated call cannot record it at the wrong point.
+    struct PostDisarm { svo_ctx* c; bool consumes; ~PostDisarm() { if (consumes && c->post_event) { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; hipStreamIsCapturing(c->stream, &cs);
+                                                                    if (cs == hipStreamCaptureStatusNone) hipEventRecord(c->post_event, c->stream); c->post_event = nullptr; } } }
+        post_disarm{ ctx, (flags & SVO_RUN_DETECT_POST) || ((flags & SVO_RUN_DETECT) && !(flags & SVO_FLAG_DETECT_NO_POST)) };
     const svo_params& p = ctx->params;
     // P:54-76: invalid selectors are hard errors; the variants outside the hot path are refused explicitly
     if (p.detect_method < 0 || p.detect_method > 3 || p.match_method < 0 || p.match_method > 2 || p.ifm_method < 0 || p.ifm_method > 3) return SVO_ERR_ARG;

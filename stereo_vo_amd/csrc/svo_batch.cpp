@@ -18,6 +18,7 @@
 // Default split (post_mode 1, one stage 3-5 stream per context): the detect stream carries the pyramid, FAST and the per-level
 // selection; the reference's own NMS / row sort (one latency-bound block per image), the description of its survivors and stages
 // 3-5 run on the context's own stream, so the latency-bound kernels of the contexts overlap each other as well as the next detect.
+#define SVO_BATCH_NO_SIZED_CREATE      // this file defines the plain symbol as well
 #include "../../include/svo_batch.h"
 #include <hip/hip_runtime.h>
 #include <string>
@@ -41,7 +42,7 @@ struct svo_batch {
     std::vector<hipStream_t> s_dets, s_rests; hipStream_t s_post = nullptr;
     std::vector<hipEvent_t> det_done, rest_done, done, pre_done, scratch_free;
     bool ahead = false;                              // the detect calls run ahead of the previous frame's stages 3-5 (post_mode 1 / 3)
-    hipEvent_t held = nullptr;                       // svo_batch_hold_for_event: what the next step's record copies wait for
+    std::vector<hipEvent_t> held;                    // svo_batch_hold_for_event: what the next step's record copies wait for (every one of them)
     uint8_t* rec = nullptr; uint8_t* own_rec = nullptr;
     std::string last_error;
 };
@@ -65,6 +66,26 @@ static int make_stream(std::string& err, hipStream_t* s, bool high)
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);                    // numerically lower = higher priority
     const hipError_t e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, high ? greatest : 0);
     return e == hipSuccess ? SVO_OK : hip_fail(err, "hipStreamCreateWithPriority", e);
+}
+
+extern "C" void svo_batch_abi_sizes(int32_t* out3)
+{
+    if (!out3) return;
+    out3[0] = (int32_t)sizeof(svo_batch_config); out3[1] = SVO_MAX_LANES; out3[2] = SVO_BATCH_ABI_VERSION;
+}
+
+// what a C / C++ host reaches through the header's svo_batch_create(): its OWN sizeof(svo_batch_config) travels with the call, so a
+// host compiled against another version of the header is refused instead of having trailing fields read from whatever follows
+extern "C" int svo_batch_create_sized(const svo_batch_config* cfg, size_t cfg_bytes, svo_batch** out)
+{
+    if (!cfg || !out) return SVO_ERR_ARG;
+    if (cfg_bytes != sizeof(svo_batch_config)) {
+        svo_batch* b = new svo_batch();
+        *out = b;
+        b->last_error = "svo_batch_config is " + std::to_string(cfg_bytes) + " bytes in the caller's header, " + std::to_string(sizeof(svo_batch_config)) + " in this library (ABI version " + std::to_string(SVO_BATCH_ABI_VERSION) + "): rebuild the host against include/svo_batch.h of this library";
+        return SVO_ERR_ARG;
+    }
+    return svo_batch_create(cfg, out);
 }
 
 extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
@@ -153,9 +174,26 @@ extern "C" int svo_batch_switch_results_buffer(svo_batch* b, void* dev_records, 
     return SVO_OK;
 }
 
+static int batch_step_impl(svo_batch* b, const svo_frame* frames, uint32_t flags);
+
 extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags)
 {
-    if (!b || !frames || (flags & ~IMG_FLAGS)) return SVO_ERR_ARG;
+    if (!b) return SVO_ERR_ARG;
+    const int rc = batch_step_impl(b, frames, flags);
+    b->held.clear();                          // the held events belong to THIS step, however it ended
+    if (rc != SVO_OK && rc != SVO_ERR_ARG) {
+        // a step that failed half way has recorded some of its events and not others: let everything enqueued so far drain and start
+        // the event chain over, so that the next step neither waits on a stale record (a no-op) nor overwrites scratch still being read
+        (void)hipSetDevice(b->cfg.ctx.device);
+        (void)hipDeviceSynchronize();
+        b->first = true;
+    }
+    return rc;
+}
+
+static int batch_step_impl(svo_batch* b, const svo_frame* frames, uint32_t flags)
+{
+    if (!frames || (flags & ~IMG_FLAGS)) return SVO_ERR_ARG;
     BHIP(b, hipSetDevice(b->cfg.ctx.device));
     const size_t rsz = sizeof(svo_result);
     const uint32_t AH = b->ahead ? (uint32_t)SVO_FLAG_DETECT_AHEAD : 0u;
@@ -181,18 +219,18 @@ extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t fl
             BSVO(b, c, svo_set_stream(c, s_rest));
             if (b->ahead) BSVO(b, c, svo_record_after_post(c, b->scratch_free[(size_t)k]));
             BSVO(b, c, svo_process(c, nullptr, REST));
-            if (b->held) BHIP(b, hipStreamWaitEvent(s_rest, b->held, 0));       // only the record copy waits for a reader of the records buffer
+            for (hipEvent_t h : b->held) BHIP(b, hipStreamWaitEvent(s_rest, h, 0));       // only the record copy waits for a reader of the records buffer
             BSVO(b, c, svo_copy_results_async(c, dst, (size_t)b->Bc * rsz));
             BHIP(b, hipEventRecord(b->rest_done[(size_t)k], s_rest));
         } else {
             BSVO(b, c, svo_set_stream(c, nullptr));
             BSVO(b, c, svo_process(c, pk, SVO_RUN_ALL | flags));
-            if (b->held) BHIP(b, hipStreamWaitEvent(b->own[(size_t)k], b->held, 0));
+            for (hipEvent_t h : b->held) BHIP(b, hipStreamWaitEvent(b->own[(size_t)k], h, 0));
             BSVO(b, c, svo_copy_results_async(c, dst, (size_t)b->Bc * rsz));
             BHIP(b, hipEventRecord(b->done[(size_t)k], b->own[(size_t)k]));
         }
     }
-    b->first = false; b->held = nullptr;
+    b->first = false;
     return SVO_OK;
 }
 
@@ -207,7 +245,7 @@ extern "C" int svo_batch_wait_on_stream(svo_batch* b, void* stream)
 extern "C" int svo_batch_hold_for_event(svo_batch* b, void* event)
 {
     if (!b || !event) return SVO_ERR_ARG;
-    b->held = (hipEvent_t)event;          // the next svo_batch_step makes each context's record copy -- and nothing before it -- wait
+    b->held.push_back((hipEvent_t)event);   // the next svo_batch_step makes each context's record copy -- and nothing before it -- wait for all of them
     return SVO_OK;
 }
 

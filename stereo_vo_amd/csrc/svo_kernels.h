@@ -14,6 +14,10 @@ struct GNParams {
 };
 
 hipError_t svo_upload_tables();
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE) and is shared by every context of the process on that
+// device: keyed by both, only ever raised -- a later, smaller context must not lower the limit under an earlier context's launches,
+// and a host with one thread per GPU must set it on every device it uses (the calling thread's current device is the context's).
+hipError_t svo_raise_dyn_smem(const void* kernel, size_t bytes);
 // stage 1 (k_prepare.hip)
 struct PrepArgs {
     const uint8_t* src[2 * SVO_MAX_LANES];   // source image pointers (device memory), by value in the kernel arguments

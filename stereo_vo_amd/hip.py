@@ -34,7 +34,7 @@ EXPORTS = [
 
 
 BATCH_EXPORTS = [
-    "svo_batch_config_defaults", "svo_batch_create", "svo_batch_destroy", "svo_batch_last_error", "svo_batch_lanes", "svo_batch_contexts",
+    "svo_batch_abi_sizes", "svo_batch_config_defaults", "svo_batch_create", "svo_batch_create_sized", "svo_batch_destroy", "svo_batch_last_error", "svo_batch_lanes", "svo_batch_contexts",
     "svo_batch_context", "svo_batch_set_params", "svo_batch_set_camera", "svo_batch_set_results_buffer", "svo_batch_switch_results_buffer", "svo_batch_step",
     "svo_batch_wait_on_stream", "svo_batch_hold_for_event", "svo_batch_synchronize", "svo_batch_results", "svo_batch_reset",
     "svo_fpstream_create", "svo_fpstream_destroy", "svo_fpstream_last_error", "svo_fpstream_contexts", "svo_fpstream_context",
@@ -89,9 +89,10 @@ def lib():
             getattr(L, n).restype = C.c_char_p; getattr(L, n).argtypes = [C.c_void_p]
         for n in ("svo_batch_context", "svo_fpstream_context", "svo_fpstream_last_owner"):
             getattr(L, n).restype = C.c_void_p
-        for n in ("svo_batch_destroy", "svo_fpstream_destroy", "svo_batch_config_defaults"):
+        for n in ("svo_batch_destroy", "svo_fpstream_destroy", "svo_batch_config_defaults", "svo_batch_abi_sizes"):
             getattr(L, n).restype = None
         L.svo_batch_destroy.argtypes = [C.c_void_p]; L.svo_fpstream_destroy.argtypes = [C.c_void_p]
+        L.svo_batch_create_sized.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         _LIB = L
     return _LIB
 

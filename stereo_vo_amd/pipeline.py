@@ -52,7 +52,7 @@ class StreamBatch:
         cfg.rest_streams = max(0, rest_streams)          # 0 = one stage 3-5 stream per context
         cfg.no_detect_ahead = int(not detect_ahead)      # False: a context's detector waits for its whole previous frame (rounds 1-3)
         h = C.c_void_p()
-        rc = self.L.svo_batch_create(C.byref(cfg), C.byref(h))
+        rc = self.L.svo_batch_create_sized(C.byref(cfg), C.c_size_t(C.sizeof(cfg)), C.byref(h))      # a stale mirror of svo_batch_config is refused by the library
         self.h = h
         if rc != 0:
             msg = self._err(rc)

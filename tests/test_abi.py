@@ -76,3 +76,24 @@ def test_batch_config_defaults_are_the_measured_schedule():
     hip.lib().svo_batch_config_defaults(C.byref(cfg))
     assert (cfg.n_contexts, cfg.schedule, cfg.det_priority_high, cfg.post_mode, cfg.det_streams, cfg.rest_streams, cfg.no_detect_ahead) == (3, 0, 1, 1, 1, 0, 0)
     assert cfg.ctx.n_lanes == 64
+
+
+def test_batch_config_size_is_checked_at_the_boundary():
+    """svo_batch_config grew a trailing field and SVO_MAX_LANES doubled without a guard.  The library now reports its own
+    sizes (svo_batch_abi_sizes), the header's svo_batch_create() macro passes the caller's sizeof along, and a mismatch is refused
+    with both numbers in svo_batch_last_error -- before any device is touched."""
+    from stereo_vo_amd import hip
+    L = hip.lib()
+    out = (C.c_int32 * 3)()
+    L.svo_batch_abi_sizes(out)
+    hdr = open(os.path.join(ROOT, "include", "svo_batch.h")).read()
+    assert out[0] == C.sizeof(hip.BatchConfig) and out[2] == int(re.search(r"#define SVO_BATCH_ABI_VERSION (\d+)", hdr).group(1))
+    assert out[1] == int(re.search(r"#define SVO_MAX_LANES (\d+)", open(os.path.join(ROOT, "include", "svo_hip.h")).read()).group(1))
+    cfg = hip.BatchConfig()
+    L.svo_batch_config_defaults(C.byref(cfg))
+    h = C.c_void_p()
+    rc = L.svo_batch_create_sized(C.byref(cfg), C.sizeof(cfg) - 4, C.byref(h))          # a host built against the round-3 header
+    assert rc == -2 and h.value
+    msg = L.svo_batch_last_error(h).decode()
+    assert str(C.sizeof(cfg) - 4) in msg and str(C.sizeof(cfg)) in msg and "ABI version" in msg
+    L.svo_batch_destroy(h)

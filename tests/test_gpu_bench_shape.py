@@ -119,6 +119,28 @@ def test_bench_two_ranks_on_one_gpu_gather_real_records(tmp_path):
     assert list(recs[0].outPose) != list(recs[8].outPose)
 
 
+def test_bench_launches_its_own_ranks_when_started_plainly(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it: the process re-runs itself as two
+    ranks and the line says n_gpus 2 -- it used to pass an assert and print a one-GPU line."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--lanes", "8", "--contexts", "2", "--frames", "3",
+           "--width", "640", "--height", "480", "--orb-nfeats", "500", "--cpu-frames", "0"]
+    pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-2000:]
+    line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2 and line["dist"]["gathered_tables_equal"]
+    # without the test hook a one-GPU box must REFUSE --gpus 2 (exit code 2, nothing that looks like a result line)
+    env.pop("BENCH_FORCE_DEVICE")
+    pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert pr.returncode == 2 and "refusing" in pr.stderr and not [l for l in pr.stdout.splitlines() if l.startswith("{")]
+
+
 def test_host_fed_path_64_lanes_matches_oracle():
     """Frames handed over as HOST images (the reference's own contract, P:100-120) at the batched shape: page-locked
     contiguous frames (one upload per step), page-locked non-contiguous frames (per-image 2-D uploads) and pageable

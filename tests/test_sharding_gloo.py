@@ -69,3 +69,35 @@ def test_frame_schedule_is_ping_pong():
     assert [bench.frame_schedule(i, 4) for i in range(9)] == [0, 1, 2, 3, 2, 1, 0, 1, 2]
     assert all(abs(bench.frame_schedule(i + 1, 6) - bench.frame_schedule(i, 6)) == 1 for i in range(40))
     assert bench.frame_schedule(5, 1) == 0
+
+
+def test_plain_multi_gpu_invocation_launches_ranks_or_refuses(monkeypatch, capsys):
+    """`python bench.py --gpus N` with no WORLD_SIZE becomes the launcher of N ranks: with fewer than N
+    devices visible it refuses (exit code 2, no result line); otherwise the command it starts is torch.distributed.run with
+    --nproc-per-node N on 127.0.0.1 followed by this script and the caller's own arguments."""
+    import subprocess
+    import sys
+    import bench
+    import torch
+    monkeypatch.delenv("BENCH_FORCE_DEVICE", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert bench.self_launch(2) == 2
+    assert "refusing" in capsys.readouterr().err
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20"])
+    assert bench.self_launch(8) == 0
+    c = seen["cmd"]
+    assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and c[c.index("--nproc-per-node") + 1] == "8"
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-4:] == ["--gpus", "8", "--steps", "20"] and c[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # a rank count that disagrees with --gpus is an error, not a one-GPU line
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    try:
+        bench.main()
+        assert False, "bench.main() accepted WORLD_SIZE 1 with --gpus 2"
+    except SystemExit as e:
+        assert "WORLD_SIZE" in str(e)
