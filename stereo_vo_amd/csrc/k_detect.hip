@@ -1285,6 +1285,7 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
 template <int NI>
 __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX, int pre, uint8_t* big)
 {
+    SVO_LATENCY_CHAIN(c);
     // dynamic LDS only (G17): keys[NS_MAX] u64 | hkey[2*NS_MAX] | hval[2*NS_MAX] | cellxy[NS_MAX] | acc_idx[NS_MAX] u16 | state[NS_MAX] u8 | scan[32] | flag
     // Above 4096 keys that is more LDS than a CU has: the first four arrays (24 of the 27 bytes per key) then live in a global
     // scratch region of this (image, octave) -- `big` -- and only the small ones stay in LDS.  Same code either way: barriers
@@ -2034,8 +2035,13 @@ hipError_t configure_nms_rowsort(const DevCtx& c)
 void launch_nms_rowsort(const DevCtx& c, int do_nms, int min_distance, int pre, hipStream_t st)
 {
     const int pmax = nms_pmax(c);
+    // threads per image: every phase strides by blockDim.x and a thread holds NI = 4 keys, so lists of up to 2048 keys also run on 512
+    // threads (8 waves instead of 16 to find room for on a CU that the detector's tiles fill); SVO_NMS_NT = 512 / 1024 for an A/B
+    static int nt_knob = -1;
+    if (nt_knob < 0) { const char* e = getenv("SVO_NMS_NT"); nt_knob = e ? atoi(e) : 0; }
+    const int nt = (pmax <= 2048 && nt_knob == 512) ? 512 : 1024;
     if (pmax > 4096) hipLaunchKernelGGL(k_nms_rowsort<8>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? (do_nms == 3 ? 3 : 0) : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, c.big_scratch);
-    else hipLaunchKernelGGL(k_nms_rowsort<4>, dim3(c.n_img, c.n_oct), dim3(1024), nms_rowsort_smem(pmax), st, c, c.fast_orb ? (do_nms == 3 ? 3 : 0) : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, (uint8_t*)nullptr);
+    else hipLaunchKernelGGL(k_nms_rowsort<4>, dim3(c.n_img, c.n_oct), dim3(nt), nms_rowsort_smem(pmax), st, c, c.fast_orb ? (do_nms == 3 ? 3 : 0) : do_nms, min_distance, pmax, (pre && !c.fast_orb) ? 1 : 0, (uint8_t*)nullptr);
 }
 
 void launch_half(const DevCtx& c, int level, hipStream_t st)

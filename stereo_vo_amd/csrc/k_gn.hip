@@ -214,9 +214,13 @@ __device__ void delta_to_pose(const double* dp, double* pose)
 
 #define GN_NSUM 28
 #define GN_NT_MAX 512        // the kernel is built for 256, 384 and 512 threads per lane (template parameter NT): SVO_GN_NT picks, see launch_gauss_newton
-#define GN_RED_BYTES(nt) ((size_t)GN_NSUM * (nt) * sizeof(double))      // the 28 x NT reduction buffer
+// Lists of up to GN_LCAP tracked pairs keep the sort / hash arrays of the stage-5 NMS mask and the two byte arrays in LDS
+// (30 bytes per entry); longer lists use the lane's region of DevCtx::gn_scratch in global memory.  The LDS a block asks for
+// therefore depends on what a frame of the workload tracks (a few hundred pairs), not on the capacity of the context's lists:
+// 33 KB instead of 123 KB at max_kps 4096, so that a lane's block finds room on a CU beside the detector's tiles (round 5).
+#define GN_LCAP 1024
 struct GnShared {
-    double part[4][GN_NSUM];
+    double part[GN_NT_MAX / 64][GN_NSUM];      // the 28 sums of every wave (reduced inside the wave on the DPP / permlane network)
     double tot[GN_NSUM];
     double step[6];
     double delta[6];
@@ -225,6 +229,53 @@ struct GnShared {
     int ok;
     int n_non_masked;
 };
+
+// ---- the 28 sums of a wave without LDS ----------------------------------------------------------------------------------
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd rows of one register with the even rows of another (the upper
+// half with the lower half): for a PAIR of sums (a, b) one swap per dword and one add leave "a over both rows" in one row and "b
+// over both rows" in the other -- each step halves the number of live values instead of doubling the work: 28 -> 14 -> 7 values,
+// then four DPP steps inside the rows of 16.  147 instructions per wave and iteration; a butterfly per sum would be 504.
+template <bool ROW16>
+__device__ __forceinline__ double gn_fold(double a, double b)
+{
+    const uint32_t a0 = (uint32_t)__double2loint(a), a1 = (uint32_t)__double2hiint(a), b0 = (uint32_t)__double2loint(b), b1 = (uint32_t)__double2hiint(b);
+    if (ROW16) {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false), r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double gn_dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+// acc[28] of every lane -> out[28] = the wave's sums (written by one lane per row of 16: 7 sums each)
+__device__ __forceinline__ void gn_wave_sums(const double* acc, double* out)
+{
+    double n[14], m[7];
+#pragma unroll
+    for (int j = 0; j < 14; j++) n[j] = gn_fold<true>(acc[j], acc[j + 14]);       // rows 0, 2: sum j over two rows; rows 1, 3: sum j + 14
+#pragma unroll
+    for (int j = 0; j < 7; j++) m[j] = gn_fold<false>(n[j], n[j + 7]);            // lanes 0..31: n[j] over both halves; lanes 32..63: n[j + 7]
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        double v = m[j];
+        v = gn_dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+        v = gn_dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+        v = gn_dpp_add<0x141>(v);      // row_half_mirror
+        v = gn_dpp_add<0x140>(v);      // row_mirror
+        m[j] = v;
+    }
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0) {
+        const int row = lane >> 4, base = (row & 1) * 14 + (row >> 1) * 7;       // row 0: sums 0..6, row 1: 14..20, row 2: 7..13, row 3: 21..27
+#pragma unroll
+        for (int j = 0; j < 7; j++) out[base + j] = m[j];
+    }
+}
 
 // Solve of the 6x6 normal equations by the square-root-free Cholesky form H = L D L^T (unit lower L), every index static
 // (registers, no scratch).  This runs on ONE thread between two barriers of every iteration, so what counts is the length of
@@ -271,7 +322,7 @@ __device__ __forceinline__ bool chol6(const double* H, const double* g, double d
 // thread sees sh.ok, sh.cost, sh.step, and sh.delta / sh.R already advanced by the step (S5:576-577).
 template <int GN_NT>
 __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T, const unsigned char* mask,
-                         const double* lmk, const float* obs, double* residual, GnShared& sh, double* red, int dbg = 0)
+                         const double* lmk, const float* obs, double* residual, GnShared& sh, int dbg = 0)
 {
     // Contraction ON inside the iteration (the file is compiled with -ffp-contract=off for the kernels that are compared bit for
     // bit): stage 5 is held to the oracle by a tolerance, and a lone wave pays ~5 cycles per instruction whatever it is, so
@@ -336,25 +387,20 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
             for (int b = a; b < 6; b++) { acc[h] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b] + J[3][a] * J[3][b]; h++; }   // ... Hessian NOT (S5:364-369)
         }
     }
-    // block reduction of the 28 sums through LDS: red[i][tid], then 16 threads per sum add 32 entries each and finish
-    // with four shuffles (28 shuffle trees of 6 steps each cost ~5x more on this latency-bound kernel)
-#pragma unroll
-    for (int i = 0; i < GN_NSUM; i++) red[i * GN_NT + tid] = acc[i];
+    // block reduction of the 28 sums: inside every wave on the permlane / DPP network (no LDS), then GN_NT / 64 x 28 doubles through
+    // LDS (1.3 KB; rounds 1-4 staged all 28 x GN_NT values there: 86 KB, and one more barrier).  Wave 0 adds the wave sums and its
+    // first thread goes on to the solve: LDS operations of one wave are ordered, so no block barrier in between.
+    gn_wave_sums(acc, sh.part[wid]);
     __syncthreads();
-    constexpr int PER = 8;                                                     // threads per sum; each adds GN_NT / 8 entries
-    static_assert(GN_NT % PER == 0 && GN_NSUM * PER <= GN_NT, "28 x 8 summing threads");
-    if (tid < GN_NSUM * PER) {
-        const int sidx = tid / PER, part = tid % PER;
-        const double* rp = red + sidx * GN_NT + part;
-        double sum = 0;
+    if (wid == 0) {
+        if (lane < GN_NSUM) {
+            double sum = sh.part[0][lane];
 #pragma unroll
-        for (int k = 0; k < GN_NT / PER; k++) sum += rp[PER * k];
-#pragma unroll
-        for (int o = 1; o < PER; o <<= 1) sum += __shfl_xor(sum, o, 64);
-        if (part == 0) sh.tot[sidx] = sum;
+            for (int w = 1; w < GN_NT / 64; w++) sum += sh.part[w][lane];
+            sh.tot[lane] = sum;
+        }
+        wave_lds_sync();
     }
-    __syncthreads();
-    (void)lane; (void)wid;
     if (tid == 0) {
         double H[36], g[6], x[6] = { 0, 0, 0, 0, 0, 0 };
         {
@@ -387,25 +433,16 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
 }
 
 template <int GN_NT>
-__global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, uint8_t* big)
+__global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, uint8_t* scratch)
 {
-    // dynamic LDS: { keys[PM] u64 | hkey[2PM] | hval[2PM] | cellxy[PM] } U red[28][GN_NT] f64 | state[PM] u8 | mask[PM] u8 | scan[40] | GnShared
-    // `big` (lists above 4096 tracks): the sort / hash arrays of the stage-5 NMS mask move to a global scratch region of the lane,
-    // LDS keeps the reduction buffer and the byte arrays
+    SVO_LATENCY_CHAIN(c);
+    // dynamic LDS: keys[LC] u64 | hkey[2 LC] | hval[2 LC] | cellxy[LC] | state[LC] u8 | mask[LC] u8 | scan[40] | GnShared, LC = min(pmax, GN_LCAP).
+    // A lane that tracks more than LC pairs (`big`) keeps the same arrays, sized pmax, in its region of c.gn_scratch.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int PM = P.pmax;
+    const int PM = P.pmax, LC = PM < GN_LCAP ? PM : GN_LCAP;
     const int lane_id = blockIdx.x, tid = threadIdx.x;
-    unsigned long long* keys = (unsigned long long*)(big ? big + (size_t)lane_id * ((size_t)PM * 28) : smem);
-    uint32_t* hkey = (uint32_t*)(keys + PM);
-    uint32_t* hval = hkey + 2 * PM;
-    uint32_t* cellxy = hval + 2 * PM;
-    // the sort/hash arrays are dead once the NMS mask exists; the same bytes then hold the 28 x GN_NT reduction buffer
-    const size_t region = (!big && (size_t)PM * 28 > GN_RED_BYTES(GN_NT)) ? (size_t)PM * 28 : GN_RED_BYTES(GN_NT);
-    unsigned char* state = smem + region;
-    unsigned char* mask = state + PM;
-    int* scan = (int*)(((uintptr_t)(mask + PM) + 15) & ~(uintptr_t)15);
+    int* scan = (int*)(smem + (size_t)LC * 30);
     GnShared& sh = *(GnShared*)(scan + 40);
-    double* redbuf = (double*)smem;
     LaneState& ls = c.lane[lane_id];
     svo_result& res = c.results[lane_id];
     if (!P.standalone && (!ls.has_prev || ls.m_error == SVO_VOEC_BAD_TRACKING)) return;      // P:305, P:332
@@ -424,6 +461,15 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     int* outl = c.outliers + (long long)lane_id * c.max_kps;
     int* cur_idx = c.trk_kq + (long long)lane_id * c.oct_cap * c.max_kps;      // tracked[..].second per point (the kept list of stage 4 is dead by now)
 
+    const bool big = T > LC;                                                     // block-uniform
+    const int AN = big ? PM : LC;
+    unsigned char* abase = big ? scratch + (size_t)lane_id * ((size_t)PM * 30) : smem;
+    unsigned long long* keys = (unsigned long long*)abase;
+    uint32_t* hkey = (uint32_t*)(keys + AN);
+    uint32_t* hval = hkey + 2 * AN;
+    uint32_t* cellxy = hval + 2 * AN;
+    unsigned char* state = (unsigned char*)(cellxy + AN);
+    unsigned char* mask = state + AN;
     int Pn = 64; while (Pn < T) Pn <<= 1;
     // ---- gather the four keypoint lists (S5:419-461, single octave) and the NMS sort keys ----
     for (int i = tid; i < Pn; i += blockDim.x) keys[i] = 0;
@@ -444,8 +490,8 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     }
     __threadfence_block();
     // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283); cap = T ----
-    if (T <= 1024 && !big) {
-        // a few hundred keys: every key counts the keys above it (the keys are unique, so the counts are the descending ranks).
+    if (!big) {
+        // at most GN_LCAP keys, a few hundred as a rule: every key counts the keys above it (the keys are unique, so the counts are the descending ranks).
         // All lanes read the same LDS word at a time (a broadcast): T reads per key and two barriers, where the bitonic network
         // needs 45 compare-exchange stages at 512 keys (~10 us of the ~25 us this kernel spends before its first iteration).
         unsigned long long* sorted = (unsigned long long*)hkey;             // 2 PM u32 = PM u64, free until the NMS builds its hash
@@ -516,7 +562,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
         while (it < limit && !done && !abort_ && !(cap1 && it >= 1)) {
             pCost = cCost;
             if (first) { for (int m = tid; m < T; m += blockDim.x) residual[m] = DBL_MAX; first = false; }            // S5:296
-            eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, redbuf, c.debug_mode);
+            eval_rgn<GN_NT>(P, cam, T, mask, lmk, obs, residual, sh, c.debug_mode);
             if (phase == 0) err_code = SVO_VOEC_NONE;                                                                // S5:299
             cCost = sh.cost;
             if (!sh.ok) {
@@ -579,11 +625,12 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
     }
 }
 
-static size_t gn_smem(int pmax, int nt)
+static size_t gn_smem(int pmax)
 {
-    const size_t region = (pmax <= 4096 && (size_t)pmax * 28 > GN_RED_BYTES(nt)) ? (size_t)pmax * 28 : GN_RED_BYTES(nt);
-    return region + (size_t)pmax * 2 + 16 + sizeof(int) * 40 + sizeof(GnShared) + 16;
+    const int lc = pmax < GN_LCAP ? pmax : GN_LCAP;
+    return (size_t)lc * 30 + sizeof(int) * 40 + sizeof(GnShared) + 16;
 }
+size_t gn_scratch_bytes_per_lane(int pmax) { return (size_t)pmax * 30; }
 
 hipError_t svo_raise_dyn_smem(const void* kernel, size_t bytes)
 {
@@ -605,7 +652,7 @@ hipError_t configure_gauss_newton(int pmax)
     const void* fn[3] = { (const void*)k_gauss_newton<256>, (const void*)k_gauss_newton<384>, (const void*)k_gauss_newton<512> };
     const int nt[3] = { 256, 384, 512 };
     for (int i = 0; i < 3; i++) {
-        const hipError_t e = svo_raise_dyn_smem(fn[i], gn_smem(pmax, nt[i]));
+        const hipError_t e = svo_raise_dyn_smem(fn[i], gn_smem(pmax)); (void)nt;
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -617,10 +664,9 @@ void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st)
     // the loop twice); SVO_GN_NT = 256 / 384 / 512 overrides the default for an A/B
     static int nt = 0;
     if (!nt) { const char* e = getenv("SVO_GN_NT"); const int v = e ? atoi(e) : 0; nt = (v == 256 || v == 384 || v == 512) ? v : 384; }
-    uint8_t* big = P.pmax > 4096 ? c.gn_scratch : (uint8_t*)nullptr;
-    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax, 512), st, c, P, big);
-    else if (nt == 384) hipLaunchKernelGGL(k_gauss_newton<384>, dim3(c.n_lanes), dim3(384), gn_smem(P.pmax, 384), st, c, P, big);
-    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax, 256), st, c, P, big);
+    if (nt == 512) hipLaunchKernelGGL(k_gauss_newton<512>, dim3(c.n_lanes), dim3(512), gn_smem(P.pmax), st, c, P, c.gn_scratch);
+    else if (nt == 384) hipLaunchKernelGGL(k_gauss_newton<384>, dim3(c.n_lanes), dim3(384), gn_smem(P.pmax), st, c, P, c.gn_scratch);
+    else hipLaunchKernelGGL(k_gauss_newton<256>, dim3(c.n_lanes), dim3(256), gn_smem(P.pmax), st, c, P, c.gn_scratch);
 }
 
 // ------------------------------------------------------------------------------------------------------------

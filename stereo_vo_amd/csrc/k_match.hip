@@ -195,6 +195,7 @@ typedef float hm_v16f __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nsplit)
 {
+    SVO_LATENCY_CHAIN(c);
     __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][8 * 32];           // [buffer][(2 s + kb) * 32 + (row ^ (2 s + kb))]: MFMA s, k-block kb
     __shared__ uint32_t lut[256];                                             // byte of TRAIN bits -> 8 nibbles (bit 1 -> +1 = 0x2, bit 0 -> -1 = 0xA); a query byte goes in complemented
     const int vl = blockIdx.x, lane_id = vl / c.oct_cap;
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nspl
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_one, double max_y_diff)
 {
+    SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* right_best = (unsigned*)smem;              // max_kps
     int* scan = (int*)(right_best + c.max_kps);          // 32
@@ -382,6 +384,7 @@ __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_o
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_match_lr_rbr(DevCtx c, int one_to_one, double max_y_diff, double minimum_response, int max_distance)
 {
+    SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* right_best = (unsigned*)smem;              // max_kps: per right feature, min over its claimants
     unsigned* left_pick = right_best + c.max_kps;        // max_kps: per left feature (min_idx << 8 | min_1) or ~0
@@ -466,6 +469,7 @@ __global__ void __launch_bounds__(256) k_match_lr_rbr(DevCtx c, int one_to_one, 
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_H)
 {
+    SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* cur_best = (unsigned*)smem;                // max_kps: (dist << 16 | pi) min over claimants
     int* scan = (int*)(cur_best + c.max_kps);
@@ -547,6 +551,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
 template <int TF_ITEMS>
 __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
 {
+    SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* firstL = (unsigned*)smem;                    // max_kps: smallest undecided k claiming left train index i
     unsigned* firstR = firstL + c.max_kps;                 // max_kps
@@ -925,6 +930,7 @@ __device__ __forceinline__ void finish_region(const DevCtx& c, int vl, int side,
 
 __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
 {
+    SVO_LATENCY_CHAIN(c);
     __shared__ int nm_s[16];
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16 + grp, side = blockIdx.y, vl = blockIdx.z;
@@ -1078,6 +1084,7 @@ __device__ __forceinline__ void gj_step(double (&A)[7][9], int (&perm)[9])
 // sixteen threads is one region: its models are packed by a row scan of the model counts.
 __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
 {
+    SVO_LATENCY_CHAIN(c);
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
@@ -1176,6 +1183,7 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
 typedef double rc_d4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 {
+    SVO_LATENCY_CHAIN(c);
     __shared__ int cnt_s[16];
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
@@ -1269,6 +1277,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 #define RC16_SUPER 256
 __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk)
 {
+    SVO_LATENCY_CHAIN(c);
     __shared__ double ops[(RC16_SUPER / 16) * 256];            // per tile of 16 pairs: B1 | B2 | phi[0..3] | phi[4..7], each [k][j]
     __shared__ int cnt_s[64];
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64, tid = threadIdx.x;     // first SLOT of the block
@@ -1399,6 +1408,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
 template <int RC_HB>
 __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 {
+    SVO_LATENCY_CHAIN(c);
     __shared__ int cnt_s[RC_HB];
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
@@ -1450,6 +1460,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 // (one launch less per frame); gate_th < 0: k_track_gate follows, after the blocks of all octaves
 __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, int gate_th)
 {
+    SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* in_l = smem;                         // max_kps
     unsigned char* in_r = in_l + c.max_kps;             // max_kps
@@ -1613,6 +1624,7 @@ __global__ void k_track_gate(DevCtx c, int bad_tracking_th)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 {
+    SVO_LATENCY_CHAIN(c);
     __shared__ int scan[32];
     __shared__ int s_next, s_kf;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -295,10 +295,8 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.sel_keys, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
     HIPCHECK(dev_alloc(ctx, &d.sel_resp, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
     d.big_scratch = nullptr; d.gn_scratch = nullptr;
-    if (MK > 4096) {
-        HIPCHECK(dev_alloc(ctx, &d.big_scratch, (size_t)NI * OC * (size_t)MK * 28));
-        HIPCHECK(dev_alloc(ctx, &d.gn_scratch, (size_t)L * (size_t)MK * 28));
-    }
+    if (MK > 4096) HIPCHECK(dev_alloc(ctx, &d.big_scratch, (size_t)NI * OC * (size_t)MK * 28));
+    HIPCHECK(dev_alloc(ctx, &d.gn_scratch, (size_t)L * gn_scratch_bytes_per_lane(MK)));      // lanes that track more than GN_LCAP pairs (k_gn.hip)
     HIPCHECK(dev_alloc(ctx, &d.sel_n, (size_t)NI * SVO_MAX_LEVELS));
     HIPCHECK(dev_alloc(ctx, &d.lvl_n, (size_t)NI * SVO_MAX_LEVELS));
     HIPCHECK(dev_alloc(ctx, &d.raw_kps, (size_t)NI * ctx->raw_cap_alloc));
@@ -342,6 +340,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.det_status, (size_t)L)); d.det_ahead = 0;
     d.bf_dist = nullptr;
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
+    { const char* rp = getenv("SVO_REST_PRIO"); d.rest_prio = rp ? (atoi(rp) & 3) : 0; }
     HIPCHECK(configure_gauss_newton(MK));
     HIPCHECK(configure_match(MK));
     return SVO_OK;

@@ -174,7 +174,16 @@ struct DevCtx {
     uint32_t* status;         // [n_lanes]
     uint32_t* det_status;     // [n_lanes] capacity bits raised by a detect call that runs ahead (SVO_FLAG_DETECT_AHEAD): folded into status / the record by its post call
     int det_ahead;            // 1 while launching the kernels of such a call: k_fast / k_select raise their bits in det_status
+    int rest_prio;            // SVO_REST_PRIO (0..3, default in svo_create): wave priority the per-lane latency chains of stages 3-5 run at (SVO_LATENCY_CHAIN)
 };
+
+// The per-lane kernels of stages 3-5 are a few waves per lane walking dependent chains; in the batched schedule they share their
+// SIMDs with the detector's tiles, which fill every issue slot they are given.  A raised wave priority lets the chain's next
+// instruction win the arbitration instead of queueing behind thirty throughput waves (it costs those almost nothing: the chains
+// issue rarely).  The value comes from DevCtx so that an A/B needs no rebuild; s_setprio takes an immediate, hence the switch.
+#ifdef __HIPCC__
+#define SVO_LATENCY_CHAIN(c) do { if ((c).rest_prio == 3) __builtin_amdgcn_s_setprio(3); else if ((c).rest_prio == 2) __builtin_amdgcn_s_setprio(2); else if ((c).rest_prio == 1) __builtin_amdgcn_s_setprio(1); } while (0)
+#endif
 
 // where a detect-phase kernel raises a capacity bit of its lane
 __device__ __forceinline__ void raise_detect_status(const DevCtx& c, int lane, uint32_t bit)

@@ -53,6 +53,7 @@ void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st);
 void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st);
 void launch_hamming_plain(const uint8_t* q, int nq, const uint8_t* t, int nt, unsigned* out, int nsplit, hipStream_t st);
 hipError_t configure_gauss_newton(int pmax);
+size_t gn_scratch_bytes_per_lane(int pmax);
 hipError_t configure_match(int max_kps);
 void launch_project_points(const float* uvu, int n, const svo_stereo_camera& cam, const double* delta6, float* pix, hipStream_t st);
 void launch_gauss_newton(const DevCtx& c, const GNParams& P, hipStream_t st);

@@ -15,6 +15,7 @@
 #   stats_ss  one stream alone (tools/single_stream_bench.py)
 #   pmc       the counter passes (tools/pmc_passes.py): traffic by request size, VALU / LDS / MFMA counters, issue fractions
 #   ab        AB="NAME=VALUE ..." : one more stats1 pass per assignment
+#   abbench   AB="NAME=VALUE ..." : the short un-profiled bench line (60 timed steps, no CPU legs) once plainly and once per assignment
 #   clocks    rocm-smi engine clock / power sampled while a 1500-step run is in flight
 #   timeline  kernel timeline of 6 steady-state steps of the benchmarked shape (per-stream co-execution)
 cd /tmp && export TMPDIR=/tmp
@@ -86,6 +87,20 @@ for step in "$@"; do
       [ -n "$f" ] && python $R/tools/trace_stats.py $f $O/${tag}_kernel_stats_1ctx_${ab}.csv --skip-steps 3 --total-steps 13 > /dev/null
       echo "A/B $ab:"; head -10 $O/${tag}_kernel_stats_1ctx_${ab}.csv
       grep '^{' $O/${tag}_prof_ab_${ab}.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('   value', d['value'], 'valid', d['valid_last_step'], 'tracked', d['mean_tracked'])"
+    done ;;
+  abbench)
+    for ab in BASE=1 $AB; do
+      ( cd $R; env $ab timeout 600 python bench.py --steps 60 --warmup 6 $SIDE --frames 210 $BENCH_ARGS ) > $O/${tag}_abbench_${ab}.json 2> $O/${tag}_abbench_${ab}.err
+      python - $O/${tag}_abbench_${ab}.json "$ab" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    k = d["kernels_ms_per_context_step"]
+    print("%-22s %9.1f pairs/s  %.4f ms/step  valid %s tracked %.1f | fast %.3f gn %.3f nms %.3f ransac_cnt %.3f track_filter %.3f hamming %.3f" % (sys.argv[2], d["value"], d["ms_per_step"], d["valid_last_step"], d["mean_tracked"],
+          k.get("fast", 0), k.get("gauss_newton", 0), k.get("nms_rowsort", 0), sum(v for n, v in k.items() if n.startswith("ransac_cnt")), k.get("track_filter", 0), sum(v for n, v in k.items() if n.startswith("hamming"))))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
     done ;;
   pmc)
     ( time timeout 1500 python $R/tools/pmc_passes.py $tag $BENCH_ARGS ) > $O/${tag}_pmc.log 2>&1
