@@ -607,6 +607,11 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
             std::vector<int> xi(g.w), xf(g.w), yi(g.h), yf(g.h);
             resize_table(lw[l - 1], g.w, xi.data(), xf.data());
             resize_table(lh[l - 1], g.h, yi.data(), yf.data());
+            // what k_resize's tile shape relies on (true for every x1/1.2 step; a geometry that broke it would be refused, not mis-sampled):
+            // adjacent columns sample at most two source columns apart, a 128 x 32 tile's taps fit the 176 x 42 window
+            for (int x = 0; x + 1 < g.w; x++) if (xi[x + 1] < xi[x] || xi[x + 1] - xi[x] > 2) return SVO_ERR_UNSUPPORTED;
+            for (int x = 0; x < g.w; x += 128) if (xi[std::min(x + 127, g.w - 1)] + 1 - (xi[x] & ~15) + 4 > 176) return SVO_ERR_UNSUPPORTED;
+            for (int y = 0; y < g.h; y += 32) if (yi[std::min(y + 31, g.h - 1)] + 1 - yi[y] > 41) return SVO_ERR_UNSUPPORTED;
             rtab.insert(rtab.end(), xi.begin(), xi.end()); rtab.insert(rtab.end(), xf.begin(), xf.end());
             rtab.insert(rtab.end(), yi.begin(), yi.end()); rtab.insert(rtab.end(), yf.begin(), yf.end());
             rt_off += 2 * (g.w + g.h);
