@@ -1275,12 +1275,20 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 // -- a failed guard, a NaN, a borderline pair -- replays the oracle's own expression (fm_inlier).
 // Result layout of the tile (pinned on the hardware, see above): lane l = j + 16 q, register r  <->  model 4 r + q, pair j.
 #define RC16_SUPER 256
+// Round 5: the PAIRS of a lane are split over RC16_NSPLIT blocks as well.  A block used to walk all n pairs (45-70 tiles of 16, ~1 us
+// each: 45 us for the two blocks per lane and side of chunk 0, with 3/4 of the GPU idle); now it walks its quarter, adds its partial
+// counts to rs_cnt (zeroed by the hypothesis kernel) and takes a ticket; the block that takes the last ticket of its 64 slots reads
+// the sums and publishes the best one.  Counts are integers: the order of the additions does not matter.  A block that finds its
+// groups out of reach (rs_bound moves while the launch runs, so the blocks of one group need not agree) still takes its ticket; the
+// sums it leaves incomplete belong to samples at or beyond rs_bound, which the finalize never visits, and a best count published from
+// incomplete sums is an under-estimate, which only loosens the bound it feeds (as the early exit's partial counts did).
+#define RC16_NSPLIT 4
 __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk)
 {
     SVO_LATENCY_CHAIN(c);
     __shared__ double ops[(RC16_SUPER / 16) * 256];            // per tile of 16 pairs: B1 | B2 | phi[0..3] | phi[4..7], each [k][j]
-    __shared__ int cnt_s[64];
-    const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64, tid = threadIdx.x;     // first SLOT of the block
+    const int sblk = blockIdx.x / RC16_NSPLIT, split = blockIdx.x % RC16_NSPLIT;                                          // the splits of a group are neighbours in dispatch order
+    const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + sblk * 64, tid = threadIdx.x;     // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 7) return;
@@ -1298,8 +1306,11 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     }
     __syncthreads();
     const int nlive_w = s_nlive[w];
-    if (s_nlive[0] <= 0 && s_nlive[1] <= 0 && s_nlive[2] <= 0 && s_nlive[3] <= 0) return;
+    const bool block_dead = s_nlive[0] <= 0 && s_nlive[1] <= 0 && s_nlive[2] <= 0 && s_nlive[3] <= 0;      // (block-uniform: read from LDS)
     bool dead = nlive_w <= 0;
+    // this block's share of the pairs: whole tiles of 16
+    const int tiles_all = (n + 15) >> 4, tiles_per = (tiles_all + RC16_NSPLIT - 1) / RC16_NSPLIT;
+    const int p0 = min(n, 16 * tiles_per * split), p1 = min(n, 16 * tiles_per * (split + 1));
     const int hs = min(hw, SVO_RANSAC_SLOTS - 16);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hs) * 9;
     const double* Gd = c.rs_guard + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hs) * 2;
@@ -1318,12 +1329,11 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     }
     const double b7 = q == 0 ? 1.0 : 0.0;
     const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
-    const int floor_cnt = chunk ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
     int cnt[4] = { 0, 0, 0, 0 };
-    for (int sb = 0; sb < n; sb += RC16_SUPER) {
+    for (int sb = p0; sb < p1 && !block_dead; sb += RC16_SUPER) {
         __syncthreads();                                                         // the previous 256 pairs have been consumed
         {
-            const float4 p = pts[min(sb + tid, n - 1)];
+            const float4 p = pts[min(sb + tid, p1 - 1)];
             const double x1 = (double)p.x, y1 = (double)p.y, x2 = (double)p.z, y2 = (double)p.w;
             double* o = ops + (tid >> 4) * 256 + (tid & 15);
             o[0] = x1; o[16] = y1; o[32] = 1.0; o[48] = 0.0;
@@ -1333,23 +1343,9 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         }
         __syncthreads();
         if (dead) continue;
-        const int ntile = min(RC16_SUPER / 16, (n - sb + 15) >> 4);
+        const int ntile = min(RC16_SUPER / 16, (p1 - sb + 15) >> 4);
         for (int t = 0; t < ntile; t++) {
             const int base = sb + 16 * t;
-            if (chunk && base && (t & 7) == 0) {
-                // records only (see k_ransac_count_mfma): a wave stops once none of its sixteen models can exceed the floor
-                bool hopeless = true;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    int gsum = cnt[r];
-                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0xB1, 0xF, 0xF, false);
-                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x4E, 0xF, 0xF, false);
-                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x141, 0xF, 0xF, false);
-                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x140, 0xF, 0xF, false);
-                    hopeless = hopeless && (gsum + (n - base) <= floor_cnt);
-                }
-                if (__ballot(hopeless) == ~0ull && c.debug_mode != 16) { dead = true; break; }
-            }
             const double* ot = ops + t * 256 + l;
             const double b1 = ot[0], b2 = ot[64], b5 = ot[128], b6 = ot[192];
             const rc_d4 z = { 0.0, 0.0, 0.0, 0.0 };
@@ -1360,7 +1356,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
             rc_d4 D = __builtin_amdgcn_mfma_f64_16x16x4f64(a5, b5, z, 0, 0, 0);
             D = __builtin_amdgcn_mfma_f64_16x16x4f64(a6, b6, D, 0, 0, 0);
             D = __builtin_amdgcn_mfma_f64_16x16x4f64(a7, b7, D, 0, 0, 0);
-            const bool valid = base + j < n;
+            const bool valid = base + j < p1;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const double denB = aB[r] * aB[r] + bB[r] * bB[r], denA = aA[r] * aA[r] + bA[r] * bA[r], dd = D[r] * D[r];
@@ -1377,6 +1373,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         }
     }
     // the 16 lanes of a DPP row hold the partial counts of models 4 r + q
+    int* gcnt = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int v = cnt[r];
@@ -1384,16 +1381,27 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
         v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
         v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
-        if (j == 0) {
-            const bool mine = nlive_w > 0 && 4 * r + q < nlive_w;            // a real model of a live group (not filler, not a leftover)
-            cnt_s[16 * w + 4 * r + q] = mine ? v : 0;
-            if (nlive_w > 0) c.rs_cnt[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hw + 4 * r + q] = mine ? v : 0;
-        }
+        // a real model of a live group (not filler, not a leftover); everything else keeps the zero the hypothesis kernel left
+        if (j == 0 && !dead && 4 * r + q < nlive_w && v > 0) atomicAdd(&gcnt[hw + 4 * r + q], v);
+    }
+    // the ticket of this block's 64 slots: every one of the RC16_NSPLIT blocks takes exactly one, computed or not
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        int* ticket = c.rs_ticket + ((long long)vl * 2 + side) * (SVO_RANSAC_SLOTS / 16) + h0 / 16;
+        const int t = atomicAdd(ticket, 1);
+        s_last = t == RC16_NSPLIT - 1;
+        if (s_last) *ticket = 0;                                                  // nobody else touches it until the next launch
     }
     __syncthreads();
+    if (!s_last) return;
+    __threadfence();
     if (tid < 64) {
-        // best count, FIRST slot that has it: max over (count << 6 | 63 - slot)
-        int key = cnt_s[tid] > 0 ? ((cnt_s[tid] << 6) | (63 - tid)) : 0;
+        // best count, FIRST slot that has it: max over (count << 6 | 63 - slot), over the slots this block still sees alive
+        const int gw = tid >> 4, nl = s_nlive[gw];
+        const int cv = (nl > 0 && (tid & 15) < nl) ? *(volatile int*)(gcnt + h0 + tid) : 0;
+        int key = cv > 0 ? ((cv << 6) | (63 - tid)) : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
         if (tid == 0 && key > 0) rs_publish_best(c, vl, side, chunk, n, key >> 6, h0 + 63 - (key & 63));
@@ -1762,7 +1770,7 @@ void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
     const bool many = c.n_lanes * c.n_oct > 8;
     if (dm == 14) hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk);
     else if (dm == 52) hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk);
-    else if (many || dm == 53 || dm == 54) hipLaunchKernelGGL(k_ransac_count_mfma16, dim3((ns + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else if (many || dm == 53 || dm == 54) hipLaunchKernelGGL(k_ransac_count_mfma16, dim3(((ns + 63) / 64) * RC16_NSPLIT, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
     else hipLaunchKernelGGL(k_ransac_count<4>, dim3((ns + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)

@@ -327,6 +327,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rs_bound, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_gen, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_floor, (size_t)NV * 4));
+    HIPCHECK(dev_alloc(ctx, &d.rs_ticket, (size_t)NV * 2 * (SVO_RANSAC_SLOTS / 16)));
     HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.gn_lmk, (size_t)L * MK * 3));

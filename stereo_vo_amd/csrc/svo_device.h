@@ -160,6 +160,7 @@ struct DevCtx {
     int* rs_nvalid;           // [n_lanes][2][PAD / 16]   models in each region
     int* rs_bound;            // [n_lanes][2]  upper limit of the SAMPLES the sequential stop can still reach
     int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
+    int* rs_ticket;           // [n_lanes][2][SLOTS / 16] blocks of k_ransac_count_mfma16 that have added their share of a group's counts (0 between launches)
     int* rs_floor;            // [n_lanes][2][2] best inlier count of chunk 0 / of chunks 0-1: what a later model must exceed to matter
     svo_index_pair* tracked;  // [n_lanes][max_kps]
     int* n_tracked;           // [n_lanes]
