@@ -40,7 +40,7 @@ from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 import ctypes as C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_PROFILES = ("r04q_pmc.json", "r04h_pmc.json", "r03e_pmc.json", "r03d_pmc.json", "r03_pmc.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")    # newest first; tools/pmc_passes.py writes them
+PMC_PROFILE = {"config2": "r05_pmc.json"}    # ONE committed counter summary per workload (tools/pmc_passes.py writes it); a line never quotes an older file silently
 
 
 def lane_seeds(rank, world_size, lanes):
@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames rendered per trajectory; 0 (default) = as many as it takes for no stream ever to see a frame twice (>= 200)")
     ap.add_argument("--trajectories", type=int, default=8, help="distinct camera trajectories rendered per rank; stream s plays trajectory s %% T from frame 7 * (s // T) on")
     ap.add_argument("--long-steps", type=int, default=100, help="N=1: when --steps is smaller than this, one more timed leg of this many steps (after --warmup untimed ones, estimators reset, the same streams from their first frame on: no stream sees a frame twice inside the leg), reported as `long_run` -- so that a short --steps run still carries a measurement over a few hundred milliseconds; 0 = skip")
+    ap.add_argument("--long-first", type=int, default=0, help="1: run the long_run leg BEFORE the --steps region instead of after the CPU legs (to separate the order of the legs from their duration)")
     ap.add_argument("--cut-steps", type=int, default=60, help="steps of the scene-cut leg (every stream jumps to another trajectory every 20 frames, estimators reset as an application would); N=1 only; 0 = skip")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
@@ -246,6 +247,46 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    def run_long_leg(order_note):
+        """`--long-steps` timed steps of the same batch, reset, every stream from its first frame on (see --long-steps); with the final
+        state checked against the oracle.  Returns the `long_run` block of the line."""
+        long_run = None
+        try:
+            # (the CPU legs before this one leave the GPU idle for tens of seconds: a first untimed pass brings the clocks back up,
+            # as the warm-up of the main run does after the rendering)
+            batch.reset()
+            for i in range(min(plan_steps, args.warmup + 30)):
+                step(i)
+            torch.cuda.synchronize()
+            batch.reset()
+            for i in range(args.warmup):
+                step(i)
+            torch.cuda.synchronize()
+            for c_ in ctxs:
+                c_.redo_count(reset=True)
+            tl = time.perf_counter()
+            for i in range(long_steps):
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+            tl = time.perf_counter() - tl
+            redo_l = sum(c_.redo_count(reset=True) for c_ in ctxs)
+            res_l = batch.results()
+            lr_parity = None
+            if args.cpu_frames > 0:
+                try:
+                    lr_parity = final_state_parity(batch, p, cam, res_l, lambda g: [frame_of(g, i) for i in range(args.warmup + long_steps)], args.warmup + long_steps)
+                except Exception as e:
+                    lr_parity = {"error": str(e)}
+            long_run = {"parity": lr_parity, "pairs_per_s": round(B * long_steps / tl, 2), "ms_per_step": round(1e3 * tl / long_steps, 4), "steps": long_steps, "warmup": args.warmup,
+                        "timed_region_s": round(tl, 4), "valid_last_step": "%d/%d" % (sum(1 for r in res_l if r.valid), B),
+                        "fast_redo_rate": round(redo_l / float(max(1, long_steps * 2 * B * (n_octaves if detect_fast_orb else 8))), 6),
+                        "note": "the same batch, reset, every stream from its first frame on (%d distinct consecutive frames per stream), timed like `value`; `value` itself is the --steps run the contract asks for" % (args.warmup + long_steps)}
+        except Exception as e:
+            long_run = {"error": str(e)}
+        if isinstance(long_run, dict):
+            long_run["order"] = order_note
+        return long_run
+
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -263,6 +304,16 @@ def main():
         c_.kernel_times_reset()
     for c_ in ctxs:
         c_.redo_count(reset=True)                 # (waits for the context: the warm-up is over)
+    long_run_early = None
+    if args.long_first and long_steps > 0 and rank == 0:
+        # A/B of the 3-4 % the long leg loses to the --steps region: the same leg BEFORE it, GPU warm from the warm-up steps
+        long_run_early = run_long_leg("before the --steps region (--long-first 1)")
+        batch.reset()
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        for c_ in ctxs:
+            c_.kernel_times_select(dom); c_.kernel_times_reset(); c_.redo_count(reset=True)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     allrec = None
@@ -314,26 +365,21 @@ def main():
         # `traffic_source` names the file so that a reader can tell a carried-over constant from a live counter.
         traffic, traffic_source, valu_frac, valu_table = None, None, None, None
         kk = "k_" + ("hamming" if dom.startswith("hamming") else dom)
-        for prof in PMC_PROFILES:
+        prof = PMC_PROFILE.get(args.workload)
+        if prof is None:
+            traffic_source = "none: no committed PMC profile for workload %s" % args.workload
+        else:
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
-                if pm.get("workload") != args.workload:
-                    continue
-                if "kernels" in pm:            # tools/pmc_passes.py (round 3 on): traffic and issue counters of every kernel, steady state
-                    e = pm["kernels"].get(kk)
-                    if e is None:
-                        continue
-                    traffic = int((e.get("read_bytes", 0) + e.get("write_bytes", 0)) * Bc / pm["lanes"])
-                    valu_frac = e.get("valu_issue_frac")
-                    valu_table = {k: v["valu_issue_frac"] for k, v in pm["kernels"].items() if "valu_issue_frac" in v}
-                elif kk in pm["read_bytes"]:
-                    traffic = int((pm["read_bytes"][kk] + pm["write_bytes"].get(kk, 0)) * Bc / pm["lanes"])
-                else:
-                    continue
+                e = pm["kernels"].get(kk) or pm["kernels"].get(kk + "_f4")
+                if pm.get("workload") != args.workload or e is None:
+                    raise KeyError("profile covers workload %s and kernels %s" % (pm.get("workload"), sorted(pm["kernels"])))
+                traffic = int((e.get("read_bytes", 0) + e.get("write_bytes", 0)) * Bc / pm["lanes"])
+                valu_frac = e.get("valu_issue_frac")
+                valu_table = {k: v["valu_issue_frac"] for k, v in pm["kernels"].items() if "valu_issue_frac" in v}
                 traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)" % prof
-                break
-            except Exception:
-                pass
+            except Exception as e_:
+                traffic_source = "MISSING: profiles/%s does not cover kernel %s of this run (%s: %s) -- traffic is null, not a number carried over from an older profile" % (prof, kk, type(e_).__name__, e_)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": int(abytes), "avg_launch_ms": round(per_kernel[dom]["ms_per_launch"], 4),
@@ -353,36 +399,9 @@ def main():
         if world == 1 and args.cpu_frames > 0:
             cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec)
             leg_done("cpu_baseline_and_parity_probe")
-        long_run = None
-        if long_steps > 0:
-            # a short --steps run (the driver's is 20 steps = ~50 ms) still gets a measurement over long_steps steps: estimators reset,
-            # the same streams from their first frame, --warmup untimed steps, then long_steps timed ones between two synchronisations
-            try:
-                # (the CPU legs before this one leave the GPU idle for tens of seconds: a first untimed pass brings the clocks back up,
-                # as the warm-up of the main run does after the rendering)
-                batch.reset()
-                for i in range(min(plan_steps, args.warmup + 30)):
-                    step(i)
-                torch.cuda.synchronize()
-                batch.reset()
-                for i in range(args.warmup):
-                    step(i)
-                torch.cuda.synchronize()
-                for c_ in ctxs:
-                    c_.redo_count(reset=True)
-                tl = time.perf_counter()
-                for i in range(long_steps):
-                    step(args.warmup + i)
-                torch.cuda.synchronize()
-                tl = time.perf_counter() - tl
-                redo_l = sum(c_.redo_count(reset=True) for c_ in ctxs)
-                res_l = batch.results()
-                long_run = {"pairs_per_s": round(B * long_steps / tl, 2), "ms_per_step": round(1e3 * tl / long_steps, 4), "steps": long_steps, "warmup": args.warmup,
-                            "timed_region_s": round(tl, 4), "valid_last_step": "%d/%d" % (sum(1 for r in res_l if r.valid), B),
-                            "fast_redo_rate": round(redo_l / float(max(1, long_steps * 2 * B * (n_octaves if detect_fast_orb else 8))), 6),
-                            "note": "the same batch, reset, every stream from its first frame on (%d distinct consecutive frames per stream), timed like `value`; `value` itself is the --steps run the contract asks for" % (args.warmup + long_steps)}
-            except Exception as e:
-                long_run = {"error": str(e)}
+        long_run = long_run_early
+        if long_steps > 0 and long_run is None:
+            long_run = run_long_leg("after the --steps region and the CPU legs (GPU idle for tens of seconds in between; an untimed pass brings the clocks back up first)")
             leg_done("long_run")
         if world == 1 and args.host_fed_steps > 0:
             host_fed = host_fed_leg(args, batch, frame_of, dev)
@@ -399,7 +418,7 @@ def main():
         if world == 1 and args.cut_steps > 0:
             batch.synchronize()
             try:
-                scene_cuts = scene_cut_leg(args, batch, frames, T, F, n_octaves if detect_fast_orb else 8)
+                scene_cuts = scene_cut_leg(args, batch, frames, T, F, n_octaves if detect_fast_orb else 8, p, cam)
             except Exception as e:
                 scene_cuts = {"error": str(e)}
             leg_done("scene_cuts")
@@ -604,20 +623,22 @@ def host_fed_leg(args, batch, frame_of, dev):
             "note": "page-locked host frames, one contiguous upload of %d pairs per context per step on the context's copy stream, two-slot device ring; the resident figure `value` excludes this copy" % batch.Bc}
 
 
-def scene_cut_leg(args, batch, frames, T, F, levels):
+def scene_cut_leg(args, batch, frames, T, F, levels, p=None, cam=None):
     """What the speculative FAST threshold costs when it is wrong.  Same batch, --cut-steps steps; every 20th step EVERY stream
     jumps to another trajectory (another scene: other textures, other corner statistics) at an arbitrary frame, and the estimators
     are reset there, as an application that detects the cut would (the reference itself keeps the pre-cut frame as `previous`
     for ever after voecBadTracking, P:86-95).  Timed like the main run, resets included."""
     B, K = batch.B, args.cut_steps
 
-    def ptrs(step):
+    def frame_at(l, step):
         seg = step // 20
+        j = (l + seg * 3) % T                                  # a new trajectory after every cut (T >= 2; with one trajectory only the frame jumps)
+        return frames[j][frame_schedule(PHASE_STRIDE * (l // T) + 53 * seg + step, F)]
+
+    def ptrs(step):
         out = []
         for l in range(B):
-            j = (l + seg * 3) % T                              # a new trajectory after every cut (T >= 2; with one trajectory only the frame jumps)
-            k = frame_schedule(PHASE_STRIDE * (l // T) + 53 * seg + step, F)
-            L_, R_ = frames[j][k]
+            L_, R_ = frame_at(l, step)
             out.append((L_.data_ptr(), R_.data_ptr()))
         return out
     sched = [ptrs(i) for i in range(K)]
@@ -636,10 +657,70 @@ def scene_cut_leg(args, batch, frames, T, F, levels):
     dt = time.perf_counter() - t0
     redo = sum(c_.redo_count(reset=True) for c_ in batch.ctxs)
     res = batch.results()
-    return {"pairs_per_s": round(B * K / dt, 1), "ms_per_step": round(1e3 * dt / K, 4), "steps": K, "cuts": cuts, "cut_every": 20,
+    parity = None
+    if p is not None and args.cpu_frames > 0:
+        try:
+            parity = final_state_parity(batch, p, cam, res, lambda g: [frame_at(g, i) for i in range(K)], K, cut_every=20)
+        except Exception as e:
+            parity = {"error": str(e)}
+    return {"parity": parity, "pairs_per_s": round(B * K / dt, 1), "ms_per_step": round(1e3 * dt / K, 4), "steps": K, "cuts": cuts, "cut_every": 20,
             "fast_redo_pairs": redo, "fast_redo_rate": round(redo / float(K * 2 * B * levels), 6),
             "valid_last_step": "%d/%d" % (sum(1 for r in res if r.valid), B),
             "note": "every stream jumps to another trajectory / scene every 20 frames, estimators reset at the cut (the resets and their synchronisation are inside the timed span); redo rate over ALL (image, level) pairs of the leg, the first frames (no speculation yet) included"}
+
+
+def final_state_parity(batch, p, cam, results, frames_for, n_steps, cut_every=0, max_lanes=28):
+    """The state a timed leg LEFT BEHIND against the oracle: every stream the HIP path reports invalid at the leg's last
+    step, plus three probe lanes of every context, is replayed from its first frame on one host thread each (a fresh estimator after
+    every cut, as the leg reset its own), and the last frame's lists, flags and pose are compared.  frames_for(lane) -> the n_steps
+    (left, right) device tensors that lane saw.  Bounded: at most max_lanes streams (the rest are counted, not replayed)."""
+    import threading
+    from oracle import oracle as O
+    from oracle import probe as PR
+    from stereo_vo_amd.abi import Result
+    B, Bc, NC = batch.B, batch.Bc, batch.NC
+    probes = sorted(set(k * Bc + l for k in range(NC) for l in (0, Bc // 2 - 1 if Bc > 1 else 0, Bc - 1)))
+    invalid = [g for g in range(B) if not results[g].valid]
+    want = list(dict.fromkeys(probes + invalid))[:max_lanes]
+    rec_cpu = batch.rec.cpu().numpy()
+    gpu = {}
+    for g in want:
+        ctx, l = batch.lane(g)
+        gpu[g] = PR.digest_of(ctx, l, Result.from_buffer_copy(rec_cpu[g].tobytes()))
+    ref, lock, todo = {}, threading.Lock(), list(want)
+
+    def work():
+        while True:
+            with lock:
+                if not todo:
+                    return
+                g = todo.pop()
+            fr = [tuple(x.cpu().numpy() for x in f) for f in frames_for(g)]
+            orc, d = O.Oracle(p), None
+            for i in range(n_steps):
+                if cut_every and i and i % cut_every == 0:
+                    orc.close(); orc = O.Oracle(p)
+                r = orc.process(fr[i][0], fr[i][1], cam)
+                if i == n_steps - 1:
+                    d = PR.digest_of(orc, 0, r)
+            orc.close()
+            with lock:
+                ref[g] = d
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work) for _ in range(max(1, min(len(want), os.cpu_count() or 1)))]
+    for t_ in ts: t_.start()
+    for t_ in ts: t_.join()
+    bad, max_t, max_r = [], 0.0, 0.0
+    for g in want:
+        lists, flags, et, er = PR.compare(gpu[g], ref[g])
+        max_t, max_r = max(max_t, et), max(max_r, er)
+        if not (lists and flags and et < 1e-3 and er < 1e-4):
+            bad.append({"lane": g, "lists": bool(lists), "flags": bool(flags), "gpu_valid": gpu[g].valid, "cpu_valid": ref[g].valid, "gpu_counts": list(gpu[g].n), "cpu_counts": list(ref[g].n)})
+    return {"lanes_replayed": len(want), "of_which_invalid_on_gpu": len([g for g in want if g in invalid]), "invalid_on_gpu_total": len(invalid), "frames_per_lane": n_steps,
+            "all_invalid_streams_checked": len(invalid) <= len([g for g in want if g in invalid]),
+            "final_lists_bit_exact_and_flags_equal": len(bad) == 0, "pose_max_err_m": max_t, "pose_max_err_rad": max_r, "mismatches": bad[:6],
+            "host_seconds": round(time.perf_counter() - t0, 1),
+            "note": "oracle replay of every stream the HIP path reports invalid at the leg's last step + 3 probe lanes per context, whole history of the leg; the final frame's keypoints / pairings / tracks / inliers, valid flag, error code and pose compared"}
 
 
 def other_workloads_leg(args):

@@ -256,18 +256,25 @@ __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nspl
     for (int v = 0; v < 16; v++) tc0[v] = (float)(8 * (v >> 2) + (v & 3) + 4 * kb) * (1.0f / 8192.0f);
     float best[2] = { 3.0e38f, 3.0e38f };
     const int one = 127;                                                      // E8M0 block scale 2^0
-    uint32_t nxt = fetch(fetch_row(j_begin));
-    int nrow = fetch_row(min(j_begin + 32, j_end - 1));
-    stage(0, nxt);
+    // Software pipeline (round 5): the dword of tile t + 1 is in a register when tile t starts, so its expansion and LDS write are
+    // issued right behind tile t's operand reads and complete under tile t's MFMAs (they sat behind the minima, on the serial chain
+    // barrier -> reads -> MFMAs -> minima -> four table reads -> write -> barrier, until round 4); rows are fetched three tiles ahead,
+    // dwords two.  The other buffer is free from the barrier on: every wave finished tile t - 1's reads before it arrived there.
+    stage(0, fetch(fetch_row(j_begin)));
+    uint32_t nxt = j_begin + 32 < j_end ? fetch(fetch_row(j_begin + 32)) : 0u;
+    int nrow = fetch_row(min(j_begin + 64, j_end - 1));
     int buf = 0;
     for (int j0 = j_begin; j0 < j_end; j0 += 32, buf ^= 1) {
         __syncthreads();                                           // tile `buf` is staged; the other buffer is free again
-        const bool more = j0 + 32 < j_end;
-        if (more) { nxt = fetch(nrow); nrow = fetch_row(min(j0 + 64, j_end - 1)); }
+        hm_v4i a4s[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) a4s[s4] = tileA[buf][(2 * s4 + kb) * 32 + (col ^ (2 * s4 + kb))];
+        if (j0 + 32 < j_end) stage(buf ^ 1, nxt);
+        if (j0 + 64 < j_end) { nxt = fetch(nrow); nrow = fetch_row(min(j0 + 96, j_end - 1)); }
         hm_v16f acc0 = tc0, acc1 = tc0;
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
-            const hm_v4i a4 = tileA[buf][(2 * s4 + kb) * 32 + (col ^ (2 * s4 + kb))];
+            const hm_v4i a4 = a4s[s4];
             const hm_v8i a = { a4.x, a4.y, a4.z, a4.w, 0, 0, 0, 0 };
             const hm_v8i b0 = { Bq[0][s4].x, Bq[0][s4].y, Bq[0][s4].z, Bq[0][s4].w, 0, 0, 0, 0 }, b1 = { Bq[1][s4].x, Bq[1][s4].y, Bq[1][s4].z, Bq[1][s4].w, 0, 0, 0, 0 };
             acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b0, acc0, 4, 4, 0, one, 0, one);
@@ -288,7 +295,6 @@ __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nspl
         const float o = (float)j0 * (1.0f / 8192.0f);
         best[0] = min2(best[0], min16(acc0) + o);
         best[1] = min2(best[1], min16(acc1) + o);
-        if (more) stage(buf ^ 1, nxt);
     }
     // ---- per query column: min over the two lane halves; D = 2 ham - 256 + index / 8192 -> (distance << 16 | index) ----
 #pragma unroll
@@ -1374,6 +1380,12 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     }
     // the 16 lanes of a DPP row hold the partial counts of models 4 r + q
     int* gcnt = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
+    // No __threadfence() anywhere here: an agent-scope fence writes back and invalidates the XCD's whole L2 on this part (eight
+    // L2s, not coherent with each other), and 17 000 blocks doing that made the launch 2.3 ms.  Everything the blocks tell each other
+    // goes through device-scope ATOMICS, which are performed at the memory side: the partial counts are RETURNING atomic adds (the wave
+    // holds their results, i.e. they have been performed, before it reaches the barrier), the ticket is taken after the barrier, and the
+    // last block reads the sums with atomic loads.
+    int seen = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int v = cnt[r];
@@ -1382,25 +1394,24 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
         v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
         // a real model of a live group (not filler, not a leftover); everything else keeps the zero the hypothesis kernel left
-        if (j == 0 && !dead && 4 * r + q < nlive_w && v > 0) atomicAdd(&gcnt[hw + 4 * r + q], v);
+        if (j == 0 && !dead && 4 * r + q < nlive_w && v > 0) seen |= __hip_atomic_fetch_add(&gcnt[hw + 4 * r + q], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (seen < 0) atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL);          // (counts are never negative: this only makes the adds above returning ones)
     // the ticket of this block's 64 slots: every one of the RC16_NSPLIT blocks takes exactly one, computed or not
     __shared__ int s_last;
-    __threadfence();
     __syncthreads();
     if (tid == 0) {
         int* ticket = c.rs_ticket + ((long long)vl * 2 + side) * (SVO_RANSAC_SLOTS / 16) + h0 / 16;
-        const int t = atomicAdd(ticket, 1);
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = t == RC16_NSPLIT - 1;
-        if (s_last) *ticket = 0;                                                  // nobody else touches it until the next launch
+        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nobody else touches it until the next launch
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (tid < 64) {
         // best count, FIRST slot that has it: max over (count << 6 | 63 - slot), over the slots this block still sees alive
         const int gw = tid >> 4, nl = s_nlive[gw];
-        const int cv = (nl > 0 && (tid & 15) < nl) ? *(volatile int*)(gcnt + h0 + tid) : 0;
+        const int cv = (nl > 0 && (tid & 15) < nl) ? __hip_atomic_load(gcnt + h0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         int key = cv > 0 ? ((cv << 6) | (63 - tid)) : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
