@@ -13,6 +13,14 @@ struct GNParams {
     double init[6];
 };
 
+// Which kernel forms are the PRODUCT and which are kept as A/B anchors only.  Every form below is compiled and run
+// against the oracle by tests/test_gpu_parity.py (test_every_ransac_kernel_form_gives_the_oracle_models,
+// test_kernel_launch_knobs_do_not_change_results); the launchers pick the product form unless a debug knob says otherwise.
+//   product, many lanes (> 8 lane-octaves):  k_hamming_f4, k_ransac_hyp_thread, k_ransac_count_mfma16
+//   product, few lanes (one stream alone):   k_hamming_f4, k_ransac_hyp (16 lanes per sample), k_ransac_count<4> (VALU, for latency)
+//   product, other entry points:             k_hamming_plain (svo_hamming_match), k_track_gate (multi-octave contexts), k_project_points
+//   A/B only (never launched by default):    k_hamming + k_gather_mdesc (the int8 matcher, SVO_HAM_FP4=0), k_ransac_count_mfma (4 x 4 tiles,
+//                                            SVO_DEBUG_MODE=52), k_ransac_count<16> (SVO_DEBUG_MODE=14)
 hipError_t svo_upload_tables();
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE) and is shared by every context of the process on that
 // device: keyed by both, only ever raised -- a later, smaller context must not lower the limit under an earlier context's launches,
