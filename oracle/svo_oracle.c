@@ -22,7 +22,6 @@
 #define EDGE_THRESHOLD 31          /* S2:486 */
 #define HARRIS_BLOCK 7
 #define RANSAC_MAX_HYP 1000        /* [frozen]  cv::findFundamentalMat's maxIters default of OpenCV >= 3.4 (2.4 sized its schedule from the confidence alone) */
-#define RANSAC_SEED 0x5EEDF00DCAFE1234ULL
 #define MAXOCT SVO_MAX_OCTAVES
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -788,18 +787,57 @@ int svo_oracle_match_lr(const svo_params* p, int orb_th, const svo_keypoint* kl,
 /* ------------------------------------------------------------------------------------------------ */
 /* fundamental-matrix RANSAC  [frozen]  (cv::findFundamentalMat(FM_RANSAC,1.0,0.99); S4:202,237,684,696) */
 /* ------------------------------------------------------------------------------------------------ */
-static uint64_t splitmix64(uint64_t x) { x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31); }
-static uint64_t xs64star(uint64_t* s) { uint64_t x = *s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *s = x; return x * 0x2545F4914F6CDD1DULL; }
+/* cv::RNG [frozen, v5; recalled: OpenCV's source is not in /root/reference].  core.hpp / operations.hpp: a multiply-with-carry generator,
+ *   state = (uint64)(unsigned)state * 4164903690U + (unsigned)(state >> 32);  next() = (unsigned)state;
+ *   uniform(int a, int b) = a == b ? a : (int)(next() % (b - a) + a);
+ * and RANSACPointSetRegistrator::run seeds a NEW one per call: `RNG rng((uint64)-1);` (modules/calib3d/src/ptsetreg.cpp), so every
+ * cv::findFundamentalMat call of the reference (S4:202, 237, 684, 696) draws the same raw sequence. */
+typedef struct { uint64_t state; } cv_rng;
+static uint32_t cv_rng_next(cv_rng* r) { r->state = (uint64_t)(uint32_t)r->state * 4164903690U + (uint32_t)(r->state >> 32); return (uint32_t)r->state; }
+void svo_oracle_cv_rng_raw(uint32_t* out, int count) { cv_rng r; r.state = 0xFFFFFFFFFFFFFFFFULL; for (int i = 0; i < count; i++) out[i] = cv_rng_next(&r); }
 
-static void ransac_sample(int h, int n, int* idx)
+/* haveCollinearPoints (modules/calib3d/src/precomp.hpp), as FMEstimatorCallback::checkSubset calls it with count = 7 for either image:
+ * is the LAST selected point on a line through two earlier ones (or do two of the three coincide)?  Float coordinates widened to double. */
+static int have_collinear(const float* pts, const int* idx, int count)
 {
-    uint64_t s = splitmix64(RANSAC_SEED + (uint64_t)h);
-    if (!s) s = 1;
-    for (int j = 0; j < 7; j++) {                 /* the minimal sample of cv::findFundamentalMat's RANSAC: modelPoints = 7 */
-        int v, dup;
-        do { v = (int)((uint32_t)(xs64star(&s) >> 32) % (uint32_t)n); dup = 0; for (int k = 0; k < j; k++) if (idx[k] == v) dup = 1; } while (dup);
-        idx[j] = v;
+    const int i = count - 1;
+    for (int j = 0; j < i; j++) {
+        const double dx1 = (double)pts[2 * idx[j]] - (double)pts[2 * idx[i]], dy1 = (double)pts[2 * idx[j] + 1] - (double)pts[2 * idx[i] + 1];
+        for (int k = 0; k < j; k++) {
+            const double dx2 = (double)pts[2 * idx[k]] - (double)pts[2 * idx[i]], dy2 = (double)pts[2 * idx[k] + 1] - (double)pts[2 * idx[i] + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return 1;    /* FLT_EPSILON */
+        }
     }
+    return 0;
+}
+
+/* RANSACPointSetRegistrator::getSubset (checkPartialSubsets = false): seven indices by rng.uniform(0, count), a draw that repeats an
+ * earlier one of the same attempt is drawn again; a complete attempt that fails checkSubset (collinearity in either image) costs one of
+ * the maxAttempts (10000, as run() passes) and is drawn afresh.  *attempts receives the attempts this call used (statistics only). */
+static int ransac_get_subset(cv_rng* rng, const float* p1, const float* p2, int n, int* idx, int max_attempts, int* attempts)
+{
+    int iters = 0;
+    for (; iters < max_attempts; iters++) {
+        for (int i = 0; i < 7; i++) {
+            int v, dup;
+            do { v = (int)(cv_rng_next(rng) % (uint32_t)n); dup = 0; for (int k = 0; k < i; k++) if (idx[k] == v) dup = 1; } while (dup);
+            idx[i] = v;
+        }
+        if (have_collinear(p1, idx, 7) || have_collinear(p2, idx, 7)) continue;
+        break;
+    }
+    if (attempts) *attempts = iters + (iters < max_attempts);
+    return iters < max_attempts;
+}
+
+/* test hook: the first `count` samples findFundamentalMat's RANSAC would draw for these points (7 indices each); returns how many exist */
+int svo_oracle_ransac_samples(const float* p1, const float* p2, int n, int count, int* idx7)
+{
+    cv_rng rng; rng.state = 0xFFFFFFFFFFFFFFFFULL;
+    int k = 0;
+    if (n < 8) return 0;
+    for (; k < count; k++) if (!ransac_get_subset(&rng, p1, p2, n, idx7 + 7 * k, 10000, NULL)) break;
+    return k;
 }
 
 /* The 7-point algorithm (cv::findFundamentalMat's run7Point, what its RANSAC solves per sample: S4:202, 237): the seven epipolar
@@ -971,21 +1009,35 @@ static int ransac_update_niters(int cnt, int n, int max_iters)
 }
 
 /* cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) (RANSACPointSetRegistrator::run with modelPoints = 7): per iteration one minimal
- * sample, every model the 7-point solver returns for it is scored in turn, a model with more inliers than any before (and than
+ * sample -- drawn by OpenCV's own generator and rejection rules since v5 (cv::RNG seeded (uint64)-1 per call, getSubset, checkSubset) --,
+ * every model the 7-point solver returns for it is scored in turn, a model with more inliers than any before (and than
  * modelPoints - 1) becomes the result and shrinks the iteration budget; the budget is tested once per iteration, so all models
- * of a sample are scored.  best_hyp = the SAMPLE the winning model came from, n_hyp_used = samples visited. */
+ * of a sample are scored.  best_hyp = the SAMPLE the winning model came from, n_hyp_used = samples visited.
+ * Exactly seven points: findFundamentalMat runs the 7-point kernel directly and sets the whole mask (no sampling; whichever model it
+ * returns, seven inliers are below the eight the reference asks for at S4:205, 240).
+ * DEVIATION, stated: for 8 <= n <= 14 OpenCV (>= 3.0) switches to its LMedS registrator; this restatement runs the RANSAC for
+ * every n >= 8.  The regime is a tracker that has all but lost its features (the reference declares bad tracking below 5 tracked pairs). */
 int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9, int* best_hyp, int* n_hyp_used)
 {
     for (int i = 0; i < n; i++) mask[i] = 0;
     if (best_hyp) *best_hyp = -1;
     if (n_hyp_used) *n_hyp_used = 0;
     if (n < 7) return 0;
+    if (n == 7) {
+        int s[7] = { 0, 1, 2, 3, 4, 5, 6 }; double Fm[27];
+        const int nm = seven_point(p1, p2, s, Fm);
+        for (int i = 0; i < n; i++) mask[i] = 1;
+        if (F9 && nm > 0) memcpy(F9, Fm, 9 * sizeof(double));
+        if (best_hyp) *best_hyp = 0;
+        return 7;
+    }
     int niters = RANSAC_MAX_HYP, best_cnt = 0, best_k = -1;
     double Fbest[9] = { 0 };
+    cv_rng rng; rng.state = 0xFFFFFFFFFFFFFFFFULL;                 /* RNG rng((uint64)-1) */
     int k;
     for (k = 0; k < niters; k++) {
         int s[7]; double Fm[27];
-        ransac_sample(k, n, s);
+        if (!ransac_get_subset(&rng, p1, p2, n, s, 10000, NULL)) break;        /* `if (!found) { if (iter == 0) return false; break; }` */
         const int nm = seven_point(p1, p2, s, Fm);
         for (int j = 0; j < nm; j++) {
             const double* F = Fm + 9 * j;

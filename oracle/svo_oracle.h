@@ -30,8 +30,13 @@ extern "C" {
  *      are commented out in OpenCV's computeOrbDescriptor), on a blur whose taps are cvRound(256 g) = {18, 34, 49, 55, ...} (sum 257,
  *      saturated) -- pinned bit for bit to scikit-image's _orb_loop (tests/test_oracle_thirdparty.py); HarrisResponses' float
  *      expression in OpenCV's operator order; the RANSAC solves the MINIMAL sample of 7 points (run7Point: null space + cubic, one or
- *      three models per sample, every model scored, modelPoints = 7 in the stop rule) instead of 8 points + rank-2 projection */
-#define SVO_ORACLE_VERSION 4
+ *      three models per sample, every model scored, modelPoints = 7 in the stop rule) instead of 8 points + rank-2 projection;
+ *   5  round 5: the samples of the F-matrix RANSAC come from OpenCV's own generator and rejection rules -- cv::RNG (multiply-with-carry,
+ *      seeded (uint64)-1 by every findFundamentalMat call), RANSACPointSetRegistrator::getSubset (uniform draws, a repeated index drawn
+ *      again) and FMEstimatorCallback::checkSubset (a sample whose last point is collinear with two earlier ones in either image is drawn
+ *      afresh) -- instead of this repository's own seeded schedule; exactly seven points take findFundamentalMat's direct path (whole mask
+ *      set).  Stated deviation: for 8..14 points OpenCV >= 3.0 runs LMedS, this restatement the RANSAC. */
+#define SVO_ORACLE_VERSION 5
 int svo_oracle_version(void);
 
 typedef struct svo_oracle svo_oracle;
@@ -102,6 +107,10 @@ int svo_oracle_match_lr(const svo_params* p, int orb_th, const svo_keypoint* kl,
                         const int64_t* idxr, int img_w, int img_h, svo_dmatch* out, int cap,
                         int64_t* row_index /* img_h+1 */);
 /* cv::findFundamentalMat(FM_RANSAC,1.0,0.99) stand-in. Returns inlier count; mask has n entries (all 0 if n<8) */
+/* cv::RNG's raw 32-bit outputs from the seed findFundamentalMat's RANSAC uses ((uint64)-1): out[0..count) (the device's table, tests) */
+void svo_oracle_cv_rng_raw(uint32_t* out, int count);
+/* the first `count` minimal samples (7 indices each) that RANSAC draws for these point pairs; returns how many there are */
+int svo_oracle_ransac_samples(const float* p1, const float* p2, int n, int count, int* idx7);
 int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9,
                                   int* best_hyp, int* n_hyp_used);
 /* stage 4 on caller data; returns T */

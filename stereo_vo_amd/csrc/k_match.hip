@@ -867,6 +867,14 @@ __device__ __forceinline__ int rs_group_live(const DevCtx& c, int vl, int side, 
     if (c.rs_k[((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + s0] >= *(volatile int*)(c.rs_bound + vl * 2 + side)) return 0;
     return nv - off;
 }
+// the part of rs_group_live that cannot change while a count launch runs: models at or after s0 in a region this chunk generated
+__device__ __forceinline__ int rs_group_generated(const DevCtx& c, int vl, int side, int s0)
+{
+    const int reg = s0 / SVO_RANSAC_RSLOTS, off = s0 - reg * SVO_RANSAC_RSLOTS;
+    if (reg * SVO_RANSAC_REG >= c.rs_gen[vl * 2 + side]) return 0;
+    const int nv = c.rs_nvalid[((long long)vl * 2 + side) * (SVO_RANSAC_PAD / SVO_RANSAC_REG) + reg];
+    return off >= nv ? 0 : nv - off;
+}
 // after a block has its counts: its best model tightens rs_bound and raises the floors of the later chunks
 __device__ __forceinline__ void rs_publish_best(const DevCtx& c, int vl, int side, int chunk, int n, int best, int best_slot)
 {
@@ -1289,11 +1297,11 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 // sums it leaves incomplete belong to samples at or beyond rs_bound, which the finalize never visits, and a best count published from
 // incomplete sums is an under-estimate, which only loosens the bound it feeds (as the early exit's partial counts did).
 #define RC16_NSPLIT 4
-__global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk)
+__global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk, int nsplit)
 {
     SVO_LATENCY_CHAIN(c);
     __shared__ double ops[(RC16_SUPER / 16) * 256];            // per tile of 16 pairs: B1 | B2 | phi[0..3] | phi[4..7], each [k][j]
-    const int sblk = blockIdx.x / RC16_NSPLIT, split = blockIdx.x % RC16_NSPLIT;                                          // the splits of a group are neighbours in dispatch order
+    const int sblk = blockIdx.x / nsplit, split = blockIdx.x % nsplit;                                          // the splits of a group are neighbours in dispatch order
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + sblk * 64, tid = threadIdx.x;     // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
@@ -1305,17 +1313,22 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     // the block leaves when none of its four groups has anything to score.  Four threads decide, one per group, and the block reads
     // their verdicts from LDS: rs_bound moves while the launch runs, so waves looking for themselves could disagree, and a block of
     // which some waves have left no longer fills `ops`
-    __shared__ int s_nlive[4];
+    __shared__ int s_nlive[4], s_gen[4];
     if (tid < 4) {
         const int s0 = h0 + 16 * tid;
-        s_nlive[tid] = (s0 < RS_SLOT_END(chunk) && s0 + 16 <= SVO_RANSAC_SLOTS) ? rs_group_live(c, vl, side, s0) : 0;
+        const bool in = s0 < RS_SLOT_END(chunk) && s0 + 16 <= SVO_RANSAC_SLOTS;
+        s_nlive[tid] = in ? rs_group_live(c, vl, side, s0) : 0;
+        s_gen[tid] = in ? rs_group_generated(c, vl, side, s0) : 0;
     }
     __syncthreads();
     const int nlive_w = s_nlive[w];
     const bool block_dead = s_nlive[0] <= 0 && s_nlive[1] <= 0 && s_nlive[2] <= 0 && s_nlive[3] <= 0;      // (block-uniform: read from LDS)
+    // a block none of whose groups was even GENERATED leaves at once, ticket and all: rs_gen and rs_nvalid do not move during the launch,
+    // so the blocks of the group agree on it (rs_bound does move: a block that finds its groups merely out of reach stays for the ticket)
+    if (s_gen[0] <= 0 && s_gen[1] <= 0 && s_gen[2] <= 0 && s_gen[3] <= 0) return;
     bool dead = nlive_w <= 0;
     // this block's share of the pairs: whole tiles of 16
-    const int tiles_all = (n + 15) >> 4, tiles_per = (tiles_all + RC16_NSPLIT - 1) / RC16_NSPLIT;
+    const int tiles_all = (n + 15) >> 4, tiles_per = (tiles_all + nsplit - 1) / nsplit;
     const int p0 = min(n, 16 * tiles_per * split), p1 = min(n, 16 * tiles_per * (split + 1));
     const int hs = min(hw, SVO_RANSAC_SLOTS - 16);
     const double* F = c.rs_F + (((long long)vl * 2 + side) * SVO_RANSAC_SLOTS + hs) * 9;
@@ -1403,7 +1416,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     if (tid == 0) {
         int* ticket = c.rs_ticket + ((long long)vl * 2 + side) * (SVO_RANSAC_SLOTS / 16) + h0 / 16;
         const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == RC16_NSPLIT - 1;
+        s_last = t == nsplit - 1;
         if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nobody else touches it until the next launch
     }
     __syncthreads();
@@ -1781,7 +1794,11 @@ void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
     const bool many = c.n_lanes * c.n_oct > 8;
     if (dm == 14) hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk);
     else if (dm == 52) hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk);
-    else if (many || dm == 53 || dm == 54) hipLaunchKernelGGL(k_ransac_count_mfma16, dim3(((ns + 63) / 64) * RC16_NSPLIT, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
+    else if (many || dm == 53 || dm == 54) {
+        static int nsplit = 0;
+        if (!nsplit) { const char* e = getenv("SVO_RC_SPLIT"); const int v = e ? atoi(e) : 0; nsplit = (v >= 1 && v <= 8) ? v : RC16_NSPLIT; }
+        hipLaunchKernelGGL(k_ransac_count_mfma16, dim3(((ns + 63) / 64) * nsplit, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk, nsplit);
+    }
     else hipLaunchKernelGGL(k_ransac_count<4>, dim3((ns + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }
 void launch_track_finalize(const DevCtx& c, int bad_tracking_th, int win_mode, hipStream_t st)

@@ -10,7 +10,7 @@ import numpy as np
 from .abi import Params, Result, StereoCamera, keypoint_dtype, dmatch_dtype, index_pair_dtype
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvo_hip.so")
+LIB_PATH = os.environ.get("SVO_HIP_LIB") or os.path.join(_HERE, "libsvo_hip.so")      # SVO_HIP_LIB: a library built from another commit, for A/B runs (tools/prof.sh abbench)
 _LIB = None
 
 MAX_LANES = 128
