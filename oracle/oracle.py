@@ -347,6 +347,24 @@ def ransac_fundamental(p1, p2):
     return cnt, mask[:n].copy(), F.reshape(3, 3), bh.value, nu.value
 
 
+def cv_rng_raw(count):
+    """cv::RNG's first `count` raw 32-bit outputs from the seed findFundamentalMat's RANSAC uses, (uint64)-1"""
+    out = np.zeros(count, np.uint32)
+    f = lib().svo_oracle_cv_rng_raw
+    f.restype = None
+    f(_ptr(out, C.POINTER(C.c_uint32)), int(count))
+    return out
+
+
+def ransac_samples(p1, p2, count):
+    """the first `count` minimal samples (rows of seven indices) cv::findFundamentalMat's RANSAC draws for these point pairs"""
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    idx = np.zeros((count, 7), np.int32)
+    k = lib().svo_oracle_ransac_samples(_ptr(p1, f32p), _ptr(p2, f32p), len(p1), int(count), _ptr(idx, C.POINTER(C.c_int32)))
+    return idx[:k].copy()
+
+
 def seven_point(p1, p2):
     """the models (1 or 3, 3x3 each) of the 7-point algorithm for the first seven correspondences"""
     p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)

@@ -673,14 +673,6 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
 // matrix that no pair fits (count 0), and every count of a region is zeroed when it is generated, so a slot that was never
 // scored reads as 0 = "no record".  Budgets and bounds (rs_bound, rs_gen, K(count)) are in SAMPLES, as the oracle's loop counter.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
-{
-    x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31);
-}
-__device__ __forceinline__ unsigned long long xs64star(unsigned long long& s)
-{
-    unsigned long long x = s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; s = x; return x * 0x2545F4914F6CDD1DULL;
-}
 
 // The sequential RANSAC's stop rule (oracle: svo_oracle_ransac_fundamental): samples are visited in order; a model whose count
 // exceeds the best so far (and 6 = modelPoints - 1) becomes the result and shrinks the iteration budget to
@@ -716,20 +708,149 @@ __device__ __forceinline__ int ransac_niters(int cnt, int n, int max_iters)
     return (int)rint(num / d);
 }
 
-// oracle: ransac_sample -- seven distinct indices below n from the sample's own generator
-__device__ __forceinline__ void ransac_sample7(int h, int n, int (&s)[7])
+// oracle: ransac_get_subset -- the seven indices of sample h, drawn by cv::RNG under getSubset's rules: k_ransac_schedule below wrote them
+__device__ __forceinline__ void ransac_sample7(const DevCtx& c, int vl, int side, int h, int (&s)[7])
 {
-    unsigned long long st = splitmix64(SVO_RANSAC_SEED + (unsigned long long)h);
-    if (!st) st = 1;
+    const uint4 w = *(const uint4*)(c.rs_smp + (((long long)vl * 2 + side) * SVO_RANSAC_PAD + h) * 8);
+    s[0] = (int)(w.x & 0xFFFFu); s[1] = (int)(w.x >> 16); s[2] = (int)(w.y & 0xFFFFu); s[3] = (int)(w.y >> 16);
+    s[4] = (int)(w.z & 0xFFFFu); s[5] = (int)(w.z >> 16); s[6] = (int)(w.w & 0xFFFFu);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The sample schedule of cv::findFundamentalMat's RANSAC (oracle v5: cv_rng_next, ransac_get_subset, have_collinear).
+// OpenCV draws from ONE multiply-with-carry stream per call, seeded (uint64)-1: draw after draw, an index that repeats inside an attempt
+// is drawn again, an attempt whose last point is collinear with two earlier ones (in either image) is drawn afresh -- so WHERE in the
+// stream sample k starts depends on everything before it.  What does not depend on anything is the stream itself: its first SVO_RNG_J
+// raw words are a table (c.rs_raw, filled by svo_create).  A block per lane-octave then works through windows of RSCH_W positions:
+//   1. v[i] = raw[pos + i] % n;
+//   2. every position i as if an attempt started there: how many draws until seven distinct values (len[i]), in parallel;
+//   3. the attempts that really happen are the orbit 0 -> len -> ... : pointer doubling over jump[i] = i + len[i] gives the k-th
+//      attempt's position q[k] in log steps (a serial walk is one dependent LDS read per attempt: 7 us per window);
+//   4. each attempt's seven indices again, the collinearity test on the lane's point pairs, per side;
+//   5. sample index = attempts of that side that passed so far (block scan): the indices go to c.rs_smp[side][sample].
+// Phase 0 (before chunk 0) stops once both sides have SVO_RANSAC_CHUNK1 samples, phase 1 (before chunk 2) continues to SVO_RANSAC_HYP
+// for the lanes whose budget still reaches that far.  The table running out before that (tiny n, or point sets on which nearly every
+// sample is collinear) ends the schedule early: the hypothesis kernels generate what exists, and SVO_ST_INTERNAL is raised if the
+// sequential algorithm could have gone further.
+// ------------------------------------------------------------------------------------------------------------
+#define RSCH_W 2048
+#define RSCH_PAD 64
+#define RSCH_Q 512          // >= RSCH_W / 7 + 1 attempts per window, a power of two
+__device__ __forceinline__ bool rs_collinear7(const float (&x)[7], const float (&y)[7])
+{
+    bool bad = false;
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        int v; bool dup;
-        do {
-            v = (int)((unsigned)(xs64star(st) >> 32) % (unsigned)n); dup = false;
+    for (int j = 0; j < 6; j++) {
+        const double dx1 = (double)x[j] - (double)x[6], dy1 = (double)y[j] - (double)y[6];
 #pragma unroll
-            for (int k = 0; k < 7; k++) if (k < j && s[k] == v) dup = true;
-        } while (dup);
-        s[j] = v;
+        for (int k = 0; k < 6; k++) if (k < j) {
+            const double dx2 = (double)x[k] - (double)x[6], dy2 = (double)y[k] - (double)y[6];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) bad = true;
+        }
+    }
+    return bad;
+}
+// the attempt that starts at v[i]: seven distinct values; returns the draws it takes, 0 when it runs off the staged stretch
+__device__ __forceinline__ int rs_attempt(const unsigned short* v, int i, int lim, int (&s)[7])
+{
+    int j = i;
+#pragma unroll
+    for (int cidx = 0; cidx < 7; cidx++) {
+        for (;;) {
+            if (j >= lim) return 0;
+            const int x = v[j++];
+            if (x == 0xFFFF) return 0;
+            bool dup = false;
+#pragma unroll
+            for (int k = 0; k < 7; k++) if (k < cidx && s[k] == x) dup = true;
+            if (!dup) { s[cidx] = x; break; }
+        }
+    }
+    return j - i;
+}
+__global__ void __launch_bounds__(256) k_ransac_schedule(DevCtx c, int phase)
+{
+    SVO_LATENCY_CHAIN(c);
+    __shared__ unsigned short v[RSCH_W + RSCH_PAD], jmp[2][RSCH_W + RSCH_PAD + 1], q[RSCH_Q];
+    __shared__ int scan[40];
+    const int vl = blockIdx.x, tid = threadIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    const int n = c.trk_nk[vl];
+    int* st = c.rs_sched + vl * 4;                                       // next stream position | attempts so far | samples left | samples right
+    if (n < 8 || n > 0xFFFE) { if (phase == 0 && tid < 4) st[tid] = 0; return; }
+    if (phase == 1 && max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= SVO_RANSAC_CHUNK1) return;      // neither side's budget reaches chunk 2
+    const int target = phase ? SVO_RANSAC_HYP : SVO_RANSAC_CHUNK1;
+    int pos = phase ? st[0] : 0, attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
+    const float4* ptsL = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
+    const float4* ptsR = (const float4*)(c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4);
+    bool exhausted = false;
+    while (min(ns[0], ns[1]) < target) {
+        const int Wn = min(RSCH_W, SVO_RNG_J - pos), lim = min(RSCH_W + RSCH_PAD, SVO_RNG_J - pos);
+        if (Wn <= 0) { exhausted = true; break; }
+        __syncthreads();
+        for (int i = tid; i < RSCH_W + RSCH_PAD; i += 256) v[i] = i < lim ? (unsigned short)(c.rs_raw[pos + i] % (unsigned)n) : (unsigned short)0xFFFF;
+        __syncthreads();
+        // positions >= Wn, and positions whose attempt cannot finish inside the staged stretch, are fixed points: the orbit stops there
+        for (int i = tid; i <= RSCH_W + RSCH_PAD; i += 256) {
+            int s[7] = { 0, 0, 0, 0, 0, 0, 0 };
+            const int len = i < Wn ? rs_attempt(v, i, lim, s) : 0;
+            jmp[0][i] = (unsigned short)(i + len);
+        }
+        if (tid == 0) q[0] = 0;
+        int cur = 0;
+        for (int r = 0; (1 << r) < RSCH_Q; r++) {
+            __syncthreads();
+            for (int k = (1 << r) + tid; k < (2 << r); k += 256) q[k] = jmp[cur][q[k - (1 << r)]];
+            for (int i = tid; i <= RSCH_W + RSCH_PAD; i += 256) jmp[cur ^ 1][i] = jmp[cur][jmp[cur][i]];
+            cur ^= 1;
+        }
+        __syncthreads();
+        // the attempts of this window: q[k] while it is not a fixed point (v / q are still intact; jmp[] holds the 2^9-fold jump now)
+        int okl[2] = { 0, 0 }, okr[2] = { 0, 0 }, isatt[2] = { 0, 0 }, sidx[2][7];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int k = tid + 256 * it;
+            const int p = q[k];
+            int s[7] = { 0, 0, 0, 0, 0, 0, 0 };
+            const int len = p < Wn ? rs_attempt(v, p, lim, s) : 0;
+            if (len > 0 && (k == 0 || q[k - 1] != p)) {
+                isatt[it] = 1;
+                float x1[7], y1[7], x2[7], y2[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) { const float4 a = ptsL[s[i]]; x1[i] = a.x; y1[i] = a.y; x2[i] = a.z; y2[i] = a.w; }
+                okl[it] = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+#pragma unroll
+                for (int i = 0; i < 7; i++) { const float4 a = ptsR[s[i]]; x1[i] = a.x; y1[i] = a.y; x2[i] = a.z; y2[i] = a.w; }
+                okr[it] = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) sidx[it][i] = s[i];
+        }
+        // sample numbers per side: passed attempts in orbit order (k = tid first, then tid + 256)
+        int tot_a = 0, tot_l = 0, tot_r = 0, end_pos = 0;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            int ta, tl, tr;
+            (void)block_exclusive_scan(isatt[it], scan, &ta);
+            const int pl = block_exclusive_scan(okl[it], scan, &tl);
+            const int pr = block_exclusive_scan(okr[it], scan, &tr);
+            const int il = ns[0] + tot_l + pl, ir = ns[1] + tot_r + pr;
+            const uint4 w = make_uint4((uint32_t)sidx[it][0] | ((uint32_t)sidx[it][1] << 16), (uint32_t)sidx[it][2] | ((uint32_t)sidx[it][3] << 16),
+                                       (uint32_t)sidx[it][4] | ((uint32_t)sidx[it][5] << 16), (uint32_t)sidx[it][6]);
+            if (okl[it] && il < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + il) * 8) = w;
+            if (okr[it] && ir < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + ir) * 8) = w;
+            tot_a += ta; tot_l += tl; tot_r += tr;
+        }
+        end_pos = q[RSCH_Q - 1];                                         // the fixed point the orbit ended in (RSCH_Q - 1 jumps are more than a window holds)
+        __syncthreads();
+        if (tot_a == 0) { exhausted = true; break; }                     // not even one attempt fits what is left of the table
+        pos += end_pos; attempts += tot_a; ns[0] += tot_l; ns[1] += tot_r;
+    }
+    if (tid == 0) {
+        st[0] = pos; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD);
+        if (exhausted && phase == 1 && (ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP) || ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP))) {
+            atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
+        }
     }
 }
 
@@ -950,16 +1071,16 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16 + grp, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 7) return;
+    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
     // rs_bound is stable while this kernel runs (only k_ransac_count lowers it, and the previous chunk's has finished): what
     // this chunk generates is [begin, gen) with gen = min(end, rs_bound); k_ransac_count must not trust anything beyond it
-    const int gen = chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk);
+    const int gen = min(chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk), c.rs_sched[vl * 4 + 2 + side]);      // (... and no further than the schedule's samples)
     if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
     if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 16 >= gen) return;          // block-uniform; inside a live block every lane stays (DPP)
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     // ---- the sample (oracle: ransac_sample), computed redundantly by the 16 lanes of the group ----
     int s[7];
-    ransac_sample7(h, n, s);
+    ransac_sample7(c, vl, side, h, s);
     float4 P[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) P[i] = pts[s[i]];
@@ -1102,14 +1223,14 @@ __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 7) return;
-    const int gen = chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk);
+    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
+    const int gen = min(chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk), c.rs_sched[vl * 4 + 2 + side]);      // (... and no further than the schedule's samples)
     if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
     if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 64 >= gen) return;          // wave-uniform: inside a live wave every lane stays (DPP scan)
     const bool live = h < gen;
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     int s[7];
-    ransac_sample7(live ? h : 0, n, s);
+    ransac_sample7(c, vl, side, live ? h : 0, s);
     float4 P[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) P[i] = pts[s[i]];
@@ -1202,7 +1323,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 7) return;
+    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
     if (h0 >= RS_SLOT_END(chunk)) return;
     // ONE thread decides for the block (rs_bound moves while the launch runs: threads reading it themselves could disagree, and a
     // block of which some waves have left no longer fills its shared arrays)
@@ -1296,7 +1417,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 // groups out of reach (rs_bound moves while the launch runs, so the blocks of one group need not agree) still takes its ticket; the
 // sums it leaves incomplete belong to samples at or beyond rs_bound, which the finalize never visits, and a best count published from
 // incomplete sums is an under-estimate, which only loosens the bound it feeds (as the early exit's partial counts did).
-#define RC16_NSPLIT 4
+#define RC16_NSPLIT 1          // default of the launcher (SVO_RC_SPLIT overrides): splitting costs more blocks than it saves at 64 lanes (70.0 k pairs/s at 1, 69.9 k at 2, 67.9 k at 4)
 __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk, int nsplit)
 {
     SVO_LATENCY_CHAIN(c);
@@ -1305,7 +1426,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + sblk * 64, tid = threadIdx.x;     // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 7) return;
+    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
     if (h0 >= RS_SLOT_END(chunk)) return;
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15;
@@ -1445,7 +1566,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 7) return;
+    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
     if (h0 >= RS_SLOT_END(chunk)) return;
     __shared__ int s_nlive;                                                   // one thread decides for the block (see k_ransac_count_mfma)
     if (tid == 0) s_nlive = rs_group_live(c, vl, side, h0);
@@ -1519,7 +1640,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         if (tid == 0) s_both = 0;
         __syncthreads();
         // samples the scan can still reach -> the slots of their regions (all generated and zeroed this frame: see rs_bound)
-        const int lim_k = n >= 7 ? min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP) : 0;
+        const int lim_k = n >= 8 ? min(min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP), c.rs_sched[vl * 4 + 2 + side]) : 0;
         const int lim = lim_k > 0 ? ((lim_k - 1) / SVO_RANSAC_REG + 1) * SVO_RANSAC_RSLOTS : 0;
         const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
         const int* gk = c.rs_k + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
@@ -1558,7 +1679,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
                 best_cnt = cnt; best_s = sl; ks = k; niters = ransac_niters(cnt, n, niters);
             }
             s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
-            s_vis[side] = n >= 7 ? max(ks + 1, niters) : 0;
+            s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * 4 + 2 + side]) : 0;
         } else if (t == 0) {
             int best_s = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1, ks = -1, start = SVO_RANSAC_HYP;
             for (int r = 0; r < nr; r++) {                                   // next record in slot order = smallest slot above `last`
@@ -1574,8 +1695,11 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
             s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
             // samples the sequential loop visits: it leaves at the first k that is no longer below the budget, and a record may
             // cut the budget below its own sample (oracle: svo_oracle_ransac_fundamental's n_hyp_used)
-            s_vis[side] = n >= 7 ? max(ks + 1, niters) : 0;
+            s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * 4 + 2 + side]) : 0;
         }
+        // exactly seven pairs: cv::findFundamentalMat runs the 7-point kernel directly and sets the whole mask -- seven "inliers", no sample
+        // visited, below the eight that S4:205, 240 ask for whichever model comes out (oracle: svo_oracle_ransac_fundamental, n == 7)
+        if (t == 0 && n == 7) { s_best[side] = -1; s_cnt[side] = 7; s_vis[side] = 0; }
         __syncthreads();
     }
     const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
@@ -1780,6 +1904,7 @@ void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
     // one stream (few lanes): 16 lanes per sample, for latency; many lanes: one thread per sample, for instruction count
     // (debug_mode 50 forces the 16-lane form, 51 the one-thread form: tests/test_gpu_parity.py runs both against the oracle)
     const bool per_thread = c.debug_mode == 51 || (c.debug_mode != 50 && c.n_lanes * c.n_oct > 8);
+    if (chunk != 1) hipLaunchKernelGGL(k_ransac_schedule, dim3(c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk ? 1 : 0);     // the samples of chunks 0-1 / of chunk 2
     if (per_thread) hipLaunchKernelGGL(k_ransac_hyp_thread, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
     else hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }

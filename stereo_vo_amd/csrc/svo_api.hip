@@ -328,6 +328,17 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rs_gen, (size_t)NV * 2));
     HIPCHECK(dev_alloc(ctx, &d.rs_floor, (size_t)NV * 4));
     HIPCHECK(dev_alloc(ctx, &d.rs_ticket, (size_t)NV * 2 * (SVO_RANSAC_SLOTS / 16)));
+    HIPCHECK(dev_alloc(ctx, &d.rs_smp, (size_t)NV * 2 * SVO_RANSAC_PAD * 8));
+    HIPCHECK(dev_alloc(ctx, &d.rs_sched, (size_t)NV * 4));
+    {   // cv::RNG from the seed findFundamentalMat's RANSAC uses, (uint64)-1: state = (uint32)state * 4164903690 + (state >> 32)
+        std::vector<uint32_t> raw(SVO_RNG_J);
+        uint64_t stt = 0xFFFFFFFFFFFFFFFFULL;
+        for (int i = 0; i < SVO_RNG_J; i++) { stt = (uint64_t)(uint32_t)stt * 4164903690ULL + (uint32_t)(stt >> 32); raw[(size_t)i] = (uint32_t)stt; }
+        uint32_t* dr = nullptr;
+        HIPCHECK(dev_alloc(ctx, &dr, (size_t)SVO_RNG_J));
+        HIPCHECK(hipMemcpy(dr, raw.data(), raw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        d.rs_raw = dr;
+    }
     HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)NV));
     HIPCHECK(dev_alloc(ctx, &d.gn_lmk, (size_t)L * MK * 3));

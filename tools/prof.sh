@@ -90,8 +90,9 @@ for step in "$@"; do
     done ;;
   abbench)
     for ab in BASE=1 $AB; do
-      ( cd $R; env $ab timeout 600 python bench.py --steps 60 --warmup 6 $SIDE --frames 210 $BENCH_ARGS ) > $O/${tag}_abbench_${ab}.json 2> $O/${tag}_abbench_${ab}.err
-      python - $O/${tag}_abbench_${ab}.json "$ab" <<'PY'
+      nm=$(echo "$ab" | sed 's|.*/||' | tr '=,' '__')
+      ( cd $R; env $(echo $ab | tr ',' ' ') timeout 600 python bench.py --steps 60 --warmup 6 $SIDE --frames 210 $BENCH_ARGS ) > $O/${tag}_abbench_${nm}.json 2> $O/${tag}_abbench_${nm}.err
+      python - $O/${tag}_abbench_${nm}.json "$nm" <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
