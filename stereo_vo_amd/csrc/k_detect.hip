@@ -269,22 +269,25 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
     const bool store = x_a < d.w;
     uint8_t* out_row = dst + (long long)y_first * d.pitch;               // wave-uniform
     const uint32_t half = 1u << 23;
-    // destination row o keeps its top source row in register set (o & 1) and the bottom one in the other: when the top row advances by one
-    // the old bottom row IS the new top and sits in the right set already -- only the new bottom row is blended, over the old top
-    uint32_t H[2][2] = { { 0, 0 }, { 0, 0 } };
-    int top = 0;
+    // The eight destination rows of the wave read the source rows t0 .. t7 + 1, a contiguous stretch of at most eleven (every row of
+    // it is the top or the bottom row of some destination row at a scale above 1): all eleven blends first -- eleven LDS reads in
+    // flight at once, where a read-wait-blend-store chain per destination row left the wave waiting on LDS eight times --, then the
+    // rows pick their pair: top row of destination row o = source row o + e, e = 0, 1 or 2 skipped rows so far (scale <= 1.25), a
+    // wave-uniform branch into one of three statically indexed copies of the blend.
+    const int t0 = __builtin_amdgcn_readlane(yrow, 0);
+    uint32_t H[RZ_ROWS + 3][2];
+#pragma unroll
+    for (int k = 0; k < RZ_ROWS + 3; k++) hrow(min(t0 + k, RZ_SH), H[k][0], H[k][1]);
+    auto mad24 = [](uint32_t a, uint32_t b_uniform, uint32_t c3) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c3)); return r; };
 #pragma unroll
     for (int o = 0; o < RZ_ROWS; o++) {
         if (o >= nrows) break;
-        const int t = __builtin_amdgcn_readlane(yrow, o), ay = __builtin_amdgcn_readlane(yrow, RZ_ROWS + o);
-        if (o == 0 || t != top + 1) hrow(t, H[o & 1][0], H[o & 1][1]);
-        hrow(t + 1, H[(o & 1) ^ 1][0], H[(o & 1) ^ 1][1]);
-        top = t;
+        const int e = __builtin_amdgcn_readlane(yrow, o) - t0 - o, ay = __builtin_amdgcn_readlane(yrow, RZ_ROWS + o);
         const uint32_t wt = 4u * (uint32_t)(2048 - ay), wb_ = 4u * (uint32_t)ay;
-        // two v_mad_u32_u24 per pixel (hipcc makes "mul, mul, add3" of the plain expression: three); result in byte 3
-        auto mad24 = [](uint32_t a, uint32_t b_uniform, uint32_t c3) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c3)); return r; };
-        const uint32_t v0 = mad24(H[(o & 1) ^ 1][0], wb_, mad24(H[o & 1][0], wt, half));
-        const uint32_t v1 = mad24(H[(o & 1) ^ 1][1], wb_, mad24(H[o & 1][1], wt, half));
+        uint32_t v0, v1;                                                      // two v_mad_u32_u24 per pixel; result in byte 3
+        if (e <= 0) { v0 = mad24(H[o + 1][0], wb_, mad24(H[o][0], wt, half)); v1 = mad24(H[o + 1][1], wb_, mad24(H[o][1], wt, half)); }
+        else if (e == 1) { v0 = mad24(H[o + 2][0], wb_, mad24(H[o + 1][0], wt, half)); v1 = mad24(H[o + 2][1], wb_, mad24(H[o + 1][1], wt, half)); }
+        else { v0 = mad24(H[o + 3][0], wb_, mad24(H[o + 2][0], wt, half)); v1 = mad24(H[o + 3][1], wb_, mad24(H[o + 2][1], wt, half)); }
         const uint32_t out = __builtin_amdgcn_perm(v1, v0, 0x0c0c0703u);       // (v0.byte3, v1.byte3)
         if (store) *(unsigned short*)(out_row + (uint32_t)x_a) = (unsigned short)out;   // x_a is even and the pitch a multiple of 64: aligned; the second byte of an odd width is padding
         out_row += d.pitch;

@@ -624,6 +624,8 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
             for (int x = 0; x + 1 < g.w; x++) if (xi[x + 1] < xi[x] || xi[x + 1] - xi[x] > 2) return SVO_ERR_UNSUPPORTED;
             for (int x = 0; x < g.w; x += 128) if (xi[std::min(x + 127, g.w - 1)] + 1 - (xi[x] & ~15) + 4 > 176) return SVO_ERR_UNSUPPORTED;
             for (int y = 0; y < g.h; y += 32) if (yi[std::min(y + 31, g.h - 1)] + 1 - yi[y] > 41) return SVO_ERR_UNSUPPORTED;
+            for (int y = 0; y < g.h; y += 8) if (yi[std::min(y + 7, g.h - 1)] - yi[y] > 9) return SVO_ERR_UNSUPPORTED;      // a wave's eight rows: at most two source rows skipped
+            for (int y = 0; y + 1 < g.h; y++) if (yi[y + 1] <= yi[y]) return SVO_ERR_UNSUPPORTED;   // (strictly increasing: every source row of the stretch is used)
             rtab.insert(rtab.end(), xi.begin(), xi.end()); rtab.insert(rtab.end(), xf.begin(), xf.end());
             rtab.insert(rtab.end(), yi.begin(), yi.end()); rtab.insert(rtab.end(), yf.begin(), yf.end());
             rt_off += 2 * (g.w + g.h);
