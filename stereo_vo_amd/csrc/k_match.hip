@@ -736,8 +736,22 @@ __device__ __forceinline__ void ransac_sample7(const DevCtx& c, int vl, int side
 #define RSCH_W 2048
 #define RSCH_PAD 64
 #define RSCH_Q 512          // >= RSCH_W / 7 + 1 attempts per window, a power of two
+// Is the last of seven points collinear with two earlier ones (haveCollinearPoints)?  The decision is the oracle's double-precision one;
+// a single-precision screen settles the pairs that are nowhere near the FLT_EPSILON-relative threshold first (|cross| above 1e-3 of the
+// scale, where a float's 6e-8 relative rounding cannot matter) -- on real point sets all of them.
 __device__ __forceinline__ bool rs_collinear7(const float (&x)[7], const float (&y)[7])
 {
+    bool maybe = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const float dx1 = x[j] - x[6], dy1 = y[j] - y[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < j) {
+            const float dx2 = x[k] - x[6], dy2 = y[k] - y[6];
+            if (!(fabsf(dx2 * dy1 - dy2 * dx1) > 1.0e-3f * (fabsf(dx1) + fabsf(dy1) + fabsf(dx2) + fabsf(dy2)))) maybe = true;
+        }
+    }
+    if (!maybe) return false;
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -750,9 +764,22 @@ __device__ __forceinline__ bool rs_collinear7(const float (&x)[7], const float (
     }
     return bad;
 }
-// the attempt that starts at v[i]: seven distinct values; returns the draws it takes, 0 when it runs off the staged stretch
+// the attempt that starts at v[i]: seven distinct values; returns the draws it takes, 0 when it runs off the staged stretch.
+// Seven draws that are all different -- the rule once n is in the hundreds -- are seven independent LDS reads and 21 compares; only an
+// attempt with a repeat walks the stream draw by draw.
 __device__ __forceinline__ int rs_attempt(const unsigned short* v, int i, int lim, int (&s)[7])
 {
+    if (i + 7 <= lim) {
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s[k] = v[i + k];
+#pragma unroll
+        for (int k = 1; k < 7; k++) {
+#pragma unroll
+            for (int m = 0; m < 7; m++) if (m < k && s[m] == s[k]) dup = true;
+        }
+        if (!dup && s[6] != 0xFFFF) return 7;                              // (0xFFFF = past the table: only ever at the tail, caught below)
+    }
     int j = i;
 #pragma unroll
     for (int cidx = 0; cidx < 7; cidx++) {
@@ -785,63 +812,73 @@ __global__ void __launch_bounds__(256) k_ransac_schedule(DevCtx c, int phase)
     const float4* ptsR = (const float4*)(c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4);
     bool exhausted = false;
     while (min(ns[0], ns[1]) < target) {
-        const int Wn = min(RSCH_W, SVO_RNG_J - pos), lim = min(RSCH_W + RSCH_PAD, SVO_RNG_J - pos);
+        // the window: as many positions as the samples still missing are likely to take (7 draws + the odd repeat each, generously), so
+        // that phase 0's 160 samples do not pay for 2048 positions; whatever falls short is made up by the next turn of the loop
+        const int missing = target - min(ns[0], ns[1]);
+        const int want = n >= 64 ? missing * 8 + 64 : missing * 16 + 64;
+        const int W = min(RSCH_W, (want + 255) & ~255);
+        const int Wn = min(W, SVO_RNG_J - pos), lim = min(W + RSCH_PAD, SVO_RNG_J - pos);
+        const int QN = min(RSCH_Q, W / 7 + 2);                               // attempts a window of W positions can hold, + the fixed point
         if (Wn <= 0) { exhausted = true; break; }
         __syncthreads();
-        for (int i = tid; i < RSCH_W + RSCH_PAD; i += 256) v[i] = i < lim ? (unsigned short)(c.rs_raw[pos + i] % (unsigned)n) : (unsigned short)0xFFFF;
+        for (int i = tid; i < W + RSCH_PAD; i += 256) v[i] = i < lim ? (unsigned short)(c.rs_raw[pos + i] % (unsigned)n) : (unsigned short)0xFFFF;
         __syncthreads();
         // positions >= Wn, and positions whose attempt cannot finish inside the staged stretch, are fixed points: the orbit stops there
-        for (int i = tid; i <= RSCH_W + RSCH_PAD; i += 256) {
+        for (int i = tid; i <= W + RSCH_PAD; i += 256) {
             int s[7] = { 0, 0, 0, 0, 0, 0, 0 };
             const int len = i < Wn ? rs_attempt(v, i, lim, s) : 0;
             jmp[0][i] = (unsigned short)(i + len);
         }
         if (tid == 0) q[0] = 0;
-        int cur = 0;
-        for (int r = 0; (1 << r) < RSCH_Q; r++) {
+        int cur = 0, filled = 1;                                             // q[0 .. filled) is known
+        for (int r = 0; (1 << r) < QN; r++) {
             __syncthreads();
-            for (int k = (1 << r) + tid; k < (2 << r); k += 256) q[k] = jmp[cur][q[k - (1 << r)]];
-            for (int i = tid; i <= RSCH_W + RSCH_PAD; i += 256) jmp[cur ^ 1][i] = jmp[cur][jmp[cur][i]];
-            cur ^= 1;
+            for (int k = (1 << r) + tid; k < min(2 << r, RSCH_Q); k += 256) q[k] = jmp[cur][q[k - (1 << r)]];
+            if ((2 << r) < QN) { for (int i = tid; i <= W + RSCH_PAD; i += 256) jmp[cur ^ 1][i] = jmp[cur][jmp[cur][i]]; cur ^= 1; }
+            filled = min(2 << r, RSCH_Q);
         }
         __syncthreads();
-        // the attempts of this window: q[k] while it is not a fixed point (v / q are still intact; jmp[] holds the 2^9-fold jump now)
-        int okl[2] = { 0, 0 }, okr[2] = { 0, 0 }, isatt[2] = { 0, 0 }, sidx[2][7];
+        // the attempts of this window: q[k] while it is not a fixed point (v / q are intact)
+        int flags[2] = { 0, 0 }, sidx[2][7];                                 // bit 0: an attempt, bit 10: passes on the left side, bit 20: on the right
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int k = tid + 256 * it;
-            const int p = q[k];
             int s[7] = { 0, 0, 0, 0, 0, 0, 0 };
-            const int len = p < Wn ? rs_attempt(v, p, lim, s) : 0;
-            if (len > 0 && (k == 0 || q[k - 1] != p)) {
-                isatt[it] = 1;
-                float x1[7], y1[7], x2[7], y2[7];
+            if (k < QN) {
+                const int p = q[k];
+                const int len = p < Wn ? rs_attempt(v, p, lim, s) : 0;
+                if (len > 0 && (k == 0 || q[k - 1] != p)) {
+                    float4 a[7], b[7];
 #pragma unroll
-                for (int i = 0; i < 7; i++) { const float4 a = ptsL[s[i]]; x1[i] = a.x; y1[i] = a.y; x2[i] = a.z; y2[i] = a.w; }
-                okl[it] = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+                    for (int i = 0; i < 7; i++) { a[i] = ptsL[s[i]]; b[i] = ptsR[s[i]]; }
+                    float x1[7], y1[7], x2[7], y2[7];
 #pragma unroll
-                for (int i = 0; i < 7; i++) { const float4 a = ptsR[s[i]]; x1[i] = a.x; y1[i] = a.y; x2[i] = a.z; y2[i] = a.w; }
-                okr[it] = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+                    for (int i = 0; i < 7; i++) { x1[i] = a[i].x; y1[i] = a[i].y; x2[i] = a[i].z; y2[i] = a[i].w; }
+                    const int okl = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { x1[i] = b[i].x; y1[i] = b[i].y; x2[i] = b[i].z; y2[i] = b[i].w; }
+                    const int okr = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+                    flags[it] = 1 | (okl << 10) | (okr << 20);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 7; i++) sidx[it][i] = s[i];
         }
-        // sample numbers per side: passed attempts in orbit order (k = tid first, then tid + 256)
-        int tot_a = 0, tot_l = 0, tot_r = 0, end_pos = 0;
+        // sample numbers per side: passed attempts in orbit order (k = tid first, then tid + 256); the three counts ride in one scan
+        int tot_a = 0, tot_l = 0, tot_r = 0;
 #pragma unroll
         for (int it = 0; it < 2; it++) {
-            int ta, tl, tr;
-            (void)block_exclusive_scan(isatt[it], scan, &ta);
-            const int pl = block_exclusive_scan(okl[it], scan, &tl);
-            const int pr = block_exclusive_scan(okr[it], scan, &tr);
-            const int il = ns[0] + tot_l + pl, ir = ns[1] + tot_r + pr;
+            if (256 * it >= QN) break;
+            int tt;
+            const int pre = block_exclusive_scan(flags[it], scan, &tt);
+            const int il = ns[0] + tot_l + ((pre >> 10) & 1023), ir = ns[1] + tot_r + (pre >> 20);
             const uint4 w = make_uint4((uint32_t)sidx[it][0] | ((uint32_t)sidx[it][1] << 16), (uint32_t)sidx[it][2] | ((uint32_t)sidx[it][3] << 16),
                                        (uint32_t)sidx[it][4] | ((uint32_t)sidx[it][5] << 16), (uint32_t)sidx[it][6]);
-            if (okl[it] && il < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + il) * 8) = w;
-            if (okr[it] && ir < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + ir) * 8) = w;
-            tot_a += ta; tot_l += tl; tot_r += tr;
+            if (((flags[it] >> 10) & 1) && il < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + il) * 8) = w;
+            if ((flags[it] >> 20) && ir < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + ir) * 8) = w;
+            tot_a += tt & 1023; tot_l += (tt >> 10) & 1023; tot_r += tt >> 20;
         }
-        end_pos = q[RSCH_Q - 1];                                         // the fixed point the orbit ended in (RSCH_Q - 1 jumps are more than a window holds)
+        const int end_pos = q[filled - 1];                                  // the fixed point the orbit ended in: filled - 1 >= W / 7 + 1 jumps are more than a window holds
         __syncthreads();
         if (tot_a == 0) { exhausted = true; break; }                     // not even one attempt fits what is left of the table
         pos += end_pos; attempts += tot_a; ns[0] += tot_l; ns[1] += tot_r;
