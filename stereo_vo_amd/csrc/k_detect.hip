@@ -174,32 +174,31 @@ void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_
 // ------------------------------------------------------------------------------------------------------------
 // K1: one pyramid level from the previous one, bilinear with the frozen 11-bit integer tables.
 // HBM-bound on paper (~1.44 source bytes read + 1 written per output pixel), VALU-issue-bound in practice, so the
-// blend is written for instruction count (round 5: 14.5 -> ~8 lane-operations per output pixel).
-// A 256-thread block produces a 128x32 destination tile: the <= 160x41 source window is staged in LDS by LDS-DMA
-// (global_load_lds_dwordx4: 42 rows x 11 chunks of 16 bytes, two wave-instructions per wave, no VGPR round trip).
-// A WAVE owns eight destination rows of the tile and a LANE two adjacent columns, so everything that depends on the row
-// alone -- source row, row weights, store offset -- is wave-uniform: scalar loads and scalar arithmetic, not VALU work.
-// The horizontal blend H(r, x) = p[r][x0] (2048 - ax) + p[r][x0 + 1] ax of a source row is computed ONCE and serves the
-// destination rows above and below it (rounds 1-4 evaluated it twice per output pixel: 1.67 evaluations per source sample):
-// the lane keeps the blends of two source rows in registers P and Q and walks down its eight destination rows; the top row
-// advances by one (the old bottom row becomes the top: only the ROLES of P and Q swap, i.e. the scalar row weights do) or
-// by two (both recomputed).  Per source row and lane: one ds_read2_b32, one v_alignbyte (both pixels' taps lie within four
-// bytes at this scale; svo_set_params checks it), two v_perm + two v_dot2_u32_u16.  Per destination row: two 24-bit
-// multiply-adds per pixel with the row weights pre-scaled by 4 so that the rounded result lands in byte 3, one v_perm, one
-// two-byte store.  Exact: p00 wx0 wy0 + p01 wx1 wy0 + p10 wx0 wy1 + p11 wx1 wy1 regrouped, every intermediate < 2^32.
+// blend is written for instruction count.  A 256-thread block produces a 128x32 destination tile: the <= 160x41
+// source window is staged in LDS by LDS-DMA (global_load_lds_dwordx4: 42 rows x 11 chunks of 16 bytes, two wave-instructions
+// per wave, no VGPR round trip), the tile's slice of the x / y tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
+// Per pixel: the two taps of each source row come out of two aligned LDS dwords as a u16 pair by one v_perm (the
+// selector is a per-column constant), v_dot2_u32_u16 applies (2048 - ax, ax), two 24-bit multiply-adds apply the
+// row weights pre-scaled by 4 so that the rounded result lands in byte 3, and three v_perm pack four results.
+// Exact: p00*wx0*wy0 + p01*wx1*wy0 + p10*wx0*wy1 + p11*wx1*wy1 regrouped, every intermediate < 2^32.
 // ------------------------------------------------------------------------------------------------------------
+// (Round 5 rebuilt this kernel twice for instruction count -- a wave owning eight rows and a lane two columns, the horizontal blend of a
+// source row computed once and shared by the rows above and below it, row tables by v_readlane: 232 -> ~150 VALU instructions per wave,
+// pyramid byte-identical -- and measured both forms SLOWER: 28.8 / 31.6 us per launch against 27.7, 69.7 k / 67.5 k pairs/s against
+// 70.9 k / 69.8 k in the same gpurun call.  The kernel runs at 4.2 TB/s of combined traffic, i.e. it waits for memory, not for issue
+// slots; what the rewrite changed was how many independent row chains a wave has in flight (four here, one there).  Kept as it was.)
 #define RZ_W 128
 #define RZ_H 32
 #define RZ_SP 176     // LDS window pitch in bytes: 11 DMA chunks of 16 (>= 128 * 1.2 + 2 + 15, the window origin is 16-byte aligned in x)
 #define RZ_SH 41      // >= 32 * 1.2 + 2
 #define RZ_CHUNK 16   // consecutive tiles per XCD turn
-#define RZ_ROWS 8     // destination rows per wave
 
 typedef unsigned short rz_u16x2 __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div_img, FastDiv div_ntx)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[(RZ_SH + 1) * (RZ_SP / 4)];
+    __shared__ uint32_t xw[RZ_W], xr[RZ_W], yw[RZ_H], yr[RZ_H];
     const int tid = threadIdx.x;
     const LevelGeom& d = c.lv[level];
     const LevelGeom& s = c.lv[level - 1];
@@ -215,26 +214,26 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
     const int dx0 = tbx * RZ_W, dy0 = tby * RZ_H;
     int spitch; const uint8_t* src = level_ptr(c, img, level - 1, spitch);
     uint8_t* dst = c.pyr + (long long)img * c.pyr_bytes + d.offset;
-    const int* __restrict__ xi = c.rtab + d.rtab_off;
-    const int* __restrict__ xf = xi + d.w, *__restrict__ yi = xf + d.w, *__restrict__ yf = yi + d.h;
+    const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
     const int sx0 = xi[dx0] & ~15, sy0 = yi[dy0];                      // window origin (block-uniform)
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    // this lane's two columns (clamped for the table reads; a lane beyond the level's width stores nothing)
-    const int x_a = dx0 + 2 * lane, xc0 = min(x_a, d.w - 1), xc1 = min(x_a + 1, d.w - 1);
-    const int rx0 = xi[xc0] - sx0, rx1 = xi[xc1] - sx0, ax0 = xf[xc0], ax1 = xf[xc1];
-    // the wave's eight row-table entries in ONE vector load (lanes 0..7: window row of the top tap, lanes 8..15: the row fraction), handed
-    // out by v_readlane in the row loop -- in flight while the window is staged
-    const int y_first = dy0 + RZ_ROWS * wid;                            // wave-uniform
-    int yrow = 0;
-    if (lane < 2 * RZ_ROWS) { const int yy = min(y_first + (lane & (RZ_ROWS - 1)), d.h - 1); yrow = lane < RZ_ROWS ? yi[yy] - sy0 : yf[yy]; }
+    if (tid < RZ_W) {
+        const int x = min(dx0 + tid, d.w - 1), rx = xi[x] - sx0, ax = xf[x];
+        xw[tid] = (uint32_t)(2048 - ax) | ((uint32_t)ax << 16);                                    // dot2 weights
+        xr[tid] = (uint32_t)rx;
+    } else if (tid < RZ_W + RZ_H) {
+        const int y = min(dy0 + tid - RZ_W, d.h - 1), ay = yf[y];
+        yw[tid - RZ_W] = (uint32_t)(4 * (2048 - ay)) | ((uint32_t)(4 * ay) << 16);
+        yr[tid - RZ_W] = (uint32_t)(yi[y] - sy0);
+    }
     if (c.debug_mode == 5) { /* ablation: no staging */ }
     else if ((spitch & 15) == 0) {
         // LDS-DMA: chunk i = (row i / 11, piece i % 11) lands at LDS byte 16 i.  The source base may sit at any byte alignment
         // (tools/ubench/glds_align.hip); with the origin 16-aligned in x and a pitch that is a multiple of 16 no chunk
         // straddles the end of a row, so the clamp to the last chunk of the row only ever moves chunks that lie wholly
-        // beyond it (never read with a non-zero weight: the taps stop at column s.w - 1).
+        // beyond it (never read: the taps stop at column s.w - 1).
         typedef const void __attribute__((address_space(1)))* gptr_t;
         typedef void __attribute__((address_space(3)))* lptr_t;
+        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         auto chunk_src = [&](int i) -> const uint8_t* {
             const int r = (i * 745) >> 13, q = i - 11 * r;                  // i / 11, i % 11 for i < 512
             const int yy = min(sy0 + r, s.h - 1), xx = min(sx0 + 16 * q, spitch - 16);
@@ -252,45 +251,44 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
         }
     }
     __syncthreads();
-    if (y_first >= d.h || c.debug_mode == 6) return;
-    const int nrows = min(RZ_ROWS, d.h - y_first);
-    // the taps of the lane's two pixels: bytes rx0, rx0 + 1 and rx1, rx1 + 1 of the window row, rx1 - rx0 <= 2 (checked at set-up), i.e.
-    // inside the four bytes that start at rx0: one aligned dword pair, funnel-shifted
-    const uint32_t sh0 = (uint32_t)rx0 & 3u, o1 = (uint32_t)(rx1 - rx0);
-    const uint32_t sel0 = 0x0c010c00u, sel1 = 0x0c010c00u + o1 * 0x00010001u;
-    const uint32_t wx0 = (uint32_t)(2048 - ax0) | ((uint32_t)ax0 << 16), wx1 = (uint32_t)(2048 - ax1) | ((uint32_t)ax1 << 16);      // dot2 weights
-    const uint32_t* colp = win + (rx0 >> 2);
-    auto hrow = [&](int r, uint32_t& h0, uint32_t& h1) {                // blends of window row r (wave-uniform)
-        const uint32_t* q = colp + r * (RZ_SP / 4);
-        const uint32_t w = __builtin_amdgcn_alignbyte(q[1], q[0], sh0);
-        h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, __builtin_amdgcn_perm(w, w, sel0)), __builtin_bit_cast(rz_u16x2, wx0), 0u, false);
-        h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, __builtin_amdgcn_perm(w, w, sel1)), __builtin_bit_cast(rz_u16x2, wx1), 0u, false);
-    };
-    const bool store = x_a < d.w;
-    uint8_t* out_row = dst + (long long)y_first * d.pitch;               // wave-uniform
-    const uint32_t half = 1u << 23;
-    // The eight destination rows of the wave read the source rows t0 .. t7 + 1, a contiguous stretch of at most eleven (every row of
-    // it is the top or the bottom row of some destination row at a scale above 1): all eleven blends first -- eleven LDS reads in
-    // flight at once, where a read-wait-blend-store chain per destination row left the wave waiting on LDS eight times --, then the
-    // rows pick their pair: top row of destination row o = source row o + e, e = 0, 1 or 2 skipped rows so far (scale <= 1.25), a
-    // wave-uniform branch into one of three statically indexed copies of the blend.
-    const int t0 = __builtin_amdgcn_readlane(yrow, 0);
-    uint32_t H[RZ_ROWS + 3][2];
+    const int gx = (tid & 31) * 4, x4 = dx0 + gx;                       // 4 adjacent pixels per row, 4 rows per thread
+    if (x4 >= d.w || c.debug_mode == 6) return;
+    // The taps of the thread's 4 adjacent pixels lie within 8 source bytes (3 x 1.2 px apart + the second tap): per source
+    // row ONE 12-byte fetch from the aligned dword of the first tap, funnel-shifted to an 8-byte window starting at that
+    // tap, serves all four -- LDS reads were what bounded this kernel (16 dword gathers per pixel quad before).
+    uint32_t wx[4], sel[4];
+    const uint32_t rx0 = xr[gx];
+    const int wi0 = (int)(rx0 >> 2);
+    const uint32_t sh0 = rx0 & 3u;
 #pragma unroll
-    for (int k = 0; k < RZ_ROWS + 3; k++) hrow(min(t0 + k, RZ_SH), H[k][0], H[k][1]);
-    auto mad24 = [](uint32_t a, uint32_t b_uniform, uint32_t c3) { uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c3)); return r; };
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = xr[gx + k] - rx0;                            // 0 .. 5 (< 7: both taps inside the window)
+        wx[k] = xw[gx + k];
+        sel[k] = 0x0c010c00u + o * 0x00010001u;                         // bytes (o, o + 1) of the 8-byte window -> u16 pair
+    }
 #pragma unroll
-    for (int o = 0; o < RZ_ROWS; o++) {
-        if (o >= nrows) break;
-        const int e = __builtin_amdgcn_readlane(yrow, o) - t0 - o, ay = __builtin_amdgcn_readlane(yrow, RZ_ROWS + o);
-        const uint32_t wt = 4u * (uint32_t)(2048 - ay), wb_ = 4u * (uint32_t)ay;
-        uint32_t v0, v1;                                                      // two v_mad_u32_u24 per pixel; result in byte 3
-        if (e <= 0) { v0 = mad24(H[o + 1][0], wb_, mad24(H[o][0], wt, half)); v1 = mad24(H[o + 1][1], wb_, mad24(H[o][1], wt, half)); }
-        else if (e == 1) { v0 = mad24(H[o + 2][0], wb_, mad24(H[o + 1][0], wt, half)); v1 = mad24(H[o + 2][1], wb_, mad24(H[o + 1][1], wt, half)); }
-        else { v0 = mad24(H[o + 3][0], wb_, mad24(H[o + 2][0], wt, half)); v1 = mad24(H[o + 3][1], wb_, mad24(H[o + 2][1], wt, half)); }
-        const uint32_t out = __builtin_amdgcn_perm(v1, v0, 0x0c0c0703u);       // (v0.byte3, v1.byte3)
-        if (store) *(unsigned short*)(out_row + (uint32_t)x_a) = (unsigned short)out;   // x_a is even and the pitch a multiple of 64: aligned; the second byte of an odd width is padding
-        out_row += d.pitch;
+    for (int j = 0; j < 4; j++) {
+        const int gy = (tid >> 5) + 8 * j, y = dy0 + gy;
+        if (y >= d.h) continue;
+        const uint32_t wy = yw[gy];
+        const uint32_t wy0 = wy & 0xFFFFu, wy1 = wy >> 16;
+        const uint32_t* r0 = win + yr[gy] * (RZ_SP / 4) + wi0, *r1 = r0 + RZ_SP / 4;
+        const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        const uint32_t w0lo = __builtin_amdgcn_alignbyte(a1, a0, sh0), w0hi = __builtin_amdgcn_alignbyte(a2, a1, sh0);
+        const uint32_t w1lo = __builtin_amdgcn_alignbyte(b1, b0, sh0), w1hi = __builtin_amdgcn_alignbyte(b2, b1, sh0);
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t t0 = __builtin_amdgcn_perm(w0hi, w0lo, sel[k]);
+            const uint32_t t1 = __builtin_amdgcn_perm(w1hi, w1lo, sel[k]);
+            const uint32_t top = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t0), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
+            const uint32_t bot = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t1), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
+            v[k] = __umul24(bot, wy1) + (__umul24(top, wy0) + (1u << 23));                       // result in byte 3
+        }
+        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x07030c0cu);
+        const uint32_t out = lo | hi;
+        if (c.debug_mode == 7 && out != 0x12345678u) continue;
+        *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64: the tail of the last dword is padding
     }
 }
 

@@ -466,6 +466,9 @@ __global__ void __launch_bounds__(256) k_match_lr_rbr(DevCtx c, int one_to_one, 
     }
 }
 
+// (defined with the RANSAC kernels below) phase 0 of the sample schedule runs at the end of the tracker kernels: same block shape, one launch less
+__device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int phase, int n, int* scan);
+
 // ------------------------------------------------------------------------------------------------------------
 // K8c: ifmDescWin -- window tracker (stage4_match_consecutive.cpp:435-738) with its quirks kept (appendix A #12):
 // ifm_win_w is the VERTICAL half-size and ifm_win_h the horizontal one; left descriptors only, uint8_t accumulator,
@@ -539,6 +542,8 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
     }
     if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], np_total); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], np_total); }
     if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
+    __syncthreads();                                                       // the point pairs are written: the sampler's collinearity test reads them
+    rs_schedule_block(c, vl, 0, np_total, scan);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -658,6 +663,8 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
     }
     if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], s_th); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], nk); }
     if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
+    __syncthreads();                                                       // the point pairs are written: the sampler's collinearity test reads them
+    rs_schedule_block(c, vl, 0, nk, scan);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -720,22 +727,17 @@ __device__ __forceinline__ void ransac_sample7(const DevCtx& c, int vl, int side
 // The sample schedule of cv::findFundamentalMat's RANSAC (oracle v5: cv_rng_next, ransac_get_subset, have_collinear).
 // OpenCV draws from ONE multiply-with-carry stream per call, seeded (uint64)-1: draw after draw, an index that repeats inside an attempt
 // is drawn again, an attempt whose last point is collinear with two earlier ones (in either image) is drawn afresh -- so WHERE in the
-// stream sample k starts depends on everything before it.  What does not depend on anything is the stream itself: its first SVO_RNG_J
-// raw words are a table (c.rs_raw, filled by svo_create).  A block per lane-octave then works through windows of RSCH_W positions:
-//   1. v[i] = raw[pos + i] % n;
-//   2. every position i as if an attempt started there: how many draws until seven distinct values (len[i]), in parallel;
-//   3. the attempts that really happen are the orbit 0 -> len -> ... : pointer doubling over jump[i] = i + len[i] gives the k-th
-//      attempt's position q[k] in log steps (a serial walk is one dependent LDS read per attempt: 7 us per window);
-//   4. each attempt's seven indices again, the collinearity test on the lane's point pairs, per side;
-//   5. sample index = attempts of that side that passed so far (block scan): the indices go to c.rs_smp[side][sample].
-// Phase 0 (before chunk 0) stops once both sides have SVO_RANSAC_CHUNK1 samples, phase 1 (before chunk 2) continues to SVO_RANSAC_HYP
-// for the lanes whose budget still reaches that far.  The table running out before that (tiny n, or point sets on which nearly every
-// sample is collinear) ends the schedule early: the hypothesis kernels generate what exists, and SVO_ST_INTERNAL is raised if the
-// sequential algorithm could have gone further.
+// stream sample k starts depends on everything before it.  But the stream is the same for every call, and the ATTEMPTS (which draws
+// form attempt a, duplicates rejected) depend on the point count n alone: svo_create tabulates them on the host, once, for every n a
+// context can meet -- c.rs_att[n][a] = the seven indices of attempt a (SVO_RS_ATT attempts per n; built and measured on the device first:
+// a parallel orbit search over the raw stream, 32-90 us per frame and lane; the table makes it a lookup).  What is left per frame is the
+// part that depends on the data: the collinearity test of each attempt on the lane's point pairs, per side, and the numbering of the
+// attempts that pass -- sample k of a side = its k-th passing attempt.  A block per lane-octave, an attempt per thread.
+// Phase 0 (before chunk 0) covers SVO_RANSAC_CHUNK1 samples per side, phase 1 (before chunk 2) continues to SVO_RANSAC_HYP for the lanes
+// whose budget still reaches that far.  Running out of tabulated attempts before that (point sets on which nearly every sample is
+// collinear) ends the schedule early: the hypothesis kernels generate what exists, and SVO_ST_INTERNAL is raised if the sequential
+// algorithm could have gone further.
 // ------------------------------------------------------------------------------------------------------------
-#define RSCH_W 2048
-#define RSCH_PAD 64
-#define RSCH_Q 512          // >= RSCH_W / 7 + 1 attempts per window, a power of two
 // Is the last of seven points collinear with two earlier ones (haveCollinearPoints)?  The decision is the oracle's double-precision one;
 // a single-precision screen settles the pairs that are nowhere near the FLT_EPSILON-relative threshold first (|cross| above 1e-3 of the
 // scale, where a float's 6e-8 relative rounding cannot matter) -- on real point sets all of them.
@@ -764,131 +766,61 @@ __device__ __forceinline__ bool rs_collinear7(const float (&x)[7], const float (
     }
     return bad;
 }
-// the attempt that starts at v[i]: seven distinct values; returns the draws it takes, 0 when it runs off the staged stretch.
-// Seven draws that are all different -- the rule once n is in the hundreds -- are seven independent LDS reads and 21 compares; only an
-// attempt with a repeat walks the stream draw by draw.
-__device__ __forceinline__ int rs_attempt(const unsigned short* v, int i, int lim, int (&s)[7])
+// one phase of the schedule for lane-octave vl; called by ALL threads of a 256-thread block (`scan`: 40 ints of LDS)
+__device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int phase, int n, int* scan)
 {
-    if (i + 7 <= lim) {
-        bool dup = false;
-#pragma unroll
-        for (int k = 0; k < 7; k++) s[k] = v[i + k];
-#pragma unroll
-        for (int k = 1; k < 7; k++) {
-#pragma unroll
-            for (int m = 0; m < 7; m++) if (m < k && s[m] == s[k]) dup = true;
-        }
-        if (!dup && s[6] != 0xFFFF) return 7;                              // (0xFFFF = past the table: only ever at the tail, caught below)
-    }
-    int j = i;
-#pragma unroll
-    for (int cidx = 0; cidx < 7; cidx++) {
-        for (;;) {
-            if (j >= lim) return 0;
-            const int x = v[j++];
-            if (x == 0xFFFF) return 0;
-            bool dup = false;
-#pragma unroll
-            for (int k = 0; k < 7; k++) if (k < cidx && s[k] == x) dup = true;
-            if (!dup) { s[cidx] = x; break; }
-        }
-    }
-    return j - i;
-}
-__global__ void __launch_bounds__(256) k_ransac_schedule(DevCtx c, int phase)
-{
-    SVO_LATENCY_CHAIN(c);
-    __shared__ unsigned short v[RSCH_W + RSCH_PAD], jmp[2][RSCH_W + RSCH_PAD + 1], q[RSCH_Q];
-    __shared__ int scan[40];
-    const int vl = blockIdx.x, tid = threadIdx.x;
-    if (vl % c.oct_cap >= c.n_oct) return;
-    const int n = c.trk_nk[vl];
-    int* st = c.rs_sched + vl * 4;                                       // next stream position | attempts so far | samples left | samples right
-    if (n < 8 || n > 0xFFFE) { if (phase == 0 && tid < 4) st[tid] = 0; return; }
+    const int tid = threadIdx.x;
+    int* st = c.rs_sched + vl * 4;                                       // (unused) | attempts consumed | samples left | samples right
+    if (n < 8 || n > c.rs_att_nmax) { if (phase == 0 && tid < 4) st[tid] = 0; return; }
     if (phase == 1 && max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= SVO_RANSAC_CHUNK1) return;      // neither side's budget reaches chunk 2
     const int target = phase ? SVO_RANSAC_HYP : SVO_RANSAC_CHUNK1;
-    int pos = phase ? st[0] : 0, attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
+    int attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
     const float4* ptsL = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
     const float4* ptsR = (const float4*)(c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4);
+    const uint4* att = (const uint4*)(c.rs_att + (long long)(n - 8) * SVO_RS_ATT * 8);
     bool exhausted = false;
     while (min(ns[0], ns[1]) < target) {
-        // the window: as many positions as the samples still missing are likely to take (7 draws + the odd repeat each, generously), so
-        // that phase 0's 160 samples do not pay for 2048 positions; whatever falls short is made up by the next turn of the loop
-        const int missing = target - min(ns[0], ns[1]);
-        const int want = n >= 64 ? missing * 8 + 64 : missing * 16 + 64;
-        const int W = min(RSCH_W, (want + 255) & ~255);
-        const int Wn = min(W, SVO_RNG_J - pos), lim = min(W + RSCH_PAD, SVO_RNG_J - pos);
-        const int QN = min(RSCH_Q, W / 7 + 2);                               // attempts a window of W positions can hold, + the fixed point
-        if (Wn <= 0) { exhausted = true; break; }
-        __syncthreads();
-        for (int i = tid; i < W + RSCH_PAD; i += 256) v[i] = i < lim ? (unsigned short)(c.rs_raw[pos + i] % (unsigned)n) : (unsigned short)0xFFFF;
-        __syncthreads();
-        // positions >= Wn, and positions whose attempt cannot finish inside the staged stretch, are fixed points: the orbit stops there
-        for (int i = tid; i <= W + RSCH_PAD; i += 256) {
-            int s[7] = { 0, 0, 0, 0, 0, 0, 0 };
-            const int len = i < Wn ? rs_attempt(v, i, lim, s) : 0;
-            jmp[0][i] = (unsigned short)(i + len);
+        if (attempts >= SVO_RS_ATT) { exhausted = true; break; }
+        const int a = attempts + tid;
+        int flags = 0;                                                    // bit 0: passes on the left side, bit 10: on the right
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (a < SVO_RS_ATT) {
+            w = att[a];
+            const int s[7] = { (int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16), (int)(w.z & 0xFFFFu), (int)(w.z >> 16), (int)(w.w & 0xFFFFu) };
+            float4 pa[7], pb[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) { pa[i] = ptsL[s[i]]; pb[i] = ptsR[s[i]]; }
+            float x1[7], y1[7], x2[7], y2[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) { x1[i] = pa[i].x; y1[i] = pa[i].y; x2[i] = pa[i].z; y2[i] = pa[i].w; }
+            const int okl = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+#pragma unroll
+            for (int i = 0; i < 7; i++) { x1[i] = pb[i].x; y1[i] = pb[i].y; x2[i] = pb[i].z; y2[i] = pb[i].w; }
+            const int okr = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
+            flags = okl | (okr << 10);
         }
-        if (tid == 0) q[0] = 0;
-        int cur = 0, filled = 1;                                             // q[0 .. filled) is known
-        for (int r = 0; (1 << r) < QN; r++) {
-            __syncthreads();
-            for (int k = (1 << r) + tid; k < min(2 << r, RSCH_Q); k += 256) q[k] = jmp[cur][q[k - (1 << r)]];
-            if ((2 << r) < QN) { for (int i = tid; i <= W + RSCH_PAD; i += 256) jmp[cur ^ 1][i] = jmp[cur][jmp[cur][i]]; cur ^= 1; }
-            filled = min(2 << r, RSCH_Q);
-        }
+        int tt;
+        const int pre = block_exclusive_scan(flags, scan, &tt);           // both counts ride in one scan (<= 256 each)
+        const int il = ns[0] + (pre & 1023), ir = ns[1] + (pre >> 10);
+        if ((flags & 1) && il < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + il) * 8) = w;
+        if ((flags >> 10) && ir < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + ir) * 8) = w;
+        attempts += 256; ns[0] += tt & 1023; ns[1] += tt >> 10;
         __syncthreads();
-        // the attempts of this window: q[k] while it is not a fixed point (v / q are intact)
-        int flags[2] = { 0, 0 }, sidx[2][7];                                 // bit 0: an attempt, bit 10: passes on the left side, bit 20: on the right
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int k = tid + 256 * it;
-            int s[7] = { 0, 0, 0, 0, 0, 0, 0 };
-            if (k < QN) {
-                const int p = q[k];
-                const int len = p < Wn ? rs_attempt(v, p, lim, s) : 0;
-                if (len > 0 && (k == 0 || q[k - 1] != p)) {
-                    float4 a[7], b[7];
-#pragma unroll
-                    for (int i = 0; i < 7; i++) { a[i] = ptsL[s[i]]; b[i] = ptsR[s[i]]; }
-                    float x1[7], y1[7], x2[7], y2[7];
-#pragma unroll
-                    for (int i = 0; i < 7; i++) { x1[i] = a[i].x; y1[i] = a[i].y; x2[i] = a[i].z; y2[i] = a[i].w; }
-                    const int okl = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
-#pragma unroll
-                    for (int i = 0; i < 7; i++) { x1[i] = b[i].x; y1[i] = b[i].y; x2[i] = b[i].z; y2[i] = b[i].w; }
-                    const int okr = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
-                    flags[it] = 1 | (okl << 10) | (okr << 20);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 7; i++) sidx[it][i] = s[i];
-        }
-        // sample numbers per side: passed attempts in orbit order (k = tid first, then tid + 256); the three counts ride in one scan
-        int tot_a = 0, tot_l = 0, tot_r = 0;
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            if (256 * it >= QN) break;
-            int tt;
-            const int pre = block_exclusive_scan(flags[it], scan, &tt);
-            const int il = ns[0] + tot_l + ((pre >> 10) & 1023), ir = ns[1] + tot_r + (pre >> 20);
-            const uint4 w = make_uint4((uint32_t)sidx[it][0] | ((uint32_t)sidx[it][1] << 16), (uint32_t)sidx[it][2] | ((uint32_t)sidx[it][3] << 16),
-                                       (uint32_t)sidx[it][4] | ((uint32_t)sidx[it][5] << 16), (uint32_t)sidx[it][6]);
-            if (((flags[it] >> 10) & 1) && il < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + il) * 8) = w;
-            if ((flags[it] >> 20) && ir < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + ir) * 8) = w;
-            tot_a += tt & 1023; tot_l += (tt >> 10) & 1023; tot_r += tt >> 20;
-        }
-        const int end_pos = q[filled - 1];                                  // the fixed point the orbit ended in: filled - 1 >= W / 7 + 1 jumps are more than a window holds
-        __syncthreads();
-        if (tot_a == 0) { exhausted = true; break; }                     // not even one attempt fits what is left of the table
-        pos += end_pos; attempts += tot_a; ns[0] += tot_l; ns[1] += tot_r;
     }
     if (tid == 0) {
-        st[0] = pos; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD);
+        st[0] = 0; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD);
         if (exhausted && phase == 1 && (ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP) || ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP))) {
             atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
         }
     }
+}
+__global__ void __launch_bounds__(256) k_ransac_schedule(DevCtx c, int phase)
+{
+    SVO_LATENCY_CHAIN(c);
+    __shared__ int scan[40];
+    const int vl = blockIdx.x;
+    if (vl % c.oct_cap >= c.n_oct) return;
+    rs_schedule_block(c, vl, phase, c.trk_nk[vl], scan);
 }
 
 // oracle: cbrt_rough (exponent / 3 on the bit pattern; integer arithmetic, hence the same bits)
@@ -1941,7 +1873,8 @@ void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
     // one stream (few lanes): 16 lanes per sample, for latency; many lanes: one thread per sample, for instruction count
     // (debug_mode 50 forces the 16-lane form, 51 the one-thread form: tests/test_gpu_parity.py runs both against the oracle)
     const bool per_thread = c.debug_mode == 51 || (c.debug_mode != 50 && c.n_lanes * c.n_oct > 8);
-    if (chunk != 1) hipLaunchKernelGGL(k_ransac_schedule, dim3(c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk ? 1 : 0);     // the samples of chunks 0-1 / of chunk 2
+    // (the samples of chunks 0-1 were numbered at the end of the tracker kernel) chunk 2: the rest, for the lanes whose budget reaches it
+    if (chunk == 2) hipLaunchKernelGGL(k_ransac_schedule, dim3(c.n_lanes * c.oct_cap), dim3(256), 0, st, c, 1);
     if (per_thread) hipLaunchKernelGGL(k_ransac_hyp_thread, dim3((nh + 63) / 64, 2, c.n_lanes * c.oct_cap), dim3(64), 0, st, c, chunk);
     else hipLaunchKernelGGL(k_ransac_hyp, dim3((nh + 15) / 16, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
 }

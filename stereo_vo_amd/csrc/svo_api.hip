@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <map>
 
 #define HIPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); return SVO_ERR_HIP; } } while (0)
 
@@ -330,14 +332,38 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rs_ticket, (size_t)NV * 2 * (SVO_RANSAC_SLOTS / 16)));
     HIPCHECK(dev_alloc(ctx, &d.rs_smp, (size_t)NV * 2 * SVO_RANSAC_PAD * 8));
     HIPCHECK(dev_alloc(ctx, &d.rs_sched, (size_t)NV * 4));
-    {   // cv::RNG from the seed findFundamentalMat's RANSAC uses, (uint64)-1: state = (uint32)state * 4164903690 + (state >> 32)
-        std::vector<uint32_t> raw(SVO_RNG_J);
-        uint64_t stt = 0xFFFFFFFFFFFFFFFFULL;
-        for (int i = 0; i < SVO_RNG_J; i++) { stt = (uint64_t)(uint32_t)stt * 4164903690ULL + (uint32_t)(stt >> 32); raw[(size_t)i] = (uint32_t)stt; }
-        uint32_t* dr = nullptr;
-        HIPCHECK(dev_alloc(ctx, &dr, (size_t)SVO_RNG_J));
-        HIPCHECK(hipMemcpy(dr, raw.data(), raw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        d.rs_raw = dr;
+    {   // The attempts of cv::findFundamentalMat's sampler for every point count a context can meet (k_match.hip, k_ransac_schedule):
+        // cv::RNG from the seed RANSACPointSetRegistrator::run uses, (uint64)-1 -- state = (uint32)state * 4164903690 + (state >> 32),
+        // output (uint32)state --, rng.uniform(0, n) = next() % n, a draw that repeats an index of the same attempt is drawn again
+        // (getSubset); the collinearity rejection depends on the data and stays on the device.  ~0.1 s and 18 KB per n, once per context.
+        const int nmax = MK;
+        static std::mutex att_mu;
+        static std::map<int, std::vector<uint16_t>> att_by_nmax;          // the table is a constant: computed once per process and size
+        std::lock_guard<std::mutex> att_lock(att_mu);
+        std::vector<uint16_t>& att = att_by_nmax[nmax];
+        if (att.empty()) {
+            att.assign((size_t)(nmax - 7) * SVO_RS_ATT * 8, 0);
+            for (int n = 8; n <= nmax; n++) {
+                uint64_t stt = 0xFFFFFFFFFFFFFFFFULL;
+                uint16_t* row = att.data() + (size_t)(n - 8) * SVO_RS_ATT * 8;
+                for (int a = 0; a < SVO_RS_ATT; a++) {
+                    uint16_t* s7 = row + (size_t)a * 8;
+                    for (int i = 0; i < 7; i++) {
+                        for (;;) {
+                            stt = (uint64_t)(uint32_t)stt * 4164903690ULL + (uint32_t)(stt >> 32);
+                            const uint16_t v = (uint16_t)((uint32_t)stt % (uint32_t)n);
+                            bool dup = false;
+                            for (int k = 0; k < i; k++) dup = dup || s7[k] == v;
+                            if (!dup) { s7[i] = v; break; }
+                        }
+                    }
+                }
+            }
+        }
+        uint16_t* da = nullptr;
+        HIPCHECK(dev_alloc(ctx, &da, att.size()));
+        HIPCHECK(hipMemcpy(da, att.data(), att.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        d.rs_att = da; d.rs_att_nmax = nmax;
     }
     HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)NV));
@@ -620,12 +646,10 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
             resize_table(lw[l - 1], g.w, xi.data(), xf.data());
             resize_table(lh[l - 1], g.h, yi.data(), yf.data());
             // what k_resize's tile shape relies on (true for every x1/1.2 step; a geometry that broke it would be refused, not mis-sampled):
-            // adjacent columns sample at most two source columns apart, a 128 x 32 tile's taps fit the 176 x 42 window
-            for (int x = 0; x + 1 < g.w; x++) if (xi[x + 1] < xi[x] || xi[x + 1] - xi[x] > 2) return SVO_ERR_UNSUPPORTED;
+            // the four adjacent pixels of a thread sample within one 8-byte window, a 128 x 32 tile's taps fit the 176 x 42 LDS window
+            for (int x = 0; x + 3 < g.w; x++) if (xi[x + 3] < xi[x] || xi[x + 3] - xi[x] > 5) return SVO_ERR_UNSUPPORTED;
             for (int x = 0; x < g.w; x += 128) if (xi[std::min(x + 127, g.w - 1)] + 1 - (xi[x] & ~15) + 4 > 176) return SVO_ERR_UNSUPPORTED;
             for (int y = 0; y < g.h; y += 32) if (yi[std::min(y + 31, g.h - 1)] + 1 - yi[y] > 41) return SVO_ERR_UNSUPPORTED;
-            for (int y = 0; y < g.h; y += 8) if (yi[std::min(y + 7, g.h - 1)] - yi[y] > 9) return SVO_ERR_UNSUPPORTED;      // a wave's eight rows: at most two source rows skipped
-            for (int y = 0; y + 1 < g.h; y++) if (yi[y + 1] <= yi[y]) return SVO_ERR_UNSUPPORTED;   // (strictly increasing: every source row of the stretch is used)
             rtab.insert(rtab.end(), xi.begin(), xi.end()); rtab.insert(rtab.end(), xf.begin(), xf.end());
             rtab.insert(rtab.end(), yi.begin(), yi.end()); rtab.insert(rtab.end(), yf.begin(), yf.end());
             rt_off += 2 * (g.w + g.h);

@@ -26,7 +26,7 @@
 #define SVO_FT_W 62          // k_fast tile (interior pixels; 64x64 score window with the NMS halo)
 #define SVO_FT_H 62
 #define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each
-#define SVO_RNG_J 16384             // raw words of cv::RNG's stream (seed (uint64)-1) kept as a table: 1000 samples take ~7 400 (n in the hundreds) to ~13 700 (n = 8)
+#define SVO_RS_ATT 1152             // tabulated attempts of cv::findFundamentalMat's sampler per point count n (1000 samples + room for rejected attempts)
 
 // status-word bits (svo_debug_get_status_word)
 #define SVO_ST_CAND_OVERFLOW 1u
@@ -160,7 +160,8 @@ struct DevCtx {
     int* rs_nvalid;           // [n_lanes][2][PAD / 16]   models in each region
     int* rs_bound;            // [n_lanes][2]  upper limit of the SAMPLES the sequential stop can still reach
     int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
-    const uint32_t* rs_raw;   // [SVO_RNG_J] cv::RNG's raw stream (k_ransac_schedule)
+    const unsigned short* rs_att;   // [rs_att_nmax - 7][SVO_RS_ATT][8] the attempts of OpenCV's sampler for n = 8 .. rs_att_nmax points (host-built, k_ransac_schedule)
+    int rs_att_nmax;
     unsigned short* rs_smp;   // [n_lanes][2][SVO_RANSAC_PAD][8] the seven indices of every sample, as OpenCV's getSubset draws them
     int* rs_sched;            // [n_lanes][4] stream position | attempts | samples left | samples right
     int* rs_ticket;           // [n_lanes][2][SLOTS / 16] blocks of k_ransac_count_mfma16 that have added their share of a group's counts (0 between launches)
