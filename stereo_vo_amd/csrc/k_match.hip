@@ -1438,6 +1438,8 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     }
     const double b7 = q == 0 ? 1.0 : 0.0;
     const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
+    bool dead_late = false;                                    // this wave stopped early: its partial counts are still published (below the floor)
+    const int floor_cnt = (chunk && nsplit == 1) ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
     int cnt[4] = { 0, 0, 0, 0 };
     for (int sb = p0; sb < p1 && !block_dead; sb += RC16_SUPER) {
         __syncthreads();                                                         // the previous 256 pairs have been consumed
@@ -1451,10 +1453,26 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
             o[192] = y1 * y2; o[208] = y2; o[224] = x1; o[240] = y1;
         }
         __syncthreads();
-        if (dead) continue;
+        if (dead || dead_late) continue;
         const int ntile = min(RC16_SUPER / 16, (p1 - sb + 15) >> 4);
         for (int t = 0; t < ntile; t++) {
             const int base = sb + 16 * t;
+            if (nsplit == 1 && chunk && base && (t & 7) == 0) {
+                // records only (see k_ransac_count_mfma): a wave that walks ALL pairs of its lane stops once none of its sixteen models can
+                // exceed the floor even if every remaining pair were an inlier; the partial counts it leaves are below the floor (no
+                // record) and, as under-estimates, only loosen the bound they feed
+                bool hopeless = true;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int gsum = cnt[r];
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0xB1, 0xF, 0xF, false);
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x4E, 0xF, 0xF, false);
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x141, 0xF, 0xF, false);
+                    gsum += __builtin_amdgcn_update_dpp(0, gsum, 0x140, 0xF, 0xF, false);
+                    hopeless = hopeless && (gsum + (n - base) <= floor_cnt);
+                }
+                if (__ballot(hopeless) == ~0ull && c.debug_mode != 16) { dead_late = true; break; }
+            }
             const double* ot = ops + t * 256 + l;
             const double b1 = ot[0], b2 = ot[64], b5 = ot[128], b6 = ot[192];
             const rc_d4 z = { 0.0, 0.0, 0.0, 0.0 };
