@@ -128,7 +128,6 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames rendered per trajectory; 0 (default) = as many as it takes for no stream ever to see a frame twice (>= 200)")
     ap.add_argument("--trajectories", type=int, default=8, help="distinct camera trajectories rendered per rank; stream s plays trajectory s %% T from frame 7 * (s // T) on")
     ap.add_argument("--long-steps", type=int, default=100, help="N=1: when --steps is smaller than this, one more timed leg of this many steps (after --warmup untimed ones, estimators reset, the same streams from their first frame on: no stream sees a frame twice inside the leg), reported as `long_run` -- so that a short --steps run still carries a measurement over a few hundred milliseconds; 0 = skip")
-    ap.add_argument("--long-first", type=int, default=0, help="1: run the long_run leg BEFORE the --steps region instead of after the CPU legs (to separate the order of the legs from their duration)")
     ap.add_argument("--cut-steps", type=int, default=60, help="steps of the scene-cut leg (every stream jumps to another trajectory every 20 frames, estimators reset as an application would); N=1 only; 0 = skip")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=960)
@@ -252,12 +251,6 @@ def main():
         state checked against the oracle.  Returns the `long_run` block of the line."""
         long_run = None
         try:
-            # (the CPU legs before this one leave the GPU idle for tens of seconds: a first untimed pass brings the clocks back up,
-            # as the warm-up of the main run does after the rendering)
-            batch.reset()
-            for i in range(min(plan_steps, args.warmup + 30)):
-                step(i)
-            torch.cuda.synchronize()
             batch.reset()
             for i in range(args.warmup):
                 step(i)
@@ -304,16 +297,6 @@ def main():
         c_.kernel_times_reset()
     for c_ in ctxs:
         c_.redo_count(reset=True)                 # (waits for the context: the warm-up is over)
-    long_run_early = None
-    if args.long_first and long_steps > 0 and rank == 0:
-        # A/B of the 3-4 % the long leg loses to the --steps region: the same leg BEFORE it, GPU warm from the warm-up steps
-        long_run_early = run_long_leg("before the --steps region (--long-first 1)")
-        batch.reset()
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        for c_ in ctxs:
-            c_.kernel_times_select(dom); c_.kernel_times_reset(); c_.redo_count(reset=True)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     allrec = None
@@ -396,13 +379,26 @@ def main():
         def leg_done(name):
             nonlocal t_leg
             legs_s[name] = round(time.perf_counter() - t_leg, 1); t_leg = time.perf_counter()
-        if world == 1 and args.cpu_frames > 0:
-            cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec)
-            leg_done("cpu_baseline_and_parity_probe")
-        long_run = long_run_early
-        if long_steps > 0 and long_run is None:
-            long_run = run_long_leg("after the --steps region and the CPU legs (GPU idle for tens of seconds in between; an untimed pass brings the clocks back up first)")
+        # the state the TIMED region left behind, for the parity probe's final check: taken now, before any other leg touches the contexts
+        timed_final = None
+        if world == 1 and args.cpu_frames >= total_steps:
+            from oracle import probe as PR          # checker only
+            rec_cpu = allrec.cpu().numpy()
+            timed_final = {}
+            for g in sorted(set(k * Bc + l for k in range(NC) for l in (0, Bc // 2 - 1 if Bc > 1 else 0, Bc - 1))):
+                ctx_, l_ = batch.lane(g)
+                timed_final[g] = PR.digest_of(ctx_, l_, Result.from_buffer_copy(rec_cpu[g].tobytes()))
+        # The long leg runs HERE, straight after the --steps region, on a GPU that is warm (round 5).  Rounds 3-4 ran it after the CPU legs and
+        # it came out 3-4 % low; the A/B of round 5 (profiles/r05j_*): the same 100 steps 69.3 k pairs/s after ~20 s of GPU idle (an untimed
+        # pass of 40 steps first notwithstanding), 71.5 k straight after the warm-up, 71.5 k over 1500 steps at a steady 2.39 GHz / 1.2 kW
+        # (`tools/prof.sh clocks`) -- the deficit was the order of the legs, not the length of the measurement.
+        long_run = None
+        if long_steps > 0:
+            long_run = run_long_leg("straight after the --steps region (GPU warm)")
             leg_done("long_run")
+        if world == 1 and args.cpu_frames > 0:
+            cpu_baseline, pose_rmse, parity_probe = cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec, timed_final)
+            leg_done("cpu_baseline_and_parity_probe")
         if world == 1 and args.host_fed_steps > 0:
             host_fed = host_fed_leg(args, batch, frame_of, dev)
             leg_done("host_fed")
@@ -745,7 +741,7 @@ def other_workloads_leg(args):
     return out
 
 
-def cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec):
+def cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, cam, allrec, timed_final=None):
     """N=1 only, after the timed region.  The oracle (CHECKER / BASELINE, never the thing measured) replays the first
     n frames of the run's own frame schedule for a few probe streams of every context:
       * leg (i): stream 0 alone on one host thread, timed          -> cpu_baseline.value (mirrors the single-threaded reference)
@@ -844,14 +840,11 @@ def cpu_baseline_and_probe(args, batch, frame_of, ptrs_by_step, worlds, T, p, ca
                                                       "note": "the parity probe's own reference replay (all %d frames of the other probe streams)" % n}}}
     # final state of the timed run itself against the oracle's state after the same history (only when the whole history was replayed)
     final_checked, final_ok = False, None
-    if n == total:
+    if n == total and timed_final is not None:          # (digests taken by main() right after the timed region: other legs have run since)
         final_checked = True
-        rec_cpu = allrec.cpu().numpy()
         final_ok = True
         for g in want:
-            ctx, l = batch.lane(g)
-            res = Result.from_buffer_copy(rec_cpu[g].tobytes())
-            lists, flags, et, er = PR.compare(PR.digest_of(ctx, l, res), ref[g][-1])
+            lists, flags, et, er = PR.compare(timed_final[g], ref[g][-1])
             final_ok = final_ok and lists and flags and et < 1e-3 and er < 1e-4
     batch.reset()
     for c_ in batch.ctxs:

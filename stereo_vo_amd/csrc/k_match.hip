@@ -770,21 +770,27 @@ __device__ __forceinline__ bool rs_collinear7(const float (&x)[7], const float (
 __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int phase, int n, int* scan)
 {
     const int tid = threadIdx.x;
-    int* st = c.rs_sched + vl * 4;                                       // (unused) | attempts consumed | samples left | samples right
-    if (n < 8 || n > c.rs_att_nmax) { if (phase == 0 && tid < 4) st[tid] = 0; return; }
+    int* st = c.rs_sched + vl * SVO_RS_ST;     // last accepted attempt (left) | attempts consumed | samples left | samples right | last accepted (right) | ended left | ended right
+    if (n < 8 || n > c.rs_att_nmax) { if (phase == 0 && tid < SVO_RS_ST) st[tid] = 0; return; }
     if (phase == 1 && max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= SVO_RANSAC_CHUNK1) return;      // neither side's budget reaches chunk 2
     const int target = phase ? SVO_RANSAC_HYP : SVO_RANSAC_CHUNK1;
     int attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
+    int last_ok[2] = { phase ? st[0] : -1, phase ? st[4] : -1 }, ended[2] = { phase ? st[5] : 0, phase ? st[6] : 0 };
     const float4* ptsL = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
     const float4* ptsR = (const float4*)(c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4);
-    const uint4* att = (const uint4*)(c.rs_att + (long long)(n - 8) * SVO_RS_ATT * 8);
+    // small point counts keep the long table: a handful of points in a narrow image are collinear more often than not (a 65 x 97 image
+    // leaves its keypoints a strip three pixels wide: three attempts in four are drawn afresh), and getSubset gives a sample up to
+    // 10000 attempts before the run ends
+    const int n_att = n < SVO_RS_SMALL_N ? SVO_RS_ATT_SMALL : SVO_RS_ATT;
+    const uint4* att = (const uint4*)c.rs_att + (n < SVO_RS_SMALL_N ? (long long)(n - 8) * SVO_RS_ATT_SMALL
+                                                                     : (long long)(SVO_RS_SMALL_N - 8) * SVO_RS_ATT_SMALL + (long long)(n - SVO_RS_SMALL_N) * SVO_RS_ATT);
     bool exhausted = false;
-    while (min(ns[0], ns[1]) < target) {
-        if (attempts >= SVO_RS_ATT) { exhausted = true; break; }
+    while ((!ended[0] && ns[0] < target) || (!ended[1] && ns[1] < target)) {
+        if (attempts >= n_att) { exhausted = true; break; }
         const int a = attempts + tid;
         int flags = 0;                                                    // bit 0: passes on the left side, bit 10: on the right
         uint4 w = make_uint4(0, 0, 0, 0);
-        if (a < SVO_RS_ATT) {
+        if (a < n_att) {
             w = att[a];
             const int s[7] = { (int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16), (int)(w.z & 0xFFFFu), (int)(w.z >> 16), (int)(w.w & 0xFFFFu) };
             float4 pa[7], pb[7];
@@ -797,19 +803,37 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
 #pragma unroll
             for (int i = 0; i < 7; i++) { x1[i] = pb[i].x; y1[i] = pb[i].y; x2[i] = pb[i].z; y2[i] = pb[i].w; }
             const int okr = !(rs_collinear7(x1, y1) || rs_collinear7(x2, y2));
-            flags = okl | (okr << 10);
+            flags = (ended[0] ? 0 : okl) | ((ended[1] ? 0 : okr) << 10);
         }
         int tt;
         const int pre = block_exclusive_scan(flags, scan, &tt);           // both counts ride in one scan (<= 256 each)
-        const int il = ns[0] + (pre & 1023), ir = ns[1] + (pre >> 10);
-        if ((flags & 1) && il < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 0) * SVO_RANSAC_PAD + il) * 8) = w;
-        if ((flags >> 10) && ir < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + 1) * SVO_RANSAC_PAD + ir) * 8) = w;
-        attempts += 256; ns[0] += tt & 1023; ns[1] += tt >> 10;
+        const int tot[2] = { tt & 1023, tt >> 10 }, mypre[2] = { pre & 1023, pre >> 10 }, mine[2] = { flags & 1, flags >> 10 };
+        // getSubset's maxAttempts (run() passes 10000): a sample that needs more attempts than that ends the run.  Gaps inside these 256
+        // attempts are shorter, so only the FIRST passing attempt of the chunk can be too late; the last one is what the next chunk measures from
+        int* fl = scan + 33;                                               // first | last passing attempt of the chunk, per side
+        __syncthreads();
+        if (tid < 4) fl[tid] = -1;
+        __syncthreads();
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++) if (mine[sd]) { if (mypre[sd] == 0) fl[2 * sd] = a; if (mypre[sd] == tot[sd] - 1) fl[2 * sd + 1] = a; }
+        __syncthreads();
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++) {
+            if (ended[sd]) continue;
+            const int first = fl[2 * sd], last = fl[2 * sd + 1];
+            if ((first >= 0 ? first : attempts + 256) - last_ok[sd] > 10000) { ended[sd] = 1; continue; }      // (no passing attempt here and none for 10000: ended as well)
+            if (first < 0) continue;
+            const int idx = ns[sd] + mypre[sd];
+            if (mine[sd] && idx < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + sd) * SVO_RANSAC_PAD + idx) * 8) = w;
+            ns[sd] += tot[sd]; last_ok[sd] = last;
+        }
+        attempts += 256;
         __syncthreads();
     }
     if (tid == 0) {
-        st[0] = 0; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD);
-        if (exhausted && phase == 1 && (ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP) || ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP))) {
+        st[0] = last_ok[0]; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD); st[4] = last_ok[1]; st[5] = ended[0]; st[6] = ended[1];
+        // the table ran out although the sequential algorithm could still draw (heavy rejection at n >= SVO_RS_SMALL_N): never silently
+        if (exhausted && phase == 1 && ((!ended[0] && ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP)) || (!ended[1] && ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP)))) {
             atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
         }
     }
@@ -1043,7 +1067,7 @@ __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
     if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
     // rs_bound is stable while this kernel runs (only k_ransac_count lowers it, and the previous chunk's has finished): what
     // this chunk generates is [begin, gen) with gen = min(end, rs_bound); k_ransac_count must not trust anything beyond it
-    const int gen = min(chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk), c.rs_sched[vl * 4 + 2 + side]);      // (... and no further than the schedule's samples)
+    const int gen = min(chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk), c.rs_sched[vl * SVO_RS_ST + 2 + side]);      // (... and no further than the schedule's samples)
     if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
     if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 16 >= gen) return;          // block-uniform; inside a live block every lane stays (DPP)
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
@@ -1193,7 +1217,7 @@ __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
     if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
-    const int gen = min(chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk), c.rs_sched[vl * 4 + 2 + side]);      // (... and no further than the schedule's samples)
+    const int gen = min(chunk ? min(RS_CHUNK_END(chunk), c.rs_bound[vl * 2 + side]) : RS_CHUNK_END(chunk), c.rs_sched[vl * SVO_RS_ST + 2 + side]);      // (... and no further than the schedule's samples)
     if (blockIdx.x == 0 && threadIdx.x == 0) c.rs_gen[vl * 2 + side] = gen;
     if (RS_CHUNK_BEGIN(chunk) + (int)blockIdx.x * 64 >= gen) return;          // wave-uniform: inside a live wave every lane stays (DPP scan)
     const bool live = h < gen;
@@ -1627,7 +1651,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         if (tid == 0) s_both = 0;
         __syncthreads();
         // samples the scan can still reach -> the slots of their regions (all generated and zeroed this frame: see rs_bound)
-        const int lim_k = n >= 8 ? min(min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP), c.rs_sched[vl * 4 + 2 + side]) : 0;
+        const int lim_k = n >= 8 ? min(min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP), c.rs_sched[vl * SVO_RS_ST + 2 + side]) : 0;
         const int lim = lim_k > 0 ? ((lim_k - 1) / SVO_RANSAC_REG + 1) * SVO_RANSAC_RSLOTS : 0;
         const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
         const int* gk = c.rs_k + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
@@ -1666,7 +1690,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
                 best_cnt = cnt; best_s = sl; ks = k; niters = ransac_niters(cnt, n, niters);
             }
             s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
-            s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * 4 + 2 + side]) : 0;
+            s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * SVO_RS_ST + 2 + side]) : 0;
         } else if (t == 0) {
             int best_s = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1, ks = -1, start = SVO_RANSAC_HYP;
             for (int r = 0; r < nr; r++) {                                   // next record in slot order = smallest slot above `last`
@@ -1682,7 +1706,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
             s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
             // samples the sequential loop visits: it leaves at the first k that is no longer below the budget, and a record may
             // cut the budget below its own sample (oracle: svo_oracle_ransac_fundamental's n_hyp_used)
-            s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * 4 + 2 + side]) : 0;
+            s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * SVO_RS_ST + 2 + side]) : 0;
         }
         // exactly seven pairs: cv::findFundamentalMat runs the 7-point kernel directly and sets the whole mask -- seven "inliers", no sample
         // visited, below the eight that S4:205, 240 ask for whichever model comes out (oracle: svo_oracle_ransac_fundamental, n == 7)
@@ -1873,7 +1897,7 @@ void launch_match_lr_rbr(const DevCtx& c, int one_to_one, double max_y_diff, dou
 }
 void launch_track_win(const DevCtx& c, int win_w, int win_h, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_track_win, dim3(c.n_lanes * c.oct_cap), dim3(256), sizeof(unsigned) * c.max_kps + sizeof(int) * 32, st, c, win_w, win_h);
+    hipLaunchKernelGGL(k_track_win, dim3(c.n_lanes * c.oct_cap), dim3(256), sizeof(unsigned) * c.max_kps + sizeof(int) * 40, st, c, win_w, win_h);      // (40: the sample schedule at its end uses scan[33..36])
 }
 void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st)
 {

@@ -331,7 +331,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rs_floor, (size_t)NV * 4));
     HIPCHECK(dev_alloc(ctx, &d.rs_ticket, (size_t)NV * 2 * (SVO_RANSAC_SLOTS / 16)));
     HIPCHECK(dev_alloc(ctx, &d.rs_smp, (size_t)NV * 2 * SVO_RANSAC_PAD * 8));
-    HIPCHECK(dev_alloc(ctx, &d.rs_sched, (size_t)NV * 4));
+    HIPCHECK(dev_alloc(ctx, &d.rs_sched, (size_t)NV * SVO_RS_ST));
     {   // The attempts of cv::findFundamentalMat's sampler for every point count a context can meet (k_match.hip, k_ransac_schedule):
         // cv::RNG from the seed RANSACPointSetRegistrator::run uses, (uint64)-1 -- state = (uint32)state * 4164903690 + (state >> 32),
         // output (uint32)state --, rng.uniform(0, n) = next() % n, a draw that repeats an index of the same attempt is drawn again
@@ -342,11 +342,13 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
         std::lock_guard<std::mutex> att_lock(att_mu);
         std::vector<uint16_t>& att = att_by_nmax[nmax];
         if (att.empty()) {
-            att.assign((size_t)(nmax - 7) * SVO_RS_ATT * 8, 0);
+            auto row_off = [](int n) -> size_t { return n < SVO_RS_SMALL_N ? (size_t)(n - 8) * SVO_RS_ATT_SMALL : (size_t)(SVO_RS_SMALL_N - 8) * SVO_RS_ATT_SMALL + (size_t)(n - SVO_RS_SMALL_N) * SVO_RS_ATT; };
+            att.assign(row_off(nmax + 1) * 8, 0);
             for (int n = 8; n <= nmax; n++) {
                 uint64_t stt = 0xFFFFFFFFFFFFFFFFULL;
-                uint16_t* row = att.data() + (size_t)(n - 8) * SVO_RS_ATT * 8;
-                for (int a = 0; a < SVO_RS_ATT; a++) {
+                uint16_t* row = att.data() + row_off(n) * 8;
+                const int n_att = n < SVO_RS_SMALL_N ? SVO_RS_ATT_SMALL : SVO_RS_ATT;
+                for (int a = 0; a < n_att; a++) {
                     uint16_t* s7 = row + (size_t)a * 8;
                     for (int i = 0; i < 7; i++) {
                         for (;;) {

@@ -27,6 +27,9 @@
 #define SVO_FT_H 62
 #define SVO_CNT_STRIDE 32          // u32 stride between hot atomic counters = one 128-byte cache line each
 #define SVO_RS_ATT 1152             // tabulated attempts of cv::findFundamentalMat's sampler per point count n (1000 samples + room for rejected attempts)
+#define SVO_RS_SMALL_N 64           // ... below this many points 11008 of them: enough for 1000 samples and getSubset's 10000 attempts on the last
+#define SVO_RS_ATT_SMALL 11008
+#define SVO_RS_ST 8                 // ints of schedule state per lane-octave (rs_sched)
 
 // status-word bits (svo_debug_get_status_word)
 #define SVO_ST_CAND_OVERFLOW 1u
@@ -160,10 +163,10 @@ struct DevCtx {
     int* rs_nvalid;           // [n_lanes][2][PAD / 16]   models in each region
     int* rs_bound;            // [n_lanes][2]  upper limit of the SAMPLES the sequential stop can still reach
     int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
-    const unsigned short* rs_att;   // [rs_att_nmax - 7][SVO_RS_ATT][8] the attempts of OpenCV's sampler for n = 8 .. rs_att_nmax points (host-built, k_ransac_schedule)
+    const unsigned short* rs_att;   // [n = 8 .. SVO_RS_SMALL_N - 1][SVO_RS_ATT_SMALL][8] then [n = SVO_RS_SMALL_N .. rs_att_nmax][SVO_RS_ATT][8]: the attempts of OpenCV's sampler for n = 8 .. rs_att_nmax points (host-built, k_ransac_schedule)
     int rs_att_nmax;
     unsigned short* rs_smp;   // [n_lanes][2][SVO_RANSAC_PAD][8] the seven indices of every sample, as OpenCV's getSubset draws them
-    int* rs_sched;            // [n_lanes][4] stream position | attempts | samples left | samples right
+    int* rs_sched;            // [n_lanes][SVO_RS_ST] schedule state (k_match.hip, rs_schedule_block)
     int* rs_ticket;           // [n_lanes][2][SLOTS / 16] blocks of k_ransac_count_mfma16 that have added their share of a group's counts (0 between launches)
     int* rs_floor;            // [n_lanes][2][2] best inlier count of chunk 0 / of chunks 0-1: what a later model must exceed to matter
     svo_index_pair* tracked;  // [n_lanes][max_kps]
@@ -326,7 +329,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
 //     representative of globally lowest rank always decides, so the loop terminates; chains are short in practice.
 // cellxy[i] = (sx << 16) | sy of the rank-i keypoint, 0xFFFFFFFF when outside the grid (such keypoints are skipped).
 // hkey/hval: LDS hash of HSZ (power of two >= 2n) slots; state[i] ends 1 (accepted) or 0.  All threads of the
-// block must call; `flag` is one LDS int.  The caller applies the num_out_points cap in rank order.
+// block must call; `flag` points at THREE LDS ints.  The caller applies the num_out_points cap in rank order.
 #define SVO_NMS_UNDECIDED 2
 __device__ __forceinline__ uint32_t nms_hash_slot(uint32_t key, int HSZ) { return ((key * 2654435761u) >> 7) & (uint32_t)(HSZ - 1); }
 
@@ -371,9 +374,13 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
     }
     __syncthreads();
     if constexpr (ITEMS == 0) {
+        if (tid < 3) flag[tid] = 0;
+        __syncthreads();
         for (int round = 0; round <= n; round++) {                     // every round decides the lowest-rank undecided representative: n rounds always suffice
-            if (tid == 0) *flag = 0;
-            __syncthreads();
+            // ONE barrier per round (three until round 4): the rounds rotate over three flag words -- this round's is raised before the
+            // barrier and read after it, the next round's is cleared now (its last readers passed the previous barrier)
+            volatile int* fl = flag + round % 3;
+            if (tid == 0) flag[(round + 1) % 3] = 0;
             bool pending = false;
             for (int i = tid; i < n; i += nt) {
                 if (state[i] != SVO_NMS_UNDECIDED) continue;
@@ -391,12 +398,11 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
                 else if (!any_und) state[i] = 1;
                 else pending = true;
             }
-            if (pending) *flag = 1;
+            if (pending) *fl = 1;
             __syncthreads();
-            const int again = *flag;
-            __syncthreads();
-            if (!again) break;
+            if (!*fl) break;
         }
+        __syncthreads();
         return;
     }
     // the lower-rank representatives of the 4 neighbour cells of each of this thread's undecided keypoints, looked up
@@ -420,9 +426,11 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
             }
         }
     }
+    if (tid < 3) flag[tid] = 0;
+    __syncthreads();
     for (int round = 0; round <= n; round++) {
-        if (tid == 0) *flag = 0;
-        __syncthreads();
+        volatile int* fl = flag + round % 3;                           // one barrier per round: see the ITEMS == 0 loop above
+        if (tid == 0) flag[(round + 1) % 3] = 0;
         bool pending = false;
 #pragma unroll
         for (int it = 0; it < NI; it++) {
@@ -436,10 +444,9 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
             else if (!any_und) state[i] = 1;
             else pending = true;
         }
-        if (pending) *flag = 1;
+        if (pending) *fl = 1;
         __syncthreads();
-        const int again = *flag;
-        __syncthreads();
-        if (!again) break;
+        if (!*fl) break;
     }
+    __syncthreads();
 }
