@@ -21,7 +21,9 @@
 #define SVO_RANSAC_RSLOTS 48        // model slots per region: a sample has one or three models (the real roots of the 7-point cubic)
 #define SVO_RANSAC_SLOTS (SVO_RANSAC_PAD / SVO_RANSAC_REG * SVO_RANSAC_RSLOTS)     // stride of the per-(lane, side) model arrays
 #define SVO_RANSAC_CHUNK0 32        // samples [0, CHUNK0) are evaluated unconditionally, [CHUNK0, CHUNK1) and [CHUNK1, HYP) only as far as
+#ifndef SVO_RANSAC_CHUNK1
 #define SVO_RANSAC_CHUNK1 160       // the 0.99-confidence stop of the sequential algorithm can still reach (rs_bound)
+#endif
 #define SVO_SEL_MAX 2048     // >= 2 * quota[0]: corners per (image, level) ranked by their Harris response
 #define SVO_FT_W 62          // k_fast tile (interior pixels; 64x64 score window with the NMS halo)
 #define SVO_FT_H 62
