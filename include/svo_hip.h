@@ -121,11 +121,6 @@ int svo_get_orb_threshold(const svo_ctx* ctx);
  * the caller has switched away it may synchronise and destroy the stream -- later svo_wait / svo_get_* / svo_destroy wait on
  * context-owned events recorded behind the work, never on the stream handle. */
 int svo_set_stream(svo_ctx* ctx, void* stream);
-/* A second stream for the head of a detect call (k_begin_frame + the pyramid) when the frames are device-resident (SVO_FLAG_DEVICE_IMAGES,
- * ORB mode, no graphs): the rest of the call waits for it by an event.  In a batched schedule the memory-bound pyramid of the next context
- * then runs beside the issue-bound FAST kernel of this one (svo_batch: SVO_BATCH_PYR_STREAM).  The CALLER orders that stream behind the
- * last reader of the context's pyramid and detector scratch, exactly as it orders the call's own stream.  NULL switches it off. */
-int svo_set_pyramid_stream(svo_ctx* ctx, void* stream);
 int svo_get_device(const svo_ctx* ctx);           /* HIP device ordinal of the context (svo_config.device); < 0 on error */
 /* Arms ONE hipEvent_t: the next svo_process call that runs the detector's post-processing (SVO_RUN_DETECT_POST, or SVO_RUN_DETECT
  * without SVO_FLAG_DETECT_NO_POST) records it on its stream right behind the last kernel that reads the detector's per-image

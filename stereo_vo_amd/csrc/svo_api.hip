@@ -66,7 +66,6 @@ struct svo_ctx {
     svo_params params;
     int fast_th, orb_th;
     hipStream_t stream, stream0; bool own_stream;      // stream0: the stream the context was created with / owns
-    hipStream_t pyr_stream = nullptr; hipEvent_t ev_pyr = nullptr;      // svo_set_pyramid_stream: where k_begin_frame + the pyramid of a detect call go
     DevCtx dc;
     bool geom_ready; int geom_w, geom_h, geom_nfe, geom_nlevels, geom_method, geom_noct;
     int raw_cap_alloc;
@@ -406,7 +405,6 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     for (auto& u : ctx->used_streams) if (u.ev) hipEventDestroy(u.ev);
     for (auto& s : ctx->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) hipEventDestroy(e);
-    if (ctx->ev_pyr) hipEventDestroy(ctx->ev_pyr);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream0);
     delete ctx;
 }
@@ -482,15 +480,6 @@ extern "C" int svo_set_stream(svo_ctx* ctx, void* stream)
     if (!ctx) return SVO_ERR_ARG;
     if (stream) ctx->stream = (hipStream_t)stream;
     else ctx->stream = ctx->stream0;
-    return SVO_OK;
-}
-
-extern "C" int svo_set_pyramid_stream(svo_ctx* ctx, void* stream)
-{
-    if (ctx) use_device(ctx);
-    if (!ctx) return SVO_ERR_ARG;
-    if (stream && !ctx->ev_pyr) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_pyr, hipEventDisableTiming));
-    ctx->pyr_stream = (hipStream_t)stream;
     return SVO_OK;
 }
 
@@ -969,12 +958,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     }
     struct CaptureGuard { hipStream_t st; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; hipStreamEndCapture(st, &g); if (g) hipGraphDestroy(g); *on = false; } } } guard{ st, &capturing };
     d.det_ahead = (ahead && (flags & SVO_RUN_DETECT)) ? 1 : 0;
-    // svo_set_pyramid_stream: k_begin_frame and the pyramid of a detect call on device-resident frames go to that stream, the rest of the
-    // call waits for them by an event -- so that in a batched schedule the (memory-bound) pyramid of the NEXT context runs beside the
-    // (issue-bound) FAST kernel of this one.  The caller orders the pyramid stream behind the last reader of this context's detector
-    // scratch and pyramid, as it does for the call's own stream (svo_batch_step: scratch_free / rest_done).
-    const hipStream_t ps = (ctx->pyr_stream && (flags & SVO_RUN_DETECT) && (flags & SVO_FLAG_DEVICE_IMAGES) && !prepare && !capturing && !ctx->use_graphs && !d.fast_orb) ? ctx->pyr_stream : st;
-    { Span s(ctx, KT_BEGIN, ps); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, ps); if (prepare) { Section sec("_stg1"); launch_prepare(prep, 2 * d.n_lanes, st); } }
+    { Span s(ctx, KT_BEGIN); launch_begin_frame(d, (flags & SVO_RUN_DETECT) ? ptrs : nullptr, flags, st); if (prepare) { Section sec("_stg1"); launch_prepare(prep, 2 * d.n_lanes, st); } }
     // the detector's per-image scratch has had its last reader: the armed event (svo_record_after_post) goes here
     auto after_post = [&]() -> hipError_t {
         if (!ctx->post_event || capturing) return hipSuccess;
@@ -993,8 +977,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
             { Span s(ctx, KT_DESCRIBE); launch_describe(d, 0, st); }
             if (!(flags & SVO_FLAG_DETECT_NO_POST)) { Span s(ctx, KT_NMS); launch_nms_rowsort(d, p.non_maximal_suppression ? 0 : 3, p.min_distance, 0, st); }   // 0: the NMS ran above; 3: none, raster order
         } else {                // stage2_detect.cpp:458-497
-            { Span s(ctx, KT_RESIZE, ps); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, ps); }
-            if (ps != st) { HIPCHECK(hipEventRecord(ctx->ev_pyr, ps)); HIPCHECK(hipStreamWaitEvent(st, ctx->ev_pyr, 0)); }
+            { Span s(ctx, KT_RESIZE); for (int l = 1; l < d.n_levels; l++) launch_resize(d, l, st); }
             { Span s(ctx, KT_FAST); launch_fast(d, st); }
             const bool split_early = (flags & SVO_FLAG_DETECT_NO_POST) && (flags & SVO_FLAG_DETECT_SPLIT_AT_SELECT);
             if (!split_early) { Span s(ctx, KT_SELECT); launch_select(d, st); }

@@ -40,7 +40,7 @@ struct svo_batch {
     bool pipelined = false, first = true;
     std::vector<svo_ctx*> ctx;
     std::vector<hipStream_t> own;                    // one per context: the stream it was created with (free schedule)
-    std::vector<hipStream_t> s_dets, s_rests; hipStream_t s_post = nullptr, s_pyr = nullptr;      // s_pyr: SVO_BATCH_PYR_STREAM=1 (A/B knob): the pyramids of the contexts on a stream of their own
+    std::vector<hipStream_t> s_dets, s_rests; hipStream_t s_post = nullptr;
     std::vector<hipEvent_t> det_done, rest_done, done, pre_done, scratch_free;
     bool ahead = false;                              // the detect calls run ahead of the previous frame's stages 3-5 (post_mode 1 / 3)
     std::vector<hipEvent_t> held;                    // svo_batch_hold_for_event: what the next step's record copies wait for (every one of them)
@@ -123,7 +123,6 @@ extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
     const int nr = cfg->rest_streams > 0 ? cfg->rest_streams : b->NC;
     for (int i = 0; i < nr; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high == 0); if (rc) return rc; b->s_rests.push_back(s); }
     if (cfg->post_mode == 2) { int rc = make_stream(b->last_error, &b->s_post, cfg->det_priority_high == 0); if (rc) return rc; }
-    { const char* e = getenv("SVO_BATCH_PYR_STREAM"); if (e && atoi(e) == 1 && b->pipelined) { int rc = make_stream(b->last_error, &b->s_pyr, cfg->det_priority_high != 0); if (rc) return rc; for (svo_ctx* c : b->ctx) BSVO(b, c, svo_set_pyramid_stream(c, b->s_pyr)); } }
     BHIP(b, hipMalloc((void**)&b->own_rec, (size_t)b->B * sizeof(svo_result)));
     BHIP(b, hipMemset(b->own_rec, 0, (size_t)b->B * sizeof(svo_result)));
     b->rec = b->own_rec;
@@ -139,7 +138,6 @@ extern "C" void svo_batch_destroy(svo_batch* b)
     for (hipStream_t s : b->s_dets) (void)hipStreamDestroy(s);
     for (hipStream_t s : b->s_rests) (void)hipStreamDestroy(s);
     if (b->s_post) (void)hipStreamDestroy(b->s_post);
-    if (b->s_pyr) (void)hipStreamDestroy(b->s_pyr);
     for (hipStream_t s : b->own) (void)hipStreamDestroy(s);
     for (auto* v : { &b->det_done, &b->rest_done, &b->done, &b->pre_done, &b->scratch_free }) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
     if (b->own_rec) (void)hipFree(b->own_rec);
@@ -209,7 +207,6 @@ static int batch_step_impl(svo_batch* b, const svo_frame* frames, uint32_t flags
         if (b->pipelined) {
             hipStream_t s_det = b->s_dets[(size_t)k % b->s_dets.size()], s_rest = b->s_rests[(size_t)k % b->s_rests.size()];
             if (!b->first) BHIP(b, hipStreamWaitEvent(s_det, b->ahead ? b->scratch_free[(size_t)k] : b->rest_done[(size_t)k], 0));
-            if (!b->first && b->s_pyr) BHIP(b, hipStreamWaitEvent(b->s_pyr, b->ahead ? b->scratch_free[(size_t)k] : b->rest_done[(size_t)k], 0));
             BSVO(b, c, svo_set_stream(c, s_det));
             BSVO(b, c, svo_process(c, pk, SVO_RUN_DETECT | AH | (b->ahead ? (uint32_t)SVO_FLAG_NO_SHIFT : 0u) | (b->cfg.post_mode ? (uint32_t)SVO_FLAG_DETECT_NO_POST : 0u) | (b->cfg.post_mode == 3 ? (uint32_t)SVO_FLAG_DETECT_SPLIT_AT_SELECT : 0u) | flags));
             if (b->cfg.post_mode == 2) {

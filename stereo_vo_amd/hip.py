@@ -29,7 +29,7 @@ EXPORTS = [
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
     "svo_get_values", "svo_put_features_oct", "svo_put_matches_oct", "svo_put_match_ids_oct",
     "svo_handover_bytes", "svo_export_frame", "svo_import_frame",
-    "svo_use_graphs", "svo_record_after_post", "svo_set_pyramid_stream", "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
+    "svo_use_graphs", "svo_record_after_post", "svo_wait_upload", "svo_host_alloc", "svo_host_free", "svo_host_register", "svo_host_unregister",
 ]
 
 
