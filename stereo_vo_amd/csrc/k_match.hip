@@ -1403,14 +1403,14 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 // -- a failed guard, a NaN, a borderline pair -- replays the oracle's own expression (fm_inlier).
 // Result layout of the tile (pinned on the hardware, see above): lane l = j + 16 q, register r  <->  model 4 r + q, pair j.
 #define RC16_SUPER 256
-// Round 5: the PAIRS of a lane are split over RC16_NSPLIT blocks as well.  A block used to walk all n pairs (45-70 tiles of 16, ~1 us
+// Round 5: the PAIRS of a lane are split over `nsplit` blocks as well.  A block used to walk all n pairs (45-70 tiles of 16, ~1 us
 // each: 45 us for the two blocks per lane and side of chunk 0, with 3/4 of the GPU idle); now it walks its quarter, adds its partial
 // counts to rs_cnt (zeroed by the hypothesis kernel) and takes a ticket; the block that takes the last ticket of its 64 slots reads
 // the sums and publishes the best one.  Counts are integers: the order of the additions does not matter.  A block that finds its
 // groups out of reach (rs_bound moves while the launch runs, so the blocks of one group need not agree) still takes its ticket; the
 // sums it leaves incomplete belong to samples at or beyond rs_bound, which the finalize never visits, and a best count published from
 // incomplete sums is an under-estimate, which only loosens the bound it feeds (as the early exit's partial counts did).
-#define RC16_NSPLIT 1          // default of the launcher (SVO_RC_SPLIT overrides): splitting costs more blocks than it saves at 64 lanes (70.0 k pairs/s at 1, 69.9 k at 2, 67.9 k at 4)
+#define RC16_NSPLIT0 1         // blocks the pairs of a lane are split over in chunk 0 (chunks 1, 2: one; launch_ransac_count)
 __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk, int nsplit)
 {
     SVO_LATENCY_CHAIN(c);
@@ -1542,7 +1542,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         if (j == 0 && !dead && 4 * r + q < nlive_w && v > 0) seen |= __hip_atomic_fetch_add(&gcnt[hw + 4 * r + q], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (seen < 0) atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL);          // (counts are never negative: this only makes the adds above returning ones)
-    // the ticket of this block's 64 slots: every one of the RC16_NSPLIT blocks takes exactly one, computed or not
+    // the ticket of this block's 64 slots: every one of the nsplit blocks takes exactly one, computed or not
     __shared__ int s_last;
     __syncthreads();
     if (tid == 0) {
@@ -1932,8 +1932,16 @@ void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
     if (dm == 14) hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk);
     else if (dm == 52) hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk);
     else if (many || dm == 53 || dm == 54) {
-        static int nsplit = 0;
-        if (!nsplit) { const char* e = getenv("SVO_RC_SPLIT"); const int v = e ? atoi(e) : 0; nsplit = (v >= 1 && v <= 8) ? v : RC16_NSPLIT; }
+        // The pairs of a lane CAN be split over several blocks per chunk (SVO_RC_SPLIT = s0[,s1[,s2]]): chunk 0 is two blocks per lane and side,
+        // a chain of dependent f64 verdicts with one wave per SIMD (43 us alone, 29 us on four blocks each).  In the batched schedule it buys
+        // nothing: 70.6 k pairs/s with (4, 1, 1), 71.0 k unsplit, 67.9 k with four everywhere (r05f, r05r).  Default: unsplit.
+        static int split[3] = { 0, 0, 0 };
+        if (!split[0]) {
+            split[0] = RC16_NSPLIT0; split[1] = split[2] = 1;
+            const char* e = getenv("SVO_RC_SPLIT");
+            if (e) { int v[3] = { 0, 0, 0 }; const int k = sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]); for (int i = 0; i < 3; i++) { const int x = i < k ? v[i] : (k > 0 ? v[k - 1] : 0); if (x >= 1 && x <= 8) split[i] = x; } }
+        }
+        const int nsplit = split[chunk];
         hipLaunchKernelGGL(k_ransac_count_mfma16, dim3(((ns + 63) / 64) * nsplit, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk, nsplit);
     }
     else hipLaunchKernelGGL(k_ransac_count<4>, dim3((ns + 3) / 4, 2, c.n_lanes * c.oct_cap), dim3(256), 0, st, c, chunk);
