@@ -1,11 +1,12 @@
-// k_gn.hip -- stage 5 on the device: one persistent 512-thread workgroup per lane runs the whole optimiser
+// k_gn.hip -- stage 5 on the device: one persistent 384-thread workgroup per lane (256 / 512 by SVO_GN_NT) runs the whole optimiser
 // (gather, grid-NMS mask, triangulation, both Gauss-Newton phases, residual gating, pose inverse) in ONE launch
 // with no host round trip.
 //
 // Replaces stage5_optimize (libstereo-odometry/src/stage5_optimization.cpp:392-736), m_evalRGN (:275-390) and
 // m_pinhole_stereo_projection (:35-257).  Double precision throughout, like the reference.  The 28 sums of one
-// iteration (21 of J^T J, 6 of J^T r, cost) are reduced with wavefront shuffles and a 4-wave LDS step: the
-// Jacobian block is 4T x 6 with a 6x6 output, far too thin for an MFMA tile.
+// iteration (21 of J^T J, 6 of J^T r, cost) are reduced inside each wave on the permlane-swap / DPP network and across the
+// waves through 28 doubles of LDS each (gn_wave_sums): the Jacobian block is 4T x 6 with a 6x6 output, far too thin for an
+// MFMA tile.  LDS per block: 33 KB (lists of up to 1024 tracked pairs; longer ones use DevCtx::gn_scratch).
 // The reduction order differs from the reference's sequential loop, so results agree with the oracle to rounding
 // (tests: 1e-4 rad / 1e-3 m), not bit for bit.
 #include <mutex>
