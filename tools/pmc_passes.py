@@ -32,7 +32,10 @@ PASSES = {
     "wr": ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"],
     "sq1": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"],
     "sq2": ["SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_WAVES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE"],
+    "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64"],      # round 5: how busy the matrix pipe really is
 }
+if os.environ.get("PMC_ONLY"):          # e.g. PMC_ONLY=sq2,mfma: a subset of the passes (the summary then lacks what the others measure)
+    PASSES = {k: v for k, v in PASSES.items() if k in os.environ["PMC_ONLY"].split(",")}
 
 
 def run_pass(name, counters):
@@ -88,6 +91,8 @@ for k, d in sorted(allc.items()):
     if cyc > 0 and "SQ_INSTS_VALU" in d:
         e["cycles"] = int(cyc)
         e["valu_issue_frac"] = round(d["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), 4)
+    if cyc > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+        e["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)      # rocprofv3's MfmaUtil: busy cycles summed over the SIMDs / (cycles x 1024 SIMDs)
     if d.get("SQ_LDS_IDX_ACTIVE", 0) > 0 and "SQ_LDS_BANK_CONFLICT" in d:
         e["lds_conflict_frac"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 4)
     if d.get("SQ_WAVES", 0) > 0 and "SQ_INSTS_VALU" in d:
