@@ -37,7 +37,7 @@ static const uint32_t IMG_FLAGS = SVO_FLAG_DEVICE_IMAGES | SVO_FLAG_PINNED_IMAGE
 struct svo_batch {
     svo_batch_config cfg;
     int NC = 0, Bc = 0, B = 0;
-    bool pipelined = false, first = true;
+    bool pipelined = false, first = true, step_started = false;
     std::vector<svo_ctx*> ctx;
     std::vector<hipStream_t> own;                    // one per context: the stream it was created with (free schedule)
     std::vector<hipStream_t> s_dets, s_rests; hipStream_t s_post = nullptr;
@@ -180,9 +180,10 @@ static int batch_step_impl(svo_batch* b, const svo_frame* frames, uint32_t flags
 extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags)
 {
     if (!b) return SVO_ERR_ARG;
+    b->step_started = false;
     const int rc = batch_step_impl(b, frames, flags);
     b->held.clear();                          // the held events belong to THIS step, however it ended
-    if (rc != SVO_OK && rc != SVO_ERR_ARG) {
+    if (rc != SVO_OK && b->step_started) {    // (an argument refused before anything was enqueued leaves the event chain intact)
         // a step that failed half way has recorded some of its events and not others: let everything enqueued so far drain and start
         // the event chain over, so that the next step neither waits on a stale record (a no-op) nor overwrites scratch still being read
         (void)hipSetDevice(b->cfg.ctx.device);
@@ -200,6 +201,7 @@ static int batch_step_impl(svo_batch* b, const svo_frame* frames, uint32_t flags
     const uint32_t AH = b->ahead ? (uint32_t)SVO_FLAG_DETECT_AHEAD : 0u;
     const uint32_t REST = SVO_RUN_MATCH | SVO_RUN_TRACK | SVO_RUN_OPTIMIZE | (b->ahead ? AH : (uint32_t)SVO_FLAG_NO_SHIFT) | (b->cfg.post_mode == 1 ? (uint32_t)SVO_RUN_DETECT_POST : 0u)
                         | (b->cfg.post_mode == 3 ? (uint32_t)(SVO_RUN_DETECT_POST | SVO_FLAG_DETECT_SPLIT_AT_SELECT) : 0u);
+    b->step_started = true;
     for (int k = 0; k < b->NC; k++) {
         svo_ctx* c = b->ctx[(size_t)k];
         const svo_frame* pk = frames + (size_t)k * b->Bc;

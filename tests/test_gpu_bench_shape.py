@@ -329,3 +329,50 @@ def test_capacity_bits_of_a_detector_running_ahead_reach_the_right_record(monkey
     batch.synchronize()
     assert all(r.status == 0 for r in batch.results())
     batch.close()
+
+
+def test_a_step_that_fails_half_way_leaves_the_batch_usable():
+    """a svo_batch_step whose SECOND context refuses its frames (one stride differs) has already enqueued the first context:
+    some events of the step are recorded, others are not.  The step reports the error, the batch drains the device and restarts its event
+    chain, the held events are dropped -- and the following steps give, lane by lane, what an oracle fed the frames that lane really
+    processed gives (the lanes of context 0 saw the failed step's frame, those of context 1 did not)."""
+    import torch
+    from oracle import oracle as OR
+    from oracle import probe as PR
+    from stereo_vo_amd.pipeline import StreamBatch
+    from stereo_vo_amd.synth import SyntheticStereoWorld
+    W, H, B, NC = 640, 480, 4, 2
+    dev = torch.device("cuda", 0)
+    world = SyntheticStereoWorld(W, H, 400.0, 0.12, seed=5, n_frames=6, device=dev)
+    frames = [world.render(t) for t in range(6)]
+    cam = world.camera()
+    p = north_star_params(hip.default_params(), orb_nfeats=500)
+    batch = StreamBatch(p, cam, W, H, B, NC, device=0, max_kps=1024)
+    ptrs = lambda t: [(frames[t][0].data_ptr(), frames[t][1].data_ptr())] * B     # noqa: E731  (every lane plays the same sequence)
+    seen = [[] for _ in range(B)]
+    for t in (0, 1):
+        batch.step(ptrs(t))
+        for l in range(B): seen[l].append(t)
+    ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev))
+    batch.hold_for(ev)                                   # a held event that the failing step must not leak into the next one
+    bad = batch.prepare(ptrs(2))
+    bad[B - 1].right.stride = W + 64                     # last lane of context 1: svo_process refuses mixed strides (SVO_ERR_ARG)
+    with pytest.raises(hip.SvoError):
+        batch.step_prepared(bad)
+    for l in range(B // NC): seen[l].append(2)           # context 0 went through
+    for t in (3, 4, 5):
+        batch.step(ptrs(t))
+        for l in range(B): seen[l].append(t)
+    batch.synchronize()
+    rec = batch.rec.cpu().numpy()
+    host = [tuple(x.cpu().numpy() for x in f) for f in frames]
+    for l in range(B):
+        orc = OR.Oracle(p)
+        for t in seen[l]:
+            r = orc.process(host[t][0], host[t][1], cam)
+        ctx, ll = batch.lane(l)
+        res = Result.from_buffer_copy(rec[l].tobytes())
+        lists, flags, et, er = PR.compare(PR.digest_of(ctx, ll, res), PR.digest_of(orc, 0, r))
+        assert lists and flags and et < 1e-3 and er < 1e-4, (l, seen[l])
+        orc.close()
+    batch.close()
