@@ -323,6 +323,38 @@ def test_few_candidates_reach_the_sampler_edge_cases(golden_dir):
     assert 7 in seen and any(8 <= n <= 14 for n in seen) and any(n < 7 for n in seen) and any(n >= 15 for n in seen), sorted(seen)
 
 
+def test_armed_post_event_is_disarmed_by_a_failing_call(golden_dir):
+    """svo_record_after_post arms ONE call.  When that call leaves early -- here with SVO_ERR_STATE: a post-processing call on a
+    context whose geometry was never set up -- the event is still recorded (a waiter is released) and disarmed, so that a later, unrelated
+    call cannot record it at the wrong point: re-recorded by the test itself behind a long kernel queue, it must stay where the test put it."""
+    import torch
+    g, cam, p = load_small(golden_dir)
+    W, H = int(g["W"]), int(g["H"])
+    ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    ev = torch.cuda.Event()
+    L = hip.lib()
+    assert L.svo_record_after_post(ctx.h, C.c_void_p(ev.cuda_event)) == 0
+    rc = L.svo_process(ctx.h, None, C.c_uint32(hip.RUN_DETECT_POST | hip.RUN_MATCH | hip.FLAG_NO_SHIFT))      # no frame has set the geometry up yet: SVO_ERR_STATE
+    assert rc < 0
+    ev.synchronize()                                     # recorded by the failing call: returns at once instead of hanging
+    # a full frame now (it runs the post-processing): the event is no longer armed, so it is NOT re-recorded behind this frame
+    ctx.process_host([(g["L0"], g["R0"])])
+    assert ev.query()                                    # still the old record: complete although the frame may be in flight
+    ctx.wait()
+    # and the armed event of a SUCCESSFUL call is recorded by that call
+    ev2 = torch.cuda.Event()
+    assert L.svo_record_after_post(ctx.h, C.c_void_p(ev2.cuda_event)) == 0
+    ctx.process_host([(g["L1"], g["R1"])])
+    ev2.synchronize()
+    ctx.wait()
+    orc = O().Oracle(p)
+    for t in (0, 1):
+        ro = orc.process(g["L%d" % t], g["R%d" % t], cam)
+    assert_same_frame(ctx, 0, orc, ctx.result(0), ro, "after the armed calls")
+    ctx.close()
+
+
 def test_device_resident_images_and_lane_independence(golden_dir):
     import torch
     g, cam, p = load_small(golden_dir)
