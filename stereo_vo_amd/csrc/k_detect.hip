@@ -1179,9 +1179,9 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
             }
             const int m10 = wave_sum_uniform((int)m10u - 15 * msum);
             m01 = wave_sum_uniform(m01);
-            const float angle = atan2_deg((float)m01, (float)m10);
-            float sn, cs;
-            sincos_f32(angle * 0.017453292f, sn, cs);
+            float angle, sn, cs;
+            if (c.debug_mode == 46) { angle = (float)(m10 & 255); sn = (float)(m01 & 255) * 0.001f; cs = 1.f - sn; }      /* ablation: no trigonometry (results differ) */
+            else { angle = atan2_deg((float)m01, (float)m10); sincos_f32(angle * 0.017453292f, sn, cs); }
             // ---- C: horizontal pass on the matrix cores: S[mt][nt] = H - 32768 for window rows 16 mt + 4 q + r, blurred columns 16 nt + n ----
             dp_v4i S[3][3];
             {
