@@ -375,18 +375,20 @@ def seven_point(p1, p2):
     return F.reshape(3, 3, 3)[:n].copy()
 
 
-def track(params, orb_th, pkl, pdl, pkr, pdr, pm, pri, ckl, cdl, ckr, cdr, cm, cri, img_w, img_h):
+def track(params, orb_th, pkl, pdl, pkr, pdr, pm, pri, ckl, cdl, ckr, cdr, cm, cri, img_w, img_h, stats=False):
+    """stage 4 on caller-supplied lists; stats=True: (tracked pairs, the call's eight SVO_TS_* counters)"""
     cap = max(len(pm), len(cm), 1)
     out = np.zeros(cap, index_pair_dtype)
     vp = C.c_void_p
     arrs = [np.ascontiguousarray(a, np.uint8) for a in (pdl, pdr, cdl, cdr)]
-    t = lib().svo_oracle_track(C.byref(params), int(orb_th),
-                               pkl.ctypes.data_as(vp), _ptr(arrs[0], u8p), pkr.ctypes.data_as(vp), _ptr(arrs[1], u8p), pm.ctypes.data_as(vp), len(pm), _ptr(pri, i64p),
-                               ckl.ctypes.data_as(vp), _ptr(arrs[2], u8p), ckr.ctypes.data_as(vp), _ptr(arrs[3], u8p), cm.ctypes.data_as(vp), len(cm), _ptr(cri, i64p),
-                               img_w, img_h, out.ctypes.data_as(vp), cap)
+    ts = np.zeros(8, np.int32)
+    t = lib().svo_oracle_track_stats(C.byref(params), int(orb_th),
+                                     pkl.ctypes.data_as(vp), _ptr(arrs[0], u8p), pkr.ctypes.data_as(vp), _ptr(arrs[1], u8p), pm.ctypes.data_as(vp), len(pm), _ptr(pri, i64p),
+                                     ckl.ctypes.data_as(vp), _ptr(arrs[2], u8p), ckr.ctypes.data_as(vp), _ptr(arrs[3], u8p), cm.ctypes.data_as(vp), len(cm), _ptr(cri, i64p),
+                                     img_w, img_h, out.ctypes.data_as(vp), cap, ts.ctypes.data_as(vp))
     if t < 0:
         raise RuntimeError("track: %d" % t)
-    return out[:t].copy()
+    return (out[:t].copy(), ts) if stats else out[:t].copy()
 
 
 def project(lmks, cam, delta):

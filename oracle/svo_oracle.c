@@ -967,8 +967,20 @@ static int fm_inlier(const double* F, float fx1, float fy1, float fx2, float fy2
     a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; c = (F[2] * x2 + F[5] * y2) + F[8];
     const double sA = 1.0 / (a * a + b * b), dA = (x1 * a + y1 * b) + c;
     const double eA = (dA * dA) * sA, eB = (dB * dB) * sB;
-    const double e = eA > eB ? eA : eB;
-    return e <= 1.0;   /* threshold 1.0 px, squared */
+    const double e = eA < eB ? eB : eA;                 /* std::max(d1*d1*s1, d2*d2*s2): a NaN first operand stays */
+    return (float)e <= 1.0f;   /* findInliers: err is stored as float, threshold 1.0 px squared as float */
+}
+
+/* the same error as FMEstimatorCallback::computeError stores it: a float */
+static float fm_error(const double* F, float fx1, float fy1, float fx2, float fy2)
+{
+    const double x1 = (double)fx1, y1 = (double)fy1, x2 = (double)fx2, y2 = (double)fy2;
+    double a = (F[0] * x1 + F[1] * y1) + F[2], b = (F[3] * x1 + F[4] * y1) + F[5], c = (F[6] * x1 + F[7] * y1) + F[8];
+    const double sB = 1.0 / (a * a + b * b), dB = (x2 * a + y2 * b) + c;
+    a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; c = (F[2] * x2 + F[5] * y2) + F[8];
+    const double sA = 1.0 / (a * a + b * b), dA = (x1 * a + y1 * b) + c;
+    const double eA = (dA * dA) * sA, eB = (dB * dB) * sB;
+    return (float)(eA < eB ? eB : eA);
 }
 
 /* natural logarithm from IEEE +, -, *, / only, one operation per operator (the HIP kernels repeat it verbatim, so
@@ -1015,8 +1027,67 @@ static int ransac_update_niters(int cnt, int n, int max_iters)
  * of a sample are scored.  best_hyp = the SAMPLE the winning model came from, n_hyp_used = samples visited.
  * Exactly seven points: findFundamentalMat runs the 7-point kernel directly and sets the whole mask (no sampling; whichever model it
  * returns, seven inliers are below the eight the reference asks for at S4:205, 240).
- * DEVIATION, stated: for 8 <= n <= 14 OpenCV (>= 3.0) switches to its LMedS registrator; this restatement runs the RANSAC for
- * every n >= 8.  The regime is a tracker that has all but lost its features (the reference declares bad tracking below 5 tracked pairs). */
+ * Eight to fourteen points (since v6): findFundamentalMat hands the set to its LMedS registrator instead (`npoints >= 15` is the RANSAC's
+ * condition, in OpenCV 2.4's cvFindFundamentalMat and in 3.x / 4.x's findFundamentalMat alike): lmeds_fundamental below. */
+/* LMeDSPointSetRegistrator::run (modelPoints = 7, confidence 0.99, maxIters 1000): niters = RANSACUpdateNumIters(0.99, outlierRatio 0.45, 7, 1000)
+ * = cvRound(ln 0.01 / ln(1 - 0.55^7)) = 300 samples, never shortened; the SAME generator and getSubset as the RANSAC (seed (uint64)-1, a sample
+ * that cannot be found ends the loop, at iteration 0 the whole call); every model of a sample: the n errors as floats, their median = the
+ * element nth_element leaves at n / 2 -- OpenCV sorts the float bit patterns AS INTS, which is the float order for the non-negative errors
+ * here and puts x86's negative default NaN (0 * inf on a degenerate line) first: a NaN is given that pattern on every platform --; a model
+ * whose median is below the smallest so far (strictly, starting from DBL_MAX: an infinite or NaN median never wins) becomes the result.
+ * Then sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(minMedian), at least 0.001, and the mask is err <= (float)(sigma^2).
+ * best_hyp = the sample of the winning model, n_hyp_used = samples visited.  The count returned is the mask's (S4:204 counts the mask;
+ * findFundamentalMat itself returns no matrix below 7 inliers, which S4 never looks at). */
+#define LMEDS_MAX_N 14
+static int lmeds_niters(void)
+{
+    const double num = log(1.0 - 0.99), denom = log(1.0 - pow(1.0 - 0.45, 7.0));
+    const int k = (denom >= 0.0 || -num >= 1000.0 * (-denom)) ? 1000 : (int)rint(num / denom);
+    return k > 3 ? k : 3;
+}
+static int32_t float_bits_x86(float e)
+{
+    union { float f; int32_t i; } v; v.f = e;
+    return e != e ? (int32_t)0xFFC00000u : v.i;
+}
+static int lmeds_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9, int* best_hyp, int* n_hyp_used)
+{
+    const int niters = lmeds_niters();
+    double minMedian = 1.7976931348623157e308, Fbest[9] = { 0 };
+    int best_k = -1, k;
+    cv_rng rng; rng.state = 0xFFFFFFFFFFFFFFFFULL;
+    for (k = 0; k < niters; k++) {
+        int s[7]; double Fm[27];
+        if (!ransac_get_subset(&rng, p1, p2, n, s, 10000, NULL)) break;
+        const int nm = seven_point(p1, p2, s, Fm);
+        for (int j = 0; j < nm; j++) {
+            const double* F = Fm + 9 * j;
+            float err[LMEDS_MAX_N]; int32_t key[LMEDS_MAX_N];
+            for (int i = 0; i < n; i++) { err[i] = fm_error(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]); key[i] = float_bits_x86(err[i]); }
+            /* nth_element(int*, +n/2, +n): the element of rank n / 2 in the int order (ties share a value: which of them is immaterial) */
+            float med = 0.f;
+            for (int i = 0; i < n; i++) {
+                int below = 0, equal = 0;
+                for (int q = 0; q < n; q++) { below += key[q] < key[i]; equal += key[q] == key[i]; }
+                if (below <= n / 2 && n / 2 < below + equal) { med = err[i]; break; }
+            }
+            const double median = (double)med;
+            if (median < minMedian) { minMedian = median; best_k = k; memcpy(Fbest, F, 9 * sizeof(double)); }
+        }
+    }
+    if (n_hyp_used) *n_hyp_used = k;
+    if (getenv("SVO_ORACLE_TRACE")) fprintf(stderr, "lmeds n=%d visited=%d best_k=%d minMedian=%.9g\n", n, k, best_k, minMedian);
+    if (best_k < 0) return 0;
+    double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / (double)(n - 7)) * sqrt(minMedian);
+    if (!(sigma > 0.001)) sigma = 0.001;                       /* MAX(sigma, 0.001) */
+    const float t = (float)(sigma * sigma);
+    int cnt = 0;
+    for (int i = 0; i < n; i++) { mask[i] = (uint8_t)(fm_error(Fbest, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= t); cnt += mask[i]; }
+    if (F9) memcpy(F9, Fbest, sizeof(Fbest));
+    if (best_hyp) *best_hyp = best_k;
+    return cnt;
+}
+
 int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8_t* mask, double* F9, int* best_hyp, int* n_hyp_used)
 {
     for (int i = 0; i < n; i++) mask[i] = 0;
@@ -1031,6 +1102,7 @@ int svo_oracle_ransac_fundamental(const float* p1, const float* p2, int n, uint8
         if (best_hyp) *best_hyp = 0;
         return 7;
     }
+    if (n <= LMEDS_MAX_N) return lmeds_fundamental(p1, p2, n, mask, F9, best_hyp, n_hyp_used);
     int niters = RANSAC_MAX_HYP, best_cnt = 0, best_k = -1;
     double Fbest[9] = { 0 };
     cv_rng rng; rng.state = 0xFFFFFFFFFFFFFFFFULL;                 /* RNG rng((uint64)-1) */
@@ -1212,6 +1284,22 @@ int svo_oracle_track(const svo_params* p, int orb_th,
     if (p->ifm_method == SVO_IFM_DESC_BF) return track_bf(orb_th, pkl, pdl, pkr, pdr, pm, npm, ckl, cdl, ckr, cdr, cm, ncm, out, cap);
     if (p->ifm_method == SVO_IFM_DESC_WIN) return track_win(p, pkl, pdl, pkr, pm, npm, pri, ckl, cdl, ckr, cm, ncm, cri, img_w, img_h, out, cap);
     return -2;   /* S4:740 THROW_EXCEPTION("Undefined inter-frame matching method") */
+}
+/* the same call with its counters (svo_result.track_stats' SVO_TS_* of this one octave) handed back: stats8 = 8 ints */
+int svo_oracle_track_stats(const svo_params* p, int orb_th,
+                           const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr,
+                           const svo_dmatch* pm, int npm, const int64_t* pri,
+                           const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr,
+                           const svo_dmatch* cm, int ncm, const int64_t* cri,
+                           int img_w, int img_h, svo_index_pair* out, int cap, int* stats8)
+{
+    int keep[8];
+    memcpy(keep, g_ts, sizeof(keep));
+    memset(g_ts, 0, sizeof(g_ts));
+    const int t = svo_oracle_track(p, orb_th, pkl, pdl, pkr, pdr, pm, npm, pri, ckl, cdl, ckr, cdr, cm, ncm, cri, img_w, img_h, out, cap);
+    if (stats8) memcpy(stats8, g_ts, sizeof(g_ts));
+    memcpy(g_ts, keep, sizeof(keep));
+    return t;
 }
 
 /* ------------------------------------------------------------------------------------------------ */

@@ -35,8 +35,13 @@ extern "C" {
  *      seeded (uint64)-1 by every findFundamentalMat call), RANSACPointSetRegistrator::getSubset (uniform draws, a repeated index drawn
  *      again) and FMEstimatorCallback::checkSubset (a sample whose last point is collinear with two earlier ones in either image is drawn
  *      afresh) -- instead of this repository's own seeded schedule; exactly seven points take findFundamentalMat's direct path (whole mask
- *      set).  Stated deviation: for 8..14 points OpenCV >= 3.0 runs LMedS, this restatement the RANSAC. */
-#define SVO_ORACLE_VERSION 5
+ *      set);
+ *   6  round 5, later: eight to fourteen points run findFundamentalMat's LMedS registrator (300 samples from the same generator, median
+ *      of the float errors as nth_element leaves it at n / 2 (the 3.x / 4.x reading; 2.4 averaged the middle pair for even n), mask at
+ *      2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median)) -- the deviation version 5 stated is gone; the inlier test compares the error
+ *      AS A FLOAT with the float threshold (computeError stores floats, findInliers compares them), the maximum of the two distances is
+ *      std::max's (a NaN first operand stays). */
+#define SVO_ORACLE_VERSION 6
 int svo_oracle_version(void);
 
 typedef struct svo_oracle svo_oracle;
@@ -120,6 +125,13 @@ int svo_oracle_track(const svo_params* p, int orb_th,
                      const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr,
                      const svo_dmatch* cm, int ncm, const int64_t* cri,
                      int img_w, int img_h, svo_index_pair* out, int cap);
+/* ... and with the call's counters (svo_result.track_stats' SVO_TS_* for this one octave) in stats8[8] */
+int svo_oracle_track_stats(const svo_params* p, int orb_th,
+                           const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr,
+                           const svo_dmatch* pm, int npm, const int64_t* pri,
+                           const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr,
+                           const svo_dmatch* cm, int ncm, const int64_t* cri,
+                           int img_w, int img_h, svo_index_pair* out, int cap, int* stats8);
 /* getChangeInPose (C:355-413): stage 5 on caller data. init6 may be NULL. residual has n_tracked entries,
  * outliers capacity n_tracked. State (m_last_computed_pose) lives in `o`. Returns result.valid. */
 int svo_oracle_change_in_pose(svo_oracle* o, const svo_index_pair* tracked, int n_tracked,

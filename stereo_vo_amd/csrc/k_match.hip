@@ -468,6 +468,10 @@ __global__ void __launch_bounds__(256) k_match_lr_rbr(DevCtx c, int one_to_one, 
 
 // (defined with the RANSAC kernels below) phase 0 of the sample schedule runs at the end of the tracker kernels: same block shape, one launch less
 __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int phase, int n, int* scan);
+// Eight to fourteen pairs: cv::findFundamentalMat runs its LMedS registrator, not the RANSAC (oracle v6: lmeds_fundamental) -- a fixed
+// budget of SVO_LMEDS_ITERS samples from the same generator, every model of every one of them ranked by its median error (k_track_finalize).
+__device__ __forceinline__ bool rs_is_lmeds(int n) { return n >= 8 && n <= SVO_LMEDS_MAX_N; }
+__device__ __forceinline__ int rs_first_bound(int n) { return rs_is_lmeds(n) ? SVO_LMEDS_ITERS : SVO_RANSAC_HYP; }      // rs_bound before any count
 
 // ------------------------------------------------------------------------------------------------------------
 // K8c: ifmDescWin -- window tracker (stage4_match_consecutive.cpp:435-738) with its quirks kept (appendix A #12):
@@ -541,7 +545,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
         __syncthreads();
     }
     if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], np_total); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], np_total); }
-    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
+    if (tid == 0) { c.trk_nk[vl] = np_total; c.rs_bound[vl * 2] = c.rs_bound[vl * 2 + 1] = rs_first_bound(np_total); c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
     __syncthreads();                                                       // the point pairs are written: the sampler's collinearity test reads them
     rs_schedule_block(c, vl, 0, np_total, scan);
 }
@@ -662,7 +666,7 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
         __syncthreads();
     }
     if (tid == 0) { atomicAdd(&c.results[lane_id].track_stats[SVO_TS_THRESHOLD], s_th); atomicAdd(&c.results[lane_id].track_stats[SVO_TS_COLLISION], nk); }
-    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = SVO_RANSAC_HYP; c.rs_bound[vl * 2 + 1] = SVO_RANSAC_HYP; c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
+    if (tid == 0) { c.trk_nk[vl] = nk; c.rs_bound[vl * 2] = c.rs_bound[vl * 2 + 1] = rs_first_bound(nk); c.rs_floor[vl * 4] = c.rs_floor[vl * 4 + 1] = c.rs_floor[vl * 4 + 2] = c.rs_floor[vl * 4 + 3] = 6; }
     __syncthreads();                                                       // the point pairs are written: the sampler's collinearity test reads them
     rs_schedule_block(c, vl, 0, nk, scan);
 }
@@ -772,8 +776,9 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
     const int tid = threadIdx.x;
     int* st = c.rs_sched + vl * SVO_RS_ST;     // last accepted attempt (left) | attempts consumed | samples left | samples right | last accepted (right) | ended left | ended right
     if (n < 8 || n > c.rs_att_nmax) { if (phase == 0 && tid < SVO_RS_ST) st[tid] = 0; return; }
-    if (phase == 1 && max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= SVO_RANSAC_CHUNK1) return;      // neither side's budget reaches chunk 2
-    const int target = phase ? SVO_RANSAC_HYP : SVO_RANSAC_CHUNK1;
+    const bool lmeds = rs_is_lmeds(n);                                     // its 300 samples are all drawn in phase 0 (nothing shortens that budget)
+    if (phase == 1 && (lmeds || max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= SVO_RANSAC_CHUNK1)) return;      // neither side's budget reaches chunk 2
+    const int target = lmeds ? SVO_LMEDS_ITERS : (phase ? SVO_RANSAC_HYP : SVO_RANSAC_CHUNK1);
     int attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
     int last_ok[2] = { phase ? st[0] : -1, phase ? st[4] : -1 }, ended[2] = { phase ? st[5] : 0, phase ? st[6] : 0 };
     const float4* ptsL = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
@@ -833,7 +838,7 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
     if (tid == 0) {
         st[0] = last_ok[0]; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD); st[4] = last_ok[1]; st[5] = ended[0]; st[6] = ended[1];
         // the table ran out although the sequential algorithm could still draw (heavy rejection at n >= SVO_RS_SMALL_N): never silently
-        if (exhausted && phase == 1 && ((!ended[0] && ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP)) || (!ended[1] && ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP)))) {
+        if (exhausted && (phase == 1 || lmeds) && ((!ended[0] && ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP)) || (!ended[1] && ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP)))) {
             atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
         }
     }
@@ -1276,8 +1281,10 @@ __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
 
 // Symmetric epipolar test e = max(dA^2 / |lA|^2, dB^2 / |lB|^2) <= 1 with the oracle's arithmetic, minus its two f64
 // divisions in all but borderline cases: the oracle's e_X = fl(fl(d*d) * fl(1 / den)) is within 2 ulp of dd / den, so
-// dd <= den * (1 - 2^-40) decides "inlier" and dd >= den * (1 + 2^-40) decides "outlier" with certainty; only a point
-// inside that band (or a degenerate line, den <= 0 / NaN) replays the exact expression.  Same decisions, bit for bit.
+// dd <= den * (1 - 2^-40) decides "inlier" with certainty; OpenCV stores the error as a FLOAT and compares that with 1.0f
+// (computeError / findInliers), so an error up to 1 + 2^-24 still rounds to an inlier and "outlier" is certain from
+// dd >= den * (1 + 2^-22) on; only a point inside that band (or a degenerate line, den <= 0 / NaN) replays the exact
+// expression.  Same decisions, bit for bit.
 __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, float fx2, float fy2)
 {
     const double x1 = (double)fx1, y1 = (double)fy1, x2 = (double)fx2, y2 = (double)fy2;
@@ -1286,15 +1293,28 @@ __device__ __forceinline__ int fm_inlier(const double* F, float fx1, float fy1, 
     a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; cc = (F[2] * x2 + F[5] * y2) + F[8];
     const double denA = a * a + b * b, dA = (x1 * a + y1 * b) + cc;
     const double ddA = dA * dA, ddB = dB * dB;
-    const double lo = 1.0 - 9.094947017729282e-13, hi = 1.0 + 9.094947017729282e-13;            // 1 -+ 2^-40
+    const double lo = 1.0 - 9.094947017729282e-13, hi = 1.0 + 2.384185791015625e-07;             // 1 - 2^-40, 1 + 2^-22
     const bool inA = ddA <= denA * lo, inB = ddB <= denB * lo, outA = ddA >= denA * hi, outB = ddB >= denB * hi;
     const bool sure = (denA > 0.0) & (denB > 0.0) & (inA | outA) & (inB | outB);
     if (__builtin_expect(sure, 1)) return inA & inB;
     const double sB = 1.0 / denB, sA = 1.0 / denA;
     const double eA = ddA * sA, eB = ddB * sB;
-    const double e = eA > eB ? eA : eB;
-    return e <= 1.0;
+    const double e = eA < eB ? eB : eA;                   // std::max(eA, eB)
+    return (float)e <= 1.0f;
 }
+// the error itself, as computeError stores it (oracle: fm_error)
+__device__ __forceinline__ float fm_error(const double* F, float fx1, float fy1, float fx2, float fy2)
+{
+    const double x1 = (double)fx1, y1 = (double)fy1, x2 = (double)fx2, y2 = (double)fy2;
+    double a = (F[0] * x1 + F[1] * y1) + F[2], b = (F[3] * x1 + F[4] * y1) + F[5], cc = (F[6] * x1 + F[7] * y1) + F[8];
+    const double sB = 1.0 / (a * a + b * b), dB = (x2 * a + y2 * b) + cc;
+    a = (F[0] * x2 + F[3] * y2) + F[6]; b = (F[1] * x2 + F[4] * y2) + F[7]; cc = (F[2] * x2 + F[5] * y2) + F[8];
+    const double sA = 1.0 / (a * a + b * b), dA = (x1 * a + y1 * b) + cc;
+    const double eA = (dA * dA) * sA, eB = (dB * dB) * sB;
+    return (float)(eA < eB ? eB : eA);
+}
+// the order nth_element gives the errors: their bit patterns as ints, a NaN in x86's default (negative) form (oracle: float_bits_x86)
+__device__ __forceinline__ int fm_error_key(float e) { return e != e ? (int)0xFFC00000u : __float_as_int(e); }
 
 // Inlier counts on the MATRIX CORES: the two epipolar lines of every (model, pair), l = F x1 and l' = F^T x2, are small
 // dense products -- [16 rows = 4 models x (a, b, c, -)] x [4 = (x, y, 1, 0)] x [16 pairs] -- i.e. one
@@ -1316,7 +1336,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
+    if (n <= SVO_LMEDS_MAX_N) return;   // (exactly seven pairs: findFundamentalMat's direct path; eight to fourteen: LMedS ranks medians, not counts -- see k_track_finalize)
     if (h0 >= RS_SLOT_END(chunk)) return;
     // ONE thread decides for the block (rs_bound moves while the launch runs: threads reading it themselves could disagree, and a
     // block of which some waves have left no longer fills its shared arrays)
@@ -1338,7 +1358,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
     // the model this lane evaluates: g = l / 16
     const double* Fe = F + 9 * (4 * w + k);
     const double dminA = Gd[2 * (4 * w + k)], dminB = Gd[2 * (4 * w + k) + 1];
-    const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
+    const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 2.384185791015625e-07;         // 1 - 2^-26, 1 + 2^-22 (the error is compared AS A FLOAT: up to 1 + 2^-24 it rounds to 1.0f = inlier)
     // A model matters only if it is a RECORD (its count exceeds that of every earlier model, k_track_finalize), and
     // every model of chunks 1, 2 comes after all of chunk 0 (chunk 2: after all of chunk 1 as well), whose best count is
     // known by now: once a model cannot exceed that floor even if every remaining pair were an inlier, its exact count is
@@ -1419,7 +1439,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + sblk * 64, tid = threadIdx.x;     // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
+    if (n <= SVO_LMEDS_MAX_N) return;   // (exactly seven pairs: findFundamentalMat's direct path; eight to fourteen: LMedS ranks medians, not counts -- see k_track_finalize)
     if (h0 >= RS_SLOT_END(chunk)) return;
     const float4* pts = (const float4*)(c.trk_pts + ((long long)vl * 2 + side) * c.max_kps * 4);
     const int w = tid >> 6, l = tid & 63, q = l >> 4, j = l & 15;
@@ -1461,7 +1481,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
         for (int r = 0; r < 4; r++) { dminA[r] = Gd[2 * (4 * r + q)]; dminB[r] = Gd[2 * (4 * r + q) + 1]; }
     }
     const double b7 = q == 0 ? 1.0 : 0.0;
-    const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 1.4901161193847656e-08;        // 1 -+ 2^-26
+    const double lo = 1.0 - 1.4901161193847656e-08, hi = 1.0 + 2.384185791015625e-07;         // 1 - 2^-26, 1 + 2^-22 (the error is compared AS A FLOAT: up to 1 + 2^-24 it rounds to 1.0f = inlier)
     bool dead_late = false;                                    // this wave stopped early: its partial counts are still published (below the floor)
     const int floor_cnt = (chunk && nsplit == 1) ? c.rs_floor[(vl * 2 + side) * 2 + (chunk - 1)] : 0x7FFFFFFF;
     int cnt[4] = { 0, 0, 0, 0 };
@@ -1580,7 +1600,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;      // first SLOT of the block
     if (vl % c.oct_cap >= c.n_oct) return;
     const int n = c.trk_nk[vl];
-    if (n < 8) return;                  // (exactly seven pairs: findFundamentalMat's direct path, see k_track_finalize)
+    if (n <= SVO_LMEDS_MAX_N) return;   // (exactly seven pairs: findFundamentalMat's direct path; eight to fourteen: LMedS ranks medians, not counts -- see k_track_finalize)
     if (h0 >= RS_SLOT_END(chunk)) return;
     __shared__ int s_nlive;                                                   // one thread decides for the block (see k_ransac_count_mfma)
     if (tid == 0) s_nlive = rs_group_live(c, vl, side, h0);
@@ -1647,7 +1667,68 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
     // sides: strict prefix maxima by a wave scan over chunks of 128 slots, the records' budgets K(count) computed in parallel,
     // then one thread walks the handful of records in order.
     __shared__ int rec_k[2][64], rec_c[2][64], rec_K[2][64], rec_n[2];
-    {
+    __shared__ float s_thr[2];
+    const bool lmeds = rs_is_lmeds(n);
+    if (lmeds) {
+        // Eight to fourteen pairs: LMeDSPointSetRegistrator::run (oracle v6: lmeds_fundamental).  The hypothesis kernels have solved all
+        // SVO_LMEDS_ITERS samples (rs_first_bound; nothing shortens this budget); a thread per model: its n float errors, their median =
+        // the element of rank n / 2 in nth_element's order; the winner is the smallest finite median, the earliest model among equals
+        // (the sequential loop replaces its best on a STRICTLY smaller one): one 64-bit minimum over (median bits, slot).  Then the
+        // mask threshold sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median), at least 0.001.
+        __shared__ unsigned long long s_med[2];
+        __shared__ int s_lkey[SVO_LMEDS_MAX_N * 256];
+        const int side = tid >> 7, t = tid & 127;
+        if (t == 0) s_med[side] = ~0ull;
+        if (tid == 0) s_both = 0;
+        __syncthreads();
+        const long long sb = (long long)vl * 2 + side;
+        const int lim_k = min(SVO_LMEDS_ITERS, c.rs_sched[vl * SVO_RS_ST + 2 + side]);          // the samples there are (getSubset may give up earlier)
+        const int lim = (lim_k + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG * SVO_RANSAC_RSLOTS;
+        const float4* pts = (const float4*)(c.trk_pts + sb * c.max_kps * 4);
+        int* key = s_lkey + tid;                                                                // this thread's keys: key[i * 256]
+        for (int sl = t; sl < lim; sl += 128) {
+            const int reg = sl / SVO_RANSAC_RSLOTS;
+            if (sl - reg * SVO_RANSAC_RSLOTS >= c.rs_nvalid[sb * (SVO_RANSAC_PAD / SVO_RANSAC_REG) + reg]) continue;      // no model in this slot
+            if (c.rs_k[sb * SVO_RANSAC_SLOTS + sl] >= lim_k) continue;
+            const double* Fg = c.rs_F + (sb * SVO_RANSAC_SLOTS + sl) * 9;
+            double F[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) F[i] = Fg[i];
+#pragma unroll 1
+            for (int i = 0; i < n; i++) { const float4 p = pts[i]; key[i * 256] = fm_error_key(fm_error(F, p.x, p.y, p.z, p.w)); }
+            int med = -1;
+#pragma unroll 1
+            for (int i = 0; i < n; i++) {
+                const int ki = key[i * 256];
+                int below = 0, equal = 0;
+#pragma unroll 1
+                for (int q = 0; q < n; q++) { const int kq = key[q * 256]; below += kq < ki; equal += kq == ki; }
+                if (below <= n / 2 && n / 2 < below + equal) { med = ki; break; }
+            }
+            // `median < minMedian` from DBL_MAX down: an infinite or NaN median never wins; the errors are non-negative
+            if (med >= 0 && med < 0x7F800000) atomicMin(&s_med[side], ((unsigned long long)(unsigned)med << 32) | (unsigned)sl);
+        }
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long best = s_med[side];
+            int cnt = 0, slot = -1; float thr = 0.f;
+            if (best != ~0ull) {
+                slot = (int)(best & 0xFFFFFFFFull);
+                const double m = (double)__uint_as_float((unsigned)(best >> 32));
+                double sigma = 2.5 * 1.4826 * (1.0 + 5.0 / (double)(n - 7)) * sqrt(m);
+                if (!(sigma > 0.001)) sigma = 0.001;
+                thr = (float)(sigma * sigma);
+                const double* Fg = c.rs_F + (sb * SVO_RANSAC_SLOTS + slot) * 9;
+                double F[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) F[i] = Fg[i];
+#pragma unroll 1
+                for (int i = 0; i < n; i++) { const float4 p = pts[i]; cnt += fm_error(F, p.x, p.y, p.z, p.w) <= thr; }
+            }
+            s_best[side] = slot; s_cnt[side] = cnt; s_thr[side] = thr; s_vis[side] = lim_k;
+        }
+        __syncthreads();
+    } else {
         const int side = tid >> 7, t = tid & 127, wv = (tid >> 6) & 1, ln = tid & 63;
         __shared__ int run_max[2], wave_max[2][2];
         if (tid < 2) { rec_n[tid] = 0; run_max[tid] = 6; }
@@ -1714,22 +1795,24 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         // exactly seven pairs: cv::findFundamentalMat runs the 7-point kernel directly and sets the whole mask -- seven "inliers", no sample
         // visited, below the eight that S4:205, 240 ask for whichever model comes out (oracle: svo_oracle_ransac_fundamental, n == 7)
         if (t == 0 && n == 7) { s_best[side] = -1; s_cnt[side] = 7; s_vis[side] = 0; }
+        if (t == 0) s_thr[side] = 1.0f;
         __syncthreads();
     }
     const bool goodFL = s_cnt[0] >= 8, goodFR = s_cnt[1] >= 8;       // S4:205, 240
     const bool use_f = goodFL && goodFR;                             // S4:243
     if (use_f) {
-        const double* FL = c.rs_F + (((long long)vl * 2 + 0) * SVO_RANSAC_SLOTS + s_best[0]) * 9;
-        const double* FR = c.rs_F + (((long long)vl * 2 + 1) * SVO_RANSAC_SLOTS + s_best[1]) * 9;
-        double fl[9], fr[9];
+        // findInliers of both winners: the float error against 1.0f (RANSAC) or LMedS's own threshold; one side after the other
+        // (the two matrices need not be live together)
+#pragma unroll 1
+        for (int sd = 0; sd < 2; sd++) {
+            const double* Fg = c.rs_F + (((long long)vl * 2 + sd) * SVO_RANSAC_SLOTS + s_best[sd]) * 9;
+            double f[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) { fl[i] = FL[i]; fr[i] = FR[i]; }
-        const float4* pl = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
-        const float4* pr = (const float4*)(c.trk_pts + ((long long)vl * 2 + 1) * c.max_kps * 4);
-        for (int i = tid; i < n; i += blockDim.x) {
-            const float4 a = pl[i], b = pr[i];
-            in_l[i] = (unsigned char)fm_inlier(fl, a.x, a.y, a.z, a.w);
-            in_r[i] = (unsigned char)fm_inlier(fr, b.x, b.y, b.z, b.w);
+            for (int i = 0; i < 9; i++) f[i] = Fg[i];
+            const float4* pp = (const float4*)(c.trk_pts + ((long long)vl * 2 + sd) * c.max_kps * 4);
+            unsigned char* dst = sd ? in_r : in_l;
+            const float thr = s_thr[sd];
+            for (int i = tid; i < n; i += blockDim.x) { const float4 a = pp[i]; dst[i] = (unsigned char)(fm_error(f, a.x, a.y, a.z, a.w) <= thr); }
         }
     }
     __syncthreads();

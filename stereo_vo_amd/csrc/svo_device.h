@@ -31,6 +31,8 @@
 #define SVO_RS_ATT 1152             // tabulated attempts of cv::findFundamentalMat's sampler per point count n (1000 samples + room for rejected attempts)
 #define SVO_RS_SMALL_N 64           // ... below this many points 11008 of them: enough for 1000 samples and getSubset's 10000 attempts on the last
 #define SVO_RS_ATT_SMALL 11008
+#define SVO_LMEDS_MAX_N 14          // 8 .. 14 point pairs: cv::findFundamentalMat's LMedS registrator instead of the RANSAC (`npoints >= 15`)
+#define SVO_LMEDS_ITERS 300          // ... its fixed budget: RANSACUpdateNumIters(0.99, outlier ratio 0.45, 7 points, 1000) = cvRound(ln 0.01 / ln(1 - 0.55^7))
 #define SVO_RS_ST 8                 // ints of schedule state per lane-octave (rs_sched)
 
 // status-word bits (svo_debug_get_status_word)

@@ -288,19 +288,20 @@ def test_precomputed_data_bypass(golden_dir):
 
 
 def test_few_candidates_reach_the_sampler_edge_cases(golden_dir):
-    """Oracle v5's sampler where the point count is tiny (VERDICT r04 missing #2): the previous frame's pairings are thinned
-    until a handful of candidates reaches the F-matrix RANSAC -- fewer than 7 (no model), exactly 7 (cv::findFundamentalMat's direct
-    path: whole mask set, below the 8 inliers S4:205 asks for), 8..14 (many repeated draws per attempt: the tabulated attempts of
-    small n) and a few dozen.  Stage 4 alone on caller-supplied lists (P:131-162), tracked pairs against the oracle's stage 4."""
+    """cv::findFundamentalMat where the point count is tiny (VERDICT r04 missing #2): the previous frame's pairings are thinned
+    until a handful of candidates reaches it -- fewer than 7 (no model), exactly 7 (the direct path: whole mask set, below the 8 inliers
+    S4:205 asks for), 8..14 (oracle v6: the LMedS registrator -- 300 samples, medians, its own mask threshold; many repeated draws per
+    attempt: the tabulated attempts of small n) and a few dozen (the RANSAC).  Stage 4 alone on caller-supplied lists (P:131-162):
+    tracked pairs AND the eight stage counters against the oracle's stage 4."""
     g, cam, p = load_small(golden_dir)
     W, H = int(g["W"]), int(g["H"])
     rng = np.random.RandomState(23)
     pm_all, cm = g["matches1"], g["matches2"]
-    seen = set()
+    seen, lmeds_inliers = set(), []
     ctx = hip.Context(n_lanes=1, max_w=W, max_h=H, max_kps=1024, max_cand=1 << 15)
     ctx.set_params(p); ctx.set_camera(cam)
     zeros = np.zeros(H + 1, np.int64)
-    for keep in (6, 7, 8, 9, 10, 12, 14, 15, 16, 20, 24, 32, 48, 64):
+    for keep in (6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 24, 32, 48, 64):
         for rep in range(6):
             sel = np.sort(rng.choice(len(pm_all), min(keep, len(pm_all)), replace=False))
             pm = np.ascontiguousarray(pm_all[sel])
@@ -309,18 +310,25 @@ def test_few_candidates_reach_the_sampler_edge_cases(golden_dir):
                 ctx.put_features(0, 0, side, g["kps%d_2" % side], g["desc%d_2" % side], W, H)
             ctx.put_matches(0, 1, pm); ctx.put_matches(0, 0, cm)
             ctx.run_stages(hip.RUN_TRACK)
-            want = O().track(p, p.orb_max_distance, g["kps0_1"], g["desc0_1"], g["kps1_1"], g["desc1_1"], pm, zeros,
-                             g["kps0_2"], g["desc0_2"], g["kps1_2"], g["desc1_2"], cm, zeros, W, H)
+            want, want_ts = O().track(p, p.orb_max_distance, g["kps0_1"], g["desc0_1"], g["kps1_1"], g["desc1_1"], pm, zeros,
+                                      g["kps0_2"], g["desc0_2"], g["kps1_2"], g["desc1_2"], cm, zeros, W, H, stats=True)
             got = ctx.tracked(0)
             assert got.tobytes() == want.tobytes(), (keep, rep, len(got), len(want))
             ts = ctx.result(0).track_stats
+            # candidates, collision survivors, inliers left / right, samples visited left / right, both masks, tracked: the oracle's, all eight
+            assert [int(v) for v in ts[:8]] == [int(v) for v in want_ts], (keep, rep, list(ts[:8]), list(want_ts))
             seen.add(min(int(ts[1]), 40))                                # candidates that reached the RANSAC (collision survivors)
             if 8 <= ts[1]:
                 assert ts[4] > 0 and ts[5] > 0                           # samples were drawn and visited on both sides
+            if 8 <= ts[1] <= 14:
+                assert (ts[4], ts[5]) == (300, 300)                      # LMedS (oracle v6): its fixed budget, never shortened
+                lmeds_inliers.append((int(ts[1]), int(ts[2]), int(ts[3])))
             if ts[1] == 7:
                 assert (ts[2], ts[3], ts[4], ts[5]) == (7, 7, 0, 0)      # direct path: seven "inliers", no sample visited
     ctx.close()
     assert 7 in seen and any(8 <= n <= 14 for n in seen) and any(n < 7 for n in seen) and any(n >= 15 for n in seen), sorted(seen)
+    # below 14 points LMedS's median is one of the seven fitted residuals: the mask is the sample (seven, under S4:205's eight); at 14 it can pass
+    assert all(7 <= l <= 9 and 7 <= r <= 9 for n, l, r in lmeds_inliers if n <= 13) and len(lmeds_inliers) >= 6, lmeds_inliers
 
 
 def test_armed_post_event_is_disarmed_by_a_failing_call(golden_dir):

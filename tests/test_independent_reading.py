@@ -261,3 +261,73 @@ def test_ransac_samples_are_cv_rng_under_getsubset_rules():
         assert not collinear(p1, list(s))
     # fewer than 8 points: no sampling at all (exactly 7 take findFundamentalMat's direct path)
     assert len(O.ransac_samples(p1[:7], p2[:7], 3)) == 0
+
+
+def test_eight_to_fourteen_points_run_lmeds():
+    """Oracle v6: cv::findFundamentalMat(FM_RANSAC) runs the RANSAC only from 15 points on (`npoints >= 15`); 8...14 points go to the LMedS
+    registrator (S4:202, 237, 684, 696 pass whatever the tracker has left).  A literal Python reading of LMeDSPointSetRegistrator::run --
+    300 samples (RANSACUpdateNumIters(0.99, 0.45, 7, 1000)), the same generator and getSubset, per model the float errors
+    (float)max(d1^2 s1, d2^2 s2), their median = the element of rank n / 2, the first strictly smaller median wins,
+    sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median) >= 0.001, mask = err <= (float)sigma^2 -- against the oracle, bit for bit
+    (Python floats are IEEE doubles without contraction, as the oracle is compiled).  Samples and models come from the oracle's entry
+    points that the tests above pin independently (cv::RNG / getSubset reading; SVD + companion-matrix solver)."""
+    import math
+    assert int(round(math.log(0.01) / math.log(1.0 - 0.55 ** 7))) == 300
+
+    def err32(F, a, b):
+        F = [float(v) for v in F.reshape(9)]
+        x1, y1, x2, y2 = float(a[0]), float(a[1]), float(b[0]), float(b[1])
+        A = (F[0] * x1 + F[1] * y1) + F[2]; B = (F[3] * x1 + F[4] * y1) + F[5]; Cc = (F[6] * x1 + F[7] * y1) + F[8]
+        with np.errstate(all="ignore"):
+            s2 = np.float64(1.0) / np.float64(A * A + B * B); d2 = (x2 * A + y2 * B) + Cc
+            A = (F[0] * x2 + F[3] * y2) + F[6]; B = (F[1] * x2 + F[4] * y2) + F[7]; Cc = (F[2] * x2 + F[5] * y2) + F[8]
+            s1 = np.float64(1.0) / np.float64(A * A + B * B); d1 = (x1 * A + y1 * B) + Cc
+            e1, e2 = (d1 * d1) * s1, (d2 * d2) * s2
+            return np.float32(e2 if e1 < e2 else e1)                      # std::max(e1, e2)
+
+    def lmeds(p1, p2):
+        n = len(p1)
+        smp = O.ransac_samples(p1, p2, 300)
+        best, best_k, Fb = None, -1, None
+        for k, idx in enumerate(smp):
+            for F in O.seven_point(p1[idx], p2[idx]):
+                e = np.array([err32(F, p1[i], p2[i]) for i in range(n)], np.float32)
+                med = np.sort(e.view(np.int32))[n // 2:n // 2 + 1].view(np.float32)[0]      # nth_element over the bit patterns as ints
+                if np.isfinite(med) and (best is None or float(med) < best):
+                    best, best_k, Fb = float(med), k, F
+        if best is None:
+            return 0, np.zeros(n, bool), -1, len(smp)
+        sigma = max(2.5 * 1.4826 * (1.0 + 5.0 / (n - 7)) * math.sqrt(best), 0.001)
+        t = np.float32(sigma * sigma)
+        mask = np.array([err32(Fb, p1[i], p2[i]) <= t for i in range(n)])
+        return int(mask.sum()), mask, best_k, len(smp)
+
+    f, cx, cy = 700.0, 600.0, 180.0
+    seen_filter_on = 0
+    for n in range(8, 15):
+        for seed in range(3):
+            r = np.random.RandomState(100 * n + seed)
+            X = np.c_[r.uniform(-3, 3, n), r.uniform(-1, 1, n), r.uniform(4, 12, n)]
+            p1 = np.c_[f * X[:, 0] / X[:, 2] + cx, f * X[:, 1] / X[:, 2] + cy].astype(np.float32)
+            Y = X + np.array([0.1, 0.02, -0.4])
+            p2 = np.c_[f * Y[:, 0] / Y[:, 2] + cx, f * Y[:, 1] / Y[:, 2] + cy]
+            p2[:seed] += r.uniform(-30, 30, (seed, 2))                    # 0, 1 or 2 gross outliers
+            p2 = (p2 + r.normal(0, 0.2, p2.shape)).astype(np.float32)
+            want = lmeds(p1, p2)
+            cnt, mask, F, bh, nu = O.ransac_fundamental(p1, p2)
+            assert (cnt, bh, nu) == (want[0], want[2], want[3]) and (mask.astype(bool) == want[1]).all(), (n, seed, cnt, bh, nu, want)
+            assert nu == 300
+            # below 14 points the element of rank n / 2 <= 6 is one of the seven errors the minimal sample fits exactly: the median is
+            # rounding noise, sigma its floor of 0.001 px, and the mask the sample itself -- seven "inliers", under the eight S4:205 asks for
+            if n <= 13:
+                assert cnt == 7
+            seen_filter_on += cnt >= 8
+    assert seen_filter_on >= 1                                             # 14 points: the median is a real residual and the mask can pass S4:205
+    # 15 points: the RANSAC again (the budget shrinks with the first good model)
+    r = np.random.RandomState(5)
+    X = np.c_[r.uniform(-3, 3, 15), r.uniform(-1, 1, 15), r.uniform(4, 12, 15)]
+    p1 = np.c_[f * X[:, 0] / X[:, 2] + cx, f * X[:, 1] / X[:, 2] + cy].astype(np.float32)
+    Y = X + np.array([0.1, 0.02, -0.4])
+    p2 = np.c_[f * Y[:, 0] / Y[:, 2] + cx, f * Y[:, 1] / Y[:, 2] + cy].astype(np.float32)
+    cnt, mask, F, bh, nu = O.ransac_fundamental(p1, p2)
+    assert cnt == 15 and nu < 300
