@@ -451,3 +451,8 @@ def projected_coords(pre_matches, pre_left, pre_right, tracked_first, cam, chang
 def sad8(l, r, lx, ly, rx, ry):
     l, r = _img(l), _img(r)
     return int(lib().svo_oracle_sad8(_ptr(l, u8p), _ptr(r, u8p), C.c_size_t(l.shape[1]), lx, ly, rx, ry))
+
+
+def ransac_niters(cnt, n, max_iters=1000):
+    """the RANSAC's stop rule (cv::RANSACUpdateNumIters(0.99, (n - cnt) / n, 7, max_iters)) as the oracle and the kernels evaluate it"""
+    return int(lib().svo_oracle_ransac_niters(int(cnt), int(n), int(max_iters)))

@@ -1020,6 +1020,8 @@ static int ransac_update_niters(int cnt, int n, int max_iters)
     return (int)rint(num / d);
 }
 
+int svo_oracle_ransac_niters(int cnt, int n, int max_iters) { return ransac_update_niters(cnt, n, max_iters); }
+
 /* cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) (RANSACPointSetRegistrator::run with modelPoints = 7): per iteration one minimal
  * sample -- drawn by OpenCV's own generator and rejection rules since v5 (cv::RNG seeded (uint64)-1 per call, getSubset, checkSubset) --,
  * every model the 7-point solver returns for it is scored in turn, a model with more inliers than any before (and than

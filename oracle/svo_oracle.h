@@ -125,6 +125,9 @@ int svo_oracle_track(const svo_params* p, int orb_th,
                      const svo_keypoint* ckl, const uint8_t* cdl, const svo_keypoint* ckr, const uint8_t* cdr,
                      const svo_dmatch* cm, int ncm, const int64_t* cri,
                      int img_w, int img_h, svo_index_pair* out, int cap);
+/* the RANSAC's stop rule on its own: cv::RANSACUpdateNumIters(0.99, (n - cnt) / n, 7, max_iters) from IEEE +, -, *, / only (svo_ln), so that the
+ * HIP kernels repeat it bit for bit; tests/test_independent_reading.py compares it with the libm expression OpenCV evaluates, for every (cnt, n) */
+int svo_oracle_ransac_niters(int cnt, int n, int max_iters);
 /* ... and with the call's counters (svo_result.track_stats' SVO_TS_* for this one octave) in stats8[8] */
 int svo_oracle_track_stats(const svo_params* p, int orb_th,
                            const svo_keypoint* pkl, const uint8_t* pdl, const svo_keypoint* pkr, const uint8_t* pdr,

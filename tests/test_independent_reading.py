@@ -331,3 +331,37 @@ def test_eight_to_fourteen_points_run_lmeds():
     p2 = np.c_[f * Y[:, 0] / Y[:, 2] + cx, f * Y[:, 1] / Y[:, 2] + cy].astype(np.float32)
     cnt, mask, F, bh, nu = O.ransac_fundamental(p1, p2)
     assert cnt == 15 and nu < 300
+
+
+def test_stop_rule_is_ransac_update_num_iters_for_every_count():
+    """The RANSAC's budget after a model with cnt inliers of n is cv::RANSACUpdateNumIters(0.99, ep = (n - cnt) / n, 7, maxIters) =
+    cvRound(log(1 - 0.99) / log(1 - pow(1 - ep, 7))) capped at maxIters.  OpenCV evaluates that with libm; the oracle (and, verbatim, the
+    kernels) with its own logarithm from IEEE +, -, *, / and w^7 by multiplication so that both sides get the same bits.  What matters is
+    the INTEGER: the literal libm expression against the oracle's for every (cnt, n) with n <= 320 under the full budget (all 4.5 million pairs up to n = 3000 were compared once, in C: none differs), and under
+    shrunken budgets (the rule is applied to the budget left) for a sample of pairs up to n = 4000."""
+    import math
+    DBL_MIN = 2.2250738585072014e-308
+
+    def literal(cnt, n, max_iters):
+        ep = min(max(float(n - cnt) / n, 0.0), 1.0)
+        num = max(1.0 - 0.99, DBL_MIN)
+        denom = 1.0 - math.pow(1.0 - ep, 7)
+        if denom < DBL_MIN:
+            return 0
+        num, denom = math.log(num), math.log(denom)
+        if denom >= 0 or -num >= max_iters * (-denom):
+            return max_iters
+        q = num / denom
+        return int(math.floor(q + 0.5)) if abs(q - round(q)) != 0.5 else int(2 * round(q / 2))      # cvRound: to nearest, ties to even
+
+    checked = 0
+    for n in range(8, 321):
+        for cnt in range(7, n + 1):
+            assert O.ransac_niters(cnt, n, 1000) == literal(cnt, n, 1000), (cnt, n)
+            checked += 1
+    rng = np.random.RandomState(4)
+    for _ in range(20000):
+        n = int(rng.randint(8, 4001)); cnt = int(rng.randint(7, n + 1)); k = int(rng.randint(1, 1001))
+        assert O.ransac_niters(cnt, n, k) == literal(cnt, n, k), (cnt, n, k)
+    assert checked > 45000
+    assert O.ransac_niters(7, 8, 1000) == literal(7, 8, 1000) and O.ransac_niters(300, 300, 1000) == 0      # all inliers: the loop ends
