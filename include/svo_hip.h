@@ -207,6 +207,8 @@ int svo_set_this_frame_as_kf(svo_ctx* ctx, int lane);   /* H:675-683; SVO_ERR_ST
  * load caller-supplied features / pairings into a lane's current (which=0) or previous (which=1) frame. */
 int svo_put_features(svo_ctx* ctx, int lane, int which, int side, const svo_keypoint* kps, const uint8_t* desc, int n,
                      int img_w, int img_h);
+/* (svo_put_matches also builds the list's matches_lr_row_index (S3:425-445) from the LEFT keypoints put before it: the reference builds that
+ * index in stage 3 only, which this path skips (P:219-251), and its windowed tracker (S4:517-530) would read an index nobody built.) */
 int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n);
 int svo_put_tracked(svo_ctx* ctx, int lane, const svo_index_pair* t, int n);
 /* request_data.precomputed_matches_ID (H:218, P:233-244): the IDs of the octave-0 pairings put before; m_last_match_ID

@@ -1327,6 +1327,30 @@ extern "C" int svo_put_matches_oct(svo_ctx* ctx, int lane, int which, int octave
     if (n > 0) HIPCHECK(hipMemcpy(ctx->dc.matches + ((long long)vl * 2 + slot) * ctx->dc.max_kps, m, sizeof(svo_dmatch) * n, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->dc.n_matches + vl * 2 + slot, &n, sizeof(int), hipMemcpyHostToDevice));
     if (which == 0) HIPCHECK(hipMemcpy(ctx->dc.results[lane].stereo_matches + octave, &n, sizeof(int), hipMemcpyHostToDevice));   // P:274-276
+    // matches_lr_row_index (S3:425-445) of the list just put.  The reference builds it in stage 3 only, which the precomputed-data path
+    // (P:219-251) and the state loader skip: its windowed tracker (S4:517-530) then reads an index nobody built.  Here it is built from the
+    // left keypoints put BEFORE the pairings (the oracle's sequential rule, ri[H] = n as there), so that ifmDescWin works on caller data.
+    if (ctx->geom_ready && octave < ctx->dc.n_oct) {
+        int nl = 0;
+        const long long kbase = (((long long)vl * 2 + slot) * 2 + 0) * ctx->dc.max_kps;
+        HIPCHECK(hipMemcpy(&nl, ctx->dc.n_kps + (vl * 2 + slot) * 2 + 0, sizeof(int), hipMemcpyDeviceToHost));
+        nl = std::max(0, std::min(nl, ctx->dc.max_kps));
+        bool ok = true;
+        for (int i = 0; i < n && ok; i++) ok = m[i].queryIdx >= 0 && m[i].queryIdx < nl;
+        if (ok) {
+            std::vector<svo_keypoint> kl((size_t)nl);
+            if (nl > 0) HIPCHECK(hipMemcpy(kl.data(), ctx->dc.kps + kbase, sizeof(svo_keypoint) * nl, hipMemcpyDeviceToHost));
+            const int H = std::max(0, std::min(ctx->dc.oh[octave], ctx->dc.max_h));
+            std::vector<int32_t> ri((size_t)H + 1);
+            int idx = 0;
+            for (int y = 0; y < H; y++) {
+                ri[y] = idx;
+                while (idx < n && kl[m[idx].queryIdx].y <= (float)y) idx++;               // S3:441
+            }
+            ri[H] = n;
+            HIPCHECK(hipMemcpy(ctx->dc.mrow_index + (long long)(vl * 2 + slot) * (ctx->dc.max_h + 1), ri.data(), sizeof(int32_t) * (H + 1), hipMemcpyHostToDevice));
+        }
+    }
     return mark_present(ctx, lane, which);
 }
 extern "C" int svo_put_matches(svo_ctx* ctx, int lane, int which, const svo_dmatch* m, int n) { return svo_put_matches_oct(ctx, lane, which, 0, m, n); }

@@ -287,14 +287,27 @@ def test_precomputed_data_bypass(golden_dir):
     ctx.close()
 
 
-def test_few_candidates_reach_the_sampler_edge_cases(golden_dir):
+@pytest.mark.parametrize("ifm_method", [0, 1])
+def test_few_candidates_reach_the_sampler_edge_cases(golden_dir, ifm_method):
     """cv::findFundamentalMat where the point count is tiny (VERDICT r04 missing #2): the previous frame's pairings are thinned
     until a handful of candidates reaches it -- fewer than 7 (no model), exactly 7 (the direct path: whole mask set, below the 8 inliers
     S4:205 asks for), 8..14 (oracle v6: the LMedS registrator -- 300 samples, medians, its own mask threshold; many repeated draws per
     attempt: the tabulated attempts of small n) and a few dozen (the RANSAC).  Stage 4 alone on caller-supplied lists (P:131-162):
-    tracked pairs AND the eight stage counters against the oracle's stage 4."""
+    tracked pairs AND the eight stage counters against the oracle's stage 4.  Both trackers: brute force (ifmDescBF, S4:88-329) and the
+    windowed search over the current pairings' row index (ifmDescWin, S4:435-738; its F-matrix filter is S4:682-705)."""
     g, cam, p = load_small(golden_dir)
+    p.ifm_method = ifm_method; p.ifm_win_w = 20; p.ifm_win_h = 30
     W, H = int(g["W"]), int(g["H"])
+
+    def pairings_row_index(m, kl):                                        # matches_lr_row_index (S3:425-445) of a thinned list
+        ri, idx = np.zeros(H + 1, np.int64), 0
+        for y in range(H):
+            ri[y] = idx
+            while idx < len(m) and kl[m[idx]["queryIdx"]]["y"] <= np.float32(y):
+                idx += 1
+        ri[H] = len(m)
+        return ri
+    assert (pairings_row_index(g["matches2"], g["kps0_2"]) == g["mrow2"]).all()
     rng = np.random.RandomState(23)
     pm_all, cm = g["matches1"], g["matches2"]
     seen, lmeds_inliers = set(), []
@@ -310,8 +323,8 @@ def test_few_candidates_reach_the_sampler_edge_cases(golden_dir):
                 ctx.put_features(0, 0, side, g["kps%d_2" % side], g["desc%d_2" % side], W, H)
             ctx.put_matches(0, 1, pm); ctx.put_matches(0, 0, cm)
             ctx.run_stages(hip.RUN_TRACK)
-            want, want_ts = O().track(p, p.orb_max_distance, g["kps0_1"], g["desc0_1"], g["kps1_1"], g["desc1_1"], pm, zeros,
-                                      g["kps0_2"], g["desc0_2"], g["kps1_2"], g["desc1_2"], cm, zeros, W, H, stats=True)
+            want, want_ts = O().track(p, p.orb_max_distance, g["kps0_1"], g["desc0_1"], g["kps1_1"], g["desc1_1"], pm, pairings_row_index(pm, g["kps0_1"]) if ifm_method else zeros,
+                                      g["kps0_2"], g["desc0_2"], g["kps1_2"], g["desc1_2"], cm, np.ascontiguousarray(g["mrow2"], np.int64) if ifm_method else zeros, W, H, stats=True)
             got = ctx.tracked(0)
             assert got.tobytes() == want.tobytes(), (keep, rep, len(got), len(want))
             ts = ctx.result(0).track_stats
