@@ -369,6 +369,7 @@ static void orb_angle_desc(const uint8_t* img, int stride, int x, int y, float* 
     }
     float angle = atan2_deg((float)m01, (float)m10);
     *angle_out = angle;
+    if (!desc) return;                                   /* the orientation alone: reads the radius-15 disc only */
     int tmp[DESC_W + 6][DESC_W];
     uint8_t bl[DESC_W][DESC_W];
     for (int r = 0; r < DESC_W + 6; r++)
@@ -396,11 +397,13 @@ void svo_oracle_steered_brief(const uint8_t* blurred, int stride, int x, int y, 
 }
 
 /* orientation (degrees, [0, 360)) and steered BRIEF-256 of ONE position: the per-keypoint step of stage 2 on its own, for the
- * third-party cross-check (tests/test_oracle_thirdparty.py).  (x, y) must keep 21 pixels from every border. */
+ * third-party cross-check (tests/test_oracle_thirdparty.py).  (x, y) must keep 21 pixels from every border; with desc32 == NULL only
+ * the orientation is computed and 15 pixels are enough (the sanitizer build found the descriptor's window read for a corner 16 pixels
+ * from the border when the descriptor was computed and thrown away). */
 float svo_oracle_orb_angle(const uint8_t* img, int stride, int x, int y, uint8_t* desc32)
 {
-    float a = 0.f; uint8_t d[32];
-    orb_angle_desc(img, stride, x, y, &a, desc32 ? desc32 : d);
+    float a = 0.f;
+    orb_angle_desc(img, stride, x, y, &a, desc32);
     return a;
 }
 
