@@ -968,8 +968,10 @@ __device__ __forceinline__ void store_filler(const DevCtx& c, int vl, int side, 
 // sample below it is scored.
 // (The tightening uses K(c - 1): one inlier less moves num / d by far more than svo_ln's rounding error, so the
 // "K falls with the count" step holds for the computed values too, not only in exact arithmetic.)
-#define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1))
-#define RS_CHUNK_END(ch) ((ch) == 0 ? SVO_RANSAC_CHUNK0 : ((ch) == 1 ? SVO_RANSAC_CHUNK1 : SVO_RANSAC_HYP))
+// (the end of chunk 0 is a run-time value, c.rs_c0: SVO_RANSAC_CHUNK0 in the batched shapes, SVO_RANSAC_CHUNK1 -- chunk 1 empty and never
+// launched -- for a handful of lanes, where one more pair of launches costs more than the samples the early bound saves; `c` = the DevCtx in scope)
+#define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? c.rs_c0 : SVO_RANSAC_CHUNK1))
+#define RS_CHUNK_END(ch) ((ch) == 0 ? c.rs_c0 : ((ch) == 1 ? SVO_RANSAC_CHUNK1 : SVO_RANSAC_HYP))
 #define RS_SLOT_END(ch) (((RS_CHUNK_END(ch) + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG) * SVO_RANSAC_RSLOTS)      // end of the chunk's model slots (whole regions)
 static_assert(SVO_RANSAC_CHUNK0 % SVO_RANSAC_REG == 0 && SVO_RANSAC_CHUNK1 % SVO_RANSAC_REG == 0 && SVO_RANSAC_RSLOTS == 3 * SVO_RANSAC_REG && SVO_RANSAC_REG == 16,
               "chunks are whole regions; a region is one DPP row of samples");
@@ -1735,11 +1737,17 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         if (tid == 0) s_both = 0;
         __syncthreads();
         // samples the scan can still reach -> the slots of their regions (all generated and zeroed this frame: see rs_bound)
-        const int lim_k = n >= 8 ? min(min(max(c.rs_bound[vl * 2 + side], SVO_RANSAC_CHUNK0), SVO_RANSAC_HYP), c.rs_sched[vl * SVO_RS_ST + 2 + side]) : 0;
-        const int lim = lim_k > 0 ? ((lim_k - 1) / SVO_RANSAC_REG + 1) * SVO_RANSAC_RSLOTS : 0;
+        int lims[2];
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++) {
+            const int lk = n >= 8 ? min(min(max(c.rs_bound[vl * 2 + sd], c.rs_c0), SVO_RANSAC_HYP), c.rs_sched[vl * SVO_RS_ST + 2 + sd]) : 0;
+            lims[sd] = lk > 0 ? ((lk - 1) / SVO_RANSAC_REG + 1) * SVO_RANSAC_RSLOTS : 0;
+        }
+        const int lim = lims[side];
+        const int lim_both = max(lims[0], lims[1]);                          // block-uniform: the scan below stops where neither side has slots left (it used to walk all SVO_RANSAC_SLOTS)
         const int* gc = c.rs_cnt + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
         const int* gk = c.rs_k + ((long long)vl * 2 + side) * SVO_RANSAC_SLOTS;
-        for (int base = 0; base < SVO_RANSAC_SLOTS; base += 128) {          // uniform trip count: barriers inside
+        for (int base = 0; base < lim_both; base += 128) {                  // uniform trip count: barriers inside
             const int k = base + t;
             const int v = k < lim ? gc[k] : 0;
             // inclusive prefix max inside the wave, then across the side's two waves

@@ -380,6 +380,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.det_status, (size_t)L)); d.det_ahead = 0;
     d.bf_dist = nullptr;
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
+    d.rs_c0 = SVO_RANSAC_CHUNK0;                                   // (set per call where the RANSAC is launched)
     { const char* rp = getenv("SVO_REST_PRIO"); d.rest_prio = rp ? (atoi(rp) & 3) : 0; }
     HIPCHECK(configure_gauss_newton(MK));
     HIPCHECK(configure_match(MK));
@@ -1029,10 +1030,18 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         }
         // F-matrix RANSAC: the first SVO_RANSAC_CHUNK0 hypotheses of the fixed schedule, then two more chunks, each only
         // as far as the 0.99-confidence stop of the sequential algorithm can still reach given what has been counted so far
+        // A handful of lanes (one stream on its own): chunk 0 takes chunk 1's samples as well -- a hypothesis + count launch pair is ~20 us of
+        // latency there, more than evaluating 128 samples the early bound might have saved.  SVO_RS_C0 = 32 | 160 forces either form (A/B).
+        {
+            static const int forced = [] { const char* e = getenv("SVO_RS_C0"); const int v = e ? atoi(e) : 0; return (v == SVO_RANSAC_CHUNK0 || v == SVO_RANSAC_CHUNK1) ? v : 0; }();
+            d.rs_c0 = forced ? forced : (d.n_lanes * d.n_oct > 8 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1);
+        }
         { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, 0, st); }
         { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, 0, st); }
-        { Span s(ctx, KT_RANSAC_HYP1); launch_ransac_hyp(d, 1, st); }
-        { Span s(ctx, KT_RANSAC_CNT1); launch_ransac_count(d, 1, st); }
+        if (d.rs_c0 < SVO_RANSAC_CHUNK1) {
+            { Span s(ctx, KT_RANSAC_HYP1); launch_ransac_hyp(d, 1, st); }
+            { Span s(ctx, KT_RANSAC_CNT1); launch_ransac_count(d, 1, st); }
+        }
         { Span s(ctx, KT_RANSAC_HYP2); launch_ransac_hyp(d, 2, st); }
         { Span s(ctx, KT_RANSAC_CNT2); launch_ransac_count(d, 2, st); }
         { Span s(ctx, KT_TRK_FINAL); launch_track_finalize(d, p.bad_tracking_th, win, st); }

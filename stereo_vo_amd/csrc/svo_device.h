@@ -169,6 +169,7 @@ struct DevCtx {
     int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
     const unsigned short* rs_att;   // [n = 8 .. SVO_RS_SMALL_N - 1][SVO_RS_ATT_SMALL][8] then [n = SVO_RS_SMALL_N .. rs_att_nmax][SVO_RS_ATT][8]: the attempts of OpenCV's sampler for n = 8 .. rs_att_nmax points (host-built, k_ransac_schedule)
     int rs_att_nmax;
+    int rs_c0;                // end of chunk 0 of the sample schedule: SVO_RANSAC_CHUNK0, or SVO_RANSAC_CHUNK1 (chunk 1 empty, its two launches skipped) for a handful of lanes, where a launch costs more than the samples it saves (svo_api.hip)
     unsigned short* rs_smp;   // [n_lanes][2][SVO_RANSAC_PAD][8] the seven indices of every sample, as OpenCV's getSubset draws them
     int* rs_sched;            // [n_lanes][SVO_RS_ST] schedule state (k_match.hip, rs_schedule_block)
     int* rs_ticket;           // [n_lanes][2][SLOTS / 16] blocks of k_ransac_count_mfma16 that have added their share of a group's counts (0 between launches)
