@@ -777,8 +777,8 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
     int* st = c.rs_sched + vl * SVO_RS_ST;     // last accepted attempt (left) | attempts consumed | samples left | samples right | last accepted (right) | ended left | ended right
     if (n < 8 || n > c.rs_att_nmax) { if (phase == 0 && tid < SVO_RS_ST) st[tid] = 0; return; }
     const bool lmeds = rs_is_lmeds(n);                                     // its 300 samples are all drawn in phase 0 (nothing shortens that budget)
-    if (phase == 1 && (lmeds || max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= SVO_RANSAC_CHUNK1)) return;      // neither side's budget reaches chunk 2
-    const int target = lmeds ? SVO_LMEDS_ITERS : (phase ? SVO_RANSAC_HYP : SVO_RANSAC_CHUNK1);
+    if (phase == 1 && (lmeds || max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= c.rs_c1)) return;      // neither side's budget reaches chunk 2
+    const int target = lmeds ? SVO_LMEDS_ITERS : (phase ? SVO_RANSAC_HYP : c.rs_c1);
     int attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
     int last_ok[2] = { phase ? st[0] : -1, phase ? st[4] : -1 }, ended[2] = { phase ? st[5] : 0, phase ? st[6] : 0 };
     const float4* ptsL = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
@@ -968,11 +968,13 @@ __device__ __forceinline__ void store_filler(const DevCtx& c, int vl, int side, 
 // sample below it is scored.
 // (The tightening uses K(c - 1): one inlier less moves num / d by far more than svo_ln's rounding error, so the
 // "K falls with the count" step holds for the computed values too, not only in exact arithmetic.)
-// (the end of chunk 0 is a run-time value, c.rs_c0: SVO_RANSAC_CHUNK0 in the batched shapes, SVO_RANSAC_CHUNK1 -- chunk 1 empty and never
-// launched -- for a handful of lanes, where one more pair of launches costs more than the samples the early bound saves; `c` = the DevCtx in scope)
-#define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? c.rs_c0 : SVO_RANSAC_CHUNK1))
-#define RS_CHUNK_END(ch) ((ch) == 0 ? c.rs_c0 : ((ch) == 1 ? SVO_RANSAC_CHUNK1 : SVO_RANSAC_HYP))
+// (the chunk ends are run-time values: c.rs_c0 / c.rs_c1 = SVO_RANSAC_CHUNK0 / SVO_RANSAC_CHUNK1 in the batched shapes; for a handful of lanes both are
+// SVO_RANSAC_FEW -- chunk 1 empty and never launched, chunk 2 rarely reached -- because there a launch costs more than the samples the early bound
+// saves; `c` = the DevCtx in scope)
+#define RS_CHUNK_BEGIN(ch) ((ch) == 0 ? 0 : ((ch) == 1 ? c.rs_c0 : c.rs_c1))
+#define RS_CHUNK_END(ch) ((ch) == 0 ? c.rs_c0 : ((ch) == 1 ? c.rs_c1 : SVO_RANSAC_HYP))
 #define RS_SLOT_END(ch) (((RS_CHUNK_END(ch) + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG) * SVO_RANSAC_RSLOTS)      // end of the chunk's model slots (whole regions)
+static_assert(SVO_RANSAC_FEW % SVO_RANSAC_REG == 0 && SVO_RANSAC_FEW >= SVO_RANSAC_CHUNK1 && SVO_RANSAC_FEW <= SVO_RANSAC_HYP, "the few-lanes chunk end is a whole number of regions");
 static_assert(SVO_RANSAC_CHUNK0 % SVO_RANSAC_REG == 0 && SVO_RANSAC_CHUNK1 % SVO_RANSAC_REG == 0 && SVO_RANSAC_RSLOTS == 3 * SVO_RANSAC_REG && SVO_RANSAC_REG == 16,
               "chunks are whole regions; a region is one DPP row of samples");
 

@@ -380,7 +380,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.det_status, (size_t)L)); d.det_ahead = 0;
     d.bf_dist = nullptr;
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
-    d.rs_c0 = SVO_RANSAC_CHUNK0;                                   // (set per call where the RANSAC is launched)
+    d.rs_c0 = SVO_RANSAC_CHUNK0; d.rs_c1 = SVO_RANSAC_CHUNK1;      // (set per call where the RANSAC is launched)
     { const char* rp = getenv("SVO_REST_PRIO"); d.rest_prio = rp ? (atoi(rp) & 3) : 0; }
     HIPCHECK(configure_gauss_newton(MK));
     HIPCHECK(configure_match(MK));
@@ -1022,6 +1022,14 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
     if (flags & SVO_RUN_TRACK) {
         Section sec("_stg4"), sec2("stg4.track");                                    // S4:76, 457
         const int win = p.ifm_method == SVO_IFM_DESC_WIN;
+        // The chunks of the RANSAC's sample schedule (set before the tracker kernels: phase 0 of the schedule rides in them).  A handful of
+        // lanes (one stream on its own): chunk 0 takes chunk 1's samples and more -- a hypothesis + count launch pair is ~20 us of latency
+        // there, more than evaluating the samples an early bound might have saved.  SVO_RS_C0 = 32 | 160 | 320 forces a form (A/B, tests).
+        {
+            static const int forced = [] { const char* e = getenv("SVO_RS_C0"); const int v = e ? atoi(e) : 0; return (v == SVO_RANSAC_CHUNK0 || v == SVO_RANSAC_CHUNK1 || v == SVO_RANSAC_FEW) ? v : 0; }();
+            d.rs_c0 = forced ? forced : (d.n_lanes * d.n_oct > 8 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_FEW);
+            d.rs_c1 = d.rs_c0 > SVO_RANSAC_CHUNK1 ? d.rs_c0 : SVO_RANSAC_CHUNK1;
+        }
         if (!win) {
             { Span s(ctx, KT_HAM_TRK); launch_hamming(d, 1, nsplit, st); }
             { Span s(ctx, KT_TRK_FILTER); launch_track_filter(d, st); }
@@ -1030,15 +1038,9 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         }
         // F-matrix RANSAC: the first SVO_RANSAC_CHUNK0 hypotheses of the fixed schedule, then two more chunks, each only
         // as far as the 0.99-confidence stop of the sequential algorithm can still reach given what has been counted so far
-        // A handful of lanes (one stream on its own): chunk 0 takes chunk 1's samples as well -- a hypothesis + count launch pair is ~20 us of
-        // latency there, more than evaluating 128 samples the early bound might have saved.  SVO_RS_C0 = 32 | 160 forces either form (A/B).
-        {
-            static const int forced = [] { const char* e = getenv("SVO_RS_C0"); const int v = e ? atoi(e) : 0; return (v == SVO_RANSAC_CHUNK0 || v == SVO_RANSAC_CHUNK1) ? v : 0; }();
-            d.rs_c0 = forced ? forced : (d.n_lanes * d.n_oct > 8 ? SVO_RANSAC_CHUNK0 : SVO_RANSAC_CHUNK1);
-        }
         { Span s(ctx, KT_RANSAC_HYP); launch_ransac_hyp(d, 0, st); }
         { Span s(ctx, KT_RANSAC_CNT); launch_ransac_count(d, 0, st); }
-        if (d.rs_c0 < SVO_RANSAC_CHUNK1) {
+        if (d.rs_c0 < d.rs_c1) {
             { Span s(ctx, KT_RANSAC_HYP1); launch_ransac_hyp(d, 1, st); }
             { Span s(ctx, KT_RANSAC_CNT1); launch_ransac_count(d, 1, st); }
         }

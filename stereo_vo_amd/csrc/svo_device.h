@@ -21,6 +21,7 @@
 #define SVO_RANSAC_RSLOTS 48        // model slots per region: a sample has one or three models (the real roots of the 7-point cubic)
 #define SVO_RANSAC_SLOTS (SVO_RANSAC_PAD / SVO_RANSAC_REG * SVO_RANSAC_RSLOTS)     // stride of the per-(lane, side) model arrays
 #define SVO_RANSAC_CHUNK0 32        // samples [0, CHUNK0) are evaluated unconditionally, [CHUNK0, CHUNK1) and [CHUNK1, HYP) only as far as
+#define SVO_RANSAC_FEW 320          // both chunk ends for a handful of lanes (DevCtx.rs_c0 / rs_c1): one hypothesis + count pair covers what the stop rule usually visits
 #ifndef SVO_RANSAC_CHUNK1
 #define SVO_RANSAC_CHUNK1 160       // the 0.99-confidence stop of the sequential algorithm can still reach (rs_bound)
 #endif
@@ -169,6 +170,7 @@ struct DevCtx {
     int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
     const unsigned short* rs_att;   // [n = 8 .. SVO_RS_SMALL_N - 1][SVO_RS_ATT_SMALL][8] then [n = SVO_RS_SMALL_N .. rs_att_nmax][SVO_RS_ATT][8]: the attempts of OpenCV's sampler for n = 8 .. rs_att_nmax points (host-built, k_ransac_schedule)
     int rs_att_nmax;
+    int rs_c1;                // end of chunk 1 (= what phase 0 of the schedule draws): SVO_RANSAC_CHUNK1, or more together with rs_c0 for a handful of lanes
     int rs_c0;                // end of chunk 0 of the sample schedule: SVO_RANSAC_CHUNK0, or SVO_RANSAC_CHUNK1 (chunk 1 empty, its two launches skipped) for a handful of lanes, where a launch costs more than the samples it saves (svo_api.hip)
     unsigned short* rs_smp;   // [n_lanes][2][SVO_RANSAC_PAD][8] the seven indices of every sample, as OpenCV's getSubset draws them
     int* rs_sched;            // [n_lanes][SVO_RS_ST] schedule state (k_match.hip, rs_schedule_block)
