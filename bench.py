@@ -40,7 +40,82 @@ from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 import ctypes as C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_PROFILE = {"config2": "r05_pmc.json"}    # ONE committed counter summary per workload (tools/pmc_passes.py writes it); a line never quotes an older file silently
+PMC_PROFILE = {"config2": "r05_pmc.json"}
+# svo_debug_timeline's kinds (stereo_vo_amd/csrc/svo_device.h, TL_*), and which of them the detect stream carries in the default split
+TIMELINE_KINDS = ["begin_frame", "resize", "fast", "select", "harris", "select_sort", "nms_rowsort", "describe", "hamming", "match_lr_filter", "track_filter",
+                  "ransac_schedule", "ransac_hyp", "ransac_count", "track_finalize", "match_ids", "gauss_newton", "other"]
+TIMELINE_DETECT = {"resize", "fast", "select", "harris", "select_sort"}
+
+
+def timeline_report(ctxs, post_on_rest, csv_path=""):
+    """SVO_TIMELINE=1: what was really in flight during the steps since the tables were last cleared.  Every launch
+    left the hull [first wave in, last wave out] of its blocks on the device-wide 100 MHz wall clock; a launch belongs to queue 0 (the
+    detect stream) or to queue 1 + k (context k's stage 3-5 stream).  Returns: the share of the busy time with 1, 2, 3 ... queues
+    executing; which kernel is alone on the chip, by time; per queue the time it executes, and the gaps between the end of one of its
+    kernels and the start of the next; per kernel the mean hull (to set beside rocprofv3's durations)."""
+    NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+    recs = []
+    for k, c in enumerate(ctxs):
+        _, a = c.timeline()
+        for s_, kind, aux in zip(*np.nonzero(a[:, :, :, 0] != NONE)):
+            t0, t1 = int(a[s_, kind, aux, 0]), int(a[s_, kind, aux, 1])
+            if t1 <= t0 or kind >= len(TIMELINE_KINDS):
+                continue
+            name = TIMELINE_KINDS[kind]
+            on_detect = (name in TIMELINE_DETECT or (name == "begin_frame" and aux == 0) or (not post_on_rest and name in ("nms_rowsort", "describe")))
+            recs.append((0 if on_detect else 1 + k, k, name, int(aux), int(s_), t0, t1))
+    if not recs:
+        return {"error": "no records: was the library built with the timeline scope and the context created under SVO_TIMELINE=1?"}
+    if csv_path:
+        with open(csv_path, "w") as f:
+            f.write("queue,context,kernel,aux,frame_mod16,t0_us,t1_us\n")
+            base = min(r[5] for r in recs)
+            for r in sorted(recs, key=lambda r: r[5]):
+                f.write("%d,%d,%s,%d,%d,%.2f,%.2f\n" % (r[0], r[1], r[2], r[3], r[4], (r[5] - base) / 100.0, (r[6] - base) / 100.0))
+    nq = 1 + len(ctxs)
+    ev = []
+    for i, r in enumerate(recs):
+        ev.append((r[5], 1, i)); ev.append((r[6], -1, i))
+    ev.sort(key=lambda e: (e[0], e[1]))
+    active = [set() for _ in range(nq)]
+    hist = [0.0] * (nq + 1)
+    alone, pair = {}, {}
+    last = ev[0][0]
+    for t, d, i in ev:
+        busy = [q for q in range(nq) if active[q]]
+        dt_ = t - last
+        hist[len(busy)] += dt_
+        if dt_ > 0 and len(busy) == 1:
+            for j in active[busy[0]]:
+                alone[recs[j][2]] = alone.get(recs[j][2], 0.0) + dt_
+        if dt_ > 0 and len(busy) == 2:
+            key = " + ".join(sorted({recs[j][2] for q in busy for j in active[q]}))
+            pair[key] = pair.get(key, 0.0) + dt_
+        last = t
+        (active[recs[i][0]].add if d > 0 else active[recs[i][0]].discard)(i)
+    span = ev[-1][0] - ev[0][0]
+    busy_t = sum(hist[1:])
+    per_queue = {}
+    for q in range(nq):
+        rs = sorted((r for r in recs if r[0] == q), key=lambda r: r[5])
+        run = sum(r[6] - r[5] for r in rs)
+        gaps = [b[5] - a_[6] for a_, b in zip(rs, rs[1:]) if b[5] > a_[6]]
+        per_queue["detect" if q == 0 else "rest%d" % (q - 1)] = {"launches": len(rs), "executing_frac_of_span": round(run / span, 4),
+                                                                "gap_us_mean": round(float(np.mean(gaps)) / 100.0, 2) if gaps else None,
+                                                                "gap_us_median": round(float(np.median(gaps)) / 100.0, 2) if gaps else None,
+                                                                "gaps_over_20us": int(sum(1 for g in gaps if g > 2000))}
+    hull = {}
+    for r in recs:
+        key = r[2] if r[2] not in ("resize", "ransac_hyp", "ransac_count", "hamming", "select", "fast", "begin_frame") else "%s[%d]" % (r[2], r[3])
+        hull.setdefault(key, []).append((r[6] - r[5]) / 100.0)
+    top = lambda d, n: {k: round(v / busy_t, 4) for k, v in sorted(d.items(), key=lambda kv: -kv[1])[:n]}
+    return {"launches": len(recs), "span_ms": round(span / 1e5, 3), "idle_frac": round(hist[0] / span, 4),
+            "queues_executing_frac_of_busy": {str(k): round(hist[k] / busy_t, 4) for k in range(1, nq + 1)},
+            "mean_queues_executing": round(sum(k * hist[k] for k in range(1, nq + 1)) / busy_t, 3),
+            "alone_on_chip_by_kernel_frac_of_busy": top(alone, 8), "two_in_flight_pairs_frac_of_busy": top(pair, 8),
+            "per_queue": per_queue, "hull_us_mean": {k: round(float(np.mean(v)), 1) for k, v in sorted(hull.items())},
+            "note": "in-kernel wall-clock stamps (s_memrealtime, 10 ns) of an UNPROFILED run; hull = first sampled wave in .. last sampled wave out of a launch (grids above 1024 blocks: every 32nd block and the last 32); queue 0 = the detect stream, 1 + k = context k's stage 3-5 stream"}
+    # ONE committed counter summary per workload (tools/pmc_passes.py writes it); a line never quotes an older file silently
 
 
 def lane_seeds(rank, world_size, lanes):
@@ -147,6 +222,8 @@ def main():
     ap.add_argument("--scene", default="street", choices=["street", "planes", "relief"], help="synthetic scene type (stereo_vo_amd/synth.py): street (default, round 4) = ground + far wall + a facade every 4.5 m along a world as long as the trajectory; planes = wall + ground + facades (rounds 1-3: a ~1 m world, needs --frames 6); relief = planes plus 28 billboards at 4..22 m")
     ap.add_argument("--relief-lanes", type=int, default=16, help="N=1, config2: streams of the extra leg on the OTHER scene type (reported as `other_scene`: pass-through counters and pose error against ground truth beside the timed scene's); 0 = skip")
     ap.add_argument("--other-workloads", type=int, default=1, help="1: after everything else, short timed legs of the other single-GPU configurations (BASELINE.json configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB) as sub-processes, reported as `other_workloads`; N=1, config2 only")
+    ap.add_argument("--timeline", type=int, default=0, help="N: create the contexts under SVO_TIMELINE=1 and, after the timed region, run N (<= 14) more steps whose launches are reported as `timeline` (what was in flight, from wall-clock stamps inside the kernels); the stamps cost a little, so a line with --timeline is not the headline")
+    ap.add_argument("--timeline-csv", default="", help="with --timeline: also write every launch hull of those steps to this CSV")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="BASELINE.json configs[1] (default, the metric's configuration), configs[2] KITTI shape, configs[4] 2048x1536 FAST+ORB 3 octaves")
     args = ap.parse_args()
@@ -186,7 +263,7 @@ def main():
     T = max(1, min(args.trajectories, B))
     total_steps = args.warmup + args.steps
     long_steps = args.long_steps if (world == 1 and args.long_steps > args.steps) else 0
-    plan_steps = max(total_steps, args.warmup + long_steps)           # frames / pointer tables cover the longer of the two legs
+    plan_steps = max(total_steps + min(max(args.timeline, 0), 14), args.warmup + long_steps)           # frames / pointer tables cover the longer of the legs
     F = args.frames if args.frames > 0 else frames_needed(B, T, plan_steps)
     focal = 718.856 if kitti else 800.0 * W / 1280.0
     baseline = 0.537 if kitti else 0.12
@@ -217,6 +294,8 @@ def main():
         from stereo_vo_amd.abi import DM_FAST_ORB
         p.detect_method = DM_FAST_ORB; p.nOctaves = n_octaves; p.use_robust_kernel = 1; p.kernel_param = 3.0
     NC = max(1, args.contexts)
+    if args.timeline > 0:
+        os.environ["SVO_TIMELINE"] = "1"
     batch = StreamBatch(p, cam, W, H, B, NC, device=local_rank, schedule=args.schedule, post_on_rest=("own" if args.post_on_rest == 2 else ("select" if args.post_on_rest == 3 else bool(args.post_on_rest))),
                         det_priority=args.det_priority, kernel_times=True, max_octaves=n_octaves, det_streams=args.det_streams, rest_streams=args.rest_streams, max_kps=args.max_kps, detect_ahead=bool(args.detect_ahead))
     Bc, pipelined, ctxs = batch.Bc, batch.pipelined, batch.ctxs
@@ -310,6 +389,21 @@ def main():
     kt = batch.pooled_kernel_times()
     redo_pairs = sum(c_.redo_count(reset=True) for c_ in ctxs)
     results = batch.results()
+    timeline = None
+    if args.timeline > 0 and world == 1:
+        nt_ = min(args.timeline, 14, plan_steps - total_steps)
+        if nt_ <= 2:
+            timeline = {"error": "--timeline needs at least 3 steps"}
+        else:
+            for i in range(2):                                   # back to the steady state after the getters above
+                step(total_steps + i)
+            for c_ in ctxs:
+                c_.timeline(reset=True)
+            for i in range(2, nt_):
+                step(total_steps + i)
+            torch.cuda.synchronize()
+            timeline = timeline_report(ctxs, bool(args.post_on_rest), args.timeline_csv)
+            timeline["steps"] = nt_ - 2
     n_valid = sum(1 for r in results if r.valid)
     mean_kps = float(np.mean([r.detected_left[0] for r in results]))
     mean_match = float(np.mean([r.stereo_matches[0] for r in results]))
@@ -486,6 +580,8 @@ def main():
             "track_funnel_note": "svo_result.track_stats of the last timed step, mean over this rank's streams: previous-frame pairings that pass the descriptor threshold on both sides -> survive the joint collision filter (S4:145-160) -> are inliers of the left / right F-matrix RANSAC (1.0 px, S4:202, 237; hyp_* = hypotheses visited before the 0.99-confidence stop) -> of both -> pass the L/R consistency check (S4:282) = tracked",
             "other_scene": other_scene,
             "dist": dist_info,
+            "env": {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "SVO_TIMELINE", "SVO_DEBUG_MODE", "SVO_REST_PRIO", "HIP_FORCE_DEV_KERNARG") if os.environ.get(k) is not None},
+            "timeline": timeline,
             "kernels_ms_per_context_step": {k: round(v["ms_per_step"], 4) for k, v in per_kernel_warm.items()},
             "legs_s": legs_s,
             "kernels_ms_note": "all kernels: HIP-event spans of the %d warm-up steps; roofline kernel: spans of the timed region" % args.warmup,

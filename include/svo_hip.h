@@ -284,6 +284,11 @@ int svo_profiler_sections_enabled(void);
 /* How often the speculative FAST threshold of k_fast failed since svo_create (or the last reset = 1 call): (image, level) pairs
  * that a frame had to run again at the caller's threshold (k_fast_redo + the second k_select pass).  Waits for the enqueued work. */
 int svo_debug_get_redo_count(svo_ctx* ctx, uint32_t* pairs, int reset);
+/* What was really in flight (SVO_TIMELINE=1 in the environment of svo_create; a measuring knob, off in production): every kernel stamps
+ * the hull [first wave in, last wave out] of its launch on the device-wide 100 MHz wall clock.  out receives 4096 records of two uint64
+ * (t0, t1; t0 = ~0: no such launch) for the last 16 frames: index = (frame % 16) * 256 + kind * 8 + aux, kinds in bench.py's
+ * TIMELINE_KINDS order.  Returns the context's frame counter (0: the knob is off); reset = 1 clears the table.  Waits for the work. */
+int svo_debug_timeline(svo_ctx* ctx, uint64_t* out, int cap_records, int reset);
 
 /* per-kernel HIP-event timing (svo_config.kernel_times = 1): names[i] points to static storage.
  * total_ms[i] / calls[i] accumulate since the last svo_kernel_times_reset. Returns number of kernels. */

@@ -82,6 +82,7 @@ struct ImgPtrs { const uint8_t* p[2 * SVO_MAX_LANES]; };
 
 __global__ void k_begin_frame(DevCtx c, ImgPtrs ptrs, unsigned flags)
 {
+    SVO_TL_SCOPE(c, TL_BEGIN, (flags & SVO_RUN_DETECT) ? 0 : 1);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     // The brute-force result words are atomicMin keys and start from all ones: filled here, ahead of the matchers of the same call
     // (it was a launch of its own; a kernel and not hipMemsetAsync because a captured byte memset of more than 64 KB came back
@@ -197,6 +198,7 @@ typedef unsigned short rz_u16x2 __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div_img, FastDiv div_ntx)
 {
+    SVO_TL_SCOPE(c, TL_RESIZE, level);
     __shared__ __attribute__((aligned(16))) uint32_t win[(RZ_SH + 1) * (RZ_SP / 4)];
     __shared__ uint32_t xw[RZ_W], xr[RZ_W], yw[RZ_H], yr[RZ_H];
     const int tid = threadIdx.x;
@@ -619,6 +621,7 @@ __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uin
 
 __global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_fast(DevCtx c)
 {
+    SVO_TL_SCOPE(c, TL_FAST, 0);
     __shared__ FastSmem sm;
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The global work list
     // (image-major, then the image's tiles of all levels) is cut into chunks of FT_CHUNK consecutive tiles and chunk k
@@ -657,6 +660,7 @@ __global__ void __launch_bounds__(FT_NT) __attribute__((amdgpu_waves_per_eu(8, 8
 // the concatenated tile lists of the listed pairs.
 __global__ void __launch_bounds__(FT_NT) k_fast_redo(DevCtx c)
 {
+    SVO_TL_SCOPE(c, TL_FAST, 1);
     __shared__ FastSmem sm;
     const unsigned n = *c.redo_n;
     if (n == 0) return;
@@ -753,6 +757,7 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
 template <int SEL_MAX>
 __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
 {
+    SVO_TL_SCOPE(c, TL_SELECT, redo_pass);
     constexpr int SEL_TIE_MAX = 2 * SEL_MAX;
     __shared__ unsigned long long keys[SEL_MAX];
     __shared__ uint32_t sel[SEL_MAX];
@@ -896,6 +901,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
 // Harris response of every selected corner, one thread each, all (image, level) lists in one launch
 __global__ void __launch_bounds__(256) k_harris(DevCtx c)
 {
+    SVO_TL_SCOPE(c, TL_HARRIS, 0);
     const int img = blockIdx.x, level = blockIdx.z, i = blockIdx.y * 256 + threadIdx.x;
     const LevelGeom& g = c.lv[level];
     const int K = g.quota > 0 ? c.sel_n[img * SVO_MAX_LEVELS + level] : 0;
@@ -919,6 +925,7 @@ __global__ void __launch_bounds__(256) k_harris(DevCtx c)
 template <int SEL_MAX>
 __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
 {
+    SVO_TL_SCOPE(c, TL_SELECT_SORT, 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];          // keys[SEL_MAX] | tmp[SEL_MAX] (72 KB of LDS in all at SEL_MAX = 4096)
     unsigned long long* keys = (unsigned long long*)ss_smem, *tmp = keys + SEL_MAX;
     __shared__ int cnt[SS_NB], off[SS_NB], scan_s[32];
@@ -1075,6 +1082,7 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t acc)
 template <int NW, bool TL>
 __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, int pre, int kpw)
 {
+    SVO_TL_SCOPE(c, TL_DESCRIBE, pre);
     __shared__ __attribute__((aligned(16))) uint32_t raw32[NW][2][DP_LROWS * DP_PW + 4];      // + 16 bytes: the last row's fourth k-group
     __shared__ __attribute__((aligned(16))) float4 s_pat[SVO_BRIEF_NPAIRS];                   // the test pairs and the disc weights: one copy per block
     __shared__ uint32_t s_disc_m[SVO_DISC_E], s_disc_x[SVO_DISC_E];
@@ -1290,6 +1298,7 @@ __global__ void __launch_bounds__(NW * 64) k_describe(DevCtx c, FastDiv gx_div, 
 template <int NI>
 __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int min_distance, int NS_MAX, int pre, uint8_t* big)
 {
+    SVO_TL_SCOPE(c, TL_NMS, pre);
     SVO_LATENCY_CHAIN(c);
     // dynamic LDS only (G17): keys[NS_MAX] u64 | hkey[2*NS_MAX] | hval[2*NS_MAX] | cellxy[NS_MAX] | acc_idx[NS_MAX] u16 | state[NS_MAX] u8 | scan[32] | flag
     // Above 4096 keys that is more LDS than a CU has: the first four arrays (24 of the 27 bytes per key) then live in a global
@@ -1618,6 +1627,7 @@ __global__ void __launch_bounds__(1024) k_nms_rowsort(DevCtx c, int do_nms, int 
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_half(DevCtx c, int level)
 {
+    SVO_TL_SCOPE(c, TL_RESIZE, level);
     const int img = blockIdx.z;
     const LevelGeom& d = c.lv[level];
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
@@ -1643,6 +1653,7 @@ __global__ void __launch_bounds__(256) k_half(DevCtx c, int level)
 #define FO_ACCEPTED 0xFFFFFFFEu
 __global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance, int do_nms, int NS_MAX, int ACC_MAX)
 {
+    SVO_TL_SCOPE(c, TL_NMS, 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NS_HASH = 4 * NS_MAX;
     unsigned long long* keys = (unsigned long long*)smem;                  // NS_MAX
@@ -1811,6 +1822,7 @@ __global__ void __launch_bounds__(1024) k_fastorb_nms(DevCtx c, int min_distance
 // radius[cand_total].
 __global__ void __launch_bounds__(1024) k_fastorb_anms(DevCtx c, uint32_t* by_score_all, uint32_t* radius_all, uint32_t* xy_all, int KMAX)
 {
+    SVO_TL_SCOPE(c, TL_NMS, 3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = (unsigned long long*)smem;                  // KMAX (power of two >= cap)
     __shared__ unsigned hist[256], start[256], prefix_len[256];

@@ -436,6 +436,7 @@ __device__ void eval_rgn(const GNParams& P, const svo_stereo_camera& cam, int T,
 template <int GN_NT>
 __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, uint8_t* scratch)
 {
+    SVO_TL_SCOPE(c, TL_GN, 0);
     SVO_LATENCY_CHAIN(c);
     // dynamic LDS: keys[LC] u64 | hkey[2 LC] | hval[2 LC] | cellxy[LC] | state[LC] u8 | mask[LC] u8 | scan[40] | GnShared, LC = min(pmax, GN_LCAP).
     // A lane that tracks more than LC pairs (`big`) keeps the same arrays, sized pmax, in its region of c.gn_scratch.

@@ -62,6 +62,7 @@ __device__ __forceinline__ void copy_words(const void* src, void* dst, size_t nb
 // grid (n_vl, 8): block (vl, part) copies a share of the lane-octave's lists
 __global__ void __launch_bounds__(256) k_export_frame(DevCtx c, uint8_t* blob)
 {
+    SVO_TL_SCOPE(c, TL_OTHER, 0);
     const int vl = blockIdx.x, lane = vl / c.oct_cap, oct = vl % c.oct_cap;
     const HandoverOffsets o = handover_offsets(c.max_kps, c.max_h);
     uint8_t* rec = blob + (size_t)vl * o.total;
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(256) k_export_frame(DevCtx c, uint8_t* blob)
 // replaces whatever sits in its previous-frame slot and the inherited estimator members; its current frame stays.
 __global__ void __launch_bounds__(256) k_import_frame(DevCtx c, const uint8_t* blob)
 {
+    SVO_TL_SCOPE(c, TL_OTHER, 1);
     const int vl = blockIdx.x, lane = vl / c.oct_cap;
     const HandoverOffsets o = handover_offsets(c.max_kps, c.max_h);
     const uint8_t* rec = blob + (size_t)vl * o.total;

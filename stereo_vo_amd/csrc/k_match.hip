@@ -195,6 +195,7 @@ typedef float hm_v16f __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nsplit)
 {
+    SVO_TL_SCOPE(c, TL_HAMMING, mode);
     SVO_LATENCY_CHAIN(c);
     __shared__ __attribute__((aligned(16))) hm_v4i tileA[2][8 * 32];           // [buffer][(2 s + kb) * 32 + (row ^ (2 s + kb))]: MFMA s, k-block kb
     __shared__ uint32_t lut[256];                                             // byte of TRAIN bits -> 8 nibbles (bit 1 -> +1 = 0x2, bit 0 -> -1 = 0xA); a query byte goes in complemented
@@ -320,6 +321,7 @@ __global__ void __launch_bounds__(256) k_hamming_f4(DevCtx c, int mode, int nspl
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_one, double max_y_diff)
 {
+    SVO_TL_SCOPE(c, TL_LR_FILTER, 0);
     SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* right_best = (unsigned*)smem;              // max_kps
@@ -390,6 +392,7 @@ __global__ void __launch_bounds__(1024) k_match_lr_filter(DevCtx c, int one_to_o
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_match_lr_rbr(DevCtx c, int one_to_one, double max_y_diff, double minimum_response, int max_distance)
 {
+    SVO_TL_SCOPE(c, TL_LR_FILTER, 1);
     SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* right_best = (unsigned*)smem;              // max_kps: per right feature, min over its claimants
@@ -482,6 +485,7 @@ __device__ __forceinline__ int rs_first_bound(int n) { return rs_is_lmeds(n) ? S
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_H)
 {
+    SVO_TL_SCOPE(c, TL_TRK_FILTER, 1);
     SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* cur_best = (unsigned*)smem;                // max_kps: (dist << 16 | pi) min over claimants
@@ -566,6 +570,7 @@ __global__ void __launch_bounds__(256) k_track_win(DevCtx c, int WIN_W, int WIN_
 template <int TF_ITEMS>
 __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
 {
+    SVO_TL_SCOPE(c, TL_TRK_FILTER, 0);
     SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* firstL = (unsigned*)smem;                    // max_kps: smallest undecided k claiming left train index i
@@ -845,6 +850,7 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
 }
 __global__ void __launch_bounds__(256) k_ransac_schedule(DevCtx c, int phase)
 {
+    SVO_TL_SCOPE(c, TL_RS_SCHED, phase);
     SVO_LATENCY_CHAIN(c);
     __shared__ int scan[40];
     const int vl = blockIdx.x;
@@ -1067,6 +1073,7 @@ __device__ __forceinline__ void finish_region(const DevCtx& c, int vl, int side,
 
 __global__ void __launch_bounds__(256) k_ransac_hyp(DevCtx c, int chunk)
 {
+    SVO_TL_SCOPE(c, TL_RS_HYP, chunk);
     SVO_LATENCY_CHAIN(c);
     __shared__ int nm_s[16];
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15;
@@ -1221,6 +1228,7 @@ __device__ __forceinline__ void gj_step(double (&A)[7][9], int (&perm)[9])
 // sixteen threads is one region: its models are packed by a row scan of the model counts.
 __global__ void __launch_bounds__(64) k_ransac_hyp_thread(DevCtx c, int chunk)
 {
+    SVO_TL_SCOPE(c, TL_RS_HYP, chunk);
     SVO_LATENCY_CHAIN(c);
     const int h = RS_CHUNK_BEGIN(chunk) + blockIdx.x * 64 + threadIdx.x, side = blockIdx.y, vl = blockIdx.z;
     if (vl % c.oct_cap >= c.n_oct) return;
@@ -1335,6 +1343,7 @@ __device__ __forceinline__ int fm_error_key(float e) { return e != e ? (int)0xFF
 typedef double rc_d4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 {
+    SVO_TL_SCOPE(c, TL_RS_COUNT, chunk);
     SVO_LATENCY_CHAIN(c);
     __shared__ int cnt_s[16];
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * 16, tid = threadIdx.x;      // first SLOT of the block
@@ -1437,6 +1446,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 #define RC16_NSPLIT0 1         // blocks the pairs of a lane are split over in chunk 0 (chunks 1, 2: one; launch_ransac_count)
 __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk, int nsplit)
 {
+    SVO_TL_SCOPE(c, TL_RS_COUNT, chunk);
     SVO_LATENCY_CHAIN(c);
     __shared__ double ops[(RC16_SUPER / 16) * 256];            // per tile of 16 pairs: B1 | B2 | phi[0..3] | phi[4..7], each [k][j]
     const int sblk = blockIdx.x / nsplit, split = blockIdx.x % nsplit;                                          // the splits of a group are neighbours in dispatch order
@@ -1599,6 +1609,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma16(DevCtx c, int chunk
 template <int RC_HB>
 __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 {
+    SVO_TL_SCOPE(c, TL_RS_COUNT, chunk);
     SVO_LATENCY_CHAIN(c);
     __shared__ int cnt_s[RC_HB];
     const int side = blockIdx.y, vl = blockIdx.z, h0 = 3 * RS_CHUNK_BEGIN(chunk) + blockIdx.x * RC_HB, tid = threadIdx.x;      // first SLOT of the block
@@ -1651,6 +1662,7 @@ __global__ void __launch_bounds__(256) k_ransac_count(DevCtx c, int chunk)
 // (one launch less per frame); gate_th < 0: k_track_gate follows, after the blocks of all octaves
 __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, int gate_th)
 {
+    SVO_TL_SCOPE(c, TL_TRK_FINAL, 0);
     SVO_LATENCY_CHAIN(c);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* in_l = smem;                         // max_kps
@@ -1867,6 +1879,7 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
 // first-frame rule (P:348-352).  One thread per lane.
 __global__ void k_track_gate(DevCtx c, int bad_tracking_th)
 {
+    SVO_TL_SCOPE(c, TL_TRK_FINAL, 1);
     const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane_id >= c.n_lanes) return;
     LaneState& ls = c.lane[lane_id];
@@ -1887,6 +1900,7 @@ __global__ void k_track_gate(DevCtx c, int bad_tracking_th)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 {
+    SVO_TL_SCOPE(c, TL_MATCH_IDS, 0);
     SVO_LATENCY_CHAIN(c);
     __shared__ int scan[32];
     __shared__ int s_next, s_kf;

@@ -382,6 +382,9 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
     d.rs_c0 = SVO_RANSAC_CHUNK0; d.rs_c1 = SVO_RANSAC_CHUNK1;      // (set per call where the RANSAC is launched)
     { const char* rp = getenv("SVO_REST_PRIO"); d.rest_prio = rp ? (atoi(rp) & 3) : 0; }
+    // SVO_TIMELINE=1: every kernel stamps the hull of its launch on the device's wall clock (svo_device.h, TlScope; svo_debug_timeline)
+    d.tl = nullptr; d.tl_step = 0;
+    { const char* tl = getenv("SVO_TIMELINE"); if (tl && tl[0] == '1') { HIPCHECK(dev_alloc(ctx, &d.tl, (size_t)SVO_TL_STEPS * 256 * SVO_TL_SUB)); HIPCHECK(svo_debug_timeline(ctx, nullptr, 0, 1) < 0 ? hipErrorUnknown : hipSuccess); } }
     HIPCHECK(configure_gauss_newton(MK));
     HIPCHECK(configure_match(MK));
     return SVO_OK;
@@ -936,6 +939,7 @@ extern "C" int svo_process(svo_ctx* ctx, const svo_frame* frames, uint32_t flags
         }
     } else if (!ctx->geom_ready && (flags & (SVO_RUN_MATCH | SVO_RUN_OPTIMIZE))) return SVO_ERR_STATE;
     d.fast_th = ctx->fast_th; d.orb_th = ctx->orb_th;
+    if (flags & SVO_RUN_DETECT) d.tl_step++;                 // (a frame of the detect-ahead schedule is a detect call and then a post call)
     // svo_use_graphs: the launches below are captured once into a hipGraph per (flags, ring slot, thresholds) and replayed:
     // ~30 kernel launches of a frame become one graph launch (what bounds ONE stream is launch latency, not the kernels)
     // every lazily allocated buffer a frame may need exists BEFORE a capture begins: hipMalloc / hipMemset are refused on a
@@ -1778,6 +1782,34 @@ extern "C" int svo_debug_get_redo_count(svo_ctx* ctx, uint32_t* pairs, int reset
     HIPCHECK(hipMemcpy(pairs, ctx->dc.redo_n + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (reset) HIPCHECK(hipMemset(ctx->dc.redo_n + 1, 0, sizeof(uint32_t)));
     return SVO_OK;
+}
+
+// SVO_TIMELINE=1: the launch hulls of the last SVO_TL_STEPS frames, 4096 records of (t0, t1) in 10 ns ticks of the device-wide wall clock
+// (t0 = ~0: no such launch); record index = (frame % 16) * 256 + kind * 8 + aux (svo_device.h).  Each is the min / max over the launch's
+// stamping waves.  Returns the frame counter; reset = 1 clears the table.  0 when the context was created without SVO_TIMELINE=1.
+// Waits for the enqueued work.
+extern "C" int svo_debug_timeline(svo_ctx* ctx, uint64_t* out, int cap_records, int reset)
+{
+    if (ctx) use_device(ctx);
+    if (!ctx) return SVO_ERR_ARG;
+    if (!ctx->dc.tl) return 0;
+    const int n = SVO_TL_STEPS * 256;
+    int rc = svo_wait(ctx); if (rc) return rc;
+    std::vector<TlRec> all((size_t)n * SVO_TL_SUB);
+    if (out) {
+        if (cap_records < n) return SVO_ERR_ARG;
+        HIPCHECK(hipMemcpy(all.data(), ctx->dc.tl, all.size() * sizeof(TlRec), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) {
+            uint64_t t0 = ~0ull, t1 = 0;
+            for (int j = 0; j < SVO_TL_SUB; j++) { const TlRec& r = all[(size_t)i * SVO_TL_SUB + j]; if (r.t0 != ~0ull) { if (r.t0 < t0) t0 = r.t0; if (r.t1 > t1) t1 = r.t1; } }
+            out[2 * i] = t0; out[2 * i + 1] = t1;
+        }
+    }
+    if (reset) {
+        for (auto& r : all) { r.t0 = ~0ull; r.t1 = 0; }
+        HIPCHECK(hipMemcpy(ctx->dc.tl, all.data(), all.size() * sizeof(TlRec), hipMemcpyHostToDevice));
+    }
+    return ctx->dc.tl_step;
 }
 
 extern "C" int svo_debug_get_status_word(svo_ctx* ctx, int lane, uint32_t* w)

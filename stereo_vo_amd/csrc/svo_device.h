@@ -190,7 +190,19 @@ struct DevCtx {
     uint32_t* det_status;     // [n_lanes] capacity bits raised by a detect call that runs ahead (SVO_FLAG_DETECT_AHEAD): folded into status / the record by its post call
     int det_ahead;            // 1 while launching the kernels of such a call: k_fast / k_select raise their bits in det_status
     int rest_prio;            // SVO_REST_PRIO (0..3, default in svo_create): wave priority the per-lane latency chains of stages 3-5 run at (SVO_LATENCY_CHAIN)
+    // SVO_TIMELINE=1 in the environment of svo_create (nullptr otherwise): what was really in flight, measured inside the kernels
+    // (svo_debug_timeline).  A launch = (tl_step % SVO_TL_STEPS) * 256 + kind * 8 + aux owns SVO_TL_SUB records, one per stamping wave
+    // (TlScope below): (time in, time out) on the device-wide 100 MHz wall clock.
+    struct TlRec* tl;
+    int tl_step;              // frame counter of the context (host side: advanced by every call that runs the detector)
+    int tl_pad;
 };
+
+struct TlRec { unsigned long long t0, t1; };
+#define SVO_TL_STEPS 16
+#define SVO_TL_SUB 128
+enum { TL_BEGIN = 0, TL_RESIZE, TL_FAST, TL_SELECT, TL_HARRIS, TL_SELECT_SORT, TL_NMS, TL_DESCRIBE, TL_HAMMING, TL_LR_FILTER, TL_TRK_FILTER,
+       TL_RS_SCHED, TL_RS_HYP, TL_RS_COUNT, TL_TRK_FINAL, TL_MATCH_IDS, TL_GN, TL_OTHER, TL_KINDS };     // < 32
 
 // The per-lane kernels of stages 3-5 are a few waves per lane walking dependent chains; in the batched schedule they share their
 // SIMDs with the detector's tiles, which fill every issue slot they are given.  A raised wave priority lets the chain's next
@@ -198,6 +210,41 @@ struct DevCtx {
 // issue rarely).  The value comes from DevCtx so that an A/B needs no rebuild; s_setprio takes an immediate, hence the switch.
 #ifdef __HIPCC__
 #define SVO_LATENCY_CHAIN(c) do { if ((c).rest_prio == 3) __builtin_amdgcn_s_setprio(3); else if ((c).rest_prio == 2) __builtin_amdgcn_s_setprio(2); else if ((c).rest_prio == 1) __builtin_amdgcn_s_setprio(1); } while (0)
+#endif
+
+#ifdef __HIPCC__
+// One line at the top of a kernel: SVO_TL_SCOPE(c, kind, aux).  Off (c.tl == nullptr): one scalar compare.  On: a few waves of the launch
+// each leave (time in, time out) in a record of their own -- plain 16-byte stores, one per stamping wave, on every way out of the kernel
+// (the destructor runs at each return; a wave that leaves in several pieces overwrites its record with the latest time).  Stamping waves:
+// wave 0 of every (gridDim.x / 32)-th block and of the last block (sub-records 0..63), and in grids of at most 64 blocks also the last wave
+// of every block (64 + blockIdx.x).  The host takes min / max over a launch's sub-records.  (A first version did atomicMin / atomicMax on
+// ONE record per launch from every wave: device-scope atomics to one address complete at the memory side at ~90 ns each, and a kernel
+// is not complete before they are -- k_harris took 790 us instead of 60, the whole step 7.7 ms instead of 2.8.)
+struct TlScope {
+    TlRec* r; unsigned long long t0;
+    __device__ __forceinline__ TlScope(const DevCtx& c, int kind, int aux) : r(nullptr), t0(0)
+    {
+        if (c.tl) {
+            const unsigned g = gridDim.x, stride = g > 32u ? g / 32u : 1u, wave = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+            int sub = -1;
+            if (wave == 0u && blockIdx.x + 1u == g) sub = 63;
+            else if (wave == 0u && blockIdx.x % stride == 0u) sub = (int)min(blockIdx.x / stride, 62u);
+            else if (g <= 64u && wave + 1u == nw) sub = 64 + (int)blockIdx.x;
+            if (sub >= 0) {
+                r = c.tl + (((((size_t)(c.tl_step & (SVO_TL_STEPS - 1)) << 8) | (size_t)((kind & 31) << 3) | (size_t)(aux & 7)) << 7) | (size_t)sub);
+                t0 = wall_clock64();
+            }
+        }
+    }
+    __device__ __forceinline__ ~TlScope()
+    {
+        if (r) {
+            const unsigned long long act = __ballot(1);
+            if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) *(ulonglong2*)r = make_ulonglong2(t0, (unsigned long long)wall_clock64());
+        }
+    }
+};
+#define SVO_TL_SCOPE(c, kind, aux) TlScope _tl_scope((c), (kind), (aux))
 #endif
 
 // where a detect-phase kernel raises a capacity bit of its lane

@@ -25,7 +25,7 @@ EXPORTS = [
     "svo_get_keypoints", "svo_get_matches", "svo_get_tracked", "svo_get_residuals", "svo_get_outliers",
     "svo_get_keypoints_oct", "svo_get_matches_oct", "svo_get_tracked_oct", "svo_get_row_index", "svo_get_matches_row_index", "svo_get_match_ids", "svo_reset_ids", "svo_set_this_frame_as_kf",
     "svo_put_features", "svo_put_matches", "svo_put_tracked", "svo_put_match_ids", "svo_save_state", "svo_load_state", "svo_change_in_pose", "svo_projected_coords", "svo_hamming_match",
-    "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word", "svo_debug_get_redo_count", "svo_profiler_sections_enabled",
+    "svo_debug_get_level", "svo_debug_get_raw_keypoints", "svo_debug_get_status_word", "svo_debug_get_redo_count", "svo_debug_timeline", "svo_profiler_sections_enabled",
     "svo_kernel_times", "svo_kernel_times_reset", "svo_kernel_times_select", "svo_abi_sizes",
     "svo_get_values", "svo_put_features_oct", "svo_put_matches_oct", "svo_put_match_ids_oct",
     "svo_handover_bytes", "svo_export_frame", "svo_import_frame",
@@ -357,6 +357,12 @@ class Context:
         v = C.c_uint32(0)
         self._ck(self.L.svo_debug_get_redo_count(self.h, C.byref(v), int(bool(reset))), "svo_debug_get_redo_count")
         return int(v.value)
+
+    def timeline(self, reset=False):
+        """SVO_TIMELINE=1: (frame counter, array [16 frames][32 kinds][8 aux][2] of wall-clock ticks (10 ns), t0 = 2**64 - 1 where nothing ran)"""
+        a = np.zeros((16, 32, 8, 2), np.uint64)
+        n = self._ck(self.L.svo_debug_timeline(self.h, _vp(a), 16 * 256, int(bool(reset))), "svo_debug_timeline")
+        return n, a
 
     def status_word(self, lane=0):
         w = C.c_uint32(0)
