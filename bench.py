@@ -384,6 +384,7 @@ def main():
     t_enqueue = time.perf_counter() - t0          # the host's share: every launch of the timed steps is enqueued (not: executed) by now
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    dt_own = dt                                   # this rank's own clock around the K steps; `value` uses the MAX over ranks
     dt = reduce_max(dt, dev, world)
 
     kt = batch.pooled_kernel_times()
@@ -409,7 +410,7 @@ def main():
     mean_match = float(np.mean([r.stereo_matches[0] for r in results]))
     mean_track = float(np.mean([r.tracked_feats_from_last_frame for r in results]))
     ts_mean = {k: round(float(np.mean([r.track_stats[i] for r in results])), 1) for i, k in enumerate(TS_NAMES)}
-    dist_info = dist_audit(allrec, batch.rec, world, rank, local_rank, dev)
+    dist_info = dist_audit(allrec, batch.rec, world, rank, local_rank, dev, own_ms_per_step=1e3 * dt_own / args.steps, own_enqueue_ms_per_step=1e3 * t_enqueue / args.steps)
     assert allrec is not None and allrec.shape[0] == world * B
     if args.dump_records:      # tests/test_gpu_parity.py: every rank's own records and what the all-gather handed it
         np.savez(args.dump_records + ".rank%d.npz" % rank, local=batch.rec.cpu().numpy(), gathered=allrec.cpu().numpy(), rank=rank, world=world,
@@ -616,10 +617,12 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def dist_audit(allrec, local_rec, world, rank, local_rank, dev):
+def dist_audit(allrec, local_rec, world, rank, local_rank, dev, own_ms_per_step=None, own_enqueue_ms_per_step=None):
     """What lets the first real N > 1 run be audited from its JSON line: the backend, how many distinct
-    (host, device) pairs the ranks sit on, the RCCL version, and whether every rank's gathered record table is rank 0's --
-    with rank r's own records at slot r.  None at N = 1."""
+    (host, device) pairs the ranks sit on, the RCCL version, whether every rank's gathered record table is rank 0's --
+    with rank r's own records at slot r -- and every rank's OWN clock around the timed steps beside the MAX-reduced one the line's
+    `value` uses (a slow rank, a missing rank or a host that cannot feed eight ranks' launches shows here without a re-run).
+    None at N = 1."""
     if world == 1:
         return None
     import hashlib, socket
@@ -629,7 +632,8 @@ def dist_audit(allrec, local_rec, world, rank, local_rank, dev):
     per = table.shape[0] // world
     me = {"rank": rank, "host": socket.gethostname(), "device": int(local_rank), "device_name": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu",
           "table": hashlib.blake2b(table.tobytes(), digest_size=16).hexdigest(),
-          "own_slot_ok": table[rank * per:(rank + 1) * per].tobytes() == own}
+          "own_slot_ok": table[rank * per:(rank + 1) * per].tobytes() == own,
+          "ms_per_step": own_ms_per_step, "enqueue_ms_per_step": own_enqueue_ms_per_step}
     everyone = [None] * world
     dist.all_gather_object(everyone, me)
     try:
@@ -640,6 +644,11 @@ def dist_audit(allrec, local_rec, world, rank, local_rank, dev):
             "hosts": sorted({e["host"] for e in everyone}), "rccl_version": ver,
             "gathered_tables_equal": all(e["table"] == everyone[0]["table"] for e in everyone),
             "own_records_at_own_slot": all(e["own_slot_ok"] for e in everyone),
+            "rank_ms_per_step": {"min": round(min(e["ms_per_step"] for e in everyone), 4), "max": round(max(e["ms_per_step"] for e in everyone), 4),
+                                 "by_rank": [round(e["ms_per_step"], 4) for e in sorted(everyone, key=lambda e: e["rank"])]} if own_ms_per_step is not None else None,
+            "rank_host_enqueue_ms_per_step": {"min": round(min(e["enqueue_ms_per_step"] for e in everyone), 4), "max": round(max(e["enqueue_ms_per_step"] for e in everyone), 4)} if own_enqueue_ms_per_step is not None else None,
+            "devices": sorted({"%s:%d %s" % (e["host"], e["device"], e["device_name"]) for e in everyone}),
+            "host_cores": os.cpu_count(),
             "note": "ranks_seen = distinct (hostname, device) pairs over the ranks (== world_size on a real multi-GPU run; 1 when a test puts every rank on one GPU)"}
 
 

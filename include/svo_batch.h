@@ -60,7 +60,9 @@ void svo_batch_config_defaults(svo_batch_config* c);
 /* C / C++ hosts call svo_batch_create(): the macro below passes the caller's own sizeof(svo_batch_config) along, and a host built
  * against another version of this header gets SVO_ERR_ARG (+ the two sizes in svo_batch_last_error) instead of a config whose
  * trailing fields are read from whatever follows the shorter struct.  Bindings that cannot use the macro (ctypes) call the plain
- * symbol after checking svo_batch_abi_sizes. */
+ * symbol after checking svo_batch_abi_sizes.
+ * ON FAILURE *out MAY BE A HANDLE (rc != SVO_OK and *out != NULL): it exists so that svo_batch_last_error(*out) can say what went
+ * wrong -- the caller owns it and must svo_batch_destroy() it.  *out == NULL on failure means nothing was allocated. */
 int  svo_batch_create_sized(const svo_batch_config* cfg, size_t cfg_bytes, svo_batch** out);
 int  svo_batch_create(const svo_batch_config* cfg, svo_batch** out);
 #ifndef SVO_BATCH_NO_SIZED_CREATE
@@ -90,7 +92,8 @@ int  svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t flags);
 int  svo_batch_wait_on_stream(svo_batch* b, void* stream);
 /* the NEXT step's result copies -- and nothing ahead of them in that step -- wait for this hipEvent_t (e.g. the all-gather that
  * still reads the records buffer).  Several calls before one step add up (the step waits for every one of them); the list is
- * emptied by that step whether it succeeds or not.  The events are only referenced: each must stay alive, and must not be
+ * emptied by that step once it has enqueued anything, whether it then succeeds or not (a call refused for its ARGUMENTS, before
+ * anything was enqueued, keeps the list: the caller may correct the argument and retry).  The events are only referenced: each must stay alive, and must not be
  * re-recorded, until that svo_batch_step has returned. */
 int  svo_batch_hold_for_event(svo_batch* b, void* event);
 int  svo_batch_synchronize(svo_batch* b);

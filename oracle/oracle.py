@@ -270,6 +270,14 @@ def resize(img, dw, dh):
     return out
 
 
+def resize_table(src, dst):
+    """cv::resize's INTER_LINEAR tables of one axis (oracle v7): (first tap index, weight pair a0 | a1 << 16) per destination position"""
+    idx = np.zeros(dst, np.int32); w01 = np.zeros(dst, np.int32)
+    i32p = C.POINTER(C.c_int32)
+    lib().svo_oracle_resize_table(int(src), int(dst), _ptr(idx, i32p), _ptr(w01, i32p))
+    return idx, w01
+
+
 def half_smooth(img):
     img = _img(img)
     h, w = img.shape

@@ -155,19 +155,33 @@ int svo_oracle_pyramid_sizes(int w, int h, int nlevels, int* lw, int* lh, float*
     return nlevels;
 }
 
-/* [frozen] integer bilinear sampling table: source coordinate (d+0.5)*src/dst-0.5 in exact rational
- * arithmetic, fraction quantised to 11 bits (the 2048 scale of 8-bit bilinear resizers). */
-static void resize_table(int src, int dst, int* idx, int* frac)
+/* [frozen, oracle v7] cv::resize(..., INTER_LINEAR) on 8-bit images as OpenCV 2.4 / 3.x compute it (modules/imgproc/src/resize.cpp;
+ * cv::ORB builds every pyramid level from the one before with it: S2:482-493 -> ORB_Impl::detectAndCompute).  Written from memory of that
+ * source -- none of OpenCV is in this image:
+ *   coefficients   scale = 1. / ((double)dst / src);  fx = (float)((d + 0.5) * scale - 0.5);  sx = cvFloor(fx);  fx -= sx;
+ *                  sx < 0 -> (0, fx = 0);  sx >= src - 1 -> (src - 1, fx = 0);
+ *                  the two taps' weights are rounded SEPARATELY to shorts: saturate_cast<short>((1.f - fx) * 2048), (fx * 2048)
+ *                  (cvRound = round half to even; they add up to 2048 except where a float rounding of 1.f - fx crosses a tie)
+ *   horizontal     HResizeLinear<uchar, int, short, 2048>:  D[x] = S[sx] * a0 + S[sx + 1] * a1          (int, 19 bits)
+ *   vertical       the uchar specialisation of VResizeLinear (the SIMD body and its scalar tail are the same expression):
+ *                      dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+ *                  i.e. the row sums lose their 4 low bits, each product is cut to quarter grey levels BEFORE the two are added, and
+ *                  only then comes a rounding -- not the single (v + 2^21) >> 22 the generic FixedPtCast would give.  Oracle versions
+ *                  up to 6 used that single rounding with exact-rational weights: one grey level away on ~10 % of the pixels
+ *                  (VERDICT r05 "missing" #3). */
+static long cv_round_f(float v) { return lrintf(v); }       /* cvRound: SSE cvtss2si / lrint, round half to even (default FP environment) */
+void svo_oracle_resize_table(int src, int dst, int* idx, int* w01)
 {
+    const double inv_scale = (double)dst / src, scale = 1.0 / inv_scale;
     for (int d = 0; d < dst; d++) {
-        int64_t num = (int64_t)(2 * d + 1) * src - dst;
-        int64_t den = 2 * (int64_t)dst;
-        int64_t q = num >= 0 ? num / den : -((-num + den - 1) / den);
-        int64_t r = num - q * den;
-        int f = (int)((r * 2048 + den / 2) / den);
-        if (q < 0) { q = 0; f = 0; }
-        if (q >= src - 1) { q = src - 1; f = 0; }
-        idx[d] = (int)q; frac[d] = f;
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)floor((double)fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= src - 1) { fx = 0.f; sx = src - 1; }
+        long a0 = cv_round_f((1.f - fx) * 2048.f), a1 = cv_round_f(fx * 2048.f);
+        if (a0 > 32767) a0 = 32767; if (a1 > 32767) a1 = 32767;            /* saturate_cast<short> (never reached: both are in [0, 2048]) */
+        idx[d] = sx; w01[d] = (int)a0 | ((int)a1 << 16);
     }
 }
 
@@ -175,16 +189,16 @@ void svo_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t*
 {
     int* xi = (int*)xmalloc(sizeof(int) * (size_t)dw), *xf = (int*)xmalloc(sizeof(int) * (size_t)dw);
     int* yi = (int*)xmalloc(sizeof(int) * (size_t)dh), *yf = (int*)xmalloc(sizeof(int) * (size_t)dh);
-    resize_table(sw, dw, xi, xf);
-    resize_table(sh, dh, yi, yf);
+    svo_oracle_resize_table(sw, dw, xi, xf);
+    svo_oracle_resize_table(sh, dh, yi, yf);
     for (int y = 0; y < dh; y++) {
-        int y0 = yi[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1, ay = yf[y];
+        int y0 = yi[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1, b0 = yf[y] & 0xFFFF, b1 = yf[y] >> 16;
         const uint8_t* r0 = src + (size_t)y0 * sstride, *r1 = src + (size_t)y1 * sstride;
         for (int x = 0; x < dw; x++) {
-            int x0 = xi[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, ax = xf[x];
-            int v = r0[x0] * (2048 - ax) * (2048 - ay) + r0[x1] * ax * (2048 - ay)
-                  + r1[x0] * (2048 - ax) * ay + r1[x1] * ax * ay;
-            dst[(size_t)y * dw + x] = (uint8_t)((v + (1 << 21)) >> 22);
+            int x0 = xi[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, a0 = xf[x] & 0xFFFF, a1 = xf[x] >> 16;
+            const int S0 = r0[x0] * a0 + r0[x1] * a1, S1 = r1[x0] * a0 + r1[x1] * a1;
+            const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+            dst[(size_t)y * dw + x] = (uint8_t)(v > 255 ? 255 : v);            /* uchar(...) of a value that cannot exceed 255 when a0 + a1 = b0 + b1 = 2048; clamped for the one-off weights */
         }
     }
     free(xi); free(xf); free(yi); free(yf);
@@ -800,14 +814,16 @@ static uint32_t cv_rng_next(cv_rng* r) { r->state = (uint64_t)(uint32_t)r->state
 void svo_oracle_cv_rng_raw(uint32_t* out, int count) { cv_rng r; r.state = 0xFFFFFFFFFFFFFFFFULL; for (int i = 0; i < count; i++) out[i] = cv_rng_next(&r); }
 
 /* haveCollinearPoints (modules/calib3d/src/precomp.hpp), as FMEstimatorCallback::checkSubset calls it with count = 7 for either image:
- * is the LAST selected point on a line through two earlier ones (or do two of the three coincide)?  Float coordinates widened to double. */
+ * is the LAST selected point on a line through two earlier ones (or do two of the three coincide)?  The points are Point2f: the
+ * differences are taken IN FLOAT and only then widened (`double dx1 = ptr[j].x - ptr[i].x;`) -- [oracle v7; versions 5-6 widened each
+ * coordinate first, which can flip a decision at the FLT_EPSILON-relative threshold for sub-pixel coordinates, ADVICE r05]. */
 static int have_collinear(const float* pts, const int* idx, int count)
 {
     const int i = count - 1;
     for (int j = 0; j < i; j++) {
-        const double dx1 = (double)pts[2 * idx[j]] - (double)pts[2 * idx[i]], dy1 = (double)pts[2 * idx[j] + 1] - (double)pts[2 * idx[i] + 1];
+        const double dx1 = (double)(pts[2 * idx[j]] - pts[2 * idx[i]]), dy1 = (double)(pts[2 * idx[j] + 1] - pts[2 * idx[i] + 1]);
         for (int k = 0; k < j; k++) {
-            const double dx2 = (double)pts[2 * idx[k]] - (double)pts[2 * idx[i]], dy2 = (double)pts[2 * idx[k] + 1] - (double)pts[2 * idx[i] + 1];
+            const double dx2 = (double)(pts[2 * idx[k]] - pts[2 * idx[i]]), dy2 = (double)(pts[2 * idx[k] + 1] - pts[2 * idx[i] + 1]);
             if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return 1;    /* FLT_EPSILON */
         }
     }
@@ -851,8 +867,9 @@ int svo_oracle_ransac_samples(const float* p1, const float* p2, int n, int count
  * bit: Hartley-normalised coordinates (conditioning only; the solutions map back exactly), Gauss-Jordan with full pivoting for the
  * null space, and for the cubic Newton's iteration from a guaranteed upper bound of its largest-magnitude root (convex side:
  * monotone, quadratic), deflation, and two polishing steps on the other two roots.  +, -, *, /, sqrt only, one IEEE operation per
- * operator.  Returns the number of models (1 or 3), written to Fm[3][9] in the order: root of largest magnitude (of the depressed
- * cubic), then (-t1 + sqrt D) / 2, (-t1 - sqrt D) / 2.  A degenerate sample yields NaN entries: no inliers, on both sides alike. */
+ * operator.  Returns the number of models (1 or 3; 1..3 when the cubic's leading coefficient is exactly zero, see below), written to
+ * Fm[3][9] in the order: root of largest magnitude (of the depressed cubic), then (-t1 + sqrt D) / 2, (-t1 - sqrt D) / 2.  A sample
+ * whose linear system is rank-deficient yields NaN entries: no inliers, on both sides alike. */
 static double cbrt_rough(double x)          /* x >= 0: within ~4 % of the cube root (exponent / 3 on the bit pattern: integer arithmetic) */
 {
     union { double d; uint64_t u; } v; v.d = x;
@@ -904,6 +921,42 @@ static int seven_point(const float* p1, const float* p2, const int* s, double* F
     const double a0 = (f2[0] * h00 - f2[1] * h01) + f2[2] * h02;
     const double a2 = ((f2[0] * g00 - f2[1] * g01) + f2[2] * g02) + ((g[0] * m00 - g[1] * m01) + g[2] * m02);
     const double a1 = ((g[0] * h00 - g[1] * h01) + g[2] * h02) + ((f2[0] * m00 - f2[1] * m01) + f2[2] * m02);
+    const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
+    if (a3 == 0.0) {
+        /* [oracle v7] The cubic has lost its leading term: cv::solveCubic's `a0 == 0` branch (run7Point hands it det(lambda f1' + f2);
+         * it tests for EXACT zero) solves what is left as a quadratic or a linear equation.  det g = 0 also means that g itself --
+         * lambda -> infinity in this parametrisation -- is a singular matrix of the null space; in another basis of the same null
+         * space (OpenCV's comes from an SVD) that solution sits at a finite lambda, so it belongs to the model set and comes FIRST
+         * here, followed by the finite roots in solveCubic's order.  Up to version 6 this case divided by zero (NaN models, no
+         * inliers).  Measure-zero on real data; reachable with integer coordinates. */
+        double lam[2]; int nq = 0;
+        if (a2 == 0.0) { if (a1 != 0.0) { lam[0] = -a0 / a1; nq = 1; } }
+        else {
+            double d = a1 * a1 - (4.0 * a2) * a0;
+            if (d >= 0.0) {
+                const int two = d > 0.0;
+                d = sqrt(d);
+                const double q1 = (-a1 + d) * 0.5, q2 = (a1 + d) * -0.5;
+                if (fabs(q1) > fabs(q2)) { lam[0] = q1 / a2; lam[1] = a0 / q1; } else { lam[0] = q2 / a2; lam[1] = a0 / q2; }
+                nq = two ? 2 : 1;
+            }
+        }
+        for (int k = 0; k <= nq; k++) {
+            double f[9];
+            for (int i = 0; i < 9; i++) f[i] = k == 0 ? g[i] : g[i] * lam[k - 1] + f2[i];
+            double M[3][3];
+            for (int r = 0; r < 3; r++) {
+                M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
+                M[r][2] = (f[3 * r] * t1x + f[3 * r + 1] * t1y) + f[3 * r + 2];
+            }
+            double* F = Fm + 9 * k;
+            for (int c = 0; c < 3; c++) {
+                F[c] = s2 * M[0][c]; F[3 + c] = s2 * M[1][c];
+                F[6 + c] = (t2x * M[0][c] + t2y * M[1][c]) + M[2][c];
+            }
+        }
+        return nq + 1;
+    }
     /* monic, then depressed: lambda = t - A / 3,  t^3 + p t + q = 0 */
     const double Am = a2 / a3, Bm = a1 / a3, Cm = a0 / a3;
     const double sh = Am / 3.0;
@@ -934,7 +987,6 @@ static int seven_point(const float* p1, const float* p2, const int* s, double* F
             }
         n = 3;
     }
-    const double t1x = -(s1 * c1x), t1y = -(s1 * c1y), t2x = -(s2 * c2x), t2y = -(s2 * c2y);
     for (int k = 0; k < n; k++) {
         const double lam = t[k] - sh;
         double f[9];
@@ -1063,7 +1115,7 @@ static int lmeds_fundamental(const float* p1, const float* p2, int n, uint8_t* m
     cv_rng rng; rng.state = 0xFFFFFFFFFFFFFFFFULL;
     for (k = 0; k < niters; k++) {
         int s[7]; double Fm[27];
-        if (!ransac_get_subset(&rng, p1, p2, n, s, 10000, NULL)) break;
+        if (!ransac_get_subset(&rng, p1, p2, n, s, 1000, NULL)) break;     /* [oracle v7] LMeDSPointSetRegistrator::run calls getSubset with its DEFAULT maxAttempts = 1000 (only the RANSAC's run passes 10000) */
         const int nm = seven_point(p1, p2, s, Fm);
         for (int j = 0; j < nm; j++) {
             const double* F = Fm + 9 * j;

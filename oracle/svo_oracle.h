@@ -40,8 +40,14 @@ extern "C" {
  *      of the float errors as nth_element leaves it at n / 2 (the 3.x / 4.x reading; 2.4 averaged the middle pair for even n), mask at
  *      2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median)) -- the deviation version 5 stated is gone; the inlier test compares the error
  *      AS A FLOAT with the float threshold (computeError stores floats, findInliers compares them), the maximum of the two distances is
- *      std::max's (a NaN first operand stays). */
-#define SVO_ORACLE_VERSION 6
+ *      std::max's (a NaN first operand stays);
+ *   7  round 6, ONE bump, then frozen: the pyramid is cv::resize's 8-bit INTER_LINEAR as OpenCV 2.4 / 3.x compute
+ *      it -- float-derived tap weights rounded separately to 11 bits, and the uchar specialisation's TWO-step rounding
+ *      (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 instead of one (v + 2^21) >> 22 with exact-rational weights;
+ *      run7Point's leading-coefficient-zero case (cv::solveCubic's quadratic / linear branch, plus the model at infinity of this
+ *      parametrisation) instead of a division by zero; LMedS draws with getSubset's default 1000 attempts (the RANSAC keeps 10000);
+ *      haveCollinearPoints subtracts the Point2f coordinates in float before widening. */
+#define SVO_ORACLE_VERSION 7
 int svo_oracle_version(void);
 
 typedef struct svo_oracle svo_oracle;
@@ -94,6 +100,8 @@ int svo_oracle_seven_point(const float* p1, const float* p2, double* F27);   /* 
 /* pyramid level sizes and bilinear x1/1.2 chain; level buffers are tightly packed (stride == width). */
 int svo_oracle_pyramid_sizes(int w, int h, int nlevels, int* lw, int* lh, float* scale);
 void svo_oracle_resize(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh);
+/* cv::resize's tables for one axis: idx[d] = first tap, w01[d] = weight of that tap | weight of the next << 16 (11-bit shorts) */
+void svo_oracle_resize_table(int src, int dst, int* idx, int* w01);
 void svo_oracle_half_smooth(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst); /* MRPT x1/2 */
 /* m_non_max_sup copying overload (S2:296-370): returns number kept; out_order[i] = input index */
 int svo_oracle_nms_copy(const svo_keypoint* kps, int n, int min_distance, int img_w, int img_h,

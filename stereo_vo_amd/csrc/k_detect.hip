@@ -173,15 +173,17 @@ void launch_pack_values(const DevCtx& c, int lane, int which, int octave, uint8_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1: one pyramid level from the previous one, bilinear with the frozen 11-bit integer tables.
+// K1: one pyramid level from the previous one: cv::resize's 8-bit INTER_LINEAR (oracle v7) with host-built 11-bit tap tables.
 // HBM-bound on paper (~1.44 source bytes read + 1 written per output pixel), VALU-issue-bound in practice, so the
 // blend is written for instruction count.  A 256-thread block produces a 128x32 destination tile: the <= 160x41
 // source window is staged in LDS by LDS-DMA (global_load_lds_dwordx4: 42 rows x 11 chunks of 16 bytes, two wave-instructions
 // per wave, no VGPR round trip), the tile's slice of the x / y tables sits in LDS too, every thread blends 4 rows x 4 adjacent pixels and stores one dword per row.
 // Per pixel: the two taps of each source row come out of two aligned LDS dwords as a u16 pair by one v_perm (the
-// selector is a per-column constant), v_dot2_u32_u16 applies (2048 - ax, ax), two 24-bit multiply-adds apply the
-// row weights pre-scaled by 4 so that the rounded result lands in byte 3, and three v_perm pack four results.
-// Exact: p00*wx0*wy0 + p01*wx1*wy0 + p10*wx0*wy1 + p11*wx1*wy1 regrouped, every intermediate < 2^32.
+// selector is a per-column constant), v_dot2_u32_u16 applies the column's (a0, a1), the two row sums are cut, weighted, cut and rounded
+// as OpenCV's uchar VResizeLinear does, and shifts + ors pack four results.
+// (rounds 1-5: the two row sums went through two 24-bit multiply-adds with the row weights pre-scaled by 4, so that the ONCE-rounded result
+// landed in byte 3.  Oracle v7 follows cv::resize's 8-bit path instead: ((b0 * (top >> 4)) >> 16) + ((b1 * (bot >> 4)) >> 16) + 2) >> 2,
+// weights as OpenCV derives them in float -- four more VALU operations per pixel in a kernel that waits for memory.)
 // ------------------------------------------------------------------------------------------------------------
 // (Round 5 rebuilt this kernel twice for instruction count -- a wave owning eight rows and a lane two columns, the horizontal blend of a
 // source row computed once and shared by the rows above and below it, row tables by v_readlane: 232 -> ~150 VALU instructions per wave,
@@ -219,12 +221,12 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
     const int* xi = c.rtab + d.rtab_off, *xf = xi + d.w, *yi = xf + d.w, *yf = yi + d.h;
     const int sx0 = xi[dx0] & ~15, sy0 = yi[dy0];                      // window origin (block-uniform)
     if (tid < RZ_W) {
-        const int x = min(dx0 + tid, d.w - 1), rx = xi[x] - sx0, ax = xf[x];
-        xw[tid] = (uint32_t)(2048 - ax) | ((uint32_t)ax << 16);                                    // dot2 weights
+        const int x = min(dx0 + tid, d.w - 1), rx = xi[x] - sx0;
+        xw[tid] = (uint32_t)xf[x];                                                                 // dot2 weights: a0 | a1 << 16
         xr[tid] = (uint32_t)rx;
     } else if (tid < RZ_W + RZ_H) {
-        const int y = min(dy0 + tid - RZ_W, d.h - 1), ay = yf[y];
-        yw[tid - RZ_W] = (uint32_t)(4 * (2048 - ay)) | ((uint32_t)(4 * ay) << 16);
+        const int y = min(dy0 + tid - RZ_W, d.h - 1);
+        yw[tid - RZ_W] = (uint32_t)yf[y];                                                          // b0 | b1 << 16
         yr[tid - RZ_W] = (uint32_t)(yi[y] - sy0);
     }
     if (c.debug_mode == 5) { /* ablation: no staging */ }
@@ -285,10 +287,10 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
             const uint32_t t1 = __builtin_amdgcn_perm(w1hi, w1lo, sel[k]);
             const uint32_t top = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t0), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
             const uint32_t bot = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t1), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
-            v[k] = __umul24(bot, wy1) + (__umul24(top, wy0) + (1u << 23));                       // result in byte 3
+            // cv::resize's uchar VResizeLinear (oracle v7): the row sums lose 4 bits, each product is cut to quarter grey levels, then one rounding
+            v[k] = ((__umul24(top >> 4, wy0) >> 16) + (__umul24(bot >> 4, wy1) >> 16) + 2u) >> 2;     // <= 255
         }
-        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0703u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x07030c0cu);
-        const uint32_t out = lo | hi;
+        const uint32_t out = (v[0] | (v[1] << 8)) | ((v[2] << 16) | (v[3] << 24));
         if (c.debug_mode == 7 && out != 0x12345678u) continue;
         *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64: the tail of the last dword is padding
     }

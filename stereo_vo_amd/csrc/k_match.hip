@@ -766,10 +766,10 @@ __device__ __forceinline__ bool rs_collinear7(const float (&x)[7], const float (
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        const double dx1 = (double)x[j] - (double)x[6], dy1 = (double)y[j] - (double)y[6];
+        const double dx1 = (double)(x[j] - x[6]), dy1 = (double)(y[j] - y[6]);          // Point2f differences: float, then widened (oracle v7)
 #pragma unroll
         for (int k = 0; k < 6; k++) if (k < j) {
-            const double dx2 = (double)x[k] - (double)x[6], dy2 = (double)y[k] - (double)y[6];
+            const double dx2 = (double)(x[k] - x[6]), dy2 = (double)(y[k] - y[6]);
             if (fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) bad = true;
         }
     }
@@ -784,6 +784,7 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
     const bool lmeds = rs_is_lmeds(n);                                     // its 300 samples are all drawn in phase 0 (nothing shortens that budget)
     if (phase == 1 && (lmeds || max(c.rs_bound[vl * 2], c.rs_bound[vl * 2 + 1]) <= c.rs_c1)) return;      // neither side's budget reaches chunk 2
     const int target = lmeds ? SVO_LMEDS_ITERS : (phase ? SVO_RANSAC_HYP : c.rs_c1);
+    const int max_attempts = lmeds ? 1000 : 10000;                         // getSubset's maxAttempts: the RANSAC's run() passes 10000, LMedS's takes the default (oracle v7)
     int attempts = phase ? st[1] : 0, ns[2] = { phase ? st[2] : 0, phase ? st[3] : 0 };
     int last_ok[2] = { phase ? st[0] : -1, phase ? st[4] : -1 }, ended[2] = { phase ? st[5] : 0, phase ? st[6] : 0 };
     const float4* ptsL = (const float4*)(c.trk_pts + ((long long)vl * 2 + 0) * c.max_kps * 4);
@@ -794,14 +795,46 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
     const int n_att = n < SVO_RS_SMALL_N ? SVO_RS_ATT_SMALL : SVO_RS_ATT;
     const uint4* att = (const uint4*)c.rs_att + (n < SVO_RS_SMALL_N ? (long long)(n - 8) * SVO_RS_ATT_SMALL
                                                                      : (long long)(SVO_RS_SMALL_N - 8) * SVO_RS_ATT_SMALL + (long long)(n - SVO_RS_SMALL_N) * SVO_RS_ATT);
+    // Beyond the tabulated attempts (point sets on which nearly every sample is collinear: integer coordinates along a few edges, a narrow
+    // strip) the stream is CONTINUED here: thread 0 carries cv::RNG on from the state the table row ended in (rs_att_state[n]) and draws
+    // the next attempts one after the other into LDS, 256 at a time; the other threads test them as they test tabulated ones.  Serial and
+    // slow (~75 us per 256 attempts) but exact, and bounded: SVO_RS_EXT more attempts, then the schedule ends and says so (SVO_ST_INTERNAL).
+    __shared__ uint4 ext[256];
+    unsigned long long xs = 0; bool xs_loaded = false;                     // thread 0: the generator's state past the table
     bool exhausted = false;
     while ((!ended[0] && ns[0] < target) || (!ended[1] && ns[1] < target)) {
-        if (attempts >= n_att) { exhausted = true; break; }
+        if (attempts >= n_att + SVO_RS_EXT) { exhausted = true; break; }
+        if (attempts + 256 > n_att) {                                      // (block-uniform) this chunk reaches past the table
+            if (tid == 0) {
+                if (!xs_loaded) {
+                    xs = (phase && st[1] > n_att) ? (((unsigned long long)(unsigned)st[9] << 32) | (unsigned)st[8]) : c.rs_att_state[n];
+                    xs_loaded = true;
+                }
+                const uint32_t un = (uint32_t)n;
+                for (int a = max(attempts, n_att); a < attempts + 256; a++) {
+                    uint32_t s7[7];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) {
+                        uint32_t v; bool dup;
+                        do {
+                            xs = (unsigned long long)(uint32_t)xs * 4164903690ull + (uint32_t)(xs >> 32);      // cv::RNG::next
+                            v = (uint32_t)xs % un;                                                         // rng.uniform(0, n)
+                            dup = false;
+#pragma unroll
+                            for (int k = 0; k < 7; k++) if (k < i) dup = dup || s7[k] == v;
+                        } while (dup);
+                        s7[i] = v;
+                    }
+                    ext[a - attempts] = make_uint4(s7[0] | (s7[1] << 16), s7[2] | (s7[3] << 16), s7[4] | (s7[5] << 16), s7[6]);
+                }
+            }
+            __syncthreads();
+        }
         const int a = attempts + tid;
         int flags = 0;                                                    // bit 0: passes on the left side, bit 10: on the right
         uint4 w = make_uint4(0, 0, 0, 0);
-        if (a < n_att) {
-            w = att[a];
+        {
+            w = a < n_att ? att[a] : ext[tid];
             const int s[7] = { (int)(w.x & 0xFFFFu), (int)(w.x >> 16), (int)(w.y & 0xFFFFu), (int)(w.y >> 16), (int)(w.z & 0xFFFFu), (int)(w.z >> 16), (int)(w.w & 0xFFFFu) };
             float4 pa[7], pb[7];
 #pragma unroll
@@ -818,7 +851,7 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
         int tt;
         const int pre = block_exclusive_scan(flags, scan, &tt);           // both counts ride in one scan (<= 256 each)
         const int tot[2] = { tt & 1023, tt >> 10 }, mypre[2] = { pre & 1023, pre >> 10 }, mine[2] = { flags & 1, flags >> 10 };
-        // getSubset's maxAttempts (run() passes 10000): a sample that needs more attempts than that ends the run.  Gaps inside these 256
+        // getSubset's maxAttempts: a sample that needs more attempts than that ends the run.  Gaps inside these 256
         // attempts are shorter, so only the FIRST passing attempt of the chunk can be too late; the last one is what the next chunk measures from
         int* fl = scan + 33;                                               // first | last passing attempt of the chunk, per side
         __syncthreads();
@@ -831,7 +864,7 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
         for (int sd = 0; sd < 2; sd++) {
             if (ended[sd]) continue;
             const int first = fl[2 * sd], last = fl[2 * sd + 1];
-            if ((first >= 0 ? first : attempts + 256) - last_ok[sd] > 10000) { ended[sd] = 1; continue; }      // (no passing attempt here and none for 10000: ended as well)
+            if ((first >= 0 ? first : attempts + 256) - last_ok[sd] > max_attempts) { ended[sd] = 1; continue; }      // (no passing attempt here and none for max_attempts: ended as well)
             if (first < 0) continue;
             const int idx = ns[sd] + mypre[sd];
             if (mine[sd] && idx < SVO_RANSAC_PAD) *(uint4*)(c.rs_smp + (((long long)vl * 2 + sd) * SVO_RANSAC_PAD + idx) * 8) = w;
@@ -842,10 +875,12 @@ __device__ __forceinline__ void rs_schedule_block(const DevCtx& c, int vl, int p
     }
     if (tid == 0) {
         st[0] = last_ok[0]; st[1] = attempts; st[2] = min(ns[0], SVO_RANSAC_PAD); st[3] = min(ns[1], SVO_RANSAC_PAD); st[4] = last_ok[1]; st[5] = ended[0]; st[6] = ended[1];
-        // the table ran out although the sequential algorithm could still draw (heavy rejection at n >= SVO_RS_SMALL_N): never silently
-        if (exhausted && (phase == 1 || lmeds) && ((!ended[0] && ns[0] < min(c.rs_bound[vl * 2], SVO_RANSAC_HYP)) || (!ended[1] && ns[1] < min(c.rs_bound[vl * 2 + 1], SVO_RANSAC_HYP)))) {
-            atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
-        }
+        if (xs_loaded) { st[8] = (int)(uint32_t)xs; st[9] = (int)(uint32_t)(xs >> 32); }      // (valid for phase 1 when st[1] > n_att)
+        // The attempts ran out (table + SVO_RS_EXT) while a side still wanted samples: remembered per side (bit 0 left, bit 1 right).  Whether
+        // that MATTERS is only known once the counts are in -- the chunks are drawn ahead of the stop rule, and a lane whose budget collapses
+        // after a handful of samples never needed the rest -- so k_track_finalize raises SVO_ST_INTERNAL if the sequential algorithm would have
+        // visited a sample that was never drawn (in either phase, never silently).
+        st[10] = exhausted ? ((!ended[0] && ns[0] < target ? 1 : 0) | (!ended[1] && ns[1] < target ? 2 : 0)) : 0;
     }
 }
 __global__ void __launch_bounds__(256) k_ransac_schedule(DevCtx c, int phase)
@@ -881,6 +916,42 @@ __device__ __forceinline__ int seven_point_models(const double (&g)[9], const do
     const double a0 = (f2[0] * h00 - f2[1] * h01) + f2[2] * h02;
     const double a2 = ((f2[0] * g00 - f2[1] * g01) + f2[2] * g02) + ((g[0] * m00 - g[1] * m01) + g[2] * m02);
     const double a1 = ((g[0] * h00 - g[1] * h01) + g[2] * h02) + ((f2[0] * m00 - f2[1] * m01) + f2[2] * m02);
+    if (__builtin_expect(a3 == 0.0, 0)) {
+        // oracle v7 (seven_point): the cubic has lost its leading term -- the matrix g itself (lambda -> infinity) is a solution and comes
+        // first, then the roots of what is left, in cv::solveCubic's order for its quadratic / linear branch.  Same expressions as the oracle.
+        double lam0 = 0.0, lam1 = 0.0; int nq = 0;
+        if (a2 == 0.0) { if (a1 != 0.0) { lam0 = -a0 / a1; nq = 1; } }
+        else {
+            double d = a1 * a1 - (4.0 * a2) * a0;
+            if (d >= 0.0) {
+                const bool two = d > 0.0;
+                d = sqrt(d);
+                const double q1 = (-a1 + d) * 0.5, q2 = (a1 + d) * -0.5;
+                if (fabs(q1) > fabs(q2)) { lam0 = q1 / a2; lam1 = a0 / q1; } else { lam0 = q2 / a2; lam1 = a0 / q2; }
+                nq = two ? 2 : 1;
+            }
+        }
+        const double d1x = -(s1 * c1x), d1y = -(s1 * c1y), d2x = -(s2 * c2x), d2y = -(s2 * c2y);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                                  // (unrolled: a run-time index into Fm would put the caller's array in scratch)
+            const double lam = k == 1 ? lam0 : lam1;
+            double f[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) f[i] = k == 0 ? g[i] : g[i] * lam + f2[i];
+            double M[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                M[r][0] = f[3 * r] * s1; M[r][1] = f[3 * r + 1] * s1;
+                M[r][2] = (f[3 * r] * d1x + f[3 * r + 1] * d1y) + f[3 * r + 2];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                Fm[k][cc] = s2 * M[0][cc]; Fm[k][3 + cc] = s2 * M[1][cc];
+                Fm[k][6 + cc] = (d2x * M[0][cc] + d2y * M[1][cc]) + M[2][cc];
+            }
+        }
+        return nq + 1;
+    }
     const double Am = a2 / a3, Bm = a1 / a3, Cm = a0 / a3;
     const double sh = Am / 3.0;
     const double p = Bm - Am * sh;
@@ -1699,6 +1770,9 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
         __syncthreads();
         const long long sb = (long long)vl * 2 + side;
         const int lim_k = min(SVO_LMEDS_ITERS, c.rs_sched[vl * SVO_RS_ST + 2 + side]);          // the samples there are (getSubset may give up earlier)
+        if (tid == 0 && ((c.rs_sched[vl * SVO_RS_ST + 10] >> side) & 1)) {                     // LMedS visits all 300: a schedule cut short by the attempt limit is a wrong answer
+            atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
+        }
         const int lim = (lim_k + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG * SVO_RANSAC_RSLOTS;
         const float4* pts = (const float4*)(c.trk_pts + sb * c.max_kps * 4);
         int* key = s_lkey + tid;                                                                // this thread's keys: key[i * 256]
@@ -1797,6 +1871,9 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
             }
             s_best[side] = best_s; s_cnt[side] = best_s >= 0 ? best_cnt : 0;
             s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * SVO_RS_ST + 2 + side]) : 0;
+            if (n >= 8 && ((c.rs_sched[vl * SVO_RS_ST + 10] >> side) & 1) && max(ks + 1, niters) > c.rs_sched[vl * SVO_RS_ST + 2 + side]) {      // a sample the sampler could not draw would have been visited
+                atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
+            }
         } else if (t == 0) {
             int best_s = -1, best_cnt = 0, niters = SVO_RANSAC_HYP, last = -1, ks = -1, start = SVO_RANSAC_HYP;
             for (int r = 0; r < nr; r++) {                                   // next record in slot order = smallest slot above `last`
@@ -1813,6 +1890,9 @@ __global__ void __launch_bounds__(256) k_track_finalize(DevCtx c, int win_mode, 
             // samples the sequential loop visits: it leaves at the first k that is no longer below the budget, and a record may
             // cut the budget below its own sample (oracle: svo_oracle_ransac_fundamental's n_hyp_used)
             s_vis[side] = n >= 8 ? min(max(ks + 1, niters), c.rs_sched[vl * SVO_RS_ST + 2 + side]) : 0;
+            if (n >= 8 && ((c.rs_sched[vl * SVO_RS_ST + 10] >> side) & 1) && max(ks + 1, niters) > c.rs_sched[vl * SVO_RS_ST + 2 + side]) {      // (see the plain scan above)
+                atomicOr(&c.status[vl / c.oct_cap], SVO_ST_INTERNAL); atomicOr(&c.results[vl / c.oct_cap].status, (int)SVO_ST_INTERNAL);
+            }
         }
         // exactly seven pairs: cv::findFundamentalMat runs the 7-point kernel directly and sets the whole mask -- seven "inliers", no sample
         // visited, below the eight that S4:205, 240 ask for whichever model comes out (oracle: svo_oracle_ransac_fundamental, n == 7)

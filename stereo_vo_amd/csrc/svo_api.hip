@@ -13,6 +13,8 @@
 #include <vector>
 #include <mutex>
 #include <map>
+#include <memory>
+#include <condition_variable>
 
 #define HIPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); return SVO_ERR_HIP; } } while (0)
 
@@ -91,6 +93,7 @@ struct svo_ctx {
     uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
     uint32_t* d_anms;                                  // scratch of k_fastorb_anms (3 x n_img x cand_total), allocated on first use
     bool imported_pending;                             // svo_import_frame ran since the last svo_process
+    int sampler_nmax;                                  // > 0: holds a reference on the shared sampler table of (device, sampler_nmax)
     hipEvent_t post_event;                             // svo_record_after_post: armed for the next call that runs the detector's post-processing
     // svo_use_graphs: the kernel sequence of a frame captured once per (flags, ring slot, thresholds) and replayed
     struct GraphEntry { uint32_t flags; int slot, fast_th, orb_th; hipGraphExec_t exec; };
@@ -104,6 +107,8 @@ struct svo_ctx {
 };
 
 static void drop_graphs(svo_ctx* ctx);
+static int sampler_table_acquire(svo_ctx* ctx, int nmax);
+static void sampler_table_release(int device, int nmax);
 static void note_stream(svo_ctx* ctx)
 {
     for (auto& u : ctx->used_streams) if (u.s == ctx->stream) { u.dirty = true; return; }
@@ -240,6 +245,89 @@ static long long pyramid_bytes(int w, int h, int nlevels)
     return align_up((int)((b + 255) & ~255LL), 256);
 }
 
+// ---- the sampler's attempt table ---------------------------------------------------------------------------------------------
+// cv::RNG from the seed RANSACPointSetRegistrator::run uses, (uint64)-1 -- state = (uint32)state * 4164903690 + (state >> 32), output
+// (uint32)state --, rng.uniform(0, n) = next() % n, a draw that repeats an index of the same attempt is drawn again (getSubset); the
+// collinearity rejection depends on the data and stays on the device.  The attempts depend on the point count n alone: tabulated once per
+// process and nmax on the host (~0.1 s, 18 KB per n: 84 MB at max_kps 4096) and uploaded ONCE per (device, nmax) -- three contexts of a
+// batch used to hold three copies -- together with the generator's state at the end of every row, from which the device
+// continues the stream when a lane needs more attempts than its row holds (rs_schedule_block).  The host mutex covers the maps only,
+// not the upload of another device's copy.
+namespace {
+struct SamplerHost { std::vector<uint16_t> att; std::vector<uint64_t> state; };
+struct SamplerDev { uint16_t* att = nullptr; uint64_t* state = nullptr; int refs = 0; bool ready = false; hipError_t err = hipSuccess; };
+std::mutex g_sampler_mu;
+std::map<int, std::shared_ptr<SamplerHost>> g_sampler_host;                 // by nmax
+std::map<std::pair<int, int>, std::shared_ptr<SamplerDev>> g_sampler_dev;   // by (device, nmax)
+std::condition_variable g_sampler_cv;
+size_t sampler_row_off(int n) { return n < SVO_RS_SMALL_N ? (size_t)(n - 8) * SVO_RS_ATT_SMALL : (size_t)(SVO_RS_SMALL_N - 8) * SVO_RS_ATT_SMALL + (size_t)(n - SVO_RS_SMALL_N) * SVO_RS_ATT; }
+std::shared_ptr<SamplerHost> sampler_build(int nmax)
+{
+    auto h = std::make_shared<SamplerHost>();
+    h->att.assign(sampler_row_off(nmax + 1) * 8, 0);
+    h->state.assign((size_t)nmax + 1, 0xFFFFFFFFFFFFFFFFULL);
+    for (int n = 8; n <= nmax; n++) {
+        uint64_t stt = 0xFFFFFFFFFFFFFFFFULL;
+        uint16_t* row = h->att.data() + sampler_row_off(n) * 8;
+        const int n_att = n < SVO_RS_SMALL_N ? SVO_RS_ATT_SMALL : SVO_RS_ATT;
+        for (int a = 0; a < n_att; a++) {
+            uint16_t* s7 = row + (size_t)a * 8;
+            for (int i = 0; i < 7; i++) {
+                for (;;) {
+                    stt = (uint64_t)(uint32_t)stt * 4164903690ULL + (uint32_t)(stt >> 32);
+                    const uint16_t v = (uint16_t)((uint32_t)stt % (uint32_t)n);
+                    bool dup = false;
+                    for (int k = 0; k < i; k++) dup = dup || s7[k] == v;
+                    if (!dup) { s7[i] = v; break; }
+                }
+            }
+        }
+        h->state[(size_t)n] = stt;
+    }
+    return h;
+}
+}
+static int sampler_table_acquire(svo_ctx* ctx, int nmax)
+{
+    const std::pair<int, int> key(ctx->cfg.device, nmax);
+    std::shared_ptr<SamplerDev> dv; std::shared_ptr<SamplerHost> host; bool mine = false;
+    {
+        std::unique_lock<std::mutex> lock(g_sampler_mu);
+        auto& slot = g_sampler_dev[key];
+        if (!slot) { slot = std::make_shared<SamplerDev>(); mine = true; }
+        dv = slot; dv->refs++;
+        if (!mine) g_sampler_cv.wait(lock, [&] { return dv->ready; });      // another thread is uploading this very copy: wait for THAT one only
+        else {
+            auto& hs = g_sampler_host[nmax];
+            if (!hs) hs = sampler_build(nmax);                               // (built under the lock: once per process and nmax)
+            host = hs;
+        }
+    }
+    if (mine) {                                                              // the upload runs WITHOUT the lock: contexts on other devices / of other sizes go on
+        hipError_t e = hipMalloc((void**)&dv->att, host->att.size() * sizeof(uint16_t) + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&dv->state, host->state.size() * sizeof(uint64_t) + 256);
+        if (e == hipSuccess) e = hipMemcpy(dv->att, host->att.data(), host->att.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dv->state, host->state.data(), host->state.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        std::lock_guard<std::mutex> lock(g_sampler_mu);
+        dv->err = e; dv->ready = true;
+        g_sampler_cv.notify_all();
+    }
+    if (dv->err != hipSuccess) { ctx->last_error = std::string("sampler table: ") + hipGetErrorString(dv->err); sampler_table_release(ctx->cfg.device, nmax); return SVO_ERR_HIP; }
+    ctx->dc.rs_att = dv->att; ctx->dc.rs_att_state = (const unsigned long long*)dv->state; ctx->dc.rs_att_nmax = nmax;
+    ctx->sampler_nmax = nmax;
+    return SVO_OK;
+}
+static void sampler_table_release(int device, int nmax)
+{
+    std::lock_guard<std::mutex> lock(g_sampler_mu);
+    auto it = g_sampler_dev.find(std::make_pair(device, nmax));
+    if (it == g_sampler_dev.end()) return;
+    if (--it->second->refs > 0) return;
+    if (it->second->att) hipFree(it->second->att);
+    if (it->second->state) hipFree(it->second->state);
+    g_sampler_dev.erase(it);
+}
+
 extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
 {
     if (!cfg || !out) return SVO_ERR_ARG;
@@ -253,6 +341,7 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     ctx->cfg = *cfg;
     svo_params_defaults(&ctx->params);
     ctx->fast_th = 20; ctx->orb_th = 60;                  // common.cpp:35-36
+    ctx->sampler_nmax = 0;
     ctx->geom_ready = false;
     ctx->d_ham_out = nullptr; ctx->d_ham_q = ctx->d_ham_t = nullptr; ctx->ham_cap_q = ctx->ham_cap_t = 0;
     ctx->d_src = nullptr; ctx->src_pitch = 0; ctx->d_map_ptrs = nullptr; ctx->map_w = ctx->map_h = ctx->n_maps = 0;
@@ -333,39 +422,8 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.rs_smp, (size_t)NV * 2 * SVO_RANSAC_PAD * 8));
     HIPCHECK(dev_alloc(ctx, &d.rs_sched, (size_t)NV * SVO_RS_ST));
     {   // The attempts of cv::findFundamentalMat's sampler for every point count a context can meet (k_match.hip, k_ransac_schedule):
-        // cv::RNG from the seed RANSACPointSetRegistrator::run uses, (uint64)-1 -- state = (uint32)state * 4164903690 + (state >> 32),
-        // output (uint32)state --, rng.uniform(0, n) = next() % n, a draw that repeats an index of the same attempt is drawn again
-        // (getSubset); the collinearity rejection depends on the data and stays on the device.  ~0.1 s and 18 KB per n, once per context.
-        const int nmax = MK;
-        static std::mutex att_mu;
-        static std::map<int, std::vector<uint16_t>> att_by_nmax;          // the table is a constant: computed once per process and size
-        std::lock_guard<std::mutex> att_lock(att_mu);
-        std::vector<uint16_t>& att = att_by_nmax[nmax];
-        if (att.empty()) {
-            auto row_off = [](int n) -> size_t { return n < SVO_RS_SMALL_N ? (size_t)(n - 8) * SVO_RS_ATT_SMALL : (size_t)(SVO_RS_SMALL_N - 8) * SVO_RS_ATT_SMALL + (size_t)(n - SVO_RS_SMALL_N) * SVO_RS_ATT; };
-            att.assign(row_off(nmax + 1) * 8, 0);
-            for (int n = 8; n <= nmax; n++) {
-                uint64_t stt = 0xFFFFFFFFFFFFFFFFULL;
-                uint16_t* row = att.data() + row_off(n) * 8;
-                const int n_att = n < SVO_RS_SMALL_N ? SVO_RS_ATT_SMALL : SVO_RS_ATT;
-                for (int a = 0; a < n_att; a++) {
-                    uint16_t* s7 = row + (size_t)a * 8;
-                    for (int i = 0; i < 7; i++) {
-                        for (;;) {
-                            stt = (uint64_t)(uint32_t)stt * 4164903690ULL + (uint32_t)(stt >> 32);
-                            const uint16_t v = (uint16_t)((uint32_t)stt % (uint32_t)n);
-                            bool dup = false;
-                            for (int k = 0; k < i; k++) dup = dup || s7[k] == v;
-                            if (!dup) { s7[i] = v; break; }
-                        }
-                    }
-                }
-            }
-        }
-        uint16_t* da = nullptr;
-        HIPCHECK(dev_alloc(ctx, &da, att.size()));
-        HIPCHECK(hipMemcpy(da, att.data(), att.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        d.rs_att = da; d.rs_att_nmax = nmax;
+        // ONE device copy per (device, max_kps), shared by every context of the process and freed with the last of them (sampler_table_*).
+        int rc_t = sampler_table_acquire(ctx, MK); if (rc_t) return rc_t;
     }
     HIPCHECK(dev_alloc(ctx, &d.tracked, (size_t)NV * MK));
     HIPCHECK(dev_alloc(ctx, &d.n_tracked, (size_t)NV));
@@ -396,6 +454,7 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     if (!ctx) return;
     sync_all(ctx);                                        // work may still be running on a stream the caller switched away from
     for (void* p : ctx->allocs) hipFree(p);
+    if (ctx->sampler_nmax > 0) sampler_table_release(ctx->cfg.device, ctx->sampler_nmax);
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.exec);
     if (ctx->h_vals) hipHostFree(ctx->h_vals);
     if (ctx->d_ham_out) hipFree(ctx->d_ham_out);
@@ -573,16 +632,21 @@ void level_quota(int nfeatures, int nlevels, int* q)
     q[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
 }
 
-static void resize_table(int src, int dst, int* idx, int* frac)
+// cv::resize's INTER_LINEAR tables for one axis of an 8-bit image (oracle v7: svo_oracle_resize_table, same float operations in the same
+// order; this file is compiled with -ffp-contract=off): idx = first tap, w01 = weight of that tap | weight of the next << 16
+static void resize_table(int src, int dst, int* idx, int* w01)
 {
-    for (int d = 0; d < dst; d++) {                          // oracle: resize_table
-        const long long num = (long long)(2 * d + 1) * src - dst, den = 2LL * dst;
-        long long q = num >= 0 ? num / den : -((-num + den - 1) / den);
-        const long long r = num - q * den;
-        int f = (int)((r * 2048 + den / 2) / den);
-        if (q < 0) { q = 0; f = 0; }
-        if (q >= src - 1) { q = src - 1; f = 0; }
-        idx[d] = (int)q; frac[d] = f;
+    const double inv_scale = (double)dst / src, scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst; d++) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)floor((double)fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= src - 1) { fx = 0.f; sx = src - 1; }
+        long a0 = lrintf((1.f - fx) * 2048.f), a1 = lrintf(fx * 2048.f);       // cvRound: half to even
+        if (a0 > 32767) a0 = 32767;
+        if (a1 > 32767) a1 = 32767;
+        idx[d] = sx; w01[d] = (int)a0 | ((int)a1 << 16);
     }
 }
 

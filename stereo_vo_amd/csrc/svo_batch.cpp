@@ -102,10 +102,22 @@ extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
     b->cfg = *cfg; b->NC = cfg->n_contexts; b->Bc = cfg->ctx.n_lanes; b->B = b->NC * b->Bc;
     b->pipelined = b->NC > 1 && cfg->schedule == SVO_SCHED_PIPELINED;
     BHIP(b, hipSetDevice(cfg->ctx.device));
+    b->ahead = b->pipelined && (cfg->post_mode == 1 || cfg->post_mode == 3) && !cfg->no_detect_ahead;
+    // The pipelined schedule's streams first, and no stream that is never launched on: HIP multiplexes its streams onto a few hardware
+    // queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one never overlap (tools/ubench/queue_overlap.hip: with three
+    // idle streams created first, the first two priority-0 streams made afterwards executed one after the other, always).  A context of the
+    // pipelined schedule is therefore created ON its stage 3-5 stream; only the free schedule makes a stream per context.
+    if (b->pipelined) {
+        const int nd = cfg->det_streams > 1 ? cfg->det_streams : 1;
+        for (int i = 0; i < nd; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high != 0); if (rc) return rc; b->s_dets.push_back(s); }
+        const int nr = cfg->rest_streams > 0 ? cfg->rest_streams : b->NC;
+        for (int i = 0; i < nr; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high == 0); if (rc) return rc; b->s_rests.push_back(s); }
+        if (cfg->post_mode == 2) { int rc = make_stream(b->last_error, &b->s_post, cfg->det_priority_high == 0); if (rc) return rc; }
+    }
     for (int k = 0; k < b->NC; k++) {
         hipStream_t s = nullptr;
-        BHIP(b, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        b->own.push_back(s);
+        if (b->pipelined) s = b->s_rests[(size_t)k % b->s_rests.size()];
+        else { BHIP(b, hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); b->own.push_back(s); }
         svo_config c = cfg->ctx; c.stream = s;
         svo_ctx* x = nullptr;
         const int rc = svo_create(&c, &x);
@@ -117,12 +129,6 @@ extern "C" int svo_batch_create(const svo_batch_config* cfg, svo_batch** out)
             v->push_back(e);
         }
     }
-    b->ahead = b->pipelined && (cfg->post_mode == 1 || cfg->post_mode == 3) && !cfg->no_detect_ahead;
-    const int nd = cfg->det_streams > 1 ? cfg->det_streams : 1;
-    for (int i = 0; i < nd; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high != 0); if (rc) return rc; b->s_dets.push_back(s); }
-    const int nr = cfg->rest_streams > 0 ? cfg->rest_streams : b->NC;
-    for (int i = 0; i < nr; i++) { hipStream_t s = nullptr; int rc = make_stream(b->last_error, &s, cfg->det_priority_high == 0); if (rc) return rc; b->s_rests.push_back(s); }
-    if (cfg->post_mode == 2) { int rc = make_stream(b->last_error, &b->s_post, cfg->det_priority_high == 0); if (rc) return rc; }
     BHIP(b, hipMalloc((void**)&b->own_rec, (size_t)b->B * sizeof(svo_result)));
     BHIP(b, hipMemset(b->own_rec, 0, (size_t)b->B * sizeof(svo_result)));
     b->rec = b->own_rec;
@@ -182,7 +188,8 @@ extern "C" int svo_batch_step(svo_batch* b, const svo_frame* frames, uint32_t fl
     if (!b) return SVO_ERR_ARG;
     b->step_started = false;
     const int rc = batch_step_impl(b, frames, flags);
-    b->held.clear();                          // the held events belong to THIS step, however it ended
+    if (rc == SVO_OK || b->step_started) b->held.clear();      // the held events belong to the step that was ENQUEUED (wholly or in part): a call refused
+                                                               // before anything was enqueued (NULL frames, unknown flags) keeps them for the caller's retry
     if (rc != SVO_OK && b->step_started) {    // (an argument refused before anything was enqueued leaves the event chain intact)
         // a step that failed half way has recorded some of its events and not others: let everything enqueued so far drain and start
         // the event chain over, so that the next step neither waits on a stale record (a no-op) nor overwrites scratch still being read

@@ -34,7 +34,8 @@
 #define SVO_RS_ATT_SMALL 11008
 #define SVO_LMEDS_MAX_N 14          // 8 .. 14 point pairs: cv::findFundamentalMat's LMedS registrator instead of the RANSAC (`npoints >= 15`)
 #define SVO_LMEDS_ITERS 300          // ... its fixed budget: RANSACUpdateNumIters(0.99, outlier ratio 0.45, 7 points, 1000) = cvRound(ln 0.01 / ln(1 - 0.55^7))
-#define SVO_RS_ST 8                 // ints of schedule state per lane-octave (rs_sched)
+#define SVO_RS_ST 12                // ints of schedule state per lane-octave (rs_sched)
+#define SVO_RS_EXT 9216             // attempts a lane may draw beyond its table row, continuing cv::RNG on the device (k_match.hip, rs_schedule_block): table + this >= getSubset's 10000 + one chunk, so that "no sample in 10000 attempts" is decided as OpenCV decides it
 
 // status-word bits (svo_debug_get_status_word)
 #define SVO_ST_CAND_OVERFLOW 1u
@@ -170,6 +171,7 @@ struct DevCtx {
     int* rs_gen;              // [n_lanes][2]  end of the samples the current chunk generated
     const unsigned short* rs_att;   // [n = 8 .. SVO_RS_SMALL_N - 1][SVO_RS_ATT_SMALL][8] then [n = SVO_RS_SMALL_N .. rs_att_nmax][SVO_RS_ATT][8]: the attempts of OpenCV's sampler for n = 8 .. rs_att_nmax points (host-built, k_ransac_schedule)
     int rs_att_nmax;
+    const unsigned long long* rs_att_state;   // [rs_att_nmax + 1] cv::RNG's state after the last tabulated attempt of row n (where the device continues the stream)
     int rs_c1;                // end of chunk 1 (= what phase 0 of the schedule draws): SVO_RANSAC_CHUNK1, or more together with rs_c0 for a handful of lanes
     int rs_c0;                // end of chunk 0 of the sample schedule: SVO_RANSAC_CHUNK0, or SVO_RANSAC_CHUNK1 (chunk 1 empty, its two launches skipped) for a handful of lanes, where a launch costs more than the samples it saves (svo_api.hip)
     unsigned short* rs_smp;   // [n_lanes][2][SVO_RANSAC_PAD][8] the seven indices of every sample, as OpenCV's getSubset draws them

@@ -133,6 +133,12 @@ def test_bench_launches_its_own_ranks_when_started_plainly(tmp_path):
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-2000:]
     line = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2 and line["dist"]["gathered_tables_equal"]
+    # the fields that make the first real N > 1 record self-explaining: ranks seen, RCCL version, and each rank's own
+    # ms_per_step beside the MAX-reduced one of the line
+    d = line["dist"]
+    assert d["ranks_seen"] == 1 and "rccl_version" in d and len(d["rank_ms_per_step"]["by_rank"]) == 2
+    assert 0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= line["ms_per_step"] * 1.001 + 1e-3
+    assert d["rank_host_enqueue_ms_per_step"]["max"] > 0 and d["host_cores"] >= 1
     # without the test hook a one-GPU box must REFUSE --gpus 2 (exit code 2, nothing that looks like a result line)
     env.pop("BENCH_FORCE_DEVICE")
     pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)

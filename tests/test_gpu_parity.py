@@ -344,6 +344,77 @@ def test_few_candidates_reach_the_sampler_edge_cases(golden_dir, ifm_method):
     assert all(7 <= l <= 9 and 7 <= r <= 9 for n, l, r in lmeds_inliers if n <= 13) and len(lmeds_inliers) >= 6, lmeds_inliers
 
 
+def line_scene(n, ys, d, outlier_frac, seed, W=640, H=480, disp=20, off_line=True):
+    """Stage-4 input lists built by hand: n pairings whose keypoints sit on the rows `ys` at INTEGER x; the current frame is the previous
+    one shifted by d pixels in x (pure translation: every correspondence satisfies F = [t]_x exactly); a fraction of the pairings is
+    moved somewhere else in the current frame (outliers).  Every keypoint has a random descriptor of its own, so the brute-force tracker
+    pairs pairing k of the previous frame with its own continuation."""
+    rng = np.random.RandomState(seed)
+    per = max(1, n // len(ys))
+    pts = []
+    for y in ys:
+        xs = rng.choice(np.arange(60, W - 60), per, replace=False)
+        pts += [(float(x), float(y)) for x in np.sort(xs)]
+    pts = np.array(pts, np.float32)
+    n = len(pts)
+
+    def kps(xy):
+        k = np.zeros(len(xy), keypoint_dtype)
+        k["x"], k["y"], k["size"], k["response"], k["class_id"] = xy[:, 0], xy[:, 1], 31.0, 1.0, -1
+        return k
+    desc, descr = rng.randint(0, 256, (n, 32)).astype(np.uint8), rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    m = np.zeros(n, dmatch_dtype); m["queryIdx"] = np.arange(n); m["trainIdx"] = np.arange(n); m["distance"] = 10.0
+    cur = pts + np.array([d, 0], np.float32)
+    out = rng.rand(n) < outlier_frac
+    if off_line:
+        cur[out, 1] = rng.randint(40, H - 40, int(out.sum())).astype(np.float32); cur[out, 0] = rng.randint(60, W - 60, int(out.sum())).astype(np.float32)
+    else:
+        yi = np.searchsorted(np.array(ys, np.float32), pts[:, 1])
+        cur[out, 1] = np.array(ys, np.float32)[(yi[out] + 1) % len(ys)]
+    order = np.lexsort((cur[:, 0], cur[:, 1]))                             # the current lists are row-sorted too
+    curL = cur[order]
+    sh = np.array([disp, 0], np.float32)
+    return dict(pkl=kps(pts), pkr=kps(pts - sh), pdl=desc, pdr=descr, pm=m, ckl=kps(curL), ckr=kps(curL - sh), cdl=desc[order], cdr=descr[order], cm=m.copy(), W=W, H=H)
+
+
+def test_collinear_point_sets_continue_the_sampler_past_its_table(golden_dir):
+    """ADVICE r05 (medium) + oracle v7.  Keypoints along a few image rows at integer coordinates: most of cv::findFundamentalMat's samples
+    are rejected by checkSubset (the last point is collinear with two earlier ones), so a lane needs far more ATTEMPTS than the 1152 a
+    row of the host-built table holds -- the device now continues cv::RNG from the state the row ended in (rs_schedule_block) instead of
+    ending the schedule early.  Cases: two / three rows with half the pairings thrown off the rows (hundreds of samples visited, most
+    all-inlier attempts rejected), every point on ONE row (no sample in getSubset's 10000 attempts: the run ends as OpenCV's does, no
+    model), few points on two rows (LMedS: getSubset's default 1000 attempts, oracle v7), and exact pure translations on an integer grid
+    (the 7-point cubic loses its leading coefficient: cv::solveCubic's quadratic branch, oracle v7).  Stage 4 alone on caller-supplied
+    lists: tracked pairs and all eight stage counters equal the oracle's, and SVO_ST_INTERNAL stays down."""
+    _, cam, p = load_small(golden_dir)
+    visited_max, n_cases, ended_without_model = 0, 0, 0
+    ctx = hip.Context(n_lanes=1, max_w=640, max_h=480, max_kps=1024, max_cand=1 << 15)
+    ctx.set_params(p); ctx.set_camera(cam)
+    zeros = np.zeros(481, np.int64)
+    cases = [([100, 300], 120, 0.5, True), ([100, 200, 300], 120, 0.5, True), ([100, 300], 80, 0.7, True), ([100, 300], 200, 0.3, True), ([100], 100, 0.5, True),
+             ([100, 300], 120, 0.5, False), ([100, 300], 14, 0.0, True), ([100, 300], 12, 0.2, True), ([100, 300], 10, 0.0, False), ([60, 100, 300, 420], 200, 0.6, True),
+             ([90, 91, 92, 93, 94, 95, 96, 97, 98, 99, 100, 101], 96, 0.2, True)]
+    for ys, n, of, off in cases:
+        for seed in range(3):
+            s = line_scene(n, ys, 4.0, of, seed, off_line=off)
+            for side, (k1, d1, k0, d0) in enumerate(((s["pkl"], s["pdl"], s["ckl"], s["cdl"]), (s["pkr"], s["pdr"], s["ckr"], s["cdr"]))):
+                ctx.put_features(0, 1, side, k1, d1, s["W"], s["H"])
+                ctx.put_features(0, 0, side, k0, d0, s["W"], s["H"])
+            ctx.put_matches(0, 1, s["pm"]); ctx.put_matches(0, 0, s["cm"])
+            ctx.run_stages(hip.RUN_TRACK)
+            want, want_ts = O().track(p, p.orb_max_distance, s["pkl"], s["pdl"], s["pkr"], s["pdr"], s["pm"], zeros, s["ckl"], s["cdl"], s["ckr"], s["cdr"], s["cm"], zeros, s["W"], s["H"], stats=True)
+            got, ts = ctx.tracked(0), ctx.result(0).track_stats
+            assert [int(v) for v in ts[:8]] == [int(v) for v in want_ts], (ys, n, of, off, seed, list(ts[:8]), list(want_ts))
+            assert got.tobytes() == want.tobytes(), (ys, n, of, off, seed, len(got), len(want))
+            assert not (ctx.status_word(0) & 8), (ys, n, of, off, seed, "SVO_ST_INTERNAL: the sampler ran out of attempts")
+            visited_max = max(visited_max, int(ts[4]), int(ts[5])); n_cases += 1
+            ended_without_model += int(ts[1] >= 15 and ts[4] == 0 and ts[5] == 0)
+    ctx.close()
+    # two rows, half the points off them: ~11 % of the all-on-the-rows attempts pass, yet several hundred samples were visited -- more than a
+    # table row of 1152 attempts can yield at that pass rate is not asserted (the pass rate is the data's), the equality above is the check
+    assert n_cases == 33 and visited_max >= 500 and ended_without_model >= 3, (n_cases, visited_max, ended_without_model)
+
+
 def test_armed_post_event_is_disarmed_by_a_failing_call(golden_dir):
     """svo_record_after_post arms ONE call.  When that call leaves early -- here with SVO_ERR_STATE: a post-processing call on a
     context whose geometry was never set up -- the event is still recorded (a waiter is released) and disarmed, so that a later, unrelated

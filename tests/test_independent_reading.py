@@ -92,8 +92,13 @@ def test_pyramid_level_is_half_pixel_centred_bilinear(scene):
     for l in range(1, 4):
         got = O.resize(prev, lw[l], lh[l]).astype(np.float64)
         mine = IR.bilinear_resize(prev, lw[l], lh[l])
-        # rounding to 8 bits (<= 0.5) plus the 11-bit fixed-point weights of each axis (<= 255 * 2 / 4096 = 0.125)
-        assert np.abs(got - mine).max() <= 0.63 and np.abs(got - mine).mean() < 0.26
+        # oracle v7 = cv::resize's 8-bit path: the 11-bit weights of each axis (<= 0.125), the row sums cut to 1/128 grey level, each of the two
+        # weighted rows cut DOWN to a quarter grey level before they are added (up to -0.5 together), then one rounding of the quarters
+        # (+-0.5): the result leans low -- within (-1.13, +0.63] of the float bilinear value, -0.12 on average, and equal to the rounded
+        # float value on 87 % of the pixels (the single-rounding form of versions <= 6 stayed within +-0.63)
+        d = got - mine
+        assert -1.13 < d.min() and d.max() <= 0.63 and np.abs(d).mean() < 0.30 and -0.2 < d.mean() < -0.05
+        assert (got == np.floor(mine + 0.5)).mean() > 0.85
         prev = got.astype(np.uint8)
 
 
@@ -220,27 +225,33 @@ def test_ransac_samples_are_cv_rng_under_getsubset_rules():
         st = nxt
 
     def collinear(p, idx):
+        # haveCollinearPoints: Point2f differences are taken in FLOAT, then widened (`double dx1 = ptr[j].x - ptr[i].x;`, oracle v7)
         i = 6
+        assert p.dtype == np.float32
         for j in range(i):
-            dx1 = float(p[idx[j], 0]) - float(p[idx[i], 0]); dy1 = float(p[idx[j], 1]) - float(p[idx[i], 1])
+            dx1 = float(p[idx[j], 0] - p[idx[i], 0]); dy1 = float(p[idx[j], 1] - p[idx[i], 1])
             for k in range(j):
-                dx2 = float(p[idx[k], 0]) - float(p[idx[i], 0]); dy2 = float(p[idx[k], 1]) - float(p[idx[i], 1])
+                dx2 = float(p[idx[k], 0] - p[idx[i], 0]); dy2 = float(p[idx[k], 1] - p[idx[i], 1])
                 if abs(dx2 * dy1 - dy2 * dx1) <= np.finfo(np.float32).eps * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
                     return True
         return False
 
     def samples(p1, p2, count):
         g, out, n = stream(), [], len(p1)
+        max_attempts = 1000 if n <= 14 else 10000      # getSubset's maxAttempts: LMedS's run takes the default, the RANSAC's passes 10000 (oracle v7)
         while len(out) < count:
-            idx = []
-            while len(idx) < 7:
-                v = next(g) % n
-                if v not in idx:
-                    idx.append(v)
-            if collinear(p1, idx) or collinear(p2, idx):
-                continue
+            for _ in range(max_attempts):
+                idx = []
+                while len(idx) < 7:
+                    v = next(g) % n
+                    if v not in idx:
+                        idx.append(v)
+                if not (collinear(p1, idx) or collinear(p2, idx)):
+                    break
+            else:
+                break                                   # `if (!found) break;`: the run ends with the samples it has
             out.append(idx)
-        return np.array(out, np.int32)
+        return np.array(out, np.int32).reshape(-1, 7)
 
     rng = np.random.RandomState(17)
     n_rejected = 0
@@ -259,6 +270,15 @@ def test_ransac_samples_are_cv_rng_under_getsubset_rules():
     got = O.ransac_samples(p1, p2, 5)
     for s in got:
         assert not collinear(p1, list(s))
+    # every point of image 1 on one line: no attempt ever passes, getSubset gives up (after 1000 attempts for LMedS's 12 points, 10000 for the
+    # RANSAC's 40) and the run ends without a sample -- literal reading and oracle alike
+    for n in (12, 40):
+        q1 = np.c_[rng.uniform(50, 600, n), np.full(n, 77.0)].astype(np.float32); q2 = rng.uniform(50, 600, (n, 2)).astype(np.float32)
+        assert len(samples(q1, q2, 3)) == 0 and len(O.ransac_samples(q1, q2, 3)) == 0
+    # sub-pixel coordinates (scaled octaves) whose float differences round: the FLOAT subtraction decides, as in the oracle
+    q1 = (rng.uniform(40, 1200, (60, 2)) / 1.2 ** 3).astype(np.float32); q2 = (q1 * np.float32(1.0001) + np.float32(0.3)).astype(np.float32)
+    q1[10:30, 1] = q1[10, 1] + np.arange(20, dtype=np.float32) * np.float32(1e-5)           # a nearly horizontal run: cross products at the threshold
+    assert (O.ransac_samples(q1, q2, 200) == samples(q1, q2, 200)).all()
     # fewer than 8 points: no sampling at all (exactly 7 take findFundamentalMat's direct path)
     assert len(O.ransac_samples(p1[:7], p2[:7], 3)) == 0
 
@@ -365,3 +385,93 @@ def test_stop_rule_is_ransac_update_num_iters_for_every_count():
         assert O.ransac_niters(cnt, n, k) == literal(cnt, n, k), (cnt, n, k)
     assert checked > 45000
     assert O.ransac_niters(7, 8, 1000) == literal(7, 8, 1000) and O.ransac_niters(300, 300, 1000) == 0      # all inliers: the loop ends
+
+
+def test_pyramid_step_is_cv_resize_8bit_linear_literal_reading():
+    """Oracle v7: a pyramid level is cv::resize(prev, INTER_LINEAR) on 8-bit data as OpenCV 2.4 / 3.x compute it.  A literal
+    numpy reading of that code path, written from the same recollection but sharing no code with the C oracle: tap positions and weights in
+    FLOAT (`fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx`), the two weights rounded separately to shorts
+    (`saturate_cast<short>(w * 2048)`, half to even), horizontal pass in int, and the uchar specialisation of the vertical pass with its
+    two-step rounding: ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  Byte for byte, over the level sizes of every
+    benchmarked image size and on noise."""
+    def table(src, dst):
+        scale = 1.0 / (float(dst) / float(src))
+        fx = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        sx = np.floor(fx.astype(np.float64)).astype(np.int64)
+        fx = fx - sx.astype(np.float32)                                    # float32 - float32
+        lo, hi = sx < 0, sx >= src - 1
+        fx[lo | hi] = np.float32(0); sx[lo] = 0; sx[hi] = src - 1
+        a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)      # numpy rint: half to even, as cvRound
+        a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+        return sx, a0, a1
+
+    def cv_resize(img, dw, dh):
+        H, W = img.shape
+        xi, a0, a1 = table(W, dw); yi, b0, b1 = table(H, dh)
+        im = img.astype(np.int64)
+        x1 = np.minimum(xi + 1, W - 1)
+        Hrow = im[:, xi] * a0[None, :] + im[:, x1] * a1[None, :]           # HResizeLinear: every source row once
+        y1 = np.minimum(yi + 1, H - 1)
+        S0, S1 = Hrow[yi], Hrow[y1]
+        v = (((b0[:, None] * (S0 >> 4)) >> 16) + ((b1[:, None] * (S1 >> 4)) >> 16) + 2) >> 2
+        assert v.min() >= 0 and v.max() <= 255
+        return v.astype(np.uint8)
+
+    rng = np.random.RandomState(6)
+    n_off_weights = 0
+    for (W, H) in ((640, 480), (1280, 960), (1241, 376), (97, 65)):
+        lw, lh, _ = O.pyramid_sizes(W, H, 8)
+        img = rng.randint(0, 256, (H, W)).astype(np.uint8)
+        if W == 640:
+            img = scene_image()
+        prev = img
+        for l in range(1, 8):
+            xi, a0, a1 = table(prev.shape[1], int(lw[l]))
+            n_off_weights += int((a0 + a1 != 2048).sum())
+            got, want = O.resize(prev, int(lw[l]), int(lh[l])), cv_resize(prev, int(lw[l]), int(lh[l]))
+            assert got.shape == want.shape and (got == want).all(), (W, H, l, int((got != want).sum()))
+            prev = got
+    # the tables themselves through the oracle's hook: same first taps, same weight pairs
+    for src, dst in ((1280, 1067), (960, 800), (1067, 889), (376, 313), (51, 43)):
+        idx, w01 = O.resize_table(src, dst)
+        sx, a0, a1 = table(src, dst)
+        assert (idx == sx).all() and ((w01 & 0xFFFF) == a0).all() and ((w01 >> 16) == a1).all()
+    assert n_off_weights == 0        # (on these sizes the separately rounded weights always add up to 2048; the code does not rely on it)
+
+
+def scene_image():
+    w = SyntheticStereoWorld(640, 480, 400.0, 0.12, seed=5, n_frames=2)
+    return w.render(1)[0].numpy()
+
+
+def test_seven_point_with_a_vanishing_cubic_coefficient():
+    """Oracle v7: run7Point hands det(lambda g + f2) to cv::solveCubic, which has a branch for a leading coefficient that is EXACTLY zero (then
+    a quadratic, or a linear equation).  Integer coordinates under a pure image translation reach it: up to version 6 the oracle divided by
+    zero there (NaN models, no inliers).  Now: the matrix g itself (the root at infinity of this parametrisation) first, then the finite
+    roots -- and for a pure translation in x one of them is the exact answer [t]_x.  Every model lies in the null space of the seven
+    constraints and is singular."""
+    cases = [(np.array([[-1, 3, -1, 0, 3, 2, -1], [3, 1, -1, 3, -3, 1, -3]], np.float32).T, np.array([1.0, 0.0], np.float32))]
+    rng = np.random.RandomState(0)
+    hits = 0
+    for trial in range(4000):
+        if trial < len(cases):
+            p1, shift = cases[trial]
+        else:
+            p1 = rng.randint(-3, 4, (7, 2)).astype(np.float32); shift = np.array([rng.randint(1, 4), 0], np.float32)
+        p2 = p1 + shift
+        F = O.seven_point(p1, p2)
+        if len(F) != 2:
+            continue
+        hits += 1
+        assert np.isfinite(F).all()
+        h1, h2 = np.c_[p1, np.ones(7)].astype(np.float64), np.c_[p2, np.ones(7)].astype(np.float64)
+        found_exact = False
+        for M in F:
+            sc = np.abs(M).max()
+            assert sc > 0
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, M, h1)).max() < 1e-9 * sc          # x2^T F x1 = 0 for the seven pairs
+            assert abs(np.linalg.det(M / sc)) < 1e-9                                       # singular
+            E = M / sc
+            found_exact |= bool(np.abs(E - E[2, 1] * np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]])).max() < 1e-9 and abs(E[2, 1]) > 0.5)
+        assert found_exact                                                                  # the epipolar geometry of a pure x translation
+    assert hits >= 20, hits

@@ -81,13 +81,14 @@ def test_config1_plumbing_sequence_tracks_ground_truth():
             pose = pose @ est
     assert n_valid == 19
     errs = np.array(errs)
-    # observed on this sequence with oracle v5 (steps of 0.05-0.3 m, ~90 tracked pairs per frame): per-frame rotation error median
-    # 1.15 mrad / max 2.1 mrad, translation error median 7.9 mm / max 16 mm; after 19 chained steps 3.8 mrad and 27 mm.
-    # Bounds = observed x 1.5 (v4's other samples: median 0.7 mrad / 5 mm, chained 6 mrad / 52 mm)
-    assert np.median(errs[:, 0]) < 1.75e-3 and errs[:, 0].max() < 3.3e-3
-    assert np.median(errs[:, 1]) < 0.012 and errs[:, 1].max() < 0.025
+    # observed on this sequence with oracle v7 (steps of 0.05-0.3 m, ~92 tracked pairs per frame): per-frame rotation error median
+    # 0.98 mrad / max 3.6 mrad, translation error median 7.9 mm / max 22 mm; after 19 chained steps 2.8 mrad and 37 mm.
+    # Bounds = observed x 1.5 (v5 / v6: median 1.15 mrad / max 2.1 mrad, 7.9 mm / 16 mm, chained 3.8 mrad / 27 mm; v4: 0.7 mrad / 5 mm,
+    # chained 6 mrad / 52 mm -- what a change of the yardstick's third-party stand-ins moves)
+    assert np.median(errs[:, 0]) < 1.75e-3 and errs[:, 0].max() < 5.5e-3
+    assert np.median(errs[:, 1]) < 0.012 and errs[:, 1].max() < 0.034
     er, et = pose_error(pose, w.poses[19])
-    assert er < 6e-3 and et < 0.041
+    assert er < 6e-3 and et < 0.056
 
 
 def test_oracle_extras_against_frozen_vectors(golden_dir):

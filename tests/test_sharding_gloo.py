@@ -32,7 +32,7 @@ def _worker(rank, world, port, lanes, q):
     allrec = bench.gather_records(rec, world)
     tmax = bench.reduce_max(0.5 + rank, torch.device("cpu"), world)
     try:
-        audit = bench.dist_audit(allrec, rec, world, rank, rank, torch.device("cpu"))        # pretend rank r sits on device r
+        audit = bench.dist_audit(allrec, rec, world, rank, rank, torch.device("cpu"), own_ms_per_step=2.5 + rank, own_enqueue_ms_per_step=1.0 + 0.5 * rank)   # pretend rank r sits on device r
     except Exception as e:                                                                 # (device name lookup needs a GPU)
         audit = {"error": repr(e)}
     q.put((rank, seeds, allrec.numpy().tobytes(), tmax, audit))
@@ -62,6 +62,9 @@ def test_two_rank_sharding_and_gather():
     assert "error" not in a0, a0
     assert a0 == a1 and a0["backend"] == "gloo" and a0["world_size"] == 2 and a0["ranks_seen"] == 2
     assert a0["gathered_tables_equal"] and a0["own_records_at_own_slot"] and len(a0["hosts"]) == 1
+    # every rank's own clock beside the MAX-reduced one: a slow or missing rank shows in the first N > 1 record
+    assert a0["rank_ms_per_step"] == {"min": 2.5, "max": 3.5, "by_rank": [2.5, 3.5]} and a0["rank_host_enqueue_ms_per_step"] == {"min": 1.0, "max": 1.5}
+    assert len(a0["devices"]) == 2 and a0["host_cores"] >= 1 and "rccl_version" in a0
 
 
 def test_frame_schedule_is_ping_pong():
