@@ -287,10 +287,13 @@ __global__ void __launch_bounds__(256) k_resize(DevCtx c, int level, FastDiv div
             const uint32_t t1 = __builtin_amdgcn_perm(w1hi, w1lo, sel[k]);
             const uint32_t top = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t0), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
             const uint32_t bot = __builtin_amdgcn_udot2(__builtin_bit_cast(rz_u16x2, t1), __builtin_bit_cast(rz_u16x2, wx[k]), 0u, false);
-            // cv::resize's uchar VResizeLinear (oracle v7): the row sums lose 4 bits, each product is cut to quarter grey levels, then one rounding
-            v[k] = ((__umul24(top >> 4, wy0) >> 16) + (__umul24(bot >> 4, wy1) >> 16) + 2u) >> 2;     // <= 255
+            // cv::resize's uchar VResizeLinear (oracle v7): the row sums lose 4 bits, each product is cut to quarter grey levels, then one rounding:
+            // ((b0 * (top >> 4)) >> 16) + ((b1 * (bot >> 4)) >> 16) + 2.  The two high halves come out of ONE v_perm, their sum + 2 out of one v_sad_u16
+            const uint32_t m0 = __umul24(top >> 4, wy0), m1 = __umul24(bot >> 4, wy1);
+            v[k] = __builtin_amdgcn_sad_u16(__builtin_amdgcn_perm(m1, m0, 0x07060302u), 0u, 2u);       // <= 1022; >> 2 below, two at a time
         }
-        const uint32_t out = (v[0] | (v[1] << 8)) | ((v[2] << 16) | (v[3] << 24));
+        const rz_u16x2 p01 = __builtin_bit_cast(rz_u16x2, v[0] | (v[1] << 16)) >> 2, p23 = __builtin_bit_cast(rz_u16x2, v[2] | (v[3] << 16)) >> 2;
+        const uint32_t out = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, p23), __builtin_bit_cast(uint32_t, p01), 0x06040200u);
         if (c.debug_mode == 7 && out != 0x12345678u) continue;
         *(uint32_t*)(dst + (long long)y * d.pitch + x4) = out;   // pitch is a multiple of 64: the tail of the last dword is padding
     }
@@ -493,6 +496,10 @@ __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uin
     {
         // window row of score row r: r + 3; its N / S operands: window rows r, r + 6.  col[20 i + 1] = centre dword of window
         // row 8 rb + i (bytes 4 gq + 4 ..: the group's four positions), col[20 i] / col[20 i + 2] = the dwords left / right of it
+        // (Bank conflicts: the row blocks are 8 x 20 = 160 dwords apart, 0 modulo the LDS's 32 banks, so the two row blocks of a half-wave
+        // read the same 16 banks in every one of these loads -- a systematic 2-way conflict, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.42.
+        // The pitch cannot be padded away: the LDS-DMA lands 16-byte chunks back to back, and 8 rows x any multiple of 4 dwords is 0 modulo 32.
+        // What it costs: DESIGN.md section 4, round 6 -- 19.9 M cycles of LDS instructions against 143 M of VALU per launch.)
         const uint32_t* col = (const uint32_t*)tile + rb * (FT_ROWS * (FT_LW / 4)) + gq;
         uint32_t cc[FT_ROWS + 6];
 #pragma unroll

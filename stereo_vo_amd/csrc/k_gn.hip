@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
         keys[i] = ((unsigned long long)ord32(l1.response) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
     }
     __threadfence_block();
+    if (c.debug_mode == 64) return;                                            // timing probes 64-67: the set-up, phase by phase (tests/dev/gn_breakdown.py)
     // ---- m_non_max_sup mask overload on the previous-left coordinates (S5:465-474 -> S2:225-283); cap = T ----
     if (!big) {
         // at most GN_LCAP keys, a few hundred as a rule: every key counts the keys above it (the keys are unique, so the counts are the descending ranks).
@@ -498,16 +499,24 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
         // needs 45 compare-exchange stages at 512 keys (~10 us of the ~25 us this kernel spends before its first iteration).
         unsigned long long* sorted = (unsigned long long*)hkey;             // 2 PM u32 = PM u64, free until the NMS builds its hash
         __syncthreads();
+        // (round 6: this loop was 26 of the kernel's ~44 us of set-up at 380 tracks -- one dependent ds_read_b64 per key, ~70 cycles each.
+        // Four keys per step through two 16-byte reads, four steps unrolled: sixteen keys in flight.  The pad keys[T .. Pn) is 0: never above.)
         for (int i = tid; i < T; i += blockDim.x) {
             const unsigned long long k = keys[i];
             int above = 0;
-            for (int j = 0; j < T; j++) above += keys[j] > k ? 1 : 0;
+            const ulonglong2* k2 = (const ulonglong2*)keys;
+#pragma unroll 4
+            for (int j = 0; j < (T + 3) / 4; j++) {
+                const ulonglong2 a = k2[2 * j], b = k2[2 * j + 1];
+                above += (a.x > k ? 1 : 0) + (a.y > k ? 1 : 0) + (b.x > k ? 1 : 0) + (b.y > k ? 1 : 0);
+            }
             sorted[above] = k;
         }
         __syncthreads();
         for (int i = tid; i < T; i += blockDim.x) keys[i] = sorted[i];
         __syncthreads();
     } else bitonic_sort_lds<true>(keys, Pn);
+    if (c.debug_mode == 65) return;
     {
         const unsigned cell = (unsigned)((double)P.min_distance / 2.0);
         const float inv = 1.0f / (float)cell;
@@ -527,6 +536,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
         __syncthreads();
     }
     int n_non_masked = sh.n_non_masked;
+    if (c.debug_mode == 66) return;
     if (n_non_masked < 8) { if (tid == 0) { res.valid = 0; res.n_residual = 0; res.n_outliers = 0; } return; }       // S5:521-526
     // ---- triangulation (S5:529-544) ----
     const double cul = cam.l_cx, cvl = cam.l_cy, fl = cam.l_fx, cur_ = cam.r_cx, fr = cam.r_fx, baseline = cam.baseline;
@@ -539,6 +549,7 @@ __global__ void __launch_bounds__(GN_NT) k_gauss_newton(DevCtx c, GNParams P, ui
         }
     };
     triangulate();
+    if (c.debug_mode == 67) return;
     if (tid == 0) {
         double d6[6] = { 0, 0, 0, 0, 0, 0 };
         if (P.use_custom_initial_pose) { for (int k = 0; k < 6; k++) d6[k] = P.init[k]; }                            // S5:504-505

@@ -21,6 +21,7 @@
 // ------------------------------------------------------------------------------------------------------------
 #define HM_TILE 256
 
+#ifdef SVO_AB_KERNELS      // an A/B anchor, not a product form (svo_kernels.h): compiled into libsvo_hip_ab.so only
 __global__ void __launch_bounds__(256) k_gather_mdesc(DevCtx c)
 {
     // blockIdx.z: bit 0 = side, bit 1 = 0 previous / 1 current slot; 8 threads per descriptor (one dword each)
@@ -38,6 +39,7 @@ __global__ void __launch_bounds__(256) k_gather_mdesc(DevCtx c)
     uint32_t* dst = (uint32_t*)(c.mdesc + (feat_base(c, vl, slot, side) + m) * 32);
     dst[w] = src[w];
 }
+#endif
 
 // ---- the brute force on the matrix cores ------------------------------------------------------------------------
 // Hamming(q, t) over 256 bits IS a dot product: with bit b encoded as q' = +64 / -64 (b = 0 / 1) for the query and
@@ -177,7 +179,9 @@ __device__ __forceinline__ void hamming_body(const DevCtx& c, int mode, int nspl
 
 // (a build capped at 128 VGPRs = 4 waves per SIMD instead of 3 pays one 16-byte spill reloaded per train tile: 50.5 against 45.4 us
 // per launch at 64 lanes, profiles/r04f -- dropped)
+#ifdef SVO_AB_KERNELS      // an A/B anchor, not a product form (svo_kernels.h): compiled into libsvo_hip_ab.so only
 __global__ void __launch_bounds__(256) k_hamming(DevCtx c, int mode, int nsplit) { hamming_body(c, mode, nsplit); }
+#endif
 
 // ---- the same brute force on gfx950's block-scaled FP4 matrix path (round 4) ------------------------------------------------
 // v_mfma_scale_f32_32x32x64_f8f6f4 with both operands FP4 (E2M1) runs at twice the int8 rate on half the operand bytes, and E2M1 holds
@@ -1412,6 +1416,7 @@ __device__ __forceinline__ int fm_error_key(float e) { return e != e ? (int)0xFF
 // oracle's own expression (fm_inlier).  In practice nothing is ever that close; the replay is there so that the counts are
 // the oracle's by construction.
 typedef double rc_d4 __attribute__((ext_vector_type(4)));
+#ifdef SVO_AB_KERNELS      // an A/B anchor, not a product form (svo_kernels.h): compiled into libsvo_hip_ab.so only
 __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
 {
     SVO_TL_SCOPE(c, TL_RS_COUNT, chunk);
@@ -1491,6 +1496,7 @@ __global__ void __launch_bounds__(256) k_ransac_count_mfma(DevCtx c, int chunk)
         rs_publish_best(c, vl, side, chunk, n, best, best_h);
     }
 }
+#endif
 
 // The count for launches that fill the GPU (many lanes): SIXTEEN models x sixteen pairs per matrix-core tile, and the
 // numerator on the matrix cores as well.  d = x2^T F x1 is one bilinear form -- the oracle's dA and dB are two roundings of it --
@@ -2056,6 +2062,22 @@ hipError_t configure_match(int max_kps)
     return e;
 }
 
+// Which kernel forms this library holds: the product forms always; the A/B anchors (the int8 matcher SVO_HAM_FP4=0, the RANSAC count forms
+// SVO_DEBUG_MODE=14 / 52) only when it was compiled with -DSVO_AB_KERNELS (libsvo_hip_ab.so: tests and A/B runs load it through SVO_HIP_LIB).
+// svo_create refuses a knob that asks for a form the library does not hold.
+bool svo_ab_kernels_built()
+{
+#ifdef SVO_AB_KERNELS
+    return true;
+#else
+    return false;
+#endif
+}
+bool svo_ab_form_requested(int debug_mode)
+{
+    const char* e = getenv("SVO_HAM_FP4");
+    return (e && atoi(e) == 0) || debug_mode == 14 || debug_mode == 52;
+}
 // the FP4 form of the matrix-core brute force (k_hamming_f4) unless SVO_HAM_FP4=0
 static bool hamming_fp4()
 {
@@ -2066,12 +2088,16 @@ static bool hamming_fp4()
 
 void launch_hamming(const DevCtx& c, int mode, int nsplit, hipStream_t st)
 {
-    const bool f4 = hamming_fp4();
-    // (the int8 form reads the paired descriptors from a list laid out by a kernel of its own; the FP4 form gathers through the pairing lists)
-    if (mode && !f4) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
     const dim3 grid(c.n_lanes * c.oct_cap, (c.max_kps + HM_QB - 1) / HM_QB, (mode ? 2 : 1) * nsplit);
-    if (f4) hipLaunchKernelGGL(k_hamming_f4, grid, dim3(256), 0, st, c, mode, nsplit);
-    else hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, c, mode, nsplit);
+#ifdef SVO_AB_KERNELS
+    // (the int8 form reads the paired descriptors from a list laid out by a kernel of its own; the FP4 form gathers through the pairing lists)
+    if (!hamming_fp4()) {
+        if (mode) hipLaunchKernelGGL(k_gather_mdesc, dim3((c.max_kps * 8 + 255) / 256, c.n_lanes * c.oct_cap, 4), dim3(256), 0, st, c);
+        hipLaunchKernelGGL(k_hamming, grid, dim3(256), 0, st, c, mode, nsplit);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(k_hamming_f4, grid, dim3(256), 0, st, c, mode, nsplit);       // (svo_create refuses SVO_HAM_FP4=0 in a library without the A/B forms)
 }
 
 void launch_match_lr_filter(const DevCtx& c, int one_to_one, double max_y_diff, hipStream_t st)
@@ -2119,9 +2145,11 @@ void launch_ransac_count(const DevCtx& c, int chunk, hipStream_t st)
     const int ns = 3 * (((RS_CHUNK_END(chunk) + SVO_RANSAC_REG - 1) / SVO_RANSAC_REG) * SVO_RANSAC_REG - RS_CHUNK_BEGIN(chunk)), dm = c.debug_mode;
     const dim3 g16((ns + 15) / 16, 2, c.n_lanes * c.oct_cap);
     const bool many = c.n_lanes * c.n_oct > 8;
-    if (dm == 14) hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk);
-    else if (dm == 52) hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk);
-    else if (many || dm == 53 || dm == 54) {
+#ifdef SVO_AB_KERNELS
+    if (dm == 14) { hipLaunchKernelGGL(k_ransac_count<16>, g16, dim3(256), 0, st, c, chunk); return; }
+    if (dm == 52) { hipLaunchKernelGGL(k_ransac_count_mfma, g16, dim3(256), 0, st, c, chunk); return; }
+#endif
+    if (many || dm == 53 || dm == 54) {
         // The pairs of a lane CAN be split over several blocks per chunk (SVO_RC_SPLIT = s0[,s1[,s2]]): chunk 0 is two blocks per lane and side,
         // a chain of dependent f64 verdicts with one wave per SIMD (43 us alone, 29 us on four blocks each).  In the batched schedule it buys
         // nothing: 70.6 k pairs/s with (4, 1, 1), 71.0 k unsplit, 67.9 k with four everywhere (r05f, r05r).  Default: unsplit.

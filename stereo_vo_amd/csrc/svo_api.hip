@@ -438,6 +438,10 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.det_status, (size_t)L)); d.det_ahead = 0;
     d.bf_dist = nullptr;
     { const char* dm = getenv("SVO_DEBUG_MODE"); d.debug_mode = dm ? atoi(dm) : 0; }
+    if (svo_ab_form_requested(d.debug_mode) && !svo_ab_kernels_built()) {
+        ctx->last_error = "SVO_HAM_FP4=0 / SVO_DEBUG_MODE=14 / 52 ask for an A/B kernel form that this library was built without: load libsvo_hip_ab.so (SVO_HIP_LIB) or build with -DSVO_AB_KERNELS";
+        return SVO_ERR_UNSUPPORTED;
+    }
     d.rs_c0 = SVO_RANSAC_CHUNK0; d.rs_c1 = SVO_RANSAC_CHUNK1;      // (set per call where the RANSAC is launched)
     { const char* rp = getenv("SVO_REST_PRIO"); d.rest_prio = rp ? (atoi(rp) & 3) : 0; }
     // SVO_TIMELINE=1: every kernel stamps the hull of its launch on the device's wall clock (svo_device.h, TlScope; svo_debug_timeline)

@@ -20,7 +20,11 @@ struct GNParams {
 //   product, few lanes (one stream alone):   k_hamming_f4, k_ransac_hyp (16 lanes per sample), k_ransac_count<4> (VALU, for latency)
 //   product, other entry points:             k_hamming_plain (svo_hamming_match), k_track_gate (multi-octave contexts), k_project_points
 //   A/B only (never launched by default):    k_hamming + k_gather_mdesc (the int8 matcher, SVO_HAM_FP4=0), k_ransac_count_mfma (4 x 4 tiles,
-//                                            SVO_DEBUG_MODE=52), k_ransac_count<16> (SVO_DEBUG_MODE=14)
+//                                            SVO_DEBUG_MODE=52), k_ransac_count<16> (SVO_DEBUG_MODE=14).  Since round 6 these are compiled only
+//                                            under -DSVO_AB_KERNELS: the product libsvo_hip.so does not contain them (svo_create refuses the
+//                                            knobs there), libsvo_hip_ab.so does -- tests and A/B runs load it through SVO_HIP_LIB.
+bool svo_ab_kernels_built();                   // k_match.hip: compiled with -DSVO_AB_KERNELS (libsvo_hip_ab.so)
+bool svo_ab_form_requested(int debug_mode);    // SVO_HAM_FP4=0 or SVO_DEBUG_MODE 14 / 52 in the environment
 hipError_t svo_upload_tables();
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE) and is shared by every context of the process on that
 // device: keyed by both, only ever raised -- a later, smaller context must not lower the limit under an earlier context's launches,

@@ -31,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(json.dumps(out))
 else:
     for nt in sys.argv[1:] or ["384"]:
-        for dm in ("0", "10", "11", "60", "61", "62", "63"):
+        for dm in ("0", "64", "65", "66", "67", "10", "11", "60", "61", "62", "63"):
             env = dict(os.environ, SVO_DEBUG_MODE=dm, SVO_GN_NT=nt)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
             print("NT", nt, "debug", dm, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1])

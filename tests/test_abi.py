@@ -20,6 +20,22 @@ def test_library_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_ab_kernel_forms_live_in_their_own_library():
+    """the A/B-only kernel forms (csrc/svo_kernels.h: the int8 matcher, two RANSAC count forms) are compiled under
+    -DSVO_AB_KERNELS into libsvo_hip_ab.so only; the product library neither defines nor launches them.  Both export the same C-ABI."""
+    import subprocess
+    prod, ab = os.path.join(ROOT, "stereo_vo_amd", "libsvo_hip.so"), os.path.join(ROOT, "stereo_vo_amd", "libsvo_hip_ab.so")
+    assert os.path.exists(ab), "libsvo_hip_ab.so missing: run __graft_entry__.build()"
+    syms = {p: subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout for p in (prod, ab)}
+    for kernel in ("k_gather_mdesc", "19k_ransac_count_mfma6DevCtxi", "9k_hamming6DevCtxii"):
+        assert kernel not in syms[prod] and kernel in syms[ab], kernel
+    for kernel in ("k_hamming_f4", "k_ransac_count_mfma16", "k_ransac_hyp_thread"):
+        assert kernel in syms[prod] and kernel in syms[ab], kernel
+    Lab = C.CDLL(ab)
+    for name in hip.EXPORTS + hip.BATCH_EXPORTS:
+        assert getattr(Lab, name) is not None
+
+
 def test_batch_scheduler_exports_every_declared_symbol():
     """include/svo_batch.h: the batched / pipelined and frame-parallel schedulers live in libsvo_hip.so, behind the C-ABI"""
     L = hip.lib()

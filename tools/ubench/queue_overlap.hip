@@ -106,5 +106,24 @@ int main(int argc, char** argv)
         sweep(L, nc + 1, t);
         for (auto& evk : ev) CK(hipEventDestroy(evk));
     }
+    // D: does a grid with a BACKLOG of pending workgroups on one stream hold back the first workgroup of a launch on another stream?  (The
+    // in-kernel timeline of the real schedule shows k_harris on the high-priority detect stream starting 50 - 160 us after its predecessor
+    // ended, right when another context's k_describe -- 11 000 blocks, chip full -- had dispatched its last block.)  Fat: 30 000 blocks x
+    // 256 threads x 20 us (about 15 waves of blocks); 60 us after it the probe, 1024 blocks x 256 threads x 5 us, on the high-priority
+    // stream or on another priority-0 stream; reported: probe start and end relative to the fat kernel's start.
+    for (int probe_on_hi = 1; probe_on_hi >= 0; probe_on_hi--) for (int k = 0; k < 8; k++) {
+        double d0 = 0, d1 = 0, fd = 0; const int R = 5;
+        for (int r = 0; r < R; r++) {
+            CK(clear()); CK(hipDeviceSynchronize());
+            hipStream_t ps = probe_on_hi ? hi : st[(k + 1) % 8];
+            hipLaunchKernelGGL(spin, dim3(30000), dim3(256), 0, st[k], d, 0, 2000, 0);
+            hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, ps, d, 2, 6000, 0);                 // a 60 us delay on the probe's own stream
+            hipLaunchKernelGGL(spin, dim3(1024), dim3(256), 0, ps, d, 1, 500, 0);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(h.data(), d, sizeof(Stamp) * 8, hipMemcpyDeviceToHost));
+            d0 += ((double)h[1].t0 - (double)h[0].t0) / 100.0; d1 += ((double)h[1].t1 - (double)h[0].t0) / 100.0; fd += (double)(h[0].t1 - h[0].t0) / 100.0;
+        }
+        printf("D fat on stream %d (30000 x 256, lasts %6.1f us), probe 1024 x 256 on %s: first probe block starts %6.1f us, last ends %6.1f us after the fat kernel's start\n",
+               k, fd / R, probe_on_hi ? "the high-priority stream" : "another priority-0 stream", d0 / R, d1 / R);
+    }
     return 0;
 }
