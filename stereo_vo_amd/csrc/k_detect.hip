@@ -763,23 +763,18 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
 // the score that 1.5 x (2 * quota) + 32 of this frame's candidates reach, and when a frame's th' turns out too high
 // (fewer than 2 * quota found) it discards the list and queues the pair for k_fast_redo at the caller's threshold,
 // after which pass 1 of this kernel selects from the complete list.  Same lists as the oracle, bit for bit, either way.
+// (the body of the selection: the LDS arrays are the caller's -- keys[SEL_MAX] u64 (the tie
+// list), sel[SEL_MAX] u32, hist[256], scan_s[32], sv[5] -- and the K winners are LEFT IN sel[]; returns K (block-uniform), 0 = this block
+// has nothing to rank: its pair was queued for the redo, is not flagged in the redo pass, or has no candidates)
 template <int SEL_MAX>
-__global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
+__device__ __forceinline__ int select_block(const DevCtx& c, int redo_pass, int img, int level, unsigned long long* keys, uint32_t* sel, unsigned* hist, int* scan_s, unsigned* sv)
 {
-    SVO_TL_SCOPE(c, TL_SELECT, redo_pass);
     constexpr int SEL_TIE_MAX = 2 * SEL_MAX;
-    __shared__ unsigned long long keys[SEL_MAX];
-    __shared__ uint32_t sel[SEL_MAX];
-    __shared__ unsigned hist[256];
-    __shared__ int scan_s[32];
-    __shared__ unsigned s_prefix, s_need, s_sel, s_tie, s_ntie;
-    // image index fastest: consecutive workgroups go to consecutive XCDs, so with the level fastest every level-0 block
-    // (the heavy ones) landed on the same XCD
-    const int level = blockIdx.y, img = blockIdx.x;
+    unsigned& s_prefix = sv[0]; unsigned& s_need = sv[1]; unsigned& s_sel = sv[2]; unsigned& s_tie = sv[3]; unsigned& s_ntie = sv[4];
     const LevelGeom& g = c.lv[level];
     const int tid = threadIdx.x;
     const int il = img * SVO_MAX_LEVELS + level;
-    if (redo_pass && !c.redo_flag[il]) return;
+    if (redo_pass && !c.redo_flag[il]) return 0;
     unsigned nc = c.cand_cnt[il * SVO_CNT_STRIDE];
     if (nc > (unsigned)g.cand_cap) nc = g.cand_cap;
     const unsigned K = min(nc, (unsigned)(2 * g.quota));
@@ -791,9 +786,9 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
             atomicAdd(c.redo_n + 1, 1u);                               // running total since svo_create (svo_debug_get_redo_count)
             c.cand_cnt[il * SVO_CNT_STRIDE] = 0; c.fast_th_used[il] = th_base; c.fast_th_dyn[il] = 0;
         }
-        return;
+        return 0;
     }
-    if (K == 0 || g.quota <= 0) { if (tid == 0) { c.lvl_n[il] = 0; c.sel_n[il] = 0; c.fast_th_dyn[il] = 0; } return; }
+    if (K == 0 || g.quota <= 0) { if (tid == 0) { c.lvl_n[il] = 0; c.sel_n[il] = 0; c.fast_th_dyn[il] = 0; } return 0; }
     const uint32_t* ck = c.cand_keys + (long long)img * c.cand_total + g.cand_off;
     // ---- the K largest of the unique 32-bit keys (score << 24 | inverted position) ----
     // Two sweeps over the candidate list, eight independent loads in flight per thread (a one-load-per-iteration loop
@@ -812,7 +807,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
         for (int u = 0; u < 8; u++) if (base + u * 512 < nc) atomicAdd(&hist[k[u] >> 24], 1u);
     }
     __syncthreads();
-    if (c.debug_mode == 31) return;
+    if (c.debug_mode == 31) return 0;
     unsigned prefix = 0, mask = 0, need = K;
     {
         const int mine = tid < 256 ? (int)hist[255 - tid] : 0;         // bins in DESCENDING order: thread t owns bin 255 - t
@@ -847,10 +842,7 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
             for (int u = 0; u < 8; u++) if (base + u * 512 < nc && k[u] >= cutoff) sel[atomicAdd(&s_sel, 1u)] = k[u];
         }
         __syncthreads();
-        uint32_t* gsel_t = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
-        for (unsigned i = tid; i < K_ties; i += blockDim.x) gsel_t[i] = sel[i];
-        if (tid == 0) c.sel_n[il] = (int)K_ties;
-        return;
+        return (int)K_ties;
     }
     if (tid == 0) raise_detect_status(c, img >> 1, SVO_ST_CAND_OVERFLOW);
     if (n_tie <= SEL_TIE_MAX) {
@@ -900,11 +892,29 @@ __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
         for (unsigned i = tid; i < nc; i += blockDim.x) { const uint32_t k = ck[i]; if (k >= cutoff) { const unsigned sl = atomicAdd(&s_sel, 1u); if (sl < SEL_MAX) sel[sl] = k; } }
         __syncthreads();
     }
+    return (int)K;
+}
+
+// K3a: the selection; its winners go to k_harris through sel_keys
+template <int SEL_MAX>
+__global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
+{
+    SVO_TL_SCOPE(c, TL_SELECT, redo_pass);
+    __shared__ unsigned long long keys[SEL_MAX];
+    __shared__ uint32_t sel[SEL_MAX];
+    __shared__ unsigned hist[256];
+    __shared__ int scan_s[32];
+    __shared__ unsigned sv[5];
+    // image index fastest: consecutive workgroups go to consecutive XCDs, so with the level fastest every level-0 block
+    // (the heavy ones) landed on the same XCD
+    const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
+    const int K = select_block<SEL_MAX>(c, redo_pass, img, level, keys, sel, hist, scan_s, sv);
+    if (K <= 0) return;
     // hand the K winners to k_harris: one CU gathering 868 x 9 scattered rows was bound by its own outstanding-request
     // budget (55 us of this kernel's 108), the whole GPU does it in a few
     uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
-    for (unsigned i = tid; i < K; i += blockDim.x) gsel[i] = sel[i];
-    if (tid == 0) c.sel_n[il] = (int)K;
+    for (int i = tid; i < K; i += blockDim.x) gsel[i] = sel[i];
+    if (tid == 0) c.sel_n[img * SVO_MAX_LEVELS + level] = K;
 }
 
 // Harris response of every selected corner, one thread each, all (image, level) lists in one launch
@@ -931,24 +941,20 @@ __global__ void __launch_bounds__(256) k_harris(DevCtx c)
 // spaced, which suits the heavy-tailed Harris response), bucket sizes by LDS atomics, scan, scatter, and each key ranks
 // itself inside its bucket by full 64-bit compares.  Any bucket function monotone in the key gives the exact order.
 #define SS_NB 1024
+// (the body of the ranking: mykey[it] = the (response, position) key of entry
+// tid + 512 it of the K entries (0 beyond K), in registers; LDS arrays are the caller's: keys / tmp [SEL_MAX] u64, cnt / off [SS_NB], scan_s[32],
+// sv[4]; called by all 512 threads with K > 0)
 template <int SEL_MAX>
-__global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
+__device__ __forceinline__ void rank_block(const DevCtx& c, int img, int level, int K, const unsigned long long (&mykey)[SEL_MAX / 512],
+                                           unsigned long long* keys, unsigned long long* tmp, int* cnt, int* off, int* scan_s, unsigned* sv)
 {
-    SVO_TL_SCOPE(c, TL_SELECT_SORT, 0);
-    extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];          // keys[SEL_MAX] | tmp[SEL_MAX] (72 KB of LDS in all at SEL_MAX = 4096)
-    unsigned long long* keys = (unsigned long long*)ss_smem, *tmp = keys + SEL_MAX;
-    __shared__ int cnt[SS_NB], off[SS_NB], scan_s[32];
-    __shared__ unsigned s_mn, s_mx, s_mnp; __shared__ int s_np;
-    const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
+    unsigned& s_mn = sv[0]; unsigned& s_mx = sv[1]; unsigned& s_mnp = sv[2]; int& s_np = *(int*)(sv + 3);
+    const int tid = threadIdx.x;
     const LevelGeom& g = c.lv[level];
-    if (g.quota <= 0) return;
-    const int K = c.sel_n[img * SVO_MAX_LEVELS + level];
-    if (K <= 0) return;                                      // lvl_n was zeroed by k_select
-    const unsigned long long* gk = c.sel_resp + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
     if (tid == 0) { s_mn = 0xFFFFFFFFu; s_mx = 0u; s_mnp = 0xFFFFFFFFu; s_np = 0; }
     for (int i = tid; i < SS_NB; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    unsigned long long mykey[SEL_MAX / 512]; int mypos[SEL_MAX / 512], myb[SEL_MAX / 512];
+    int mypos[SEL_MAX / 512], myb[SEL_MAX / 512];
     // Only the best `quota` keys are emitted, so only they need their exact order: the buckets span the POSITIVE responses
     // (corners; the order-preserving pattern of a positive float is >= 0x80000000) when there are at least quota of them,
     // and everything below shares the last bucket, which then starts past the output range and is never ranked.
@@ -956,7 +962,6 @@ __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
 #pragma unroll
     for (int it = 0; it < SEL_MAX / 512; it++) {
         const int i = tid + it * 512;
-        mykey[it] = i < K ? gk[i] : 0ull;
         if (i < K) {
             const unsigned h = (unsigned)(mykey[it] >> 32);
             lmn = min(lmn, h); lmx = max(lmx, h);
@@ -1020,6 +1025,33 @@ __global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
     }
     if (tid == 0) c.lvl_n[img * SVO_MAX_LEVELS + level] = nout;
 }
+
+
+// K3c: order the keys k_harris left in sel_resp
+template <int SEL_MAX>
+__global__ void __launch_bounds__(512) k_select_sort(DevCtx c)
+{
+    SVO_TL_SCOPE(c, TL_SELECT_SORT, 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];          // keys[SEL_MAX] | tmp[SEL_MAX] (72 KB of LDS in all at SEL_MAX = 4096)
+    unsigned long long* keys = (unsigned long long*)ss_smem, *tmp = keys + SEL_MAX;
+    __shared__ int cnt[SS_NB], off[SS_NB], scan_s[32];
+    __shared__ unsigned sv[4];
+    const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
+    if (c.lv[level].quota <= 0) return;
+    const int K = c.sel_n[img * SVO_MAX_LEVELS + level];
+    if (K <= 0) return;                                      // lvl_n was zeroed by k_select
+    const unsigned long long* gk = c.sel_resp + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
+    unsigned long long mykey[SEL_MAX / 512];
+#pragma unroll
+    for (int it = 0; it < SEL_MAX / 512; it++) { const int i = tid + it * 512; mykey[it] = i < K ? gk[i] : 0ull; }
+    rank_block<SEL_MAX>(c, img, level, K, mykey, keys, tmp, cnt, off, scan_s, sv);
+}
+
+// (Round 6 built the fused form -- selection, Harris responses and ranking of one (image, level) in ONE 512-thread block, three launches per
+// frame instead of five -- on top of select_block / rank_block, lists bit-exact, and measured it SLOWER in both regimes: 65.5 k against
+// 67.5 k pairs/s at 3 x 64 lanes, 0.3546 against 0.3511 ms per frame for one stream (gpurun r06l).  The level-0 block ranks 868 corners:
+// their 9 x 12-byte patch reads from ONE CU cost more than the two launches saved, and at 128 VGPRs only two such blocks fit a CU.
+// Removed; k_harris keeps spreading the patch reads over the whole chip.)
 
 // ------------------------------------------------------------------------------------------------------------
 // K4+K5: cv::ORB per keypoint (oracle: orb_angle_desc): orientation (intensity centroid, radius 15) and the 256 tests of
