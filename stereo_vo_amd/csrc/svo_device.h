@@ -223,26 +223,26 @@ enum { TL_BEGIN = 0, TL_RESIZE, TL_FAST, TL_SELECT, TL_HARRIS, TL_SELECT_SORT, T
 // ONE record per launch from every wave: device-scope atomics to one address complete at the memory side at ~90 ns each, and a kernel
 // is not complete before they are -- k_harris took 790 us instead of 60, the whole step 7.7 ms instead of 2.8.)
 struct TlScope {
-    TlRec* r; unsigned long long t0;
-    __device__ __forceinline__ TlScope(const DevCtx& c, int kind, int aux) : r(nullptr), t0(0)
+    // Off: ONE wave-uniform flag (an SGPR compare at the top of the kernel and one scalar branch per way out) -- k_fast's waves run ~600
+    // instructions each, and a first form that decided per lane which record to stamp cost it 15 of them (2.4 %) with the knob off.
+    TlRec* base; unsigned long long t0;
+    __device__ __forceinline__ TlScope(const DevCtx& c, int kind, int aux) : base(nullptr), t0(0)
     {
         if (c.tl) {
+            base = c.tl + ((((size_t)(c.tl_step & (SVO_TL_STEPS - 1)) << 8) | (size_t)((kind & 31) << 3) | (size_t)(aux & 7)) << 7);
+            t0 = wall_clock64();
+        }
+    }
+    __device__ __forceinline__ ~TlScope()
+    {
+        if (base) {
             const unsigned g = gridDim.x, stride = g > 32u ? g / 32u : 1u, wave = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
             int sub = -1;
             if (wave == 0u && blockIdx.x + 1u == g) sub = 63;
             else if (wave == 0u && blockIdx.x % stride == 0u) sub = (int)min(blockIdx.x / stride, 62u);
             else if (g <= 64u && wave + 1u == nw) sub = 64 + (int)blockIdx.x;
-            if (sub >= 0) {
-                r = c.tl + (((((size_t)(c.tl_step & (SVO_TL_STEPS - 1)) << 8) | (size_t)((kind & 31) << 3) | (size_t)(aux & 7)) << 7) | (size_t)sub);
-                t0 = wall_clock64();
-            }
-        }
-    }
-    __device__ __forceinline__ ~TlScope()
-    {
-        if (r) {
             const unsigned long long act = __ballot(1);
-            if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) *(ulonglong2*)r = make_ulonglong2(t0, (unsigned long long)wall_clock64());
+            if (sub >= 0 && (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) *(ulonglong2*)(base + sub) = make_ulonglong2(t0, (unsigned long long)wall_clock64());
         }
     }
 };
@@ -484,6 +484,9 @@ __device__ __forceinline__ void grid_nms_block(int n, unsigned gly, const uint32
     }
     if (tid < 3) flag[tid] = 0;
     __syncthreads();
+    // (Round 6 handed the chains' tails -- what is still undecided after six rounds -- to ONE wave with wave-level LDS ordering instead of a
+    // block barrier per link: lists equal, k_nms_rowsort's NMS phase 24.5 -> 25.0 us (tests/dev/nms_breakdown.py, r06n).  The phase's time is
+    // the hash build and the cached neighbour look-ups above, not these rounds; removed again.)
     for (int round = 0; round <= n; round++) {
         volatile int* fl = flag + round % 3;                           // one barrier per round: see the ITEMS == 0 loop above
         if (tid == 0) flag[(round + 1) % 3] = 0;
