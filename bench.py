@@ -40,7 +40,7 @@ from stereo_vo_amd.pipeline import StreamBatch  # noqa: E402
 import ctypes as C  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_PROFILE = {"config2": "r06_pmc.json"}
+PMC_PROFILE = {"config2": "r06_pmc.json", "config3": "r06_pmc_config3.json", "config5": "r06_pmc_config5.json"}
 # svo_debug_timeline's kinds (stereo_vo_amd/csrc/svo_device.h, TL_*), and which of them the detect stream carries in the default split
 TIMELINE_KINDS = ["begin_frame", "resize", "fast", "select", "harris", "select_sort", "nms_rowsort", "describe", "hamming", "match_lr_filter", "track_filter",
                   "ransac_schedule", "ransac_hyp", "ransac_count", "track_finalize", "match_ids", "gauss_newton", "other"]

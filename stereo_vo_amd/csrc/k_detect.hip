@@ -419,8 +419,7 @@ struct FastSmem {
     unsigned s_count, s_nout;
 };
 // the NMS survivors' keys (3x3 NMS leaves at most one per 2x2 block) go where the window was: it is dead once the scores exist
-#define FT_PATCH_MAX 256                             // NMS survivors of a tile whose Harris patches k_fast writes (a textured tile has ~10)
-static_assert((FT_W * FT_H / 4 + 64) * 4 + FT_PATCH_MAX * 2 <= FT_LH * FT_LW, "out_keys and out_e alias the window");
+static_assert((FT_W * FT_H / 4 + 64) * 4 <= FT_LH * FT_LW, "out_keys aliases the window");
 
 // one 62x62 tile of one level of one image with FAST threshold th_fast (>= the caller's threshold, see k_select)
 // (src, pitch, gw, gh: the level's image; x0, y0: the tile's interior origin -- the caller has them from the tile table)
@@ -470,7 +469,7 @@ __device__ __forceinline__ void fast_reset(uint8_t* score, unsigned& s_count, un
 }
 
 __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uint8_t* score, unsigned short* list, unsigned& s_count, unsigned& s_nout,
-                                             int img, int level, int gw, int gh, int x0, int y0, int th_fast, const uint8_t* src, int pitch);
+                                             int img, int level, int gw, int gh, int x0, int y0, int th_fast);
 
 __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img, int level, const uint8_t* src, int pitch, int gw, int gh, int x0, int y0, int th_fast)
 {
@@ -478,15 +477,14 @@ __device__ __forceinline__ void fast_tile(const DevCtx& c, FastSmem& sm, int img
     fast_stage<false>(sm.tile, src, pitch, gw, gh, x0, y0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's DMA chunks have landed; the barrier covers the other wave's
     __syncthreads();
-    fast_compute(c, sm.tile, sm.score, sm.list, sm.s_count, sm.s_nout, img, level, gw, gh, x0, y0, th_fast, src, pitch);
+    fast_compute(c, sm.tile, sm.score, sm.list, sm.s_count, sm.s_nout, img, level, gw, gh, x0, y0, th_fast);
 }
 
 // everything of a tile after its window is in LDS (block-uniform early exits only; the caller's next barrier is its own)
 __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uint8_t* score, unsigned short* list, unsigned& s_count, unsigned& s_nout,
-                                             int img, int level, int gw, int gh, int x0, int y0, int th_fast, const uint8_t* src, int pitch)
+                                             int img, int level, int gw, int gh, int x0, int y0, int th_fast)
 {
     uint32_t* out_keys = (uint32_t*)tile;
-    unsigned short* out_e = (unsigned short*)(tile + (FT_W * FT_H / 4 + 64) * 4);       // behind out_keys, still inside the dead window
     const int tid = threadIdx.x;
     if (c.debug_mode == 1) return;
     // ---- (1) packed cardinal test: thread -> group column gq (positions q = 4 gq .. 4 gq + 3), score rows 8 rb .. 8 rb + 7 ----
@@ -594,11 +592,7 @@ __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uin
             const int leader = __ffsll((long long)m) - 1;
             if ((tid & 63) == leader) b2 = atomicAdd(&s_nout, (unsigned)__popcll(m));
             b2 = __shfl(b2, leader, 64);
-            if (keep) {
-                const unsigned j = b2 + (unsigned)__popcll(m & ((1ull << (tid & 63)) - 1ull));
-                out_keys[j] = key;
-                if (j < FT_PATCH_MAX) out_e[j] = (unsigned short)e;          // where it sits in the tile: the publishing wave fetches its Harris patch
-            }
+            if (keep) out_keys[b2 + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = key;
         }
     };
     // out_keys aliases the window, which the overflow path still scores from: every score is in the map by now (barrier above)
@@ -619,27 +613,9 @@ __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uin
     // only the first wave publishes: the other retires here, so the returning global atomic (a ~2-3 us round trip)
     // stalls one wave per tile instead of the whole workgroup
     if (tid < 64) {
-        const unsigned nout = (unsigned)__builtin_amdgcn_readfirstlane((int)s_nout);      // wave-uniform: the pass loops below branch on scalars
+        const unsigned nout = s_nout;
         if (nout != 0 && c.debug_mode != 4) {
             const LevelGeom& g = c.lv[level];
-            // Harris patches (round 6): k_harris needs 9 rows x 12 aligned bytes around a corner -- nine cache lines of a pyramid that left
-            // every cache long ago (295 MB per 64-lane launch for 26 MB of patches, 66 us at 4.5 TB/s).  Here the tile's lines were fetched
-            // microseconds ago: lane 9 s + r copies row r of survivor s from L2 into the candidate's patch slot (three dwords in, three out,
-            // seven survivors per pass).  The loads of the first three passes go out BEFORE the counter atomic and wait under its round trip;
-            // the stores need the slot it returns.  k_harris then reads 108 contiguous bytes per corner.
-            const bool patches = c.cand_patch != nullptr && ((((uintptr_t)src) | (uintptr_t)pitch) & 3) == 0;
-            const unsigned sl = ((unsigned)tid * 57u) >> 9, prow = (unsigned)tid - 9u * sl;          // tid / 9, tid % 9 for tid < 64
-            auto patch_row = [&](unsigned s_) -> uint3 {                                              // row prow of survivor s_ of this tile
-                int x, y;
-                if (s_ < FT_PATCH_MAX) { const int e = out_e[s_]; x = x0 - 1 + (e & 63); y = y0 - 1 + (e >> 6); }
-                else { const uint32_t pos = 0xFFFFFFu - (out_keys[s_] & 0xFFFFFFu); y = (int)(pos / (uint32_t)gw); x = (int)(pos - (uint32_t)y * (uint32_t)gw); }   // (a tile with more survivors than out_e holds: noise)
-                return *(const uint3*)(src + (long long)(y - 4 + (int)prow) * pitch + ((x - 4) & ~3));
-            };
-            uint3 pv[3] = { make_uint3(0, 0, 0), make_uint3(0, 0, 0), make_uint3(0, 0, 0) };
-            if (patches && tid < 63) {
-#pragma unroll
-                for (int p = 0; p < 3; p++) if (7u * p < nout) { if (7u * p + sl < nout) pv[p] = patch_row(7u * p + sl); }
-            }
             unsigned gbase = 0;
             if (tid == 0) gbase = atomicAdd(&c.cand_cnt[(img * SVO_MAX_LEVELS + level) * SVO_CNT_STRIDE], nout);
             gbase = __shfl(gbase, 0, 64);
@@ -647,12 +623,6 @@ __device__ __forceinline__ void fast_compute(const DevCtx& c, uint8_t* tile, uin
             for (unsigned i = tid; i < nout; i += 64) {
                 if (gbase + i < (unsigned)g.cand_cap) dst[gbase + i] = out_keys[i];
                 else raise_detect_status(c, img >> 1, SVO_ST_CAND_OVERFLOW);
-            }
-            if (patches && tid < 63) {
-                uint32_t* pb = c.cand_patch + ((long long)img * c.patch_total + g.patch_off) * 27;
-#pragma unroll
-                for (int p = 0; p < 3; p++) if (7u * p < nout) { const unsigned s_ = 7u * p + sl; if (s_ < nout && gbase + s_ < (unsigned)g.patch_cap) *(uint3*)(pb + (long long)(gbase + s_) * 27 + prow * 3) = pv[p]; }
-                for (unsigned b0 = 21; b0 < nout; b0 += 7) { const unsigned s_ = b0 + sl; if (s_ < nout && gbase + s_ < (unsigned)g.patch_cap) *(uint3*)(pb + (long long)(gbase + s_) * 27 + prow * 3) = patch_row(s_); }
             }
         }
     }
@@ -797,7 +767,7 @@ __device__ __forceinline__ float harris_at_dw(const uint8_t* img, int pitch, int
 // list), sel[SEL_MAX] u32, hist[256], scan_s[32], sv[5] -- and the K winners are LEFT IN sel[]; returns K (block-uniform), 0 = this block
 // has nothing to rank: its pair was queued for the redo, is not flagged in the redo pass, or has no candidates)
 template <int SEL_MAX>
-__device__ __forceinline__ int select_block(const DevCtx& c, int redo_pass, int img, int level, unsigned long long* keys, uint32_t* sel, uint32_t* selslot, unsigned* hist, int* scan_s, unsigned* sv)
+__device__ __forceinline__ int select_block(const DevCtx& c, int redo_pass, int img, int level, unsigned long long* keys, uint32_t* sel, unsigned* hist, int* scan_s, unsigned* sv)
 {
     constexpr int SEL_TIE_MAX = 2 * SEL_MAX;
     unsigned& s_prefix = sv[0]; unsigned& s_need = sv[1]; unsigned& s_sel = sv[2]; unsigned& s_tie = sv[3]; unsigned& s_ntie = sv[4];
@@ -869,13 +839,12 @@ __device__ __forceinline__ int select_block(const DevCtx& c, int redo_pass, int 
 #pragma unroll
             for (int u = 0; u < 8; u++) { const unsigned i = base + u * 512; k[u] = i < nc ? ck[i] : 0u; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (base + u * 512 < nc && k[u] >= cutoff) { const unsigned j = atomicAdd(&s_sel, 1u); sel[j] = k[u]; selslot[j] = base + u * 512; }
+            for (int u = 0; u < 8; u++) if (base + u * 512 < nc && k[u] >= cutoff) sel[atomicAdd(&s_sel, 1u)] = k[u];
         }
         __syncthreads();
         return (int)K_ties;
     }
     if (tid == 0) raise_detect_status(c, img >> 1, SVO_ST_CAND_OVERFLOW);
-    for (int i = tid; i < SEL_MAX; i += blockDim.x) selslot[i] = 0xFFFFFFFFu;       // (the cut paths below do not track slots: k_harris reads the pyramid for these)
     if (n_tie <= SEL_TIE_MAX) {
         for (unsigned base = tid; base < nc; base += 8 * 512) {
             uint32_t k[8];
@@ -931,21 +900,20 @@ template <int SEL_MAX>
 __global__ void __launch_bounds__(512) k_select(DevCtx c, int redo_pass)
 {
     SVO_TL_SCOPE(c, TL_SELECT, redo_pass);
-    extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];          // keys[SEL_MAX] u64 | sel[SEL_MAX] u32 | selslot[SEL_MAX] u32
-    unsigned long long* keys = (unsigned long long*)sl_smem;
-    uint32_t* sel = (uint32_t*)(keys + SEL_MAX), *selslot = sel + SEL_MAX;
+    __shared__ unsigned long long keys[SEL_MAX];
+    __shared__ uint32_t sel[SEL_MAX];
     __shared__ unsigned hist[256];
     __shared__ int scan_s[32];
     __shared__ unsigned sv[5];
     // image index fastest: consecutive workgroups go to consecutive XCDs, so with the level fastest every level-0 block
     // (the heavy ones) landed on the same XCD
     const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;
-    const int K = select_block<SEL_MAX>(c, redo_pass, img, level, keys, sel, selslot, hist, scan_s, sv);
+    const int K = select_block<SEL_MAX>(c, redo_pass, img, level, keys, sel, hist, scan_s, sv);
     if (K <= 0) return;
     // hand the K winners to k_harris: one CU gathering 868 x 9 scattered rows was bound by its own outstanding-request
     // budget (55 us of this kernel's 108), the whole GPU does it in a few
-    uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max, *gslot = c.sel_slot + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
-    for (int i = tid; i < K; i += blockDim.x) { gsel[i] = sel[i]; gslot[i] = selslot[i]; }
+    uint32_t* gsel = c.sel_keys + ((long long)img * SVO_MAX_LEVELS + level) * c.sel_max;
+    for (int i = tid; i < K; i += blockDim.x) gsel[i] = sel[i];
     if (tid == 0) c.sel_n[img * SVO_MAX_LEVELS + level] = K;
 }
 
@@ -963,11 +931,7 @@ __global__ void __launch_bounds__(256) k_harris(DevCtx c)
     const int x = (int)(pos % (uint32_t)g.w), y = (int)(pos / (uint32_t)g.w);
     int pitch; const uint8_t* lim = level_ptr(c, img, level, pitch);
     const bool aligned = (((uintptr_t)lim | (uintptr_t)pitch) & 3) == 0;
-    const uint32_t slot = c.sel_slot[o];
-    float r;
-    if (aligned && c.cand_patch != nullptr && slot < (uint32_t)g.patch_cap)        // the 27 dwords k_fast copied: rows 12 bytes apart, the corner's column at byte 4 + ((x - 4) & 3)
-        r = harris_at_dw((const uint8_t*)(c.cand_patch + ((long long)img * c.patch_total + g.patch_off + slot) * 27), 12, 4 + ((x - 4) & 3), 4);
-    else r = aligned ? harris_at_dw(lim, pitch, x, y) : harris_at(lim, pitch, x, y);
+    const float r = aligned ? harris_at_dw(lim, pitch, x, y) : harris_at(lim, pitch, x, y);
     c.sel_resp[o] = ((unsigned long long)ord32(r) << 32) | (unsigned long long)(0xFFFFFFFFu - pos);
 }
 
@@ -2069,12 +2033,12 @@ void launch_fast(const DevCtx& c, hipStream_t st)
 void launch_select(const DevCtx& c, hipStream_t st)
 {
     const bool big = c.sel_max > 2048;
-    if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)4096 * 16, st, c, 0);
-    else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)2048 * 16, st, c, 0);
+    if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
+    else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 0);
     // the pairs whose speculated FAST threshold was too high (normally none: both launches retire at once)
     hipLaunchKernelGGL(k_fast_redo, dim3(4096), dim3(FT_NT), 0, st, c);
-    if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)4096 * 16, st, c, 1);
-    else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)2048 * 16, st, c, 1);
+    if (big) hipLaunchKernelGGL(k_select<4096>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
+    else hipLaunchKernelGGL(k_select<2048>, dim3(c.n_img, c.n_levels), dim3(512), 0, st, c, 1);
     hipLaunchKernelGGL(k_harris, dim3(c.n_img, c.sel_max / 256, c.n_levels), dim3(256), 0, st, c);
     if (big) hipLaunchKernelGGL(k_select_sort<4096>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)4096 * 16, st, c);
     else hipLaunchKernelGGL(k_select_sort<2048>, dim3(c.n_img, c.n_levels), dim3(512), (size_t)2048 * 16, st, c);
@@ -2118,7 +2082,6 @@ hipError_t configure_nms_rowsort(const DevCtx& c)
     e = svo_raise_dyn_smem((const void*)k_fastorb_anms, (size_t)kmax * 8);
     if (e != hipSuccess) return e;
     e = svo_raise_dyn_smem((const void*)k_select_sort<4096>, 4096 * 16);
-    if (e == hipSuccess) e = svo_raise_dyn_smem((const void*)k_select<4096>, 4096 * 16);
     if (e != hipSuccess) return e;
     const int pmax = nms_pmax(c);
     if (pmax > 8192) return hipErrorInvalidValue;

@@ -93,7 +93,6 @@ struct svo_ctx {
     uint8_t* d_vals; uint8_t* h_vals; size_t vals_bytes;
     uint32_t* d_anms;                                  // scratch of k_fastorb_anms (3 x n_img x cand_total), allocated on first use
     bool imported_pending;                             // svo_import_frame ran since the last svo_process
-    uint32_t* d_patch; size_t patch_alloc;              // k_fast's Harris patches (DevCtx.cand_patch): sized by the geometry in use, grown when it grows
     int sampler_nmax;                                  // > 0: holds a reference on the shared sampler table of (device, sampler_nmax)
     hipEvent_t post_event;                             // svo_record_after_post: armed for the next call that runs the detector's post-processing
     // svo_use_graphs: the kernel sequence of a frame captured once per (flags, ring slot, thresholds) and replayed
@@ -385,8 +384,6 @@ extern "C" int svo_create(const svo_config* cfg, svo_ctx** out)
     HIPCHECK(dev_alloc(ctx, &d.lvl_resp, (size_t)NI * ctx->raw_cap_alloc));
     d.sel_max = MK > 4096 ? 2 * SVO_SEL_MAX : SVO_SEL_MAX;
     HIPCHECK(dev_alloc(ctx, &d.sel_keys, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
-    HIPCHECK(dev_alloc(ctx, &d.sel_slot, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
-    d.cand_patch = nullptr; d.patch_total = 0; ctx->d_patch = nullptr; ctx->patch_alloc = 0;
     HIPCHECK(dev_alloc(ctx, &d.sel_resp, (size_t)NI * SVO_MAX_LEVELS * d.sel_max));
     d.big_scratch = nullptr; d.gn_scratch = nullptr;
     if (MK > 4096) HIPCHECK(dev_alloc(ctx, &d.big_scratch, (size_t)NI * OC * (size_t)MK * 28));
@@ -461,7 +458,6 @@ extern "C" void svo_destroy(svo_ctx* ctx)
     if (!ctx) return;
     sync_all(ctx);                                        // work may still be running on a stream the caller switched away from
     for (void* p : ctx->allocs) hipFree(p);
-    if (ctx->d_patch) hipFree(ctx->d_patch);
     if (ctx->sampler_nmax > 0) sampler_table_release(ctx->cfg.device, ctx->sampler_nmax);
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.exec);
     if (ctx->h_vals) hipHostFree(ctx->h_vals);
@@ -704,7 +700,7 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     }
     for (int o = 0; o < SVO_MAX_OCTAVES; o++) { d.ow[o] = fast_orb ? (o < noct ? lw[o] : 0) : (o == 0 ? w : 0); d.oh[o] = fast_orb ? (o < noct ? lh[o] : 0) : (o == 0 ? h : 0); }
     d.W = w; d.H = h; d.n_levels = nlev;
-    long long off = 0; int tile_off = 0, slot_off = 0, cand_off = 0, rt_off = 0, patch_off = 0;
+    long long off = 0; int tile_off = 0, slot_off = 0, cand_off = 0, rt_off = 0;
     std::vector<int> rtab;
     for (int l = 0; l < nlev; l++) {
         LevelGeom& g = d.lv[l];
@@ -718,9 +714,6 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
         long long cc = (long long)ctx->cfg.max_cand * ((long long)g.w * g.h) / ((long long)lw[0] * lh[0]);
         if (cc < 1024) cc = 1024;
         g.cand_cap = (int)cc; g.cand_off = cand_off; cand_off += g.cand_cap;
-        // Harris patches for the first 4 x quota + 64 candidates of the level (k_select's speculated threshold aims at 3 x quota + 32;
-        // a candidate beyond has none and k_harris reads the pyramid for it): ORB mode only
-        g.patch_cap = (live && !fast_orb) ? std::min(g.cand_cap, 4 * g.quota + 64) : 0; g.patch_off = patch_off; patch_off += g.patch_cap;
         g.rtab_off = rt_off;
         if (l >= 1 && !fast_orb) {
             std::vector<int> xi(g.w), xf(g.w), yi(g.h), yf(g.h);
@@ -744,17 +737,6 @@ static int ensure_geometry(svo_ctx* ctx, int w, int h)
     if (off > ctx->pyr_bytes_alloc || cand_off > ctx->cand_total_alloc || (int)rtab.size() > ctx->rtab_alloc || slot_off > d.raw_cap) return SVO_ERR_CAPACITY;
     if (!fast_orb && slot_off > d.max_kps) return SVO_ERR_CAPACITY;                 // ORB mode: all levels feed one list
     d.n_tiles = tile_off; d.n_slots = slot_off; d.cand_total = ctx->cand_total_alloc;
-    {   // the patch block: n_img x patch_off x 108 bytes (173 MB for 64 lanes at orb_nfeats 2000); kept when the geometry shrinks
-        const size_t need = (size_t)d.n_img * (size_t)patch_off * 27;
-        if (need > ctx->patch_alloc) {
-            if (ctx->d_patch) { (void)hipFree(ctx->d_patch); ctx->d_patch = nullptr; ctx->patch_alloc = 0; }
-            void* q = nullptr;
-            if (hipMalloc(&q, need * sizeof(uint32_t) + 256) == hipSuccess) { ctx->d_patch = (uint32_t*)q; ctx->patch_alloc = need; }
-            else (void)hipGetLastError();              // no room: the detector works without (k_harris reads the pyramid)
-        }
-        d.patch_total = patch_off;
-        d.cand_patch = (patch_off > 0 && ctx->d_patch && !getenv("SVO_NO_PATCHES")) ? ctx->d_patch : nullptr;
-    }
     d.div_tiles = make_fastdiv((uint32_t)(tile_off > 0 ? tile_off : 1));
     if (!rtab.empty()) HIPCHECK(hipMemcpy(d.rtab, rtab.data(), rtab.size() * sizeof(int), hipMemcpyHostToDevice));
     {   // k_fast's tile table (same for every image and frame of this geometry)

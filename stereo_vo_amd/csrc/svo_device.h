@@ -68,7 +68,6 @@ struct LevelGeom {
     int tiles_x, tiles_y, tile_off;   // FAST tiling of the [EDGE, w-EDGE) x [EDGE, h-EDGE) interior
     int quota, slot_off;              // per-level keypoint quota and its offset in the level-segmented arrays
     int cand_cap, cand_off;
-    int patch_cap, patch_off;         // Harris patches of the level's first patch_cap candidates (DevCtx.cand_patch), offset in an image's patch block
     long long offset;                 // byte offset of the level in one image's pyramid block (levels >= 1)
     float scale;
     int rtab_off;                     // offset of this level's resize tables (x table then y table)
@@ -138,10 +137,6 @@ struct DevCtx {
     uint32_t* lvl_pos;
     float* lvl_resp;
     uint32_t* sel_keys;             // [n_img][SVO_MAX_LEVELS][SVO_SEL_MAX]  k_select's winners (FAST key), input of k_harris
-    uint32_t* sel_slot;             // same shape: the winner's slot in its level's candidate list (0xFFFFFFFF: unknown), where its patch is
-    uint32_t* cand_patch;           // [n_img][patch_total][27]  the 9 x 12 aligned bytes around each FAST candidate that k_harris sums over, written by k_fast
-                                    // while the tile's lines are hot in L2 (round 6); nullptr: k_harris reads the pyramid (FAST+ORB mode, unaligned images)
-    int patch_total;                // patch slots per image
     unsigned long long* sel_resp;   // same shape: (Harris response, position) keys, input of k_select_sort
     int* sel_n;                     // [n_img][SVO_MAX_LEVELS]
     int* lvl_n;               // [n_img][SVO_MAX_LEVELS]

@@ -1329,7 +1329,7 @@ def test_hand_over_record_of_another_layout_is_refused(golden_dir):
 @pytest.mark.parametrize("env", [{"SVO_DESC_KPW": "1"}, {"SVO_DESC_KPW": "3", "SVO_DESC_TL": "0"}, {"SVO_DESC_KPW": "64"}, {"SVO_HAM_SPLITS": "1"}, {"SVO_HAM_SPLITS": "7"}, {"SVO_HAM_FP4": "0"}, {"SVO_HAM_FP4": "0", "SVO_HAM_SPLITS": "7"},
                                  {"SVO_DEBUG_MODE": "53", "SVO_RC_SPLIT": "4,2,3"}, {"SVO_DEBUG_MODE": "53", "SVO_RC_SPLIT": "1"},
                                  {"SVO_NMS_NT": "512"}, {"SVO_REST_PRIO": "3"}, {"SVO_RS_C0": "32"}, {"SVO_RS_C0": "160"}, {"SVO_RS_C0": "160", "SVO_DEBUG_MODE": "53"}, {"SVO_RS_C0": "320", "SVO_DEBUG_MODE": "53"}, {"SVO_RS_C0": "320", "SVO_DEBUG_MODE": "51"},
-                                 {"SVO_DEBUG_MODE": "14"}, {"SVO_DEBUG_MODE": "52"}, {"SVO_DEBUG_MODE": "14", "SVO_RS_C0": "160"}, {"SVO_TIMELINE": "1"}, {"SVO_NO_PATCHES": "1"}])
+                                 {"SVO_DEBUG_MODE": "14"}, {"SVO_DEBUG_MODE": "52"}, {"SVO_DEBUG_MODE": "14", "SVO_RS_C0": "160"}, {"SVO_TIMELINE": "1"}])
 def test_kernel_launch_knobs_do_not_change_results(golden_dir, env):
     """The launch-shape knobs the library reads from the environment once per process (keypoints per wave of k_describe and where
     its Gaussian operands live, train splits of k_hamming, pair splits of the matrix-core RANSAC count with its ticket protocol, the chunk ends of the sample schedule -- 320 / 320 by default for a handful of lanes, 32 / 160 in the batched shapes --) select other code paths of the same arithmetic: the committed small
