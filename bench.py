@@ -25,6 +25,12 @@ import os
 import sys
 import time
 
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams that share one never overlap.  Which
+# streams share depends on every stream the process has made (torch's included): the two-context shape of configs[4] ran at 23.7 k or at
+# 36.7 k pairs/s depending on nothing else (profiles/r06_config5_hw_queues.txt).  Eight queues give every stream of the schedules here one of
+# its own; the variable must be in the environment before the HIP runtime initialises, hence here, and only if the caller has not chosen.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

@@ -173,6 +173,9 @@ static void rank_main(Rank* r)
 
 int main(int argc, char** argv)
 {
+    // HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); streams that share one never overlap.
+    // Before the first HIP call, and only if the caller has not chosen:
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Options o;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];

@@ -106,6 +106,9 @@ static void rank_main(Shared* sh, int rank)
 
 int main(int argc, char** argv)
 {
+    // HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); streams that share one never overlap.
+    // Before the first HIP call, and only if the caller has not chosen:
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Shared sh; sh.prefix = "camera_pose";
     std::vector<const char*> files;
     for (int i = 1; i < argc; i++) {
