@@ -10,8 +10,8 @@ through a long "street" world (stereo_vo_amd/synth.py), stream s plays trajector
 chosen so that no stream ever wraps (F >= 200).  The speculative FAST threshold of k_fast is therefore always applied to a frame
 it has not seen: `fast_redo_rate` reports how often it failed, `scene_cuts` times the same batch with a cut every 20 frames.
 Workload at N=1: BASELINE.json configs[1] -- 1280x960 synthetic stereo streams, ~2000 ORB keypoints per image
-(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton; 192 streams per GPU held by three
-contexts of 64 (the per-stream latency-bound kernels of stages 3-5 of one context overlap the throughput kernels of
+(orb_nfeats=2000, 8 levels), BF left-right matching, BF tracking, robust Gauss-Newton; 192 streams per GPU held by two
+contexts of 96 since round 6 (three of 64 in rounds 2-5: 69.9 k against 70.8 k pairs/s in one call, profiles/r06_contexts_sweep.txt) (the per-stream latency-bound kernels of stages 3-5 of one context overlap the throughput kernels of
 stage 2 of the next on a second HIP stream; kernel times below are per launch = per context of 64 streams).
 Streams shard by independent stream across ranks with no data-path collective ("weak" scaling); the per-frame
 result records are all-gathered over RCCL as in configs[3] (512 B-class, latency only).
@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--lanes", type=int, default=192, help="independent stereo streams per GPU (all contexts together)")
-    ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
+    ap.add_argument("--contexts", type=int, default=2, help="contexts per GPU, each on its own HIP stream with lanes/contexts streams: the latency-bound per-stream kernels of one overlap the throughput kernels of the other")
     ap.add_argument("--frames", type=int, default=0, help="frames rendered per trajectory; 0 (default) = as many as it takes for no stream ever to see a frame twice (>= 200)")
     ap.add_argument("--trajectories", type=int, default=8, help="distinct camera trajectories rendered per rank; stream s plays trajectory s %% T from frame 7 * (s // T) on")
     ap.add_argument("--long-steps", type=int, default=100, help="N=1: when --steps is smaller than this, one more timed leg of this many steps (after --warmup untimed ones, estimators reset, the same streams from their first frame on: no stream sees a frame twice inside the leg), reported as `long_run` -- so that a short --steps run still carries a measurement over a few hundred milliseconds; 0 = skip")

@@ -15,10 +15,10 @@
  * Conventions as in svo_hip.h: plain pointers and sizes, int status (0 ok, < 0 error), nothing throws, no CPU fallback.
  * Neither object is thread-safe; one host thread drives one batch (one batch per GPU and thread on a multi-GPU node).
  *
- * The default shape -- three contexts: one detect stream + three stage 3-5 streams -- is exactly the four hardware queues a HIP
- * process has by default.  More contexts share queues and serialise behind each other (4 x 48 streams: 39.5 k pairs/s against
- * 68 k for 3 x 64; with GPU_MAX_HW_QUEUES=8 in the environment 58.8 k: DESIGN.md section 4, round 4): stay at three, or raise
- * GPU_MAX_HW_QUEUES before the HIP runtime initialises.
+ * The default shape is two contexts of 96 streams: one detect stream + two stage 3-5 streams (round 6: 70.8 k pairs/s against 69.9 k for
+ * 3 x 64 and 49.7 k for 4 x 64, profiles/r06_contexts_sweep.txt).  HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by
+ * default) and two streams that share one never overlap: a host should export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises
+ * (the two-context 2048 x 1536 shape ran at 23.7 k or 36.7 k pairs/s on that alone).
  */
 #ifndef SVO_BATCH_H
 #define SVO_BATCH_H

@@ -52,8 +52,8 @@ extern "C" void svo_batch_config_defaults(svo_batch_config* c)
 {
     if (!c) return;
     svo_config_defaults(&c->ctx);
-    c->ctx.n_lanes = 64;                       // the measured default (3 x 64); SVO_MAX_LANES is the limit of the pointer tables in the kernel arguments
-    c->n_contexts = 3; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 1; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0; c->no_detect_ahead = 0;
+    c->ctx.n_lanes = 96;                       // the measured default (2 x 96 since round 6, 3 x 64 before); SVO_MAX_LANES is the limit of the pointer tables in the kernel arguments
+    c->n_contexts = 2; c->schedule = SVO_SCHED_PIPELINED; c->det_priority_high = 1; c->post_mode = 1; c->det_streams = 1; c->rest_streams = 0; c->no_detect_ahead = 0;
 }
 
 extern "C" const char* svo_batch_last_error(const svo_batch* b) { return b ? b->last_error.c_str() : ""; }

@@ -90,8 +90,8 @@ def test_batch_config_defaults_are_the_measured_schedule():
     from stereo_vo_amd import hip
     cfg = hip.BatchConfig()
     hip.lib().svo_batch_config_defaults(C.byref(cfg))
-    assert (cfg.n_contexts, cfg.schedule, cfg.det_priority_high, cfg.post_mode, cfg.det_streams, cfg.rest_streams, cfg.no_detect_ahead) == (3, 0, 1, 1, 1, 0, 0)
-    assert cfg.ctx.n_lanes == 64
+    assert (cfg.n_contexts, cfg.schedule, cfg.det_priority_high, cfg.post_mode, cfg.det_streams, cfg.rest_streams, cfg.no_detect_ahead) == (2, 0, 1, 1, 1, 0, 0)
+    assert cfg.ctx.n_lanes == 96
 
 
 def test_batch_config_size_is_checked_at_the_boundary():

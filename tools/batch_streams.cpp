@@ -51,7 +51,7 @@ static bool load_sequence(const char* path, Sequence& s)
 static int ping_pong(int step, int F) { if (F <= 1) return 0; const int period = 2 * (F - 1), k = step % period; return k < F ? k : period - k; }
 
 struct Options {
-    int contexts = 3, lanes = 64, steps = 20, warmup = 4, nfeats = 2000, gpus = 1, device = 0; bool rccl = false; std::string dump;
+    int contexts = 2, lanes = 96, steps = 20, warmup = 4, nfeats = 2000, gpus = 1, device = 0; bool rccl = false; std::string dump;
     std::vector<const char*> files;
 };
 

@@ -10,7 +10,7 @@
 #   tests     the whole GPU suite (pytest -m gpu)
 #   bench     a short bench line (40 timed steps, 12-frame parity probe, no side legs)
 #   default   bench.py as the driver calls it (--gpus 1 --steps 20 --warmup 5: every leg, several minutes)
-#   stats3    rocprofv3 --kernel-trace --stats of the benchmarked shape (3 x 64 lanes), steady state
+#   stats3    rocprofv3 --kernel-trace --stats of the benchmarked shape (2 x 96 lanes since round 6; the files keep the `3ctx` tag of rounds 2-5), steady state
 #   stats1    the same with one context of 64 lanes alone (exclusive kernel times)
 #   stats_ss  one stream alone (tools/single_stream_bench.py)
 #   pmc       the counter passes (tools/pmc_passes.py): traffic by request size, VALU / LDS / MFMA counters, issue fractions
