@@ -836,7 +836,7 @@ def other_workloads_leg(args):
     so that the driver's record holds a pairs/s figure for every single-GPU configuration."""
     import subprocess
     out = {}
-    for wl, extra in (("config3", ["--lanes", "192", "--contexts", "3"]), ("config5", ["--lanes", "64", "--contexts", "2"])):
+    for wl, extra in (("config3", ["--lanes", "192", "--contexts", "2"]), ("config5", ["--lanes", "64", "--contexts", "2"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "40", "--warmup", "6", "--cpu-frames", "12", "--long-steps", "0", "--host-fed-steps", "0",
                "--single-stream", "0", "--relief-lanes", "0", "--cut-steps", "0", "--other-workloads", "0", "--exclusive", "1"] + extra
         try:
