@@ -593,22 +593,27 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
     const unsigned* gL = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 1) * c.max_kps;
     const unsigned* gR = (const unsigned*)c.bf_idx + ((long long)vl * 3 + 2) * c.max_kps;
     // state per owned k: 0 rejected, 1 kept, 2 undecided
-    unsigned tlr[TF_ITEMS]; unsigned char st[TF_ITEMS];
+    // a thread's candidates k = tid + 256 j: (train indices, state).  Up to 16 per thread they live in registers; the 32 of a max_kps = 8192
+    // context spilled there (512 VGPRs + 1.4 KB of scratch per thread, hipcc's report): those live in LDS behind the tables above
+    unsigned tlr_r[TF_ITEMS <= 16 ? TF_ITEMS : 1]; unsigned char st_r[TF_ITEMS <= 16 ? TF_ITEMS : 1];
+    unsigned* tlr_s = takenR + c.max_kps / 32; unsigned char* st_s = (unsigned char*)(tlr_s + (TF_ITEMS <= 16 ? 0 : TF_ITEMS * 256));
+    auto TLR = [&](int j) -> unsigned& { if constexpr (TF_ITEMS <= 16) return tlr_r[j]; else return tlr_s[j * 256 + tid]; };
+    auto ST = [&](int j) -> unsigned char& { if constexpr (TF_ITEMS <= 16) return st_r[j]; else return st_s[j * 256 + tid]; };
 #pragma unroll
     for (int j = 0; j < TF_ITEMS; j++) {
         const int k = tid + 256 * j;
-        tlr[j] = 0; st[j] = 0;
+        TLR(j) = 0; ST(j) = 0;
         if (k < npm) {
             const unsigned a = gL[k], b = gR[k];
-            tlr[j] = (a & 0xFFFFu) | (b << 16);                                   // tl | tr << 16
-            st[j] = ((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th) ? 0 : 2;      // S4:149
-            if ((int)(a & 0xFFFFu) >= ncm || (int)(b & 0xFFFFu) >= ncm) { st[j] = 0; atomicOr(&c.status[lane_id], SVO_ST_INTERNAL); }   // no match was written for k: never the case on a sound frame
+            TLR(j) = (a & 0xFFFFu) | (b << 16);                                   // tl | tr << 16
+            ST(j) = ((float)(a >> 16) > (float)c.orb_th || (float)(b >> 16) > (float)c.orb_th) ? 0 : 2;      // S4:149
+            if ((int)(a & 0xFFFFu) >= ncm || (int)(b & 0xFFFFu) >= ncm) { ST(j) = 0; atomicOr(&c.status[lane_id], SVO_ST_INTERNAL); }   // no match was written for k: never the case on a sound frame
         }
     }
     {   // svo_result.track_stats[SVO_TS_THRESHOLD]: candidates that pass the distance threshold on both sides
         int nth = 0;
 #pragma unroll
-        for (int j = 0; j < TF_ITEMS; j++) nth += st[j] == 2 ? 1 : 0;
+        for (int j = 0; j < TF_ITEMS; j++) nth += ST(j) == 2 ? 1 : 0;
         if (tid == 0) s_th = 0;
         __syncthreads();
         nth = wave_sum_uniform(nth);
@@ -626,21 +631,21 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < TF_ITEMS; j++)
-            if (j < n_items && st[j] == 2) { atomicMin(&firstL[tlr[j] & 0xFFFFu], (unsigned)(tid + 256 * j)); atomicMin(&firstR[tlr[j] >> 16], (unsigned)(tid + 256 * j)); }
+            if (j < n_items && ST(j) == 2) { atomicMin(&firstL[TLR(j) & 0xFFFFu], (unsigned)(tid + 256 * j)); atomicMin(&firstR[TLR(j) >> 16], (unsigned)(tid + 256 * j)); }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < TF_ITEMS; j++)
-            if (j < n_items && st[j] == 2) {
-                const unsigned k = (unsigned)(tid + 256 * j), tl = tlr[j] & 0xFFFFu, tr = tlr[j] >> 16;
-                if (firstL[tl] == k && firstR[tr] == k) { st[j] = 1; atomicOr(&takenL[tl >> 5], 1u << (tl & 31)); atomicOr(&takenR[tr >> 5], 1u << (tr & 31)); }
+            if (j < n_items && ST(j) == 2) {
+                const unsigned k = (unsigned)(tid + 256 * j), tl = TLR(j) & 0xFFFFu, tr = TLR(j) >> 16;
+                if (firstL[tl] == k && firstR[tr] == k) { ST(j) = 1; atomicOr(&takenL[tl >> 5], 1u << (tl & 31)); atomicOr(&takenR[tr >> 5], 1u << (tr & 31)); }
             }
         __syncthreads();
         bool und = false;
 #pragma unroll
         for (int j = 0; j < TF_ITEMS; j++)
-            if (j < n_items && st[j] == 2) {
-                const unsigned tl = tlr[j] & 0xFFFFu, tr = tlr[j] >> 16;
-                if (((takenL[tl >> 5] >> (tl & 31)) & 1u) || ((takenR[tr >> 5] >> (tr & 31)) & 1u)) st[j] = 0; else und = true;
+            if (j < n_items && ST(j) == 2) {
+                const unsigned tl = TLR(j) & 0xFFFFu, tr = TLR(j) >> 16;
+                if (((takenL[tl >> 5] >> (tl & 31)) & 1u) || ((takenR[tr >> 5] >> (tr & 31)) & 1u)) ST(j) = 0; else und = true;
             }
         if (und) s_und = 1;
         __syncthreads();
@@ -658,12 +663,12 @@ __global__ void __launch_bounds__(256) k_track_filter(DevCtx c)
 #pragma unroll
     for (int j = 0; j < TF_ITEMS; j++) {
         if (j >= n_items) break;                                                    // block-uniform
-        const int keep = st[j] == 1 ? 1 : 0;
+        const int keep = ST(j) == 1 ? 1 : 0;
         int tot;
         const int off = block_exclusive_scan(keep, scan, &tot);
         if (keep) {
             const int o = nk + off, k = tid + 256 * j;
-            const int tl = (int)(tlr[j] & 0xFFFFu), tr = (int)(tlr[j] >> 16);
+            const int tl = (int)(TLR(j) & 0xFFFFu), tr = (int)(TLR(j) >> 16);
             kq[o] = k;
             const svo_dmatch mp = pm[k];
             const svo_keypoint a = pkl[mp.queryIdx], b = ckl[cm[tl].queryIdx];
@@ -2056,7 +2061,7 @@ __global__ void __launch_bounds__(256) k_match_ids(DevCtx c, unsigned flags)
 hipError_t configure_match(int max_kps)
 {
     if (max_kps <= 4096) return hipSuccess;
-    hipError_t e = svo_raise_dyn_smem((const void*)k_track_filter<32>, (size_t)(max_kps / 32) * 8 + (size_t)max_kps * 8);
+    hipError_t e = svo_raise_dyn_smem((const void*)k_track_filter<32>, (size_t)(max_kps / 32) * 8 + (size_t)max_kps * 8 + (size_t)32 * 256 * 5);
     if (e != hipSuccess) return e;
     e = svo_raise_dyn_smem((const void*)k_match_lr_rbr, sizeof(unsigned) * 2 * max_kps + sizeof(int) * 32);
     return e;
@@ -2122,7 +2127,7 @@ void launch_match_ids(const DevCtx& c, unsigned flags, hipStream_t st)
 void launch_track_filter(const DevCtx& c, hipStream_t st)
 {
     const size_t sm = (size_t)(c.max_kps / 32) * 2 * sizeof(unsigned) + (size_t)c.max_kps * 2 * sizeof(unsigned);
-    if (c.max_kps > 4096) hipLaunchKernelGGL(k_track_filter<32>, dim3(c.n_lanes * c.oct_cap), dim3(256), sm, st, c);
+    if (c.max_kps > 4096) hipLaunchKernelGGL(k_track_filter<32>, dim3(c.n_lanes * c.oct_cap), dim3(256), sm + (size_t)32 * 256 * 5, st, c);      // + the per-thread candidates (4 + 1 bytes each) in LDS
     else hipLaunchKernelGGL(k_track_filter<16>, dim3(c.n_lanes * c.oct_cap), dim3(256), sm, st, c);
 }
 void launch_ransac_hyp(const DevCtx& c, int chunk, hipStream_t st)
